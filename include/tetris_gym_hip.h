@@ -1,0 +1,215 @@
+/*
+ * tetris_gym_hip.h — C ABI of the MI355X-native batched Tetris step engine (libtetris_gym_hip.so).
+ *
+ * The reference (Max-We/Tetris-Gymnasium 0.3.1) has no FFI boundary: the hot path is Python calling
+ * NumPy / JAX.  This header is the boundary a maintainer would bind with ctypes to replace
+ *   - tetris_gymnasium/envs/tetris.py:203-272   Tetris.step            (ruleset TG_RULESET_NUMPY)
+ *   - tetris_gymnasium/envs/tetris.py:274-307   Tetris.reset
+ *   - tetris_gymnasium/envs/tetris_fn.py:276-315 step / :416-435 batched_step  (TG_RULESET_FUNCTIONAL)
+ *   - tetris_gymnasium/envs/tetris_fn.py:318-367 reset / :438-467 batched_reset
+ *   - tetris_gymnasium/wrappers/grouped.py:124-269 grouped placement mask + step (TG_ACTIONS_GROUPED)
+ * Plain pointers and sizes only; no torch / numpy types.  All functions return 0 on success or a
+ * negative TG_E* code; the message is available from tg_last_error().  No exceptions cross the ABI.
+ *
+ * Threading: calls on one handle must be serialised by the caller.  Different handles (one per GPU)
+ * are independent.  Each handle owns one HIP stream; tg_step* are asynchronous on it, tg_fetch /
+ * tg_get_state / tg_sync synchronise.
+ */
+#ifndef TETRIS_GYM_HIP_H
+#define TETRIS_GYM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_ABI_VERSION 1
+
+/* ---- rule-sets (the reference contains two different Tetris rule-sets) ---- */
+#define TG_RULESET_NUMPY 0      /* envs/tetris.py (the graded oracle) */
+#define TG_RULESET_FUNCTIONAL 1 /* functional/core.py + envs/tetris_fn.py */
+
+/* ---- observation surfaces ---- */
+#define TG_OBS_NONE 0  /* nothing written */
+#define TG_OBS_BOARD 1 /* u8 [B][H][W]  = crop_padding(obs["board"]): locked cell values + active piece
+                          (envs/tetris.py:543-564, 514-523) */
+#define TG_OBS_DICT 2  /* NUMPY only. u8 board[B][Hp][Wp] | mask[B][Hp][Wp] | holder[B][p][p] |
+                          queue[B][p][p*Q]  (envs/tetris.py:566-615) */
+#define TG_OBS_FN 3    /* i8 [B][H][W] in {-1,0,1} (envs/tetris_fn.py:137-158) */
+
+/* ---- autoreset ---- */
+#define TG_AUTORESET_NONE 0      /* caller resets via tg_reset(mask) — reference behaviour */
+#define TG_AUTORESET_SAME_STEP 1 /* env is reset inside the step that terminated it; the observation
+                                    returned is the reset observation (gymnasium<=0.29 SyncVectorEnv) */
+#define TG_AUTORESET_NEXT_STEP 2 /* the step after termination ignores its action and resets
+                                    (gymnasium 1.x default) */
+
+/* ---- action sets ---- */
+#define TG_ACTIONS_BASE 0    /* NUMPY: mappings/actions.py:12-19 (8 ids); FUNCTIONAL: tetris_fn.py:470-478 (7 ids) */
+#define TG_ACTIONS_GROUPED 1 /* NUMPY only: column*4+rotation → teleport + hard drop (wrappers/grouped.py:209-269) */
+
+/* ---- memory kinds for caller-provided action buffers ---- */
+#define TG_MEM_HOST 0
+#define TG_MEM_DEVICE 1
+
+/* ---- error codes ---- */
+#define TG_OK 0
+#define TG_EINVAL (-1)      /* bad argument / unsupported configuration */
+#define TG_EHIP (-2)        /* a HIP runtime call failed */
+#define TG_ENOMEM (-3)
+#define TG_EUNSUPPORTED (-4) /* e.g. board size not compiled in, custom tetromino tables */
+
+typedef struct tg_config {
+  int32_t struct_size; /* = sizeof(tg_config); ABI guard */
+  int32_t width;       /* playfield columns (reference default 10) */
+  int32_t height;      /* playfield rows    (reference default 20) */
+  int32_t padding;     /* must be 4 (reference: max tetromino extent, envs/tetris.py:130) */
+  int32_t queue_size;  /* NUMPY: visible queue length 1..7 (reference 4); FUNCTIONAL: must be 7 */
+  int32_t gravity;     /* 0/1 */
+  int32_t ruleset;     /* TG_RULESET_* */
+  int32_t obs_mode;    /* TG_OBS_* */
+  int32_t autoreset;   /* TG_AUTORESET_* */
+  int32_t action_set;  /* TG_ACTIONS_* */
+  int32_t batch;       /* number of environments owned by this handle */
+  int32_t device;      /* HIP device ordinal */
+  int32_t env_offset;  /* global index of env 0 of this handle (multi-GPU sharding; informational) */
+  int32_t grouped_terminate_on_illegal; /* wrappers/grouped.py:49 (default 1) */
+  int32_t reserved[2];
+} tg_config;
+
+/* ---- per-env state records (tg_get_state / tg_set_state; also the device layout) ----
+ * board: u8 [B][H][W], playfield only (bedrock padding is implicit: it is a collision convenience,
+ *        envs/tetris.py:632-641), cell = 0 empty or the tetromino value 2..8. */
+typedef struct tg_env_rec { /* 32 bytes */
+  uint8_t piece;        /* active tetromino index 0..6 (I O T S Z J L) */
+  uint8_t rot;          /* number of np.rot90(k=+1) applied, 0..3 */
+  uint8_t x;            /* padded-board column of the matrix' left edge */
+  uint8_t y;            /* padded-board row of the matrix' top edge */
+  uint8_t val;          /* value written into the board on lock (piece + 2 unless poked) */
+  uint8_t flags;        /* TG_F_* */
+  uint8_t holder_piece; /* 0..6 or TG_NONE (NUMPY only) */
+  uint8_t holder_rot;
+  uint8_t holder_val;
+  uint8_t bag_index;    /* NUMPY: BagRandomizer.index 0..6; FUNCTIONAL: queue_index 0..7 */
+  uint8_t bag[7];       /* NUMPY: BagRandomizer.bag; FUNCTIONAL: State.queue */
+  uint8_t queue[7];     /* NUMPY: visible TetrominoQueue (first queue_size entries); FUNCTIONAL: unused */
+  float score;          /* FUNCTIONAL: State.score (float32). NUMPY: unused (0) */
+  uint32_t reserved;
+} tg_env_rec;
+
+#define TG_NONE 0xFF
+#define TG_F_GAME_OVER 0x01
+#define TG_F_HAS_SWAPPED 0x02
+#define TG_F_PENDING_RESET 0x04 /* NEXT_STEP autoreset: reset on the next step */
+
+typedef struct tg_rng_rec { /* 48 bytes */
+  /* NUMPY: numpy PCG64 bit-generator state (state, inc as 128-bit little-endian pairs) + the
+   * buffered 32-bit half used by next_uint32 (numpy/random/src/pcg64/pcg64.h pcg64_next32). */
+  uint64_t state_lo, state_hi;
+  uint64_t inc_lo, inc_hi;
+  uint32_t uinteger;
+  uint32_t has_uint32;
+  /* FUNCTIONAL: State.rng_key (threefry2x32 key data) */
+  uint32_t key[2];
+} tg_rng_rec;
+
+/* ---- output buffers (engine-owned device memory, see tg_device_ptr / tg_fetch) ---- */
+#define TG_BUF_OBS 0        /* layout per obs_mode */
+#define TG_BUF_REWARD 1     /* f32 [B] (NUMPY rewards are integer-valued; grouped illegal = -0.1f) */
+#define TG_BUF_TERMINATED 2 /* u8 [B] */
+#define TG_BUF_LINES 3      /* u8 [B]  info["lines_cleared"] */
+#define TG_BUF_ACTIONS 4    /* i32 [B] staging buffer used for TG_MEM_HOST actions */
+#define TG_BUF_BOARD 5      /* u8 [B][H][W] state boards */
+#define TG_BUF_REC 6        /* tg_env_rec [B] */
+#define TG_BUF_RNG 7        /* tg_rng_rec [B] */
+#define TG_BUF_LEGAL_MASK 8 /* u8 [B][4*W]  grouped legal-action mask (TG_ACTIONS_GROUPED) */
+#define TG_BUF_FINAL_OBS 9  /* SAME_STEP autoreset: observation of the terminal state (valid where terminated) */
+#define TG_BUF_EPISODE 10   /* tg_episode_rec [B] */
+#define TG_BUF_COUNT 11
+
+typedef struct tg_episode_rec { /* 16 bytes: device-side RecordEpisodeStatistics */
+  float ret;           /* running return of the current episode */
+  uint32_t len;        /* running length */
+  float last_ret;      /* return of the last finished episode */
+  uint32_t last_len;   /* length of the last finished episode */
+} tg_episode_rec;
+
+typedef struct tg_handle tg_handle;
+
+int tg_abi_version(void);
+
+/* Number of visible HIP devices (does not initialise a context beyond hipGetDeviceCount). */
+int tg_device_count(void);
+
+/* Create an engine instance: allocates all device state (SoA) for cfg->batch envs on cfg->device.
+ * Envs are NOT reset by create; call tg_reset. */
+int tg_create(const tg_config* cfg, tg_handle** out);
+void tg_destroy(tg_handle* h);
+
+/* Last error message for this handle (h == NULL: last tg_create failure on this thread). */
+const char* tg_last_error(const tg_handle* h);
+
+/* Reset envs.  seeds: host u64[B] or NULL; mask: host u8[B] or NULL (NULL = all envs).
+ * NUMPY: seeds[i] > 0 reseeds env i's generator exactly like Tetris.reset(seed=seeds[i])
+ *        (SeedSequence → PCG64); seeds == NULL or seeds[i] == 0 keeps the running generator
+ *        (components/tetromino_randomizer.py:40-46).  An env that was never seeded gets
+ *        SeedSequence(1 + env_offset + i).
+ * FUNCTIONAL: seeds[i] = ((u64)key[0] << 32) | key[1]  is the PRNG key passed to reset
+ *        (envs/tetris_fn.py:318-328); seeds == NULL re-uses State.rng_key. */
+int tg_reset(tg_handle* h, const uint64_t* seeds, const uint8_t* mask);
+
+/* One transition for every env.  actions: i32[B] in host or device memory (kind = TG_MEM_*).
+ * Asynchronous on the handle's stream; results land in the TG_BUF_* device buffers. */
+int tg_step(tg_handle* h, const int32_t* actions, int kind);
+
+/* K consecutive transitions with pre-generated actions i8 [K][B] resident in DEVICE memory
+ * (launch-bound regime helper; observations/rewards of the last step remain in the buffers,
+ *  rewards/terminated/lines of every step are accumulated only if accum != 0 into TG_BUF_EPISODE). */
+int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K);
+
+/* Device pointer and size of an engine-owned buffer. */
+int tg_device_ptr(tg_handle* h, int which, void** ptr, size_t* bytes);
+
+/* Synchronous copy of an engine-owned buffer to host memory (waits for the stream). */
+int tg_fetch(tg_handle* h, int which, void* host_dst, size_t bytes);
+
+/* Full state snapshot / restore (host buffers; any pointer may be NULL to skip).
+ * board u8[B][H][W], rec tg_env_rec[B], rng tg_rng_rec[B].  (envs/tetris.py:681-708) */
+int tg_get_state(tg_handle* h, uint8_t* board, tg_env_rec* rec, tg_rng_rec* rng);
+int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, const tg_rng_rec* rng);
+
+/* Re-pack the observation buffer from the current state without stepping (after tg_set_state). */
+int tg_observe(tg_handle* h);
+
+/* Grouped action surface: recompute TG_BUF_LEGAL_MASK (and, if boards_dev != NULL, write all 4*W
+ * placement boards u8 [B][4W][Hp][Wp] there) for the current state (wrappers/grouped.py:124-207). */
+int tg_grouped_enumerate(tg_handle* h, uint8_t* boards_dev);
+
+int tg_sync(tg_handle* h);
+
+/* Stream timing with HIP events recorded on the handle's own stream (bench.py). */
+int tg_timer_start(tg_handle* h);
+int tg_timer_stop(tg_handle* h, float* elapsed_ms); /* records stop, synchronises, returns ms */
+
+/* Host utility: numpy SeedSequence(seed) → PCG64 initial state, as tg_rng_rec (pinned by tests). */
+int tg_seed_pcg64(uint64_t seed, tg_rng_rec* out);
+
+/* Sizes derived from a config (bytes per env of the observation buffer, number of actions). */
+int tg_obs_bytes_per_env(const tg_config* cfg);
+int tg_num_actions(const tg_config* cfg);
+
+/* Device memory helpers so a ctypes-only host program needs no other GPU library. */
+int tg_dev_alloc(tg_handle* h, size_t bytes, void** ptr);
+int tg_dev_free(tg_handle* h, void* ptr);
+int tg_dev_upload(tg_handle* h, void* dst_dev, const void* src_host, size_t bytes);
+int tg_dev_download(tg_handle* h, void* dst_host, const void* src_dev, size_t bytes);
+
+/* Stream-copy kernel (float4 grid-stride) used by bench.py to report the practical HBM ceiling. */
+int tg_stream_copy_gbps(tg_handle* h, size_t bytes, int iters, float* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TETRIS_GYM_HIP_H */

@@ -1,0 +1,380 @@
+"""Generate the golden fixtures under tests/golden/ from the UNMODIFIED reference NumPy env.
+
+TEST INFRASTRUCTURE.  Runs only in the build container (needs /root/reference); the GPU box sees only
+the committed .npz outputs.  Nothing of the reference's source is stored — inputs (seeds, actions,
+initial boards) and the reference's outputs (rewards, dones, lines, boards, observation checksums).
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.refgen.make_golden [--only NAME]
+
+Fixtures (all NumPy rule-set, i.e. envs/tetris.py — the graded oracle of BASELINE.json):
+  pcg64_streams.npz      SeedSequence→PCG64 initial states + first 70 bag pieces per seed
+  trace_<cfg>.npz        random-policy traces, harness reset() on done
+  clears_<cfg>.npz       line-clear-dense traces from pre-filled boards
+  grouped_<cfg>.npz      grouped wrapper: legal masks, placement boards, traces (grouped_clears_*: on dense stacks)
+  features.npz           FeatureVectorObservation outputs on trace states
+  ref_tests_grouped.npz  the reference tests' own mock board / CSV board / 40-entry mask (data only)
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+
+from oracle.refgen.standins import import_reference
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden")
+
+
+def obs_crc(obs) -> int:
+    c = 0
+    for k in ("board", "active_tetromino_mask", "holder", "queue"):
+        c = zlib.crc32(np.ascontiguousarray(obs[k], dtype=np.uint8).tobytes(), c)
+    return c
+
+
+def matrix16(t) -> np.ndarray:
+    m = np.zeros((4, 4), np.uint8)
+    n = t.matrix.shape[0]
+    m[:n, :n] = t.matrix
+    return m.reshape(16)
+
+
+def make_env(ref, width, height, gravity, queue_size):
+    env = ref.Tetris(width=width, height=height, gravity=gravity)
+    if queue_size != 4:
+        # the reference's queue=/holder= kwargs are broken (envs/tetris.py:139-144 leave the attribute
+        # unset); config 5 patches the queue after construction
+        from tetris_gymnasium.components.tetromino_queue import TetrominoQueue
+
+        env.queue = TetrominoQueue(env.randomizer, queue_size)
+    return env
+
+
+def snapshot(env):
+    hold = env.holder.get_tetrominoes()
+    return dict(
+        board=env.board.copy(),
+        x=env.x, y=env.y,
+        piece=env.active_tetromino.id - 2,
+        matrix=matrix16(env.active_tetromino),
+        queue=np.array(list(env.queue.queue), np.uint8),
+        holder_piece=(hold[0].id - 2) if hold else 255,
+        holder_matrix=matrix16(hold[0]) if hold else np.zeros(16, np.uint8),
+        bag=env.randomizer.bag.astype(np.uint8).copy(),
+        bag_index=env.randomizer.index,
+        has_swapped=int(env.has_swapped),
+        game_over=int(env.game_over),
+    )
+
+
+def gen_pcg64_streams():
+    """numpy SeedSequence → PCG64 state, and the BagRandomizer stream (reference component)."""
+    ref = import_reference()
+    from tetris_gymnasium.components.tetromino_randomizer import BagRandomizer
+
+    seeds = np.array([1, 2, 3, 42, 123, 2**31 - 1, 2**32 + 5, 2**63 + 11, 65536, 524288], dtype=np.uint64)
+    states = np.zeros((len(seeds), 4), np.uint64)  # state_lo, state_hi, inc_lo, inc_hi
+    streams = np.zeros((len(seeds), 70), np.uint8)
+    next32 = np.zeros((len(seeds), 9), np.uint32)
+    for k, s in enumerate(seeds):
+        bg = np.random.PCG64(np.random.SeedSequence(int(s)))
+        st = bg.state["state"]
+        states[k] = [st["state"] & (2**64 - 1), st["state"] >> 64, st["inc"] & (2**64 - 1), st["inc"] >> 64]
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(int(s))))
+        # 9 consecutive 32-bit draws (odd count exercises the buffered high half)
+        next32[k] = g.integers(0, 2**32, size=9, dtype=np.uint32)
+        r = BagRandomizer(7)
+        r.reset(seed=int(s))
+        streams[k] = [r.get_next_tetromino() for _ in range(70)]
+    np.savez_compressed(os.path.join(OUT, "pcg64_streams.npz"), seeds=seeds, states=states, streams=streams,
+                        next32=next32, numpy_version=np.__version__)
+    print("pcg64_streams: seed 42 stream", streams[3][:14])
+
+
+class SeekPolicy:
+    """Scripted controller used only to make line clears frequent: per piece pick a target rotation and a
+    target column inside the stack's gap, rotate, walk there, hard-drop.  Its decisions are stored in the
+    fixture as plain actions, so tests replay actions only."""
+
+    def __init__(self, rng, gap_lo, gap_hi, padding=4):
+        self.rng, self.lo, self.hi, self.p = rng, gap_lo, gap_hi, padding
+        self.plan = False
+
+    def act(self, env):
+        if not self.plan:
+            self.rots = int(self.rng.integers(0, 4))
+            self.tx = int(self.rng.integers(self.lo + self.p - 1, self.hi + self.p + 1))
+            self.moves = 0
+            self.plan = True
+        if self.rots > 0:
+            self.rots -= 1
+            return 3
+        if env.x != self.tx and self.moves < 14:
+            self.moves += 1
+            return 0 if env.x > self.tx else 1
+        self.plan = False
+        return 5 if self.rng.random() < 0.9 else int(self.rng.integers(0, 8))
+
+
+def run_trace(ref, name, width, height, gravity, queue_size, B, T, action_seed, n_actions=8,
+              snap_every=64, init_boards=None, action_p=None, seek=None):
+    rng = np.random.default_rng(action_seed)
+    if action_p is None:
+        actions = rng.integers(0, n_actions, size=(T, B)).astype(np.int8)
+    else:
+        actions = rng.choice(n_actions, size=(T, B), p=action_p).astype(np.int8)
+    reward = np.zeros((T, B), np.int16)
+    done = np.zeros((T, B), np.uint8)
+    lines = np.zeros((T, B), np.uint8)
+    crc = np.zeros((T, B), np.uint32)
+    reset_crc = np.zeros((T, B), np.uint32)
+    xs = np.zeros((T, B), np.uint8)
+    ys = np.zeros((T, B), np.uint8)
+    pieces = np.zeros((T, B), np.uint8)
+    snaps = {}
+    snap_steps = [t for t in range(T) if (t % snap_every) == snap_every - 1]
+    Hp, Wp = height + 4, width + 8
+    snap_board = np.zeros((len(snap_steps), B, Hp, Wp), np.uint8)
+    snap_rec = {k: [] for k in ("x", "y", "piece", "matrix", "queue", "holder_piece", "holder_matrix", "bag",
+                                "bag_index", "has_swapped", "game_over")}
+    for k in snap_rec:
+        snap_rec[k] = [[None] * B for _ in snap_steps]
+    first_obs_crc = np.zeros(B, np.uint32)
+    t0 = time.time()
+    for i in range(B):
+        env = make_env(ref, width, height, gravity, queue_size)
+        obs, _ = env.reset(seed=1 + i)
+        if init_boards is not None:
+            env.board = init_boards[i].copy()
+            obs = env._get_obs()
+        first_obs_crc[i] = obs_crc(obs)
+        pol = SeekPolicy(rng, *seek[i]) if seek is not None else None
+        for t in range(T):
+            if pol is not None:
+                actions[t, i] = pol.act(env)
+            obs, r, d, _, info = env.step(int(actions[t, i]))
+            assert r == int(r)
+            reward[t, i], done[t, i], lines[t, i] = int(r), int(d), int(info["lines_cleared"])
+            crc[t, i] = obs_crc(obs)
+            xs[t, i], ys[t, i], pieces[t, i] = env.x, env.y, env.active_tetromino.id - 2
+            if (t % snap_every) == snap_every - 1:
+                si = snap_steps.index(t)
+                s = snapshot(env)
+                snap_board[si, i] = s["board"]
+                for k in snap_rec:
+                    snap_rec[k][si][i] = s[k]
+            if d:
+                obs, _ = env.reset()
+                if init_boards is not None:  # re-inject the dense stack after every harness reset
+                    env.board = init_boards[i].copy()
+                    obs = env._get_obs()
+                reset_crc[t, i] = obs_crc(obs)
+                if pol is not None:
+                    pol.plan = False
+    out = dict(
+        width=width, height=height, gravity=int(gravity), queue_size=queue_size, B=B, T=T,
+        actions=actions, reward=reward, done=done, lines=lines, crc=crc, reset_crc=reset_crc,
+        x=xs, y=ys, piece=pieces, first_obs_crc=first_obs_crc,
+        snap_steps=np.array(snap_steps), snap_board=snap_board,
+    )
+    for k, v in snap_rec.items():
+        out["snap_" + k] = np.array(v).astype(np.uint8)
+    if init_boards is not None:
+        out["init_boards"] = init_boards
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: {B*T} steps in {time.time()-t0:.1f}s  episodes={int(done.sum())}  "
+          f"lock-steps={(reward>0).sum()}  lines total={int(lines.sum())} max={int(lines.max())}")
+
+
+def dense_boards(width, height, B, seed):
+    """Nearly-full stacks: rows [H-k, H) filled with cell values 2..8 except a gap of 1-4 columns (the
+    same columns in every row, so dropped pieces complete several rows at once).  Returns boards, gaps."""
+    rng = np.random.default_rng(seed)
+    Hp, Wp, P = height + 4, width + 8, 4
+    boards = np.ones((B, Hp, Wp), np.uint8)
+    boards[:, :height, P:P + width] = 0
+    gaps = []
+    for i in range(B):
+        k = int(rng.integers(3, max(4, height // 2 - 2)))
+        gw = int(rng.integers(1, 5))
+        g = int(rng.integers(0, width - gw + 1))
+        gaps.append((g, g + gw - 1))
+        for r in range(height - k, height):
+            row = rng.integers(2, 9, size=width).astype(np.uint8)
+            row[g:g + gw] = 0
+            if rng.random() < 0.15:
+                row[int(rng.integers(0, width))] = 0
+            boards[i, r, P:P + width] = row
+    return boards, gaps
+
+
+def gen_clears(ref, name, width, height, queue_size, B, T, seed, board_seed):
+    boards, gaps = dense_boards(width, height, B, board_seed)
+    run_trace(ref, name, width, height, True, queue_size, B, T, seed, snap_every=32, init_boards=boards,
+              seek=gaps)
+
+
+def gen_grouped(ref, name, width, height, queue_size, B, T, seed, n_enum, init_boards=None):
+    """Grouped wrapper traces (random LEGAL action, like examples/train_lin_grouped.py's epsilon branch)
+    plus full enumerations (mask + 4W boards) on mid-game states."""
+    rng = np.random.default_rng(seed)
+    NA = 4 * width
+    Hp, Wp = height + 4, width + 8
+    actions = np.zeros((T, B), np.int16)
+    reward = np.zeros((T, B), np.float32)
+    done = np.zeros((T, B), np.uint8)
+    lines = np.zeros((T, B), np.uint8)
+    masks = np.zeros((T, B, NA), np.uint8)
+    board_after = np.zeros((T, B, Hp, Wp), np.uint8)
+    enum_state_board = np.zeros((n_enum, Hp, Wp), np.uint8)
+    enum_piece = np.zeros(n_enum, np.uint8)
+    enum_matrix = np.zeros((n_enum, 16), np.uint8)
+    enum_mask = np.zeros((n_enum, NA), np.uint8)
+    enum_boards = np.zeros((n_enum, NA, Hp, Wp), np.uint8)
+    ne = 0
+    reset_mask = np.zeros((B, NA), np.uint8)
+    t0 = time.time()
+    for i in range(B):
+        base = make_env(ref, width, height, True, queue_size)
+        env = ref.GroupedActionsObservations(base, terminate_on_illegal_action=True)
+        obs, info = env.reset(seed=1 + i)
+        if init_boards is not None:
+            base.board = init_boards[i].copy()
+            env.observation(base._get_obs())  # refresh the cached legal mask
+        reset_mask[i] = env.legal_actions_mask
+        for t in range(T):
+            mask = env.legal_actions_mask
+            legal = np.flatnonzero(mask == 1)
+            # mostly legal actions, sometimes any action (exercises the illegal → terminate branch)
+            if len(legal) == 0 or rng.random() < 0.03:
+                a = int(rng.integers(0, NA))
+            else:
+                a = int(rng.choice(legal))
+            actions[t, i] = a
+            obs, r, d, _, info = env.step(a)
+            reward[t, i], done[t, i], lines[t, i] = r, int(d), int(info["lines_cleared"])
+            masks[t, i] = info["action_mask"]
+            board_after[t, i] = base.board
+            if ne < n_enum and not d and rng.random() < 0.08:
+                enum_state_board[ne] = base.board
+                enum_piece[ne] = base.active_tetromino.id - 2
+                enum_matrix[ne] = matrix16(base.active_tetromino)
+                enum_mask[ne] = env.legal_actions_mask
+                enum_boards[ne] = obs.astype(np.uint8)
+                ne += 1
+            if d:
+                obs, info = env.reset()
+                if init_boards is not None:
+                    base.board = init_boards[i].copy()
+                    env.observation(base._get_obs())
+                masks[t, i] = env.legal_actions_mask  # mask the next action is drawn from
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), width=width, height=height, queue_size=queue_size, B=B, T=T,
+        actions=actions, reward=reward, done=done, lines=lines, masks=masks, board_after=board_after,
+        reset_mask=reset_mask, init_boards=(init_boards if init_boards is not None else np.zeros(0, np.uint8)),
+        enum_state_board=enum_state_board[:ne], enum_piece=enum_piece[:ne],
+        enum_matrix=enum_matrix[:ne], enum_mask=enum_mask[:ne], enum_boards=enum_boards[:ne])
+    print(f"{name}: {B*T} grouped steps in {time.time()-t0:.1f}s episodes={int(done.sum())} "
+          f"lines={int(lines.sum())} enums={ne} illegal={(reward<0).sum()}")
+
+
+def gen_ref_tests_grouped(ref):
+    """Data held by the reference's own grouped tests: the mock board (tests/helpers/mock.py:5-47 applied to
+    a fresh env), the CSV board after action 21 (tests/test_grouped_env/expected_result_i_placement.csv) and
+    the 40-entry legal mask the reference computes on the mock board with a vertical I piece
+    (tests/test_grouped_env/actions/test_grouped_actions.py:11-31)."""
+    env = ref.Tetris()
+    g = ref.GroupedActionsObservations(env)
+    g.reset(seed=42)
+    board = np.copy(env.board)
+    th = env.height // 2
+    board[th:env.height, env.padding:-(env.padding + 1)] = 2
+    board[th - 1, env.padding + 1] = 2
+    board[th - 1, env.padding + 4] = 2
+    board[th - 1, env.padding + 5] = 2
+    board[th + 2, env.padding + 2] = 0
+    board[th + 4, env.padding + 3] = 0
+    board[th + 6, env.padding + 6] = 0
+    import copy
+
+    vi = copy.deepcopy(ref.Tetris.TETROMINOES[0])
+    vi.matrix = np.rot90(vi.matrix)
+    env.board = board.copy()
+    env.active_tetromino = vi
+    obs = {"board": board, "holder": None, "queue": None, "active_tetromino_mask": np.zeros_like(board)}
+    boards40 = g.observation(obs).astype(np.uint8)
+    mask = g.legal_actions_mask.astype(np.uint8).copy()
+    g.step(5 * 4 + 1)
+    after = env.board.copy()
+    csv = np.genfromtxt("/root/reference/tests/test_grouped_env/expected_result_i_placement.csv",
+                        delimiter=",").astype(np.uint8)
+    assert np.array_equal(after, csv)
+    expected_mask = np.array(
+        [[0, 1, 1, 1, 1, 1, 1, 1, 1, 1], [0, 0, 1, 1, 1, 1, 1, 1, 1, 0], [1] * 10, [0, 0, 1, 1, 1, 1, 1, 1, 1, 0]],
+        np.uint8).reshape(40, order="F")
+    assert np.array_equal(mask, expected_mask)
+    # feature-vector expectations of tests/helpers/mock.py:35-39
+    np.savez_compressed(os.path.join(OUT, "ref_tests_grouped.npz"), mock_board=board, csv_board=csv, mask=mask,
+                        boards40=boards40, heights=np.array([10, 11, 10, 10, 11, 11, 10, 10, 10, 0], np.uint8),
+                        max_height=11, holes=3, bumpiness=14)
+    print("ref_tests_grouped: ok (CSV and mask reproduce)")
+
+
+def gen_features(ref):
+    """FeatureVectorObservation on random mid-game observations (wrappers/observation.py:236-278)."""
+    rng = np.random.default_rng(99)
+    N = 256
+    boards = np.zeros((N, 24, 18), np.uint8)
+    masks = np.zeros((N, 24, 18), np.uint8)
+    feats = np.zeros((N, 13), np.uint8)
+    env = ref.Tetris()
+    fv = ref.FeatureVectorObservation(env)
+    env.reset(seed=7)
+    k = 0
+    while k < N:
+        obs, r, d, _, _ = env.step(int(rng.integers(0, 8)))
+        if d:
+            env.reset()
+            continue
+        if rng.random() < 0.5:
+            boards[k] = obs["board"]
+            masks[k] = obs["active_tetromino_mask"]
+            feats[k] = fv.observation({k2: v.copy() for k2, v in obs.items()})
+            k += 1
+    np.savez_compressed(os.path.join(OUT, "features.npz"), boards=boards, masks=masks, feats=feats)
+    print("features: ok", feats[:3])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    ref = import_reference()
+    jobs = {
+        "pcg64": gen_pcg64_streams,
+        "trace_10x20_g1": lambda: run_trace(ref, "trace_10x20_g1", 10, 20, True, 4, 96, 512, 12345),
+        "trace_10x20_g0": lambda: run_trace(ref, "trace_10x20_g0", 10, 20, False, 4, 48, 512, 12346),
+        "trace_20x40_g1": lambda: run_trace(ref, "trace_20x40_g1", 20, 40, True, 7, 32, 768, 12347),
+        "trace_6x12_g1": lambda: run_trace(ref, "trace_6x12_g1", 6, 12, True, 4, 32, 256, 12348),
+        "clears_10x20": lambda: gen_clears(ref, "clears_10x20", 10, 20, 4, 96, 256, 777, 5),
+        "clears_20x40": lambda: gen_clears(ref, "clears_20x40", 20, 40, 7, 32, 384, 778, 6),
+        "grouped_10x20": lambda: gen_grouped(ref, "grouped_10x20", 10, 20, 4, 16, 96, 31, 48),
+        "grouped_20x40": lambda: gen_grouped(ref, "grouped_20x40", 20, 40, 7, 4, 64, 32, 12),
+        "grouped_clears_10x20": lambda: gen_grouped(ref, "grouped_clears_10x20", 10, 20, 4, 16, 96, 33, 16,
+                                                    init_boards=dense_boards(10, 20, 16, 8)[0]),
+        "ref_tests_grouped": lambda: gen_ref_tests_grouped(ref),
+        "features": lambda: gen_features(ref),
+    }
+    for name, fn in jobs.items():
+        if args.only and args.only != name:
+            continue
+        fn()
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,88 @@
+"""Third-party arithmetic restated in the oracle, pinned:
+  - numpy SeedSequence → PCG64 → next_uint32 → Generator.shuffle (against fixtures made with numpy AND
+    against the numpy installed on this machine),
+  - threefry2x32 (Random123 known-answer vectors, the same three jax's own test-suite uses)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import replay
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_seedsequence_pcg64_state_matches_fixture(golden_dir):
+    fx = replay.load(golden_dir, "pcg64_streams")
+    for k, s in enumerate(fx["seeds"]):
+        r = po.seed_pcg64(int(s))
+        got = [int(r["state_lo"][0]), int(r["state_hi"][0]), int(r["inc_lo"][0]), int(r["inc_hi"][0])]
+        assert got == [int(v) for v in fx["states"][k]], f"seed {s}"
+
+
+def test_next32_and_bag_stream_match_fixture(golden_dir):
+    fx = replay.load(golden_dir, "pcg64_streams")
+    L = po.lib()
+    for k, s in enumerate(fx["seeds"]):
+        r = po.seed_pcg64(int(s))
+        got = [L.tgo_pcg64_next32(_p(r)) for _ in range(9)]
+        assert got == [int(v) for v in fx["next32"][k]]
+        # BagRandomizer stream = successive in-place shuffles of arange(7)
+        r = po.seed_pcg64(int(s))
+        bag = np.arange(7, dtype=np.uint8)
+        stream = []
+        for _ in range(10):
+            L.tgo_pcg64_shuffle7(_p(r), _p(bag))
+            stream += list(bag)
+        assert stream == [int(v) for v in fx["streams"][k]]
+
+
+@pytest.mark.parametrize("seed", [1, 7, 42, 99991, 2**32 - 1, 2**32, 2**40 + 3, 2**64 - 1])
+def test_against_live_numpy(seed):
+    r = po.seed_pcg64(seed)
+    st = np.random.PCG64(np.random.SeedSequence(seed)).state["state"]
+    assert (int(r["state_hi"][0]) << 64) | int(r["state_lo"][0]) == st["state"]
+    assert (int(r["inc_hi"][0]) << 64) | int(r["inc_lo"][0]) == st["inc"]
+    g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+    bag_np = np.arange(7, dtype=np.int8)
+    bag = np.arange(7, dtype=np.uint8)
+    for _ in range(25):
+        g.shuffle(bag_np)
+        po.lib().tgo_pcg64_shuffle7(_p(r), _p(bag))
+        assert list(bag) == list(bag_np)
+
+
+def test_threefry2x32_known_answers():
+    L = po.lib()
+    kats = [
+        ((0x0, 0x0), (0x0, 0x0), (0x6B200159, 0x99BA4EFE)),
+        ((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF), (0x1CB996FC, 0xBB002BE7)),
+        ((0x13198A2E, 0x03707344), (0x243F6A88, 0x85A308D3), (0xC4923A9C, 0x483DF7A0)),
+    ]
+    for key, ctr, exp in kats:
+        k = np.array(key, np.uint32)
+        c = np.array(ctr, np.uint32)
+        o = np.zeros(2, np.uint32)
+        L.tgo_threefry2x32(_p(k), _p(c), _p(o))
+        assert tuple(int(v) for v in o) == exp
+
+
+def test_jax_permutation_is_a_permutation_and_deterministic():
+    # mirrors reference tests/test_functional/test_queue.py:24-33 (set property; exact values unpinned)
+    L = po.lib()
+    for part in (1, 0):
+        L.tgo_set_threefry_partitionable(part)
+        seen = set()
+        for s in range(50):
+            key = np.array([0, s], np.uint32)
+            out = np.zeros(7, np.uint8)
+            out2 = np.zeros(7, np.uint8)
+            L.tgo_jax_permutation7(_p(key), _p(out))
+            L.tgo_jax_permutation7(_p(key), _p(out2))
+            assert sorted(out) == list(range(7)) and list(out) == list(out2)
+            seen.add(tuple(out))
+        assert len(seen) > 40
+    L.tgo_set_threefry_partitionable(1)
