@@ -1,0 +1,256 @@
+"""GPU parity tests proper: the HIP engine (through the C ABI) against (a) golden vectors generated from
+the reference NumPy env and (b) the CPU oracle on identical seeds and actions.  Bit-exact: boards,
+rewards, terminated, lines, observations, piece/queue/bag/RNG state."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import replay
+
+pytestmark = pytest.mark.gpu
+
+from tetris_gymnasium_amd import Engine, _native as N  # noqa: E402
+
+
+class EngineBackend:
+    def __init__(self, batch, width, height, gravity, queue_size):
+        self.e = Engine(batch, width, height, ruleset=N.RULESET_NUMPY, gravity=gravity, queue_size=queue_size,
+                        obs_mode=N.OBS_DICT)
+
+    def reset(self, seeds=None, mask=None):
+        self.e.reset(seeds, mask)
+
+    def step(self, actions):
+        return self.e.step(actions)
+
+    def observe_dict(self):
+        return self.e.observe()
+
+    def get_state(self):
+        return self.e.get_state()
+
+    def set_state(self, **kw):
+        self.e.set_state(**kw)
+
+
+TRACES = ["trace_10x20_g1", "trace_10x20_g0", "trace_20x40_g1", "trace_6x12_g1", "clears_10x20", "clears_20x40"]
+
+
+@pytest.mark.parametrize("name", TRACES)
+def test_engine_replays_reference_trace(golden_dir, name):
+    replay.replay_trace(EngineBackend, replay.load(golden_dir, name))
+
+
+def _cmp_state(e, o, msg=""):
+    be, re_, ge = e.get_state()
+    bo, ro, go = o.get_state()
+    np.testing.assert_array_equal(be, bo, err_msg="board " + msg)
+    for k in re_.dtype.names:
+        if k == "reserved":
+            continue
+        np.testing.assert_array_equal(re_[k], ro[k], err_msg=f"rec.{k} {msg}")
+    return ge, go
+
+
+@pytest.mark.parametrize("W,H,Q,gravity", [(10, 20, 4, True), (10, 20, 4, False), (20, 40, 7, True), (8, 16, 2, True),
+                                            (12, 24, 4, True), (10, 24, 1, True)])
+@pytest.mark.parametrize("autoreset", [N.AUTORESET_NONE, N.AUTORESET_SAME_STEP, N.AUTORESET_NEXT_STEP])
+def test_numpy_rules_engine_vs_oracle(W, H, Q, gravity, autoreset):
+    B, T = 512, 300
+    e = Engine(B, W, H, ruleset=N.RULESET_NUMPY, gravity=gravity, queue_size=Q, obs_mode=N.OBS_BOARD,
+               autoreset=autoreset)
+    o = po.OracleBatch(B, W, H, po.RULESET_NUMPY, gravity, Q)
+    seeds = np.arange(1000, 1000 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_BOARD))
+    rng = np.random.default_rng(W * 100 + H + autoreset)
+    done_total = 0
+    for t in range(T):
+        a = rng.integers(0, 8, B)
+        re_, te, le = e.step(a)
+        ro, to, lo = o.step(a, autoreset=autoreset)
+        np.testing.assert_array_equal(re_, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(te, to, err_msg=f"terminated t={t}")
+        np.testing.assert_array_equal(le, lo, err_msg=f"lines t={t}")
+        np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_BOARD), err_msg=f"obs t={t}")
+        done_total += int(te.sum())
+        if autoreset == N.AUTORESET_NONE and te.any():
+            e.reset(mask=te); o.reset(mask=te)
+        if t % 25 == 0 or t == T - 1:
+            ge, go = _cmp_state(e, o, f"t={t}")
+            for k in ("state_lo", "state_hi", "inc_lo", "inc_hi", "uinteger", "has_uint32"):
+                np.testing.assert_array_equal(ge[k], go[k], err_msg=f"rng.{k} t={t}")
+    assert done_total > B  # several episodes per env ended (reset/autoreset path exercised)
+
+
+@pytest.mark.parametrize("W,H,gravity", [(10, 20, True), (10, 20, False), (20, 40, True), (6, 12, True)])
+@pytest.mark.parametrize("autoreset", [N.AUTORESET_NONE, N.AUTORESET_SAME_STEP])
+def test_functional_rules_engine_vs_oracle(W, H, gravity, autoreset):
+    B, T = 512, 300
+    e = Engine(B, W, H, ruleset=N.RULESET_FUNCTIONAL, gravity=gravity, obs_mode=N.OBS_FN, autoreset=autoreset)
+    o = po.OracleBatch(B, W, H, po.RULESET_FUNCTIONAL, gravity)
+    keys = (np.arange(B, dtype=np.uint64) * 7919 + 42)
+    e.reset(keys); o.reset(keys)
+    np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_FN))
+    rng = np.random.default_rng(5 + W + autoreset)
+    done_total = 0
+    for t in range(T):
+        a = rng.integers(-1, 9, B) if t % 10 == 0 else rng.integers(0, 7, B)  # incl. ids lax.switch clamps
+        re_, te, le = e.step(a)
+        ro, to, lo = o.step(a, autoreset=autoreset)
+        np.testing.assert_array_equal(re_, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(te, to, err_msg=f"terminated t={t}")
+        np.testing.assert_array_equal(le, lo, err_msg=f"lines t={t}")
+        np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_FN), err_msg=f"obs t={t}")
+        done_total += int(te.sum())
+        if autoreset == N.AUTORESET_NONE and te.all():
+            e.reset(mask=te); o.reset(mask=te)  # reset(rng_key) continuation
+        if t % 25 == 0 or t == T - 1:
+            ge, go = _cmp_state(e, o, f"t={t}")
+            np.testing.assert_array_equal(ge["key"], go["key"], err_msg=f"rng_key t={t}")
+    assert done_total > 0
+
+
+def test_line_clear_dense_boards_engine_vs_oracle():
+    """Constructed boards (the reference's own test style): every lock completes rows."""
+    B, W, H = 256, 10, 20
+    rng = np.random.default_rng(11)
+    for ruleset, obs in ((N.RULESET_NUMPY, N.OBS_BOARD), (N.RULESET_FUNCTIONAL, N.OBS_FN)):
+        e = Engine(B, W, H, ruleset=ruleset, obs_mode=obs)
+        o = po.OracleBatch(B, W, H, ruleset)
+        seeds = np.arange(1, B + 1, dtype=np.uint64)
+        e.reset(seeds); o.reset(seeds)
+        total = 0
+        for rep in range(40):
+            b = rng.integers(2, 9, (B, H, W)).astype(np.uint8)
+            top = rng.integers(0, 14, B)
+            for i in range(B):
+                b[i, : top[i]] = 0
+                g = rng.integers(0, W - 3)
+                b[i, :, g:g + rng.integers(1, 5)] = 0
+                if rep % 4 == 0:
+                    b[i, 0, :] = rng.integers(0, 9, W)  # non-empty row 0: the jnp.take wrap corner
+            be, rc, _ = e.get_state()
+            rc["flags"] = 0
+            rc["x"] = rng.integers(3, 13, B); rc["y"] = 0; rc["rot"] = rng.integers(0, 4, B)
+            e.set_state(board=b, rec=rc); o.set_state(board=b, rec=rc)
+            drop = 5 if ruleset == N.RULESET_NUMPY else 6
+            for _ in range(3):
+                a = np.full(B, drop)
+                re_, te, le = e.step(a)
+                ro, to, lo = o.step(a)
+                np.testing.assert_array_equal(re_, ro); np.testing.assert_array_equal(te, to)
+                np.testing.assert_array_equal(le, lo)
+                total += int(le.sum())
+                _cmp_state(e, o, f"rep={rep}")
+        assert total > 300
+
+
+def test_swap_and_hold_paths():
+    B = 256
+    e = Engine(B, obs_mode=N.OBS_DICT)
+    o = po.OracleBatch(B)
+    seeds = np.arange(50, 50 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(2)
+    for t in range(400):
+        a = rng.choice([5, 6, 6, 7, 0, 1, 3], B)
+        re_, te, le = e.step(a)
+        ro, to, lo = o.step(a)
+        np.testing.assert_array_equal(re_, ro); np.testing.assert_array_equal(te, to)
+        od = o.observe(po.OBS_DICT)
+        ed = e.observation()
+        for k in od:
+            np.testing.assert_array_equal(ed[k], od[k], err_msg=f"{k} t={t}")
+        if te.any():
+            e.reset(mask=te); o.reset(mask=te)
+    _cmp_state(e, o)
+
+
+def test_post_game_over_stepping_matches_reference_quirk():
+    """NUMPY rules keep stepping after game over (SURVEY §8.0 'After game over')."""
+    B = 64
+    e = Engine(B, obs_mode=N.OBS_BOARD)
+    o = po.OracleBatch(B)
+    e.reset(np.arange(1, B + 1, dtype=np.uint64)); o.reset(np.arange(1, B + 1, dtype=np.uint64))
+    rng = np.random.default_rng(9)
+    for t in range(600):
+        a = rng.integers(0, 8, B)
+        assert all(np.array_equal(x, y) for x, y in zip(e.step(a), o.step(a)))
+    _cmp_state(e, o)
+    assert (e.get_state()[1]["flags"] & 1).sum() > 0
+
+
+def test_invalid_action_is_rejected_host_side():
+    e = Engine(8)
+    e.reset(np.arange(1, 9, dtype=np.uint64))
+    from tetris_gymnasium_amd import EngineError
+    with pytest.raises(EngineError, match="outside Discrete"):
+        e.step(np.array([0, 1, 2, 3, 4, 5, 6, 8]))
+
+
+def test_step_k_equals_k_steps_and_episode_stats():
+    B, K = 2048, 64
+    rng = np.random.default_rng(4)
+    acts = rng.integers(0, 8, (K, B)).astype(np.int8)
+    seeds = np.arange(1, B + 1, dtype=np.uint64)
+    e1 = Engine(B, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP)
+    e2 = Engine(B, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP)
+    e1.reset(seeds); e2.reset(seeds)
+    ret = np.zeros(B)
+    for k in range(K):
+        r, t, l = e1.step(acts[k].astype(np.int32))
+    d = e2.dev_alloc(acts.nbytes)
+    e2.dev_upload(d, acts)
+    e2.step_k_device(d, K)
+    assert all(np.array_equal(x, y) for x, y in zip(e1.fetch_outputs(), e2.fetch_outputs()))
+    np.testing.assert_array_equal(e1.observation(), e2.observation())
+    s1, s2 = e1.get_state(), e2.get_state()
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(s1, s2))
+    np.testing.assert_array_equal(e1.episode_stats(), e2.episode_stats())
+    assert e1.episode_stats()["last_len"].max() > 0
+    e2.dev_free(d)
+
+
+def test_full_size_determinism_and_invariants():
+    """BASELINE size (65 536 envs): size-independent properties — two identical runs agree bit-for-bit,
+    cell counts are consistent with locks/clears, boards never hold a full row, sharding is transparent."""
+    B, T = 65536, 48
+    rng = np.random.default_rng(8)
+    acts = rng.integers(0, 8, (T, B)).astype(np.int32)
+    seeds = np.arange(1, B + 1, dtype=np.uint64)
+    runs = []
+    for rep in range(2):
+        e = Engine(B, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP)
+        e.reset(seeds)
+        tot_r = np.zeros(B)
+        for t in range(T):
+            r, te, l = e.step(acts[t])
+            tot_r += r
+        board, rec, g = e.get_state()
+        runs.append((board.copy(), rec.copy(), g.copy(), tot_r, e.observation().copy()))
+        e.close()
+    for a, b in zip(runs[0], runs[1]):
+        assert a.tobytes() == b.tobytes()
+    board, rec = runs[0][0], runs[0][1]
+    assert not (board != 0).all(axis=2).any(), "a completed row survived"
+    assert ((board == 0) | ((board >= 2) & (board <= 8))).all()
+    assert (board != 0).sum(axis=(1, 2)).max() % 1 == 0 and ((board != 0).sum(axis=(1, 2)) % 2 == 0).all()  # 4 cells per lock, 10 per clear
+    # sharding transparency: two half-size engines with env_offset reproduce the full batch
+    halves = []
+    for k in range(2):
+        sl = slice(k * B // 2, (k + 1) * B // 2)
+        e = Engine(B // 2, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP, env_offset=k * B // 2)
+        e.reset(seeds[sl])
+        for t in range(T):
+            e.step_async(acts[t][sl])
+        halves.append(e.get_state()[0])
+        e.close()
+    np.testing.assert_array_equal(np.concatenate(halves), board)
+    # a 256-env sample against the oracle at this size
+    idx = rng.choice(B, 256, replace=False)
+    o = po.OracleBatch(256)
+    o.reset(seeds[idx])
+    for t in range(T):
+        o.step(acts[t][idx], autoreset=po.AUTORESET_SAME_STEP)
+    np.testing.assert_array_equal(o.get_state()[0], board[idx])

@@ -1,0 +1,90 @@
+"""CPU-side checks of the product's C-ABI library: it loads, exports every symbol include/tetris_gym_hip.h
+declares, its host-side tables/utilities agree with the oracle, and it FAILS LOUDLY without a GPU
+(no compute calls happen here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tetris_gymnasium_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = N.load()
+    header = open(os.path.join(ROOT, "include", "tetris_gym_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:const\s+)?(?:int|void|const char\*)\s+\*?(tg_[a-z0-9_]+)\s*\(", header, re.M))
+    assert {"tg_create", "tg_step", "tg_reset", "tg_step_k", "tg_get_state", "tg_set_state"} <= declared
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared <= set(N.SYMBOLS), "ctypes binding is missing a declared symbol"
+    assert lib.tg_abi_version() == 1
+
+
+def test_record_layouts_match_header():
+    assert N.ENV_REC.itemsize == 32 and N.RNG_REC.itemsize == 48
+    assert N.ENV_REC.fields["bag"][1] == 10 and N.ENV_REC.fields["queue"][1] == 17 and N.ENV_REC.fields["score"][1] == 24
+    assert C.sizeof(N.TgConfig) == 16 * 4
+
+
+def test_shape_table_matches_reference_matrices():
+    lib = N.load()
+    buf = np.zeros(16, np.uint8)
+    for p in range(7):
+        for r in range(4):
+            n = po.lib().tgo_np_matrix(p, r, buf.ctypes.data_as(C.c_void_p))
+            m = buf[: n * n].reshape(n, n)
+            mask = lib.tg_shape_mask(p, r)
+            got = np.zeros((4, 4), np.uint8)
+            for k in range(4):
+                for c in range(4):
+                    got[k, c] = (mask >> (4 * k + c)) & 1
+            exp = np.zeros((4, 4), np.uint8)
+            exp[:n, :n] = m > 0
+            np.testing.assert_array_equal(got, exp, err_msg=f"piece {p} rot {r}")
+
+
+@pytest.mark.parametrize("seed", [1, 42, 65536, 2**32 + 5, 2**63 + 11])
+def test_host_seedsequence_matches_numpy(seed):
+    r = np.zeros(1, N.RNG_REC)
+    assert N.load().tg_seed_pcg64(seed, N.ptr(r)) == 0
+    st = np.random.PCG64(np.random.SeedSequence(seed)).state["state"]
+    assert (int(r["state_hi"][0]) << 64) | int(r["state_lo"][0]) == st["state"]
+    assert (int(r["inc_hi"][0]) << 64) | int(r["inc_lo"][0]) == st["inc"]
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    lib = N.load()
+    if lib.tg_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from tetris_gymnasium_amd import Engine, EngineError
+
+    with pytest.raises(EngineError, match="no HIP device|no CPU fallback"):
+        Engine(4)
+
+
+def test_create_rejects_bad_configs_before_touching_the_gpu():
+    lib = N.load()
+    cfg = N.TgConfig()
+    cfg.struct_size = C.sizeof(N.TgConfig)
+    cfg.width, cfg.height, cfg.padding, cfg.queue_size, cfg.batch = 10, 20, 4, 4, 8
+    h = C.c_void_p()
+    cfg.padding = 3
+    assert lib.tg_create(C.byref(cfg), C.byref(h)) == -4 and b"padding" in lib.tg_last_error(None)
+    cfg.padding, cfg.width = 4, 11
+    assert lib.tg_create(C.byref(cfg), C.byref(h)) == -4 and b"not compiled in" in lib.tg_last_error(None)
+    cfg.width, cfg.struct_size = 10, 12
+    assert lib.tg_create(C.byref(cfg), C.byref(h)) == -1
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "tetris_gymnasium_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in src and "tg_oracle" not in src and "from oracle" not in src, f

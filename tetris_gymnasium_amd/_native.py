@@ -1,0 +1,114 @@
+"""ctypes binding of libtetris_gym_hip.so (the C ABI in include/tetris_gym_hip.h).
+
+No PyTorch, no Triton, no JAX: plain ctypes over hand-written HIP.  There is no CPU fallback — if the
+shared library is missing or cannot be loaded this module raises, it never degrades silently.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libtetris_gym_hip.so")
+
+RULESET_NUMPY, RULESET_FUNCTIONAL = 0, 1
+OBS_NONE, OBS_BOARD, OBS_DICT, OBS_FN = 0, 1, 2, 3
+AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = 0, 1, 2
+ACTIONS_BASE, ACTIONS_GROUPED = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+(BUF_OBS, BUF_REWARD, BUF_TERMINATED, BUF_LINES, BUF_ACTIONS, BUF_BOARD, BUF_REC, BUF_RNG, BUF_LEGAL_MASK,
+ BUF_FINAL_OBS, BUF_EPISODE) = range(11)
+NONE = 0xFF
+F_GAME_OVER, F_HAS_SWAPPED, F_PENDING_RESET = 1, 2, 4
+
+ENV_REC = np.dtype(
+    [
+        ("piece", "u1"), ("rot", "u1"), ("x", "u1"), ("y", "u1"), ("val", "u1"), ("flags", "u1"),
+        ("holder_piece", "u1"), ("holder_rot", "u1"), ("holder_val", "u1"), ("bag_index", "u1"),
+        ("bag", "u1", (7,)), ("queue", "u1", (7,)), ("score", "<f4"), ("reserved", "<u4"),
+    ]
+)
+RNG_REC = np.dtype(
+    [
+        ("state_lo", "<u8"), ("state_hi", "<u8"), ("inc_lo", "<u8"), ("inc_hi", "<u8"),
+        ("uinteger", "<u4"), ("has_uint32", "<u4"), ("key", "<u4", (2,)),
+    ]
+)
+EPISODE_REC = np.dtype([("ret", "<f4"), ("len", "<u4"), ("last_ret", "<f4"), ("last_len", "<u4")])
+assert ENV_REC.itemsize == 32 and RNG_REC.itemsize == 48 and EPISODE_REC.itemsize == 16
+
+
+class TgConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("padding", C.c_int32),
+        ("queue_size", C.c_int32), ("gravity", C.c_int32), ("ruleset", C.c_int32), ("obs_mode", C.c_int32),
+        ("autoreset", C.c_int32), ("action_set", C.c_int32), ("batch", C.c_int32), ("device", C.c_int32),
+        ("env_offset", C.c_int32), ("grouped_terminate_on_illegal", C.c_int32), ("reserved", C.c_int32 * 2),
+    ]
+
+
+# every symbol include/tetris_gym_hip.h declares: (restype, argtypes)
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+SYMBOLS = {
+    "tg_abi_version": (_i, []),
+    "tg_device_count": (_i, []),
+    "tg_create": (_i, [C.POINTER(TgConfig), C.POINTER(_vp)]),
+    "tg_destroy": (None, [_vp]),
+    "tg_last_error": (C.c_char_p, [_vp]),
+    "tg_reset": (_i, [_vp, _vp, _vp]),
+    "tg_step": (_i, [_vp, _vp, _i]),
+    "tg_step_k": (_i, [_vp, _vp, _i]),
+    "tg_device_ptr": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_sz)]),
+    "tg_fetch": (_i, [_vp, _i, _vp, _sz]),
+    "tg_get_state": (_i, [_vp, _vp, _vp, _vp]),
+    "tg_set_state": (_i, [_vp, _vp, _vp, _vp]),
+    "tg_observe": (_i, [_vp]),
+    "tg_grouped_enumerate": (_i, [_vp, _vp]),
+    "tg_sync": (_i, [_vp]),
+    "tg_timer_start": (_i, [_vp]),
+    "tg_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "tg_seed_pcg64": (_i, [C.c_uint64, _vp]),
+    "tg_obs_bytes_per_env": (_i, [C.POINTER(TgConfig)]),
+    "tg_num_actions": (_i, [C.POINTER(TgConfig)]),
+    "tg_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "tg_dev_free": (_i, [_vp, _vp]),
+    "tg_dev_upload": (_i, [_vp, _vp, _vp, _sz]),
+    "tg_dev_download": (_i, [_vp, _vp, _vp, _sz]),
+    "tg_stream_copy_gbps": (_i, [_vp, _sz, _i, C.POINTER(C.c_float)]),
+    "tg_shape_mask": (_i, [_i, _i]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP engine.  Raises NativeLibraryError (never falls back) when it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            f"`make -C tetris_gymnasium_amd/csrc` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tg_abi_version() != 1:
+        raise NativeLibraryError("libtetris_gym_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,579 @@
+// tg_engine.hip — host side of libtetris_gym_hip.so: the C ABI declared in include/tetris_gym_hip.h.
+//
+// One handle = one GPU = one HIP stream.  All per-env state lives in device memory as SoA arrays
+// (board u8[B][H][W] | tg_env_rec[B] | tg_rng_rec[B]); outputs stay on the device until fetched.
+// There is NO CPU fallback: every entry point that computes launches a HIP kernel.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "tg_kernels.h"
+
+// ---- board sizes compiled in (W, H).  Extend the list and rebuild to support another size. ----
+#define TG_FOR_EACH_SIZE(X) X(10, 20) X(20, 40) X(6, 12) X(8, 16) X(10, 24) X(12, 24)
+
+namespace {
+
+thread_local std::string g_create_err;
+
+struct Launchers {
+  void (*step)(const tg::KParams&, hipStream_t);
+  void (*reset)(const tg::ResetParams&, hipStream_t);
+  void (*observe)(const tg::ObserveParams&, hipStream_t);
+};
+
+inline int grid_for(int batch) { return (batch + tg::kWavesPerBlock - 1) / tg::kWavesPerBlock; }
+
+template <int W, int H, int RS>
+void launch_step(const tg::KParams& p, hipStream_t s) {
+  hipLaunchKernelGGL((tg::step_kernel<W, H, RS>), dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p);
+}
+template <int W, int H, int RS>
+void launch_reset(const tg::ResetParams& p, hipStream_t s) {
+  hipLaunchKernelGGL((tg::reset_kernel<W, H, RS>), dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p);
+}
+template <int W, int H>
+void launch_observe(const tg::ObserveParams& p, hipStream_t s) {
+  hipLaunchKernelGGL((tg::observe_kernel<W, H>), dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p);
+}
+
+bool find_launchers(int W, int H, int ruleset, Launchers* out) {
+#define X(w, h)                                                                                     \
+  if (W == w && H == h) {                                                                           \
+    if (ruleset == TG_RULESET_NUMPY)                                                                \
+      *out = {launch_step<w, h, TG_RULESET_NUMPY>, launch_reset<w, h, TG_RULESET_NUMPY>, launch_observe<w, h>}; \
+    else                                                                                            \
+      *out = {launch_step<w, h, TG_RULESET_FUNCTIONAL>, launch_reset<w, h, TG_RULESET_FUNCTIONAL>,  \
+              launch_observe<w, h>};                                                                \
+    return true;                                                                                    \
+  }
+  TG_FOR_EACH_SIZE(X)
+#undef X
+  return false;
+}
+
+std::string built_sizes() {
+  std::string s;
+#define X(w, h) s += std::string(s.empty() ? "" : ", ") + #w "x" #h;
+  TG_FOR_EACH_SIZE(X)
+#undef X
+  return s;
+}
+
+}  // namespace
+
+struct tg_handle {
+  tg_config cfg;
+  int B, W, H, Q;
+  size_t cells;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  Launchers L{};
+  void* buf[TG_BUF_COUNT] = {};
+  size_t bytes[TG_BUF_COUNT] = {};
+  tg_rng_rec* d_new_rng = nullptr;
+  uint8_t* d_reseed = nullptr;
+  uint8_t* d_mask = nullptr;
+  std::vector<uint8_t> rng_valid;
+  std::vector<tg_rng_rec> h_new_rng;
+  std::vector<uint8_t> h_reseed;
+  std::string err;
+};
+
+namespace {
+
+int fail(tg_handle* h, int code, const char* fmt, ...) {
+  char msg[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(msg, sizeof(msg), fmt, ap);
+  va_end(ap);
+  if (h) h->err = msg;
+  else g_create_err = msg;
+  return code;
+}
+
+#define HIPCHK(h, call)                                                                              \
+  do {                                                                                               \
+    hipError_t e_ = (call);                                                                          \
+    if (e_ != hipSuccess) return fail((h), TG_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+size_t obs_bytes_per_env(const tg_config* c) {
+  const size_t cells = (size_t)c->width * c->height;
+  const size_t pc = (size_t)(c->width + 8) * (c->height + 4);
+  switch (c->obs_mode) {
+    case TG_OBS_BOARD:
+    case TG_OBS_FN: return cells;
+    case TG_OBS_DICT: return 2 * pc + 16 + 16 * (size_t)c->queue_size;
+    default: return 0;
+  }
+}
+
+// numpy SeedSequence(seed).generate_state(4, uint64) → PCG64 seeding (numpy/random/bit_generator.pyx,
+// _pcg64.pyx, src/pcg64/pcg64.h pcg_setseq_128_srandom_r).  Host-only set-up code, pinned by tests.
+void seed_pcg64_host(uint64_t seed, tg_rng_rec* out) {
+  typedef unsigned __int128 u128;
+  const uint32_t INIT_A = 0x43b0d7e5u, MULT_A = 0x931e8875u, INIT_B = 0x8b51f9ddu, MULT_B = 0x58f38dedu;
+  const uint32_t MIX_L = 0xca01f9ddu, MIX_R = 0x4973f715u;
+  uint32_t ent[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  const int n_ent = ent[1] ? 2 : 1;
+  uint32_t hc = INIT_A;
+  auto hashmix = [&](uint32_t v) {
+    v ^= hc;
+    hc *= MULT_A;
+    v *= hc;
+    v ^= v >> 16;
+    return v;
+  };
+  auto mix = [&](uint32_t x, uint32_t y) {
+    uint32_t r = MIX_L * x - MIX_R * y;
+    r ^= r >> 16;
+    return r;
+  };
+  uint32_t pool[4];
+  for (int i = 0; i < 4; ++i) pool[i] = hashmix(i < n_ent ? ent[i] : 0u);
+  for (int s = 0; s < 4; ++s)
+    for (int d = 0; d < 4; ++d)
+      if (s != d) pool[d] = mix(pool[d], hashmix(pool[s]));
+  uint32_t w[8], hb = INIT_B;
+  for (int i = 0; i < 8; ++i) {
+    uint32_t v = pool[i & 3] ^ hb;
+    hb *= MULT_B;
+    v *= hb;
+    v ^= v >> 16;
+    w[i] = v;
+  }
+  uint64_t q[4];
+  for (int i = 0; i < 4; ++i) q[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+  const u128 mult = ((u128)0x2360ED051FC65DA4ULL << 64) | 0x4385DF649FCCF645ULL;
+  const u128 initstate = ((u128)q[0] << 64) | q[1];
+  const u128 inc = ((((u128)q[2] << 64) | q[3]) << 1) | 1;
+  u128 st = 0;
+  st = st * mult + inc;
+  st += initstate;
+  st = st * mult + inc;
+  std::memset(out, 0, sizeof(*out));
+  out->state_lo = (uint64_t)st;
+  out->state_hi = (uint64_t)(st >> 64);
+  out->inc_lo = (uint64_t)inc;
+  out->inc_hi = (uint64_t)(inc >> 64);
+}
+
+int alloc_buf(tg_handle* h, int which, size_t n) {
+  h->bytes[which] = n;
+  if (n == 0) return TG_OK;
+  HIPCHK(h, hipMalloc(&h->buf[which], n));
+  HIPCHK(h, hipMemsetAsync(h->buf[which], 0, n, h->stream));
+  return TG_OK;
+}
+
+tg::KParams step_params(tg_handle* h) {
+  tg::KParams p{};
+  p.board = (uint8_t*)h->buf[TG_BUF_BOARD];
+  p.rec = (uint32_t*)h->buf[TG_BUF_REC];
+  p.rng = (tg_rng_rec*)h->buf[TG_BUF_RNG];
+  p.obs = (uint8_t*)h->buf[TG_BUF_OBS];
+  p.final_obs = (uint8_t*)h->buf[TG_BUF_FINAL_OBS];
+  p.reward = (float*)h->buf[TG_BUF_REWARD];
+  p.terminated = (uint8_t*)h->buf[TG_BUF_TERMINATED];
+  p.lines = (uint8_t*)h->buf[TG_BUF_LINES];
+  p.episode = (tg_episode_rec*)h->buf[TG_BUF_EPISODE];
+  p.batch = h->B;
+  p.gravity = h->cfg.gravity;
+  p.autoreset = h->cfg.autoreset;
+  p.obs_mode = h->cfg.obs_mode;
+  p.queue_size = h->Q;
+  return p;
+}
+
+int launch_observe_dict(tg_handle* h) {
+  tg::ObserveParams o{};
+  o.board = (const uint8_t*)h->buf[TG_BUF_BOARD];
+  o.rec = (const uint32_t*)h->buf[TG_BUF_REC];
+  o.obs = (uint8_t*)h->buf[TG_BUF_OBS];
+  o.batch = h->B;
+  o.obs_mode = h->cfg.obs_mode;
+  o.queue_size = h->Q;
+  o.ruleset = h->cfg.ruleset;
+  h->L.observe(o, h->stream);
+  HIPCHK(h, hipGetLastError());
+  return TG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tg_abi_version(void) { return TG_ABI_VERSION; }
+
+int tg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* tg_last_error(const tg_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int tg_obs_bytes_per_env(const tg_config* cfg) { return cfg ? (int)obs_bytes_per_env(cfg) : TG_EINVAL; }
+
+int tg_num_actions(const tg_config* cfg) {
+  if (!cfg) return TG_EINVAL;
+  if (cfg->action_set == TG_ACTIONS_GROUPED) return 4 * cfg->width;
+  return cfg->ruleset == TG_RULESET_NUMPY ? 8 : 7;
+}
+
+int tg_seed_pcg64(uint64_t seed, tg_rng_rec* out) {
+  if (!out) return TG_EINVAL;
+  seed_pcg64_host(seed, out);
+  return TG_OK;
+}
+
+int tg_create(const tg_config* cfg, tg_handle** out) {
+  if (!cfg || !out) return fail(nullptr, TG_EINVAL, "tg_create: null argument");
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(tg_config))
+    return fail(nullptr, TG_EINVAL, "tg_create: tg_config.struct_size %d != %zu (ABI mismatch)", cfg->struct_size,
+                sizeof(tg_config));
+  if (cfg->padding != 4)
+    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: padding must be 4 (stock tetromino set), got %d", cfg->padding);
+  if (cfg->batch <= 0) return fail(nullptr, TG_EINVAL, "tg_create: batch must be > 0");
+  if (cfg->ruleset != TG_RULESET_NUMPY && cfg->ruleset != TG_RULESET_FUNCTIONAL)
+    return fail(nullptr, TG_EINVAL, "tg_create: unknown ruleset %d", cfg->ruleset);
+  if (cfg->obs_mode < TG_OBS_NONE || cfg->obs_mode > TG_OBS_FN)
+    return fail(nullptr, TG_EINVAL, "tg_create: unknown obs_mode %d", cfg->obs_mode);
+  if (cfg->autoreset < TG_AUTORESET_NONE || cfg->autoreset > TG_AUTORESET_NEXT_STEP)
+    return fail(nullptr, TG_EINVAL, "tg_create: unknown autoreset mode %d", cfg->autoreset);
+  if (cfg->ruleset == TG_RULESET_NUMPY && (cfg->queue_size < 1 || cfg->queue_size > 7))
+    return fail(nullptr, TG_EINVAL, "tg_create: NUMPY queue_size must be 1..7, got %d", cfg->queue_size);
+  if (cfg->ruleset == TG_RULESET_FUNCTIONAL && cfg->queue_size != 7)
+    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: FUNCTIONAL rule-set needs queue_size 7 (the 7-bag), got %d",
+                cfg->queue_size);
+  if (cfg->obs_mode == TG_OBS_DICT && cfg->ruleset != TG_RULESET_NUMPY)
+    return fail(nullptr, TG_EINVAL, "tg_create: TG_OBS_DICT is the NUMPY rule-set's observation");
+  if (cfg->action_set == TG_ACTIONS_GROUPED)
+    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: grouped action set not built yet");
+  Launchers L{};
+  if (!find_launchers(cfg->width, cfg->height, cfg->ruleset, &L))
+    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: board %dx%d not compiled in (built sizes: %s)", cfg->width,
+                cfg->height, built_sizes().c_str());
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, TG_EHIP, "tg_create: no HIP device available (this engine has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(nullptr, TG_EINVAL, "tg_create: device %d out of range (0..%d)", cfg->device, ndev - 1);
+
+  tg_handle* h = new (std::nothrow) tg_handle();
+  if (!h) return fail(nullptr, TG_ENOMEM, "tg_create: out of host memory");
+  h->cfg = *cfg;
+  h->B = cfg->batch; h->W = cfg->width; h->H = cfg->height; h->Q = cfg->queue_size;
+  h->cells = (size_t)h->W * h->H;
+  h->L = L;
+  auto bail = [&](int code) {
+    g_create_err = h->err;
+    tg_destroy(h);
+    return code;
+  };
+#define CRCHK(call)                                                                               \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      h->err = std::string(#call " failed: ") + hipGetErrorString(e_);                            \
+      return bail(TG_EHIP);                                                                       \
+    }                                                                                             \
+  } while (0)
+  CRCHK(hipSetDevice(cfg->device));
+  CRCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CRCHK(hipEventCreate(&h->ev0));
+  CRCHK(hipEventCreate(&h->ev1));
+  const size_t B = (size_t)h->B;
+  const size_t sizes[TG_BUF_COUNT] = {
+      /*OBS*/ B * obs_bytes_per_env(cfg), /*REWARD*/ B * 4, /*TERMINATED*/ B, /*LINES*/ B, /*ACTIONS*/ B * 4,
+      /*BOARD*/ B * h->cells, /*REC*/ B * sizeof(tg_env_rec), /*RNG*/ B * sizeof(tg_rng_rec),
+      /*LEGAL_MASK*/ 0,
+      /*FINAL_OBS*/ (cfg->autoreset == TG_AUTORESET_SAME_STEP && (cfg->obs_mode == TG_OBS_BOARD || cfg->obs_mode == TG_OBS_FN))
+          ? B * h->cells : 0,
+      /*EPISODE*/ B * sizeof(tg_episode_rec)};
+  for (int i = 0; i < TG_BUF_COUNT; ++i) {
+    int rc = alloc_buf(h, i, sizes[i]);
+    if (rc != TG_OK) return bail(rc);
+  }
+  CRCHK(hipMalloc((void**)&h->d_new_rng, B * sizeof(tg_rng_rec)));
+  CRCHK(hipMalloc((void**)&h->d_reseed, B));
+  CRCHK(hipMalloc((void**)&h->d_mask, B));
+  // a valid (if arbitrary) initial record so that a step before the first reset cannot index out of range
+  {
+    std::vector<tg_env_rec> init(B);
+    std::memset(init.data(), 0, B * sizeof(tg_env_rec));
+    for (size_t i = 0; i < B; ++i) { init[i].val = 2; init[i].x = 7; init[i].holder_piece = TG_NONE; }
+    CRCHK(hipMemcpyAsync(h->buf[TG_BUF_REC], init.data(), B * sizeof(tg_env_rec), hipMemcpyHostToDevice, h->stream));
+    CRCHK(hipStreamSynchronize(h->stream));
+  }
+#undef CRCHK
+  h->rng_valid.assign(B, 0);
+  *out = h;
+  return TG_OK;
+}
+
+void tg_destroy(tg_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (int i = 0; i < TG_BUF_COUNT; ++i)
+    if (h->buf[i]) (void)hipFree(h->buf[i]);
+  if (h->d_new_rng) (void)hipFree(h->d_new_rng);
+  if (h->d_reseed) (void)hipFree(h->d_reseed);
+  if (h->d_mask) (void)hipFree(h->d_mask);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int tg_reset(tg_handle* h, const uint64_t* seeds, const uint8_t* mask) {
+  if (!h) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  const size_t B = (size_t)h->B;
+  bool any_reseed = false;
+  h->h_new_rng.resize(B);
+  h->h_reseed.assign(B, 0);
+  for (size_t i = 0; i < B; ++i) {
+    if (mask && !mask[i]) continue;
+    if (h->cfg.ruleset == TG_RULESET_NUMPY) {
+      uint64_t sd = seeds ? seeds[i] : 0;
+      if (sd == 0 && !h->rng_valid[i]) sd = 1 + (uint64_t)h->cfg.env_offset + i;  // never-seeded env
+      if (sd > 0) {  // components/tetromino_randomizer.py:40-46: `if seed and seed > 0`
+        seed_pcg64_host(sd, &h->h_new_rng[i]);
+        h->h_reseed[i] = 1;
+        h->rng_valid[i] = 1;
+        any_reseed = true;
+      }
+    } else if (seeds) {
+      std::memset(&h->h_new_rng[i], 0, sizeof(tg_rng_rec));
+      h->h_new_rng[i].key[0] = (uint32_t)(seeds[i] >> 32);
+      h->h_new_rng[i].key[1] = (uint32_t)seeds[i];
+      h->h_reseed[i] = 1;
+      any_reseed = true;
+    }
+  }
+  tg::ResetParams p{};
+  p.board = (uint8_t*)h->buf[TG_BUF_BOARD];
+  p.rec = (uint32_t*)h->buf[TG_BUF_REC];
+  p.rng = (tg_rng_rec*)h->buf[TG_BUF_RNG];
+  p.obs = (uint8_t*)h->buf[TG_BUF_OBS];
+  p.episode = (tg_episode_rec*)h->buf[TG_BUF_EPISODE];
+  p.batch = h->B;
+  p.obs_mode = h->cfg.obs_mode;
+  p.queue_size = h->Q;
+  if (any_reseed) {
+    HIPCHK(h, hipMemcpyAsync(h->d_new_rng, h->h_new_rng.data(), B * sizeof(tg_rng_rec), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_reseed, h->h_reseed.data(), B, hipMemcpyHostToDevice, h->stream));
+    p.new_rng = h->d_new_rng;
+    p.reseed = h->d_reseed;
+  }
+  if (mask) {
+    HIPCHK(h, hipMemcpyAsync(h->d_mask, mask, B, hipMemcpyHostToDevice, h->stream));
+    p.mask = h->d_mask;
+  }
+  h->L.reset(p, h->stream);
+  HIPCHK(h, hipGetLastError());
+  if (h->cfg.obs_mode == TG_OBS_DICT) {
+    int rc = launch_observe_dict(h);
+    if (rc != TG_OK) return rc;
+  }
+  // host staging vectors are reused by the next call: wait for the uploads
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return TG_OK;
+}
+
+int tg_step(tg_handle* h, const int32_t* actions, int kind) {
+  if (!h || !actions) return h ? fail(h, TG_EINVAL, "tg_step: null actions") : TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  tg::KParams p = step_params(h);
+  if (kind == TG_MEM_HOST) {
+    const int na = tg_num_actions(&h->cfg);
+    for (int i = 0; i < h->B; ++i)  // envs/tetris.py:215-217: the reference asserts action_space.contains(action)
+      if (h->cfg.ruleset == TG_RULESET_NUMPY && (actions[i] < 0 || actions[i] >= na))
+        return fail(h, TG_EINVAL, "tg_step: action %d of env %d outside Discrete(%d)", actions[i], i, na);
+    HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_ACTIONS], actions, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
+    p.act32 = (const int32_t*)h->buf[TG_BUF_ACTIONS];
+  } else if (kind == TG_MEM_DEVICE) {
+    p.act32 = actions;
+  } else {
+    return fail(h, TG_EINVAL, "tg_step: unknown memory kind %d", kind);
+  }
+  h->L.step(p, h->stream);
+  HIPCHK(h, hipGetLastError());
+  if (h->cfg.obs_mode == TG_OBS_DICT) return launch_observe_dict(h);
+  return TG_OK;
+}
+
+int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K) {
+  if (!h || !actions_dev || K <= 0) return h ? fail(h, TG_EINVAL, "tg_step_k: bad arguments") : TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  tg::KParams p = step_params(h);
+  for (int k = 0; k < K; ++k) {
+    p.act8 = actions_dev + (size_t)k * h->B;
+    h->L.step(p, h->stream);
+  }
+  HIPCHK(h, hipGetLastError());
+  if (h->cfg.obs_mode == TG_OBS_DICT) return launch_observe_dict(h);
+  return TG_OK;
+}
+
+int tg_device_ptr(tg_handle* h, int which, void** ptr, size_t* bytes) {
+  if (!h || which < 0 || which >= TG_BUF_COUNT) return h ? fail(h, TG_EINVAL, "tg_device_ptr: bad buffer id %d", which) : TG_EINVAL;
+  if (ptr) *ptr = h->buf[which];
+  if (bytes) *bytes = h->bytes[which];
+  return TG_OK;
+}
+
+int tg_fetch(tg_handle* h, int which, void* host_dst, size_t bytes) {
+  if (!h || which < 0 || which >= TG_BUF_COUNT || !host_dst) return h ? fail(h, TG_EINVAL, "tg_fetch: bad arguments") : TG_EINVAL;
+  if (bytes > h->bytes[which]) return fail(h, TG_EINVAL, "tg_fetch: %zu bytes requested, buffer %d holds %zu", bytes, which, h->bytes[which]);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  if (bytes) HIPCHK(h, hipMemcpyAsync(host_dst, h->buf[which], bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return TG_OK;
+}
+
+int tg_get_state(tg_handle* h, uint8_t* board, tg_env_rec* rec, tg_rng_rec* rng) {
+  if (!h) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  const size_t B = (size_t)h->B;
+  if (board) HIPCHK(h, hipMemcpyAsync(board, h->buf[TG_BUF_BOARD], B * h->cells, hipMemcpyDeviceToHost, h->stream));
+  if (rec) HIPCHK(h, hipMemcpyAsync(rec, h->buf[TG_BUF_REC], B * sizeof(tg_env_rec), hipMemcpyDeviceToHost, h->stream));
+  if (rng) HIPCHK(h, hipMemcpyAsync(rng, h->buf[TG_BUF_RNG], B * sizeof(tg_rng_rec), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return TG_OK;
+}
+
+int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, const tg_rng_rec* rng) {
+  if (!h) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  const size_t B = (size_t)h->B;
+  if (rec)
+    for (size_t i = 0; i < B; ++i) {
+      const tg_env_rec& r = rec[i];
+      if (r.piece > 6 || r.rot > 3 || (r.holder_piece != TG_NONE && (r.holder_piece > 6 || r.holder_rot > 3)) ||
+          r.bag_index > 7)
+        return fail(h, TG_EINVAL, "tg_set_state: record %zu out of range (piece %d rot %d holder %d bag_index %d)", i,
+                    r.piece, r.rot, r.holder_piece, r.bag_index);
+      for (int k = 0; k < 7; ++k)
+        if (r.bag[k] > 6 || (k < h->Q && h->cfg.ruleset == TG_RULESET_NUMPY && r.queue[k] > 6))
+          return fail(h, TG_EINVAL, "tg_set_state: record %zu holds a tetromino index > 6", i);
+    }
+  if (board) HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_BOARD], board, B * h->cells, hipMemcpyHostToDevice, h->stream));
+  if (rec) HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_REC], rec, B * sizeof(tg_env_rec), hipMemcpyHostToDevice, h->stream));
+  if (rng) {
+    HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_RNG], rng, B * sizeof(tg_rng_rec), hipMemcpyHostToDevice, h->stream));
+    h->rng_valid.assign(B, 1);
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return TG_OK;
+}
+
+int tg_observe(tg_handle* h) {
+  if (!h) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  if (h->cfg.obs_mode == TG_OBS_NONE) return TG_OK;
+  return launch_observe_dict(h);
+}
+
+int tg_grouped_enumerate(tg_handle* h, uint8_t* boards_dev) {
+  (void)boards_dev;
+  return h ? fail(h, TG_EUNSUPPORTED, "tg_grouped_enumerate: grouped action set not built yet") : TG_EINVAL;
+}
+
+int tg_sync(tg_handle* h) {
+  if (!h) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return TG_OK;
+}
+
+int tg_timer_start(tg_handle* h) {
+  if (!h) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  return TG_OK;
+}
+
+int tg_timer_stop(tg_handle* h, float* elapsed_ms) {
+  if (!h || !elapsed_ms) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipEventSynchronize(h->ev1));
+  HIPCHK(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+  return TG_OK;
+}
+
+int tg_dev_alloc(tg_handle* h, size_t bytes, void** ptr) {
+  if (!h || !ptr) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipMalloc(ptr, bytes));
+  return TG_OK;
+}
+
+int tg_dev_free(tg_handle* h, void* ptr) {
+  if (!h) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipFree(ptr));
+  return TG_OK;
+}
+
+int tg_dev_upload(tg_handle* h, void* dst_dev, const void* src_host, size_t bytes) {
+  if (!h || !dst_dev || !src_host) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return TG_OK;
+}
+
+int tg_dev_download(tg_handle* h, void* dst_host, const void* src_dev, size_t bytes) {
+  if (!h || !dst_host || !src_dev) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return TG_OK;
+}
+
+int tg_stream_copy_gbps(tg_handle* h, size_t bytes, int iters, float* gbps) {
+  if (!h || !gbps || iters <= 0) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  bytes &= ~(size_t)15;
+  void *a = nullptr, *b = nullptr;
+  HIPCHK(h, hipMalloc(&a, bytes));
+  if (hipMalloc(&b, bytes) != hipSuccess) { (void)hipFree(a); return fail(h, TG_ENOMEM, "tg_stream_copy_gbps: hipMalloc failed"); }
+  (void)hipMemsetAsync(a, 1, bytes, h->stream);
+  const size_t n = bytes / 16;
+  hipLaunchKernelGGL(tg::stream_copy_kernel, dim3(2048), dim3(256), 0, h->stream, (const float4*)a, (float4*)b, n);
+  (void)hipEventRecord(h->ev0, h->stream);
+  for (int i = 0; i < iters; ++i)
+    hipLaunchKernelGGL(tg::stream_copy_kernel, dim3(2048), dim3(256), 0, h->stream, (const float4*)a, (float4*)b, n);
+  (void)hipEventRecord(h->ev1, h->stream);
+  hipError_t e = hipEventSynchronize(h->ev1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->ev0, h->ev1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  if (e != hipSuccess) return fail(h, TG_EHIP, "tg_stream_copy_gbps: %s", hipGetErrorString(e));
+  *gbps = (float)(2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9);
+  return TG_OK;
+}
+
+// host-side view of the shape table (tests compare it with the oracle's matrices)
+int tg_shape_mask(int piece, int rot) {
+  if (piece < 0 || piece > 6 || rot < 0 || rot > 3) return TG_EINVAL;
+  static constexpr tg::ShapeTable t = tg::make_shape_table();
+  return t.mask[piece][rot];
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+"""`Engine`: the batched device-resident Tetris state behind the C ABI (one handle = one GPU)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Engine:
+    """Owns `batch` environments on one MI355X.  All arrays in/out are NumPy; state stays on the device.
+
+    ruleset NUMPY mirrors tetris_gymnasium/envs/tetris.py (Tetris.step / reset), FUNCTIONAL mirrors
+    tetris_gymnasium/envs/tetris_fn.py (step / reset).
+    """
+
+    def __init__(self, batch, width=10, height=20, *, ruleset=N.RULESET_NUMPY, gravity=True, queue_size=None,
+                 obs_mode=None, autoreset=N.AUTORESET_NONE, device=0, env_offset=0, padding=4):
+        self.lib = N.load()
+        if queue_size is None:
+            queue_size = 4 if ruleset == N.RULESET_NUMPY else 7
+        if obs_mode is None:
+            obs_mode = N.OBS_DICT if ruleset == N.RULESET_NUMPY else N.OBS_FN
+        cfg = N.TgConfig()
+        cfg.struct_size = C.sizeof(N.TgConfig)
+        cfg.width, cfg.height, cfg.padding, cfg.queue_size = width, height, padding, queue_size
+        cfg.gravity, cfg.ruleset, cfg.obs_mode, cfg.autoreset = int(bool(gravity)), ruleset, obs_mode, autoreset
+        cfg.action_set, cfg.batch, cfg.device, cfg.env_offset = N.ACTIONS_BASE, batch, device, env_offset
+        cfg.grouped_terminate_on_illegal = 1
+        self.cfg = cfg
+        self.B, self.W, self.H, self.P, self.Q = batch, width, height, padding, queue_size
+        self.Wp, self.Hp = width + 2 * padding, height + padding
+        self.ruleset, self.obs_mode, self.autoreset = ruleset, obs_mode, autoreset
+        self.n_actions = self.lib.tg_num_actions(C.byref(cfg))
+        h = C.c_void_p()
+        rc = self.lib.tg_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise EngineError(f"tg_create failed ({rc}): {self.lib.tg_last_error(None).decode()}")
+        self.h = h
+
+    # -- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise EngineError(f"{what} failed ({rc}): {self.lib.tg_last_error(self.h).decode()}")
+
+    # -- transitions ---------------------------------------------------------------------------
+    def reset(self, seeds=None, mask=None):
+        s = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint64)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        if s is not None and s.shape != (self.B,):
+            raise ValueError("seeds must have shape (batch,)")
+        if m is not None and m.shape != (self.B,):
+            raise ValueError("mask must have shape (batch,)")
+        self._chk(self.lib.tg_reset(self.h, N.ptr(s), N.ptr(m)), "tg_reset")
+
+    def step_async(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        if a.shape != (self.B,):
+            raise ValueError("actions must have shape (batch,)")
+        self._chk(self.lib.tg_step(self.h, N.ptr(a), N.MEM_HOST), "tg_step")
+
+    def step_device(self, actions_dev_ptr):
+        """actions: raw device pointer to int32[B] (e.g. from another library's tensor)."""
+        self._chk(self.lib.tg_step(self.h, C.c_void_p(actions_dev_ptr), N.MEM_DEVICE), "tg_step")
+
+    def step_k_device(self, actions_dev_ptr, k):
+        self._chk(self.lib.tg_step_k(self.h, C.c_void_p(actions_dev_ptr), int(k)), "tg_step_k")
+
+    def step(self, actions):
+        """One transition; returns (reward f32[B], terminated u8[B], lines u8[B])."""
+        self.step_async(actions)
+        return self.fetch_outputs()
+
+    def fetch_outputs(self):
+        rew = np.empty(self.B, np.float32)
+        term = np.empty(self.B, np.uint8)
+        lines = np.empty(self.B, np.uint8)
+        self._chk(self.lib.tg_fetch(self.h, N.BUF_REWARD, N.ptr(rew), rew.nbytes), "tg_fetch(reward)")
+        self._chk(self.lib.tg_fetch(self.h, N.BUF_TERMINATED, N.ptr(term), term.nbytes), "tg_fetch(terminated)")
+        self._chk(self.lib.tg_fetch(self.h, N.BUF_LINES, N.ptr(lines), lines.nbytes), "tg_fetch(lines)")
+        return rew, term, lines
+
+    # -- observations --------------------------------------------------------------------------
+    def _fetch(self, which, arr):
+        self._chk(self.lib.tg_fetch(self.h, which, N.ptr(arr), arr.nbytes), f"tg_fetch({which})")
+        return arr
+
+    def observation(self, which=N.BUF_OBS):
+        """The observation buffer of the engine's obs_mode as NumPy array(s)."""
+        if self.obs_mode == N.OBS_BOARD:
+            return self._fetch(which, np.empty((self.B, self.H, self.W), np.uint8))
+        if self.obs_mode == N.OBS_FN:
+            return self._fetch(which, np.empty((self.B, self.H, self.W), np.int8))
+        if self.obs_mode == N.OBS_DICT:
+            cells, pp, B = self.Hp * self.Wp, self.P * self.P, self.B
+            flat = self._fetch(which, np.empty(B * (2 * cells + pp + pp * self.Q), np.uint8))
+            o = 0
+            board = flat[o:o + B * cells].reshape(B, self.Hp, self.Wp); o += B * cells
+            mask = flat[o:o + B * cells].reshape(B, self.Hp, self.Wp); o += B * cells
+            holder = flat[o:o + B * pp].reshape(B, self.P, self.P); o += B * pp
+            queue = flat[o:o + B * pp * self.Q].reshape(B, self.P, self.P * self.Q)
+            return {"board": board, "active_tetromino_mask": mask, "holder": holder, "queue": queue}
+        raise EngineError("engine was created with obs_mode NONE")
+
+    def final_observation(self):
+        return self.observation(N.BUF_FINAL_OBS)
+
+    def observe(self):
+        """Re-pack the observation buffer from the current state (after set_state)."""
+        self._chk(self.lib.tg_observe(self.h), "tg_observe")
+        return self.observation()
+
+    # -- state snapshot / restore (envs/tetris.py:681-708 get_state / set_state, batched) --------
+    def get_state(self):
+        board = np.empty((self.B, self.H, self.W), np.uint8)
+        rec = np.empty(self.B, N.ENV_REC)
+        rng = np.empty(self.B, N.RNG_REC)
+        self._chk(self.lib.tg_get_state(self.h, N.ptr(board), N.ptr(rec), N.ptr(rng)), "tg_get_state")
+        return board, rec, rng
+
+    def set_state(self, board=None, rec=None, rng=None):
+        b = None if board is None else np.ascontiguousarray(board, dtype=np.uint8)
+        r = None if rec is None else np.ascontiguousarray(rec, dtype=N.ENV_REC)
+        g = None if rng is None else np.ascontiguousarray(rng, dtype=N.RNG_REC)
+        if b is not None and b.shape != (self.B, self.H, self.W):
+            raise ValueError(f"board must have shape {(self.B, self.H, self.W)}")
+        self._chk(self.lib.tg_set_state(self.h, N.ptr(b), N.ptr(r), N.ptr(g)), "tg_set_state")
+
+    def episode_stats(self):
+        return self._fetch(N.BUF_EPISODE, np.empty(self.B, N.EPISODE_REC))
+
+    # -- device memory / timing helpers (bench.py) ---------------------------------------------
+    def device_ptr(self, which):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.tg_device_ptr(self.h, which, C.byref(p), C.byref(n)), "tg_device_ptr")
+        return p.value, n.value
+
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.lib.tg_dev_alloc(self.h, nbytes, C.byref(p)), "tg_dev_alloc")
+        return p.value
+
+    def dev_free(self, p):
+        self._chk(self.lib.tg_dev_free(self.h, C.c_void_p(p)), "tg_dev_free")
+
+    def dev_upload(self, dptr, arr):
+        a = np.ascontiguousarray(arr)
+        self._chk(self.lib.tg_dev_upload(self.h, C.c_void_p(dptr), N.ptr(a), a.nbytes), "tg_dev_upload")
+
+    def dev_download(self, dptr, arr):
+        self._chk(self.lib.tg_dev_download(self.h, N.ptr(arr), C.c_void_p(dptr), arr.nbytes), "tg_dev_download")
+        return arr
+
+    def sync(self):
+        self._chk(self.lib.tg_sync(self.h), "tg_sync")
+
+    def timer_start(self):
+        self._chk(self.lib.tg_timer_start(self.h), "tg_timer_start")
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._chk(self.lib.tg_timer_stop(self.h, C.byref(ms)), "tg_timer_stop")
+        return ms.value
+
+    def stream_copy_gbps(self, nbytes=1 << 30, iters=10) -> float:
+        g = C.c_float()
+        self._chk(self.lib.tg_stream_copy_gbps(self.h, nbytes, iters, C.byref(g)), "tg_stream_copy_gbps")
+        return g.value
