@@ -54,6 +54,10 @@ extern "C" {
 #define TG_MEM_HOST 0
 #define TG_MEM_DEVICE 1
 
+/* ---- tg_config.flags ---- */
+#define TG_FLAG_EPISODE_STATS 1 /* keep device-side episode return/length (RecordEpisodeStatistics) */
+#define TG_FLAG_FINAL_OBS 2     /* SAME_STEP autoreset: also write the terminal observation to TG_BUF_FINAL_OBS */
+
 /* ---- error codes ---- */
 #define TG_OK 0
 #define TG_EINVAL (-1)      /* bad argument / unsupported configuration */
@@ -76,7 +80,8 @@ typedef struct tg_config {
   int32_t device;      /* HIP device ordinal */
   int32_t env_offset;  /* global index of env 0 of this handle (multi-GPU sharding; informational) */
   int32_t grouped_terminate_on_illegal; /* wrappers/grouped.py:49 (default 1) */
-  int32_t reserved[2];
+  int32_t flags;       /* TG_FLAG_* */
+  int32_t reserved;
 } tg_config;
 
 /* ---- per-env state records (tg_get_state / tg_set_state; also the device layout) ----
@@ -115,19 +120,24 @@ typedef struct tg_rng_rec { /* 48 bytes */
   uint32_t key[2];
 } tg_rng_rec;
 
-/* ---- output buffers (engine-owned device memory, see tg_device_ptr / tg_fetch) ---- */
+/* ---- engine-owned device buffers (see tg_device_ptr / tg_fetch) ---- */
 #define TG_BUF_OBS 0        /* layout per obs_mode */
-#define TG_BUF_REWARD 1     /* f32 [B] (NUMPY rewards are integer-valued; grouped illegal = -0.1f) */
-#define TG_BUF_TERMINATED 2 /* u8 [B] */
-#define TG_BUF_LINES 3      /* u8 [B]  info["lines_cleared"] */
-#define TG_BUF_ACTIONS 4    /* i32 [B] staging buffer used for TG_MEM_HOST actions */
-#define TG_BUF_BOARD 5      /* u8 [B][H][W] state boards */
-#define TG_BUF_REC 6        /* tg_env_rec [B] */
-#define TG_BUF_RNG 7        /* tg_rng_rec [B] */
-#define TG_BUF_LEGAL_MASK 8 /* u8 [B][4*W]  grouped legal-action mask (TG_ACTIONS_GROUPED) */
-#define TG_BUF_FINAL_OBS 9  /* SAME_STEP autoreset: observation of the terminal state (valid where terminated) */
-#define TG_BUF_EPISODE 10   /* tg_episode_rec [B] */
-#define TG_BUF_COUNT 11
+#define TG_BUF_STEP_OUT 1   /* tg_step_out [B]: reward, terminated, info["lines_cleared"] of the last step */
+#define TG_BUF_ACTIONS 2    /* i32 [B] staging buffer used for TG_MEM_HOST actions */
+#define TG_BUF_BOARD 3      /* u8 [B][H][W] state boards */
+#define TG_BUF_REC 4        /* tg_env_rec [B] */
+#define TG_BUF_RNG 5        /* tg_rng_rec [B] */
+#define TG_BUF_LEGAL_MASK 6 /* u8 [B][4*W]  grouped legal-action mask (TG_ACTIONS_GROUPED) */
+#define TG_BUF_FINAL_OBS 7  /* SAME_STEP autoreset: observation of the terminal state (valid where terminated) */
+#define TG_BUF_EPISODE 8    /* tg_episode_rec [B] (TG_FLAG_EPISODE_STATS) */
+#define TG_BUF_COUNT 9
+
+typedef struct tg_step_out { /* 8 bytes, written by the step kernel with one store per env */
+  float reward;        /* NUMPY rewards are integer-valued (envs/tetris.py:468-474); grouped illegal = -0.1f */
+  uint8_t terminated;
+  uint8_t lines;       /* info["lines_cleared"] */
+  uint16_t reserved;
+} tg_step_out;
 
 typedef struct tg_episode_rec { /* 16 bytes: device-side RecordEpisodeStatistics */
   float ret;           /* running return of the current episode */
@@ -161,12 +171,12 @@ const char* tg_last_error(const tg_handle* h);
 int tg_reset(tg_handle* h, const uint64_t* seeds, const uint8_t* mask);
 
 /* One transition for every env.  actions: i32[B] in host or device memory (kind = TG_MEM_*).
- * Asynchronous on the handle's stream; results land in the TG_BUF_* device buffers. */
+ * Asynchronous on the handle's stream; results land in TG_BUF_STEP_OUT / TG_BUF_OBS. */
 int tg_step(tg_handle* h, const int32_t* actions, int kind);
 
 /* K consecutive transitions with pre-generated actions i8 [K][B] resident in DEVICE memory
- * (launch-bound regime helper; observations/rewards of the last step remain in the buffers,
- *  rewards/terminated/lines of every step are accumulated only if accum != 0 into TG_BUF_EPISODE). */
+ * (rollout / benchmark helper: one kernel launch per transition, no host round trip; the outputs of
+ *  the last step remain in the buffers, per-episode sums go to TG_BUF_EPISODE when enabled). */
 int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K);
 
 /* Device pointer and size of an engine-owned buffer. */

@@ -194,8 +194,8 @@ def test_step_k_equals_k_steps_and_episode_stats():
     rng = np.random.default_rng(4)
     acts = rng.integers(0, 8, (K, B)).astype(np.int8)
     seeds = np.arange(1, B + 1, dtype=np.uint64)
-    e1 = Engine(B, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP)
-    e2 = Engine(B, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP)
+    e1 = Engine(B, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP, episode_stats=True)
+    e2 = Engine(B, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP, episode_stats=True)
     e1.reset(seeds); e2.reset(seeds)
     ret = np.zeros(B)
     for k in range(K):

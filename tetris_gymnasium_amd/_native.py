@@ -18,8 +18,9 @@ OBS_NONE, OBS_BOARD, OBS_DICT, OBS_FN = 0, 1, 2, 3
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = 0, 1, 2
 ACTIONS_BASE, ACTIONS_GROUPED = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
-(BUF_OBS, BUF_REWARD, BUF_TERMINATED, BUF_LINES, BUF_ACTIONS, BUF_BOARD, BUF_REC, BUF_RNG, BUF_LEGAL_MASK,
- BUF_FINAL_OBS, BUF_EPISODE) = range(11)
+(BUF_OBS, BUF_STEP_OUT, BUF_ACTIONS, BUF_BOARD, BUF_REC, BUF_RNG, BUF_LEGAL_MASK, BUF_FINAL_OBS,
+ BUF_EPISODE) = range(9)
+FLAG_EPISODE_STATS, FLAG_FINAL_OBS = 1, 2
 NONE = 0xFF
 F_GAME_OVER, F_HAS_SWAPPED, F_PENDING_RESET = 1, 2, 4
 
@@ -37,7 +38,8 @@ RNG_REC = np.dtype(
     ]
 )
 EPISODE_REC = np.dtype([("ret", "<f4"), ("len", "<u4"), ("last_ret", "<f4"), ("last_len", "<u4")])
-assert ENV_REC.itemsize == 32 and RNG_REC.itemsize == 48 and EPISODE_REC.itemsize == 16
+STEP_OUT = np.dtype([("reward", "<f4"), ("terminated", "u1"), ("lines", "u1"), ("reserved", "<u2")])
+assert ENV_REC.itemsize == 32 and RNG_REC.itemsize == 48 and EPISODE_REC.itemsize == 16 and STEP_OUT.itemsize == 8
 
 
 class TgConfig(C.Structure):
@@ -45,7 +47,8 @@ class TgConfig(C.Structure):
         ("struct_size", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("padding", C.c_int32),
         ("queue_size", C.c_int32), ("gravity", C.c_int32), ("ruleset", C.c_int32), ("obs_mode", C.c_int32),
         ("autoreset", C.c_int32), ("action_set", C.c_int32), ("batch", C.c_int32), ("device", C.c_int32),
-        ("env_offset", C.c_int32), ("grouped_terminate_on_illegal", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("env_offset", C.c_int32), ("grouped_terminate_on_illegal", C.c_int32), ("flags", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

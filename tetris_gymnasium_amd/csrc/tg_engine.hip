@@ -30,9 +30,13 @@ struct Launchers {
 
 inline int grid_for(int batch) { return (batch + tg::kWavesPerBlock - 1) / tg::kWavesPerBlock; }
 
+int g_step_blocks = 0;  // persistent grid size (blocks); set once per process from the device's CU count
+
 template <int W, int H, int RS>
 void launch_step(const tg::KParams& p, hipStream_t s) {
-  hipLaunchKernelGGL((tg::step_kernel<W, H, RS>), dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p);
+  int grid = grid_for(p.batch);
+  if (g_step_blocks > 0 && grid > g_step_blocks) grid = g_step_blocks;
+  hipLaunchKernelGGL((tg::step_kernel<W, H, RS>), dim3(grid), dim3(tg::kBlock), 0, s, p);
 }
 template <int W, int H, int RS>
 void launch_reset(const tg::ResetParams& p, hipStream_t s) {
@@ -166,11 +170,15 @@ void seed_pcg64_host(uint64_t seed, tg_rng_rec* out) {
   out->inc_hi = (uint64_t)(inc >> 64);
 }
 
+// Device buffers carry kTailPad bytes of zeroed padding: the step kernel's dword-per-lane slab loads are
+// unmasked (lanes past the end of the last env's slab read padding instead of faulting).
+constexpr size_t kTailPad = 4096;
+
 int alloc_buf(tg_handle* h, int which, size_t n) {
   h->bytes[which] = n;
   if (n == 0) return TG_OK;
-  HIPCHK(h, hipMalloc(&h->buf[which], n));
-  HIPCHK(h, hipMemsetAsync(h->buf[which], 0, n, h->stream));
+  HIPCHK(h, hipMalloc(&h->buf[which], n + kTailPad));
+  HIPCHK(h, hipMemsetAsync(h->buf[which], 0, n + kTailPad, h->stream));
   return TG_OK;
 }
 
@@ -181,10 +189,14 @@ tg::KParams step_params(tg_handle* h) {
   p.rng = (tg_rng_rec*)h->buf[TG_BUF_RNG];
   p.obs = (uint8_t*)h->buf[TG_BUF_OBS];
   p.final_obs = (uint8_t*)h->buf[TG_BUF_FINAL_OBS];
-  p.reward = (float*)h->buf[TG_BUF_REWARD];
-  p.terminated = (uint8_t*)h->buf[TG_BUF_TERMINATED];
-  p.lines = (uint8_t*)h->buf[TG_BUF_LINES];
+  p.out = (uint2*)h->buf[TG_BUF_STEP_OUT];
   p.episode = (tg_episode_rec*)h->buf[TG_BUF_EPISODE];
+  {
+    static constexpr tg::ShapeTable t = tg::make_shape_table();
+    for (int i = 0; i < 7; ++i)
+      p.shapes[i] = (uint64_t)t.mask[i][0] | ((uint64_t)t.mask[i][1] << 16) | ((uint64_t)t.mask[i][2] << 32) |
+                    ((uint64_t)t.mask[i][3] << 48);
+  }
   p.batch = h->B;
   p.gravity = h->cfg.gravity;
   p.autoreset = h->cfg.autoreset;
@@ -244,6 +256,8 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   if (cfg->padding != 4)
     return fail(nullptr, TG_EUNSUPPORTED, "tg_create: padding must be 4 (stock tetromino set), got %d", cfg->padding);
   if (cfg->batch <= 0) return fail(nullptr, TG_EINVAL, "tg_create: batch must be > 0");
+  if ((uint64_t)cfg->batch * (uint64_t)cfg->width * (uint64_t)cfg->height >= (1ull << 31))
+    return fail(nullptr, TG_EINVAL, "tg_create: batch*width*height must stay below 2^31 (32-bit slab offsets)");
   if (cfg->ruleset != TG_RULESET_NUMPY && cfg->ruleset != TG_RULESET_FUNCTIONAL)
     return fail(nullptr, TG_EINVAL, "tg_create: unknown ruleset %d", cfg->ruleset);
   if (cfg->obs_mode < TG_OBS_NONE || cfg->obs_mode > TG_OBS_FN)
@@ -289,17 +303,28 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     }                                                                                             \
   } while (0)
   CRCHK(hipSetDevice(cfg->device));
+  if (g_step_blocks == 0) {
+    hipDeviceProp_t prop;
+    CRCHK(hipGetDeviceProperties(&prop, cfg->device));
+    // Grid of the step kernel.  Default: one wave per env (measured fastest for the one-env-per-wavefront
+    // kernel, profiles/r01_*).  TG_BLOCKS_PER_CU=n makes it persistent: n blocks of 4 waves per CU, each wave
+    // looping over its envs with the next env's loads in flight.
+    int per_cu = 0;
+    if (const char* e = getenv("TG_BLOCKS_PER_CU")) per_cu = atoi(e);
+    g_step_blocks = per_cu > 0 ? prop.multiProcessorCount * per_cu : -1;
+  }
   CRCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CRCHK(hipEventCreate(&h->ev0));
   CRCHK(hipEventCreate(&h->ev1));
   const size_t B = (size_t)h->B;
+  const bool want_final = (cfg->flags & TG_FLAG_FINAL_OBS) && cfg->autoreset == TG_AUTORESET_SAME_STEP &&
+                          (cfg->obs_mode == TG_OBS_BOARD || cfg->obs_mode == TG_OBS_FN);
   const size_t sizes[TG_BUF_COUNT] = {
-      /*OBS*/ B * obs_bytes_per_env(cfg), /*REWARD*/ B * 4, /*TERMINATED*/ B, /*LINES*/ B, /*ACTIONS*/ B * 4,
+      /*OBS*/ B * obs_bytes_per_env(cfg), /*STEP_OUT*/ B * sizeof(tg_step_out), /*ACTIONS*/ B * 4,
       /*BOARD*/ B * h->cells, /*REC*/ B * sizeof(tg_env_rec), /*RNG*/ B * sizeof(tg_rng_rec),
       /*LEGAL_MASK*/ 0,
-      /*FINAL_OBS*/ (cfg->autoreset == TG_AUTORESET_SAME_STEP && (cfg->obs_mode == TG_OBS_BOARD || cfg->obs_mode == TG_OBS_FN))
-          ? B * h->cells : 0,
-      /*EPISODE*/ B * sizeof(tg_episode_rec)};
+      /*FINAL_OBS*/ want_final ? B * h->cells : 0,
+      /*EPISODE*/ (cfg->flags & TG_FLAG_EPISODE_STATS) ? B * sizeof(tg_episode_rec) : 0};
   for (int i = 0; i < TG_BUF_COUNT; ++i) {
     int rc = alloc_buf(h, i, sizes[i]);
     if (rc != TG_OK) return bail(rc);
@@ -402,9 +427,9 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind) {
       if (h->cfg.ruleset == TG_RULESET_NUMPY && (actions[i] < 0 || actions[i] >= na))
         return fail(h, TG_EINVAL, "tg_step: action %d of env %d outside Discrete(%d)", actions[i], i, na);
     HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_ACTIONS], actions, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
-    p.act32 = (const int32_t*)h->buf[TG_BUF_ACTIONS];
+    p.actions = h->buf[TG_BUF_ACTIONS];
   } else if (kind == TG_MEM_DEVICE) {
-    p.act32 = actions;
+    p.actions = actions;
   } else {
     return fail(h, TG_EINVAL, "tg_step: unknown memory kind %d", kind);
   }
@@ -418,8 +443,10 @@ int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K) {
   if (!h || !actions_dev || K <= 0) return h ? fail(h, TG_EINVAL, "tg_step_k: bad arguments") : TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   tg::KParams p = step_params(h);
+  if (h->B % 4 != 0) return fail(h, TG_EINVAL, "tg_step_k: batch must be a multiple of 4 (packed int8 action rows)");
+  p.act_i8 = 1;
   for (int k = 0; k < K; ++k) {
-    p.act8 = actions_dev + (size_t)k * h->B;
+    p.actions = actions_dev + (size_t)k * h->B;
     h->L.step(p, h->stream);
   }
   HIPCHK(h, hipGetLastError());

@@ -28,22 +28,21 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = 64 * kWavesPerBlock;
 
 struct KParams {
-  uint8_t* board;        // [B][H][W]
-  uint32_t* rec;         // [B][8]
-  tg_rng_rec* rng;       // [B]
-  const int32_t* act32;  // [B] or null
-  const int8_t* act8;    // [B] or null
-  uint8_t* obs;          // per obs_mode
-  uint8_t* final_obs;    // optional (SAME_STEP autoreset)
-  float* reward;         // [B]
-  uint8_t* terminated;   // [B]
-  uint8_t* lines;        // [B]
+  uint8_t* board;           // [B][H][W]
+  uint32_t* rec;            // [B][8]
+  tg_rng_rec* rng;          // [B]
+  const void* actions;      // i32[B] or i8[B] (act_i8)
+  uint8_t* obs;             // per obs_mode
+  uint8_t* final_obs;       // optional (SAME_STEP autoreset)
+  uint2* out;               // [B] tg_step_out {f32 reward; u8 terminated; u8 lines; u16 0}
   tg_episode_rec* episode;  // optional
+  uint64_t shapes[7];       // per piece: 4 rotations x 16-bit cell masks (tg_tables.h)
   int batch;
   int gravity;
   int autoreset;
   int obs_mode;
   int queue_size;
+  int act_i8;
 };
 
 struct ResetParams {
@@ -78,7 +77,8 @@ struct Geo {
   static constexpr int CELLS = W * H;
   static constexpr int NDW = CELLS / 4;
   static constexpr int DPL = (NDW + 63) / 64;             // dwords per lane
-  static constexpr int SLAB = ((CELLS + 15) / 16) * 16;   // LDS bytes per wave
+  static constexpr int SLAB = ((CELLS + 15) / 16) * 16;   // slab bytes
+  static constexpr int LDS_SLAB = 256 * DPL;              // LDS bytes per wave (whole dword-per-lane passes)
   static constexpr int WP = W + 8;
   static constexpr int HP = H + 4;
   static_assert(CELLS % 4 == 0, "W*H must be a multiple of 4 (dword-per-lane slab transfers)");
@@ -199,7 +199,8 @@ __device__ __forceinline__ uint64_t jax_permutation7(uint32_t k0, uint32_t k1) {
 // wave-level board primitives (slab = this wave's LDS copy of the playfield, H*W bytes)
 // ------------------------------------------------------------------------------------------------
 // 4 candidate placements tested at once.  Lane group q = lane>>4 tests candidate q, lane&15 = matrix
-// cell.  q0 = (shapeT, xT, yT)   q1 = (shapeT, xT, yT+1)   q2 = (shapeC, xC, yC+1)   q3 = (shapeC, xC, yC)
+// cell.  q0 = (shapeT, xT, yT)   q1 = (shapeT, xT, yT+1)   q2 = (shapeC, xC, yC)   q3 = (shapeC, xC, yC+1)
+// → low dword of the ballot = tentative {here | below << 16}, high dword = current {here | below << 16}.
 // Cells outside the playfield are bedrock (envs/tetris.py:632-641 pads with 1) → hit.
 template <int W, int H>
 __device__ __forceinline__ uint64_t test4(const uint8_t* slab, int lane, uint32_t shapeT, int xT, int yT,
@@ -207,7 +208,7 @@ __device__ __forceinline__ uint64_t test4(const uint8_t* slab, int lane, uint32_
   const bool useT = lane < 32;
   const uint32_t shape = useT ? shapeT : shapeC;
   const int x = useT ? xT : xC;
-  const int y = (useT ? yT : yC) + (((lane + 16) >> 5) & 1);
+  const int y = (useT ? yT : yC) + ((lane >> 4) & 1);
   const int cell = lane & 15;
   const int row = y + (cell >> 2), col = x + (cell & 3) - 4;
   const bool filled = (shape >> cell) & 1u;
@@ -417,7 +418,9 @@ __device__ __forceinline__ void emit_obs(uint8_t* slab, int lane, uint8_t* dst_e
                                          uint32_t shape, int x, int y, int val) {
   using G = Geo<W, H>;
   if (mode != TG_OBS_BOARD && mode != TG_OBS_FN) return;
-  if (show) stamp<W, H>(slab, lane, shape, x, y, mode == TG_OBS_FN ? 0xFFu : (uint32_t)val, mode == TG_OBS_BOARD);
+  // the piece is only ever drawn onto free cells (NUMPY: hidden when it collides, envs/tetris.py:558-560;
+  // FUNCTIONAL: hidden when game over), so a plain byte write equals the reference's `+=`
+  if (show) stamp<W, H>(slab, lane, shape, x, y, mode == TG_OBS_FN ? 0xFFu : (uint32_t)val, false);
   wave_sync();
   const uint32_t* slab_dw = reinterpret_cast<const uint32_t*>(slab);
   uint32_t* dst = reinterpret_cast<uint32_t*>(dst_env);
@@ -438,164 +441,232 @@ __device__ __forceinline__ void emit_obs(uint8_t* slab, int lane, uint8_t* dst_e
 
 // ------------------------------------------------------------------------------------------------
 // THE step kernel: one env per wavefront
+//
+// Measured on MI355X (profiles/r01_*): with one env per wave the rule logic is scalar and the kernel is
+// bound by the CU's single scalar ALU (1 SALU instruction / cycle / CU), not by HBM.  The hot path
+// (no lock: ~82 % of random-policy steps) is therefore written to minimise scalar instructions:
+//   * the 32-byte record arrives with one s_load_dwordx8 and only d0/d1 are unpacked;
+//   * the action switch is a shift of a 64-bit LUT constant (branch-free: dx, dy, drot, flags);
+//   * both shapes come from one 8-byte row of the shape table carried in the kernel arguments;
+//   * bag / queue / holder / generator state are unpacked only inside the rare lock, swap and reset
+//     paths, and only the first 8 record bytes are stored back when nothing else changed;
+//   * reward / terminated / lines leave as ONE 8-byte record.
 // ------------------------------------------------------------------------------------------------
-template <int W, int H, int RULESET>
-__global__ __launch_bounds__(kBlock) void step_kernel(const KParams p) {
-  using G = Geo<W, H>;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * G::SLAB];
-  const int lane = threadIdx.x & 63;
-  const int wave = rfl((int)(threadIdx.x >> 6));
-  const int env = blockIdx.x * kWavesPerBlock + wave;
-  if (env >= p.batch) return;
-  uint8_t* slab = lds + wave * G::SLAB;
-  uint32_t* slab_dw = reinterpret_cast<uint32_t*>(slab);
-  uint32_t* gboard = reinterpret_cast<uint32_t*>(p.board + (size_t)env * G::CELLS);
+// per-action LUT byte: [1:0] dx+1, [2] dy, [4:3] drot, [5] needs collision check, [6] hard drop, [7] swap
+constexpr uint64_t kActLutNumpy =  // mappings/actions.py:12-19
+    0x20ULL | (0x22ULL << 8) | (0x25ULL << 16) | (0x29ULL << 24) | (0x39ULL << 32) | (0x41ULL << 40) |
+    (0x81ULL << 48) | (0x01ULL << 56);
+constexpr uint64_t kActLutFn =  // envs/tetris_fn.py:470-478 (3 = rotation-1, 4 = rotation+1, 5 = no-op, 6 = hard drop)
+    0x20ULL | (0x22ULL << 8) | (0x25ULL << 16) | (0x39ULL << 24) | (0x29ULL << 32) | (0x01ULL << 40) |
+    (0x41ULL << 48) | (0x41ULL << 56);
 
-  // stage the playfield slab: coalesced dword-per-lane load → LDS
+__device__ __forceinline__ void raw_to_env(EnvS& s, const uint32_t d[8]) {
+  s.piece = d[0] & 0xFF; s.rot = (d[0] >> 8) & 0xFF; s.x = (d[0] >> 16) & 0xFF; s.y = d[0] >> 24;
+  s.val = d[1] & 0xFF; s.flags = (d[1] >> 8) & 0xFF; s.hp = (d[1] >> 16) & 0xFF; s.hr = d[1] >> 24;
+  s.hv = d[2] & 0xFF; s.bidx = (d[2] >> 8) & 0xFF;
+  s.bag = (uint64_t)(d[2] >> 16) | ((uint64_t)d[3] << 16) | ((uint64_t)(d[4] & 0xFF) << 48);
+  s.queue = (uint64_t)(d[4] >> 8) | ((uint64_t)d[5] << 24);
+  s.score = __uint_as_float(d[6]);
+  s.reserved = d[7];
+}
+
+__device__ __forceinline__ void env_to_raw(const EnvS& s, uint32_t d[8]) {
+  d[0] = (uint32_t)s.piece | ((uint32_t)s.rot << 8) | ((uint32_t)s.x << 16) | ((uint32_t)s.y << 24);
+  d[1] = (uint32_t)s.val | ((uint32_t)s.flags << 8) | ((uint32_t)s.hp << 16) | ((uint32_t)s.hr << 24);
+  d[2] = (uint32_t)s.hv | ((uint32_t)s.bidx << 8) | ((uint32_t)(s.bag & 0xFFFF) << 16);
+  d[3] = (uint32_t)(s.bag >> 16);
+  d[4] = (uint32_t)((s.bag >> 48) & 0xFF) | ((uint32_t)(s.queue & 0xFFFFFF) << 8);
+  d[5] = (uint32_t)(s.queue >> 24);
+  d[6] = __float_as_uint(s.score);
+  d[7] = s.reserved;
+}
+
+// prefetchable per-env inputs: the slab's dwords (one or more per lane) and one word per lane holding the
+// 32-byte record (lanes 0..7) and the action word (lanes >= 8).  All loads are unmasked: buffers carry
+// tail padding (tg_engine.hip) so that lanes past the slab read harmless bytes.
+template <int W, int H>
+__device__ __forceinline__ void load_env(const KParams& p, const uint32_t env, const int lane,
+                                         uint32_t (&bv)[Geo<W, H>::DPL], uint32_t& recv) {
+  using G = Geo<W, H>;
+  const uint32_t* gb = reinterpret_cast<const uint32_t*>(p.board + env * (uint32_t)G::CELLS);
 #pragma unroll
-  for (int k = 0; k < G::DPL; ++k) {
-    const int idx = lane + 64 * k;
-    if (idx < G::NDW) slab_dw[idx] = gboard[idx];
-  }
-  EnvS s;
-  rec_unpack(s, p.rec + (size_t)env * 8);
-  const int action = rfl(p.act32 ? p.act32[env] : (int)p.act8[env]);
-  Rng r;
-  r.loaded = false;
-  r.dirty = false;
+  for (int k = 0; k < G::DPL; ++k) bv[k] = gb[lane + 64 * k];
+  const uint32_t* rw = p.rec + env * 8u + (uint32_t)(lane & 7);
+  const uint32_t* aw = reinterpret_cast<const uint32_t*>(p.actions) + (p.act_i8 ? (env >> 2) : env);
+  recv = *(lane < 8 ? rw : aw);
+}
+
+template <int W, int H, int RULESET>
+__device__ __forceinline__ void process_env(const KParams& p, const uint32_t env, const int lane, uint8_t* slab,
+                                            const uint32_t (&bv)[Geo<W, H>::DPL], const uint32_t recv) {
+  using G = Geo<W, H>;
+  uint32_t* slab_dw = reinterpret_cast<uint32_t*>(slab);
+  const uint32_t boff = env * (uint32_t)G::CELLS;  // byte offset of this env's slab (B*H*W < 2^31 checked host-side)
+  uint32_t* gboard = reinterpret_cast<uint32_t*>(p.board + boff);
+  // stage the playfield slab in LDS (the per-wave LDS region is 256*DPL bytes: unmasked writes are safe)
+#pragma unroll
+  for (int k = 0; k < G::DPL; ++k) slab_dw[lane + 64 * k] = bv[k];
+  uint32_t d[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_readlane(recv, i);
+  const uint32_t aword = __builtin_amdgcn_readlane(recv, 8);
+  const int action = p.act_i8 ? (int)(int8_t)(aword >> (8 * (env & 3))) : (int)aword;
   const tg_rng_rec* rp = p.rng + env;
   const int Q = p.queue_size;
   wave_sync();
 
-  float reward = 0.0f;
-  int lines = 0;
-  bool board_dirty = false;
-  bool final_coll = false;  // does the active piece collide at its final position (NUMPY projection rule)
-  bool stepped = true;
-
-  if (p.autoreset == TG_AUTORESET_NEXT_STEP && (s.flags & TG_F_PENDING_RESET)) {
-    env_reset<W, H, RULESET>(s, r, rp, slab_dw, lane, Q);
-    board_dirty = true;
-    stepped = false;
-  } else if (RULESET == TG_RULESET_FUNCTIONAL && (s.flags & TG_F_GAME_OVER)) {
-    stepped = false;  // envs/tetris_fn.py:284-289: identity
+  // ---------------- fast path: plain move / rotate / no-op + gravity, nothing locks -----------------
+  // (≈ 80 % of random-policy steps).  Straight-line, branch-free action handling with integer masks
+  // (keeps the scalar unit on s_cmp/s_cselect instead of lane-mask juggling); anything rarer (lock, hard
+  // drop, effective swap, game-over / pending-reset states) falls through to the general path below,
+  // which recomputes everything from the raw record.
+  {
+    const uint32_t fl = d[1] >> 8;  // flags in bits 0..7
+    uint32_t e;
+    if (RULESET == TG_RULESET_NUMPY) {
+      e = (uint32_t)(kActLutNumpy >> (8 * (action & 7)));
+    } else {
+      const int br = action < 0 ? 0 : (action > 6 ? 6 : action);
+      e = (uint32_t)(kActLutFn >> (8 * br));
+    }
+    const uint32_t swap_eff = (e >> 7) & ~(fl >> 1) & 1u;  // swap requested and not yet swapped (LUT bit 7: NUMPY only)
+    const uint32_t slow0 = (fl & (TG_F_GAME_OVER | TG_F_PENDING_RESET)) | (e & 0x40u) | swap_eff;
+    if (slow0 == 0) {
+      const uint32_t piece = d[0] & 0xFFu, rot = (d[0] >> 8) & 0xFFu, x = (d[0] >> 16) & 0xFFu, y = d[0] >> 24;
+      const uint64_t row = p.shapes[piece];
+      const uint32_t tx = x + (e & 3u) - 1u;
+      const uint32_t ty = y + ((e >> 2) & 1u);
+      const uint32_t tr = (rot + (e >> 3)) & 3u;
+      const uint32_t shapeC = (uint32_t)(row >> (16 * rot));  // bits above 15 are never tested (cell < 16)
+      const uint32_t shapeT = (uint32_t)(row >> (16 * tr));
+      const uint64_t m = test4<W, H>(slab, lane, shapeT, (int)tx, (int)ty, shapeC, (int)x, (int)y);
+      const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+      const uint32_t accept = ((lo & 0xFFFFu) == 0 ? 1u : 0u) & (e >> 5);
+      const uint32_t w = accept ? lo : hi;
+      const uint32_t grav = (uint32_t)p.gravity;
+      const uint32_t blocked = (w >> 16) != 0 ? grav : 0u;
+      if (blocked == 0) {
+        const uint32_t nx = accept ? tx : x;
+        const uint32_t nr = accept ? tr : rot;
+        const uint32_t ny = (accept ? ty : y) + grav;
+        // NUMPY projection rule: the piece is drawn unless it collides where it stands (only possible
+        // without gravity; after a gravity move the piece is free)
+        const uint32_t hide = RULESET == TG_RULESET_NUMPY ? ((w & 0xFFFFu) != 0 ? (grav ^ 1u) : 0u) : 0u;
+        emit_obs<W, H>(slab, lane, p.obs + boff, p.obs_mode, hide == 0, accept ? shapeT : shapeC, (int)nx, (int)ny,
+                       (int)(d[1] & 0xFFu));
+        const uint32_t nd0 = piece | (nr << 8) | (nx << 16) | (ny << 24);
+        float reward = 0.0f;
+        uint32_t nd6 = d[6];
+        if (RULESET == TG_RULESET_FUNCTIONAL) {
+          if (accept & (e >> 2) & 1u) {  // soft drop +1 (tetris_fn.py:183-190)
+            const float old = __uint_as_float(d[6]);
+            const float t = (old + 1.0f) + 0.0f;
+            nd6 = __float_as_uint(t);
+            reward = t - old;
+          }
+        }
+        if (lane == 0) {
+          uint32_t* rec_out = p.rec + env * 8u;
+          rec_out[0] = nd0;
+          if (RULESET == TG_RULESET_FUNCTIONAL && nd6 != d[6]) rec_out[6] = nd6;
+          p.out[env] = make_uint2(__float_as_uint(reward), 0u);
+          if (p.episode) {
+            tg_episode_rec ep = p.episode[env];
+            ep.ret += reward;
+            ep.len += 1;
+            p.episode[env] = ep;
+          }
+        }
+        return;
+      }
+    }
   }
 
-  if (stepped) {
-    const uint32_t shapeC = c_shapes.mask[s.piece][s.rot];
-    int tp = s.piece, tr = s.rot, tx = s.x, ty = s.y, tv = s.val;
-    bool check = false, forced = false, hard = false;
+  // hot fields only
+  int piece = d[0] & 0xFF, rot = (d[0] >> 8) & 0xFF, x = (d[0] >> 16) & 0xFF, y = d[0] >> 24;
+  int val = d[1] & 0xFF;
+  uint32_t flags = (d[1] >> 8) & 0xFF;
+
+  float reward = 0.0f;
+  int lines = 0;
+  bool board_dirty = false;  // slab changed → write back
+  bool full_dirty = false;   // more than d[0]/d[1] changed → store the whole record
+  bool final_coll = false;   // NUMPY: the active piece collides at its final position (projection rule)
+  Rng r;
+  r.loaded = false;
+  r.dirty = false;
+
+  const bool pending = p.autoreset == TG_AUTORESET_NEXT_STEP && (flags & TG_F_PENDING_RESET);
+  const bool frozen = RULESET == TG_RULESET_FUNCTIONAL && (flags & TG_F_GAME_OVER);  // tetris_fn.py:284-289
+  if (pending) {
+    EnvS s;
+    raw_to_env(s, d);
+    env_reset<W, H, RULESET>(s, r, rp, slab_dw, lane, Q);
+    env_to_raw(s, d);
+    piece = s.piece; rot = 0; x = s.x; y = 0; val = s.val; flags = 0;
+    board_dirty = true;
+    full_dirty = true;
+  } else if (!frozen) {
+    const uint64_t row = p.shapes[piece];
+    const uint32_t shapeC = (uint32_t)(row >> (16 * rot)) & 0xFFFFu;
+    uint32_t e;
     if (RULESET == TG_RULESET_NUMPY) {
-      // mappings/actions.py:12-19; envs/tetris.py:223-256
-      switch (action) {
-        case 0: tx -= 1; check = true; break;
-        case 1: tx += 1; check = true; break;
-        case 2: ty += 1; check = true; break;
-        case 3: tr = (s.rot + 1) & 3; check = true; break;  // np.rot90(k=+1)
-        case 4: tr = (s.rot + 3) & 3; check = true; break;  // np.rot90(k=-1)
-        case 5: hard = true; break;
-        case 6:
-          if (!(s.flags & TG_F_HAS_SWAPPED)) {  // components/tetromino_holder.py:31-49
-            const int op = s.piece, orot = s.rot, ov = s.val;
-            if (s.hp == TG_NONE) {
-              tp = np_queue_pop(s, r, rp, Q);  // spawn_tetromino (collision result ignored, :248-250)
-              tr = 0;
-              tv = tp + 2;
-            } else {
-              tp = s.hp; tr = s.hr; tv = s.hv;
-            }
-            s.hp = op; s.hr = orot; s.hv = ov;
-            s.flags |= TG_F_HAS_SWAPPED;
-            tx = np_spawn_x<W>(tp);
-            ty = 0;
-            forced = true;
-          }
-          break;
-        default: break;  // 7 = no_op (ids outside 0..7 are rejected host-side; on device they are no-ops)
-      }
-      const uint32_t shapeT = c_shapes.mask[tp][tr];
-      const uint64_t m = test4<W, H>(slab, lane, shapeT, tx, ty, shapeC, s.x, s.y);
-      const bool cT = (m & 0xFFFFULL) != 0, cT1 = ((m >> 16) & 0xFFFFULL) != 0;
-      const bool cC1 = ((m >> 32) & 0xFFFFULL) != 0, cC = (m >> 48) != 0;
-      const bool accept = forced || (check && !cT);
-      if (accept) { s.piece = tp; s.rot = tr; s.x = tx; s.y = ty; s.val = tv; }
-      const uint32_t shape = accept ? shapeT : shapeC;
-      const bool coll_here = accept ? cT : cC;
-      const bool coll_below = accept ? cT1 : cC1;
-      bool commit = hard;
-      final_coll = coll_here;
-      if (p.gravity && !hard) {  // envs/tetris.py:259-264
-        if (!coll_below) { s.y += 1; final_coll = false; }
-        else commit = true;
-      }
-      if (commit) {  // envs/tetris.py:450-479 commit_active_tetromino
-        if (coll_here) {
-          reward = 0.0f;  // rewards.game_over
-          s.flags |= TG_F_GAME_OVER;
-        } else {
-          const uint64_t C = column_scan<W, H>(slab, lane, shape, s.x);
-          const int yd = drop_row(C, s.y);  // :445-448 step-wise drop
-          stamp<W, H>(slab, lane, shape, s.x, yd, (uint32_t)s.val, false);
-          wave_sync();
-          lines = clear_rows<W, H, RULESET>(slab, lane);
-          board_dirty = true;
-          const int np_ = np_queue_pop(s, r, rp, Q);  // :393-401 spawn_tetromino
-          s.piece = np_; s.rot = 0; s.val = np_ + 2;
-          s.x = np_spawn_x<W>(np_);
-          s.y = 0;
-          const bool sc = test1<W, H>(slab, lane, c_shapes.mask[np_][0], s.x, 0);
-          reward = (float)(lines * lines * W + 1);  // score + rewards.alife
-          if (sc) { s.flags |= TG_F_GAME_OVER; reward = 0.0f; }
-          else s.flags &= ~TG_F_GAME_OVER;
-          s.flags &= ~TG_F_HAS_SWAPPED;
-          final_coll = sc;
-        }
-      }
-    } else {
-      // envs/tetris_fn.py:161-273 update_state; lax.switch clamps its index, `action == 6` does not
-      const int branch = action < 0 ? 0 : (action > 6 ? 6 : action);
-      int drop_reward = 0;
-      bool lock = false;
-      uint32_t shape = shapeC;
-      if (branch == 6) {  // functional/core.py:230-251 hard_drop
-        const uint64_t C = column_scan<W, H>(slab, lane, shapeC, s.x);
-        const int yd = drop_row(C, s.y);
-        drop_reward = 2 * (yd - s.y);
-        s.y = yd;
-        lock = p.gravity || action == 6;  // blocked below by construction → should_lock iff gravity
+      e = (uint32_t)(kActLutNumpy >> (8 * (action & 7))) & 0xFFu;
+    } else {  // lax.switch clamps its index (envs/tetris_fn.py:214-241)
+      const int br = action < 0 ? 0 : (action > 6 ? 6 : action);
+      e = (uint32_t)(kActLutFn >> (8 * br)) & 0xFFu;
+    }
+    int tp = piece, tv = val;
+    int tx = x + (int)(e & 3u) - 1;
+    int ty = y + (int)((e >> 2) & 1u);
+    int tr = (rot + (int)((e >> 3) & 3u)) & 3;
+    const bool check = (e & 0x20u) != 0;
+    const bool hard = (e & 0x40u) != 0;
+    bool forced = false;
+    uint64_t rowT = row;
+    if (RULESET == TG_RULESET_NUMPY && (e & 0x80u) && !(flags & TG_F_HAS_SWAPPED)) {
+      // swap (envs/tetris.py:242-252, components/tetromino_holder.py:31-49)
+      EnvS s;
+      raw_to_env(s, d);
+      if (s.hp == TG_NONE) {
+        tp = np_queue_pop(s, r, rp, Q);  // spawn_tetromino; its collision result is ignored (:248-250)
+        tr = 0;
+        tv = tp + 2;
       } else {
-        switch (branch) {
-          case 0: tx -= 1; check = true; break;
-          case 1: tx += 1; check = true; break;
-          case 2: ty += 1; check = true; break;
-          case 3: tr = (s.rot + 3) & 3; check = true; break;  // rotation - 1
-          case 4: tr = (s.rot + 1) & 3; check = true; break;  // rotation + 1
-          default: break;                                       // 5 = do_nothing
-        }
-        const uint32_t shapeT = c_shapes.mask[s.piece][tr];
-        const uint64_t m = test4<W, H>(slab, lane, shapeT, tx, ty, shapeC, s.x, s.y);
-        const bool cT = (m & 0xFFFFULL) != 0, cT1 = ((m >> 16) & 0xFFFFULL) != 0;
-        const bool cC1 = ((m >> 32) & 0xFFFFULL) != 0;
-        const bool accept = check && !cT;
-        if (accept) { s.rot = tr; s.x = tx; s.y = ty; shape = shapeT; }
-        if (branch == 2 && accept) drop_reward = 1;
-        const bool coll_below = accept ? cT1 : cC1;
-        if (p.gravity) {  // functional/core.py:150-182 + tetris_fn.py:242-247
-          if (!coll_below) s.y += 1;
-          else lock = true;
-        }
+        tp = s.hp; tr = s.hr; tv = s.hv;
       }
+      s.hp = piece; s.hr = rot; s.hv = val;
+      env_to_raw(s, d);
+      flags |= TG_F_HAS_SWAPPED;
+      tx = np_spawn_x<W>(tp);
+      ty = 0;
+      forced = true;
+      full_dirty = true;
+      rowT = p.shapes[tp];
+    }
+    const uint32_t shapeT = (uint32_t)(rowT >> (16 * tr)) & 0xFFFFu;
+
+    if (RULESET == TG_RULESET_FUNCTIONAL && hard) {
+      // functional/core.py:230-251 hard_drop, then lock (tetris_fn.py:263-269)
+      const uint64_t C = column_scan<W, H>(slab, lane, shapeC, x);
+      const int yd = drop_row(C, y);
+      const int drop_reward = 2 * (yd - y);
+      y = yd;
       int lock_reward = 0;
-      if (lock) {  // envs/tetris_fn.py:370-413 place_active_tetromino
-        stamp<W, H>(slab, lane, shape, s.x, s.y, (uint32_t)(s.piece + 2), true);
+      if (p.gravity || action == 6) {
+        EnvS s;
+        raw_to_env(s, d);
+        s.piece = piece; s.rot = rot; s.x = x; s.y = y; s.flags = (int)flags;
+        // (shared lock code below, functional flavour)
+        stamp<W, H>(slab, lane, shapeC, x, y, (uint32_t)(piece + 2), true);
         wave_sync();
         lines = clear_rows<W, H, RULESET>(slab, lane);
         board_dirty = true;
-        lock_reward = lines == 4 ? 800 : (lines > 0 ? lines * 200 - 100 : 0);  // core.py:124-146
+        lock_reward = lines == 4 ? 800 : (lines > 0 ? lines * 200 - 100 : 0);
         rng_load(r, rp);
         uint32_t a0, a1;
-        threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);  // split(rng_key)[0] → new rng_key (:399)
-        if (s.bidx >= 7) {                         // functional/queue.py:59-67 refill from split(rng_key)[1]
+        threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);
+        if (s.bidx >= 7) {
           uint32_t b0, b1;
           threefry2x32(r.k0, r.k1, 0u, 1u, b0, b1);
           s.bag = jax_permutation7(b0, b1);
@@ -605,33 +676,139 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const KParams p) {
         s.bidx += 1;
         r.k0 = a0; r.k1 = a1;
         r.dirty = true;
-        s.rot = 0; s.val = s.piece + 2;
-        s.x = (W + 8) / 2 - 2;
-        s.y = 0;
-        if (test1<W, H>(slab, lane, c_shapes.mask[s.piece][0], s.x, 0)) s.flags |= TG_F_GAME_OVER;
+        s.rot = 0; s.val = s.piece + 2; s.x = (W + 8) / 2 - 2; s.y = 0;
+        if (test1<W, H>(slab, lane, (uint32_t)p.shapes[s.piece] & 0xFFFFu, s.x, 0)) s.flags |= TG_F_GAME_OVER;
+        piece = s.piece; rot = 0; x = s.x; y = 0; val = s.val; flags = (uint32_t)s.flags;
+        const float old = s.score;
+        float t = old + (float)drop_reward;
+        t = t + (float)lock_reward;
+        s.score = t;
+        reward = t - old;
+        env_to_raw(s, d);
+        full_dirty = true;
+      } else {
+        float old = __uint_as_float(d[6]);
+        float t = old + (float)drop_reward;
+        t = t + 0.0f;
+        d[6] = __float_as_uint(t);
+        reward = t - old;
+        full_dirty = true;
       }
-      const float old = s.score;
-      float t = old + (float)drop_reward;
-      t = t + (float)lock_reward;
-      s.score = t;
-      reward = t - old;  // tetris_fn.py:312
+    } else {
+      const uint64_t m = test4<W, H>(slab, lane, shapeT, tx, ty, shapeC, x, y);
+      const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+      const bool accept = forced || (check && (lo & 0xFFFFu) == 0);
+      uint32_t shape = shapeC;
+      bool coll_here, coll_below;
+      if (accept) {
+        piece = tp; rot = tr; x = tx; y = ty; val = tv; shape = shapeT;
+        coll_here = (lo & 0xFFFFu) != 0;
+        coll_below = (lo >> 16) != 0;
+      } else {
+        coll_here = (hi & 0xFFFFu) != 0;
+        coll_below = (hi >> 16) != 0;
+      }
+      bool lock = false;
+      if (RULESET == TG_RULESET_NUMPY) {
+        final_coll = coll_here;
+        lock = hard;
+        if (p.gravity && !hard) {  // envs/tetris.py:259-264
+          if (!coll_below) { y += 1; final_coll = false; }
+          else lock = true;
+        }
+      } else {
+        if (p.gravity) {  // functional/core.py:150-182 + tetris_fn.py:242-247
+          if (!coll_below) y += 1;
+          else lock = true;
+        }
+      }
+      int drop_reward = (RULESET == TG_RULESET_FUNCTIONAL && accept && (e & 4u)) ? 1 : 0;
+      int lock_reward = 0;
+      if (lock) {
+        EnvS s;
+        raw_to_env(s, d);
+        s.flags = (int)flags;
+        if (RULESET == TG_RULESET_NUMPY) {  // envs/tetris.py:450-479 commit_active_tetromino
+          if (coll_here) {
+            reward = 0.0f;  // rewards.game_over
+            flags |= TG_F_GAME_OVER;
+          } else {
+            const uint64_t C = column_scan<W, H>(slab, lane, shape, x);
+            const int yd = drop_row(C, y);  // :445-448 step-wise drop
+            stamp<W, H>(slab, lane, shape, x, yd, (uint32_t)val, false);
+            wave_sync();
+            lines = clear_rows<W, H, RULESET>(slab, lane);
+            board_dirty = true;
+            const int np_ = np_queue_pop(s, r, rp, Q);  // :393-401 spawn_tetromino
+            piece = np_; rot = 0; val = np_ + 2; x = np_spawn_x<W>(np_); y = 0;
+            const bool sc = test1<W, H>(slab, lane, (uint32_t)p.shapes[np_] & 0xFFFFu, x, 0);
+            reward = (float)(lines * lines * W + 1);  // score + rewards.alife
+            if (sc) { flags |= TG_F_GAME_OVER; reward = 0.0f; }
+            else flags &= ~(uint32_t)TG_F_GAME_OVER;
+            flags &= ~(uint32_t)TG_F_HAS_SWAPPED;
+            final_coll = sc;
+            s.piece = piece; s.rot = 0; s.x = x; s.y = 0; s.val = val; s.flags = (int)flags;
+            env_to_raw(s, d);
+            full_dirty = true;
+          }
+        } else {  // envs/tetris_fn.py:370-413 place_active_tetromino
+          stamp<W, H>(slab, lane, shape, x, y, (uint32_t)(piece + 2), true);
+          wave_sync();
+          lines = clear_rows<W, H, RULESET>(slab, lane);
+          board_dirty = true;
+          lock_reward = lines == 4 ? 800 : (lines > 0 ? lines * 200 - 100 : 0);  // core.py:124-146
+          rng_load(r, rp);
+          uint32_t a0, a1;
+          threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);  // split(rng_key)[0] → new rng_key (:399)
+          if (s.bidx >= 7) {                         // functional/queue.py:59-67 refill from split(rng_key)[1]
+            uint32_t b0, b1;
+            threefry2x32(r.k0, r.k1, 0u, 1u, b0, b1);
+            s.bag = jax_permutation7(b0, b1);
+            s.bidx = 0;
+          }
+          piece = (int)((s.bag >> (8 * s.bidx)) & 0xFF);
+          s.bidx += 1;
+          r.k0 = a0; r.k1 = a1;
+          r.dirty = true;
+          rot = 0; val = piece + 2; x = (W + 8) / 2 - 2; y = 0;
+          if (test1<W, H>(slab, lane, (uint32_t)p.shapes[piece] & 0xFFFFu, x, 0)) flags |= TG_F_GAME_OVER;
+          s.piece = piece; s.rot = 0; s.x = x; s.y = 0; s.val = val; s.flags = (int)flags;
+          env_to_raw(s, d);
+          full_dirty = true;
+        }
+      }
+      if (RULESET == TG_RULESET_FUNCTIONAL) {
+        const float old = __uint_as_float(d[6]);
+        float t = old + (float)drop_reward;
+        t = t + (float)lock_reward;
+        if (t != old) { d[6] = __float_as_uint(t); full_dirty = true; }
+        reward = t - old;  // tetris_fn.py:312
+      }
     }
   }
 
-  const int terminated = (s.flags & TG_F_GAME_OVER) ? 1 : 0;
-  const size_t obs_stride = (size_t)G::CELLS;
-  if (terminated && p.autoreset == TG_AUTORESET_SAME_STEP) {
-    if (p.final_obs) {
-      const bool show = RULESET == TG_RULESET_NUMPY ? !final_coll : false;
-      if (board_dirty) wave_sync();
-      emit_obs<W, H>(slab, lane, p.final_obs + (size_t)env * obs_stride, p.obs_mode, show,
-                     c_shapes.mask[s.piece][s.rot], s.x, s.y, s.val);
+  const int terminated = (flags & TG_F_GAME_OVER) ? 1 : 0;
+  if (terminated && p.autoreset != TG_AUTORESET_NONE) {
+    if (p.autoreset == TG_AUTORESET_SAME_STEP) {
+      if (p.final_obs) {
+        const bool show = RULESET == TG_RULESET_NUMPY ? !final_coll : false;
+        if (board_dirty) wave_sync();
+        emit_obs<W, H>(slab, lane, p.final_obs + boff, p.obs_mode, show,
+                       (uint32_t)(p.shapes[piece] >> (16 * rot)) & 0xFFFFu, x, y, val);
+      }
+      EnvS s;
+      d[0] = (uint32_t)piece | ((uint32_t)rot << 8) | ((uint32_t)x << 16) | ((uint32_t)y << 24);
+      d[1] = (d[1] & 0xFFFF0000u) | (uint32_t)val | (flags << 8);
+      raw_to_env(s, d);
+      env_reset<W, H, RULESET>(s, r, rp, slab_dw, lane, Q);
+      env_to_raw(s, d);
+      piece = s.piece; rot = 0; x = s.x; y = 0; val = s.val; flags = 0;
+      board_dirty = true;
+      full_dirty = true;
+      final_coll = false;
+    } else {
+      flags |= TG_F_PENDING_RESET;
     }
-    env_reset<W, H, RULESET>(s, r, rp, slab_dw, lane, Q);
-    board_dirty = true;
-    final_coll = false;
-  } else if (terminated && p.autoreset == TG_AUTORESET_NEXT_STEP) {
-    s.flags |= TG_F_PENDING_RESET;
   }
 
   if (board_dirty) {  // write the slab back (only on lock / reset: ~18 % of random-policy steps)
@@ -643,23 +820,64 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const KParams p) {
     }
   }
   {
-    const bool show = RULESET == TG_RULESET_NUMPY ? !final_coll : !(s.flags & TG_F_GAME_OVER);
-    emit_obs<W, H>(slab, lane, p.obs + (size_t)env * obs_stride, p.obs_mode, show, c_shapes.mask[s.piece][s.rot],
-                   s.x, s.y, s.val);
+    const bool show = RULESET == TG_RULESET_NUMPY ? !final_coll : !(flags & TG_F_GAME_OVER);
+    emit_obs<W, H>(slab, lane, p.obs + boff, p.obs_mode, show, (uint32_t)(p.shapes[piece] >> (16 * rot)) & 0xFFFFu, x,
+                   y, val);
   }
-  rec_pack(s, p.rec + (size_t)env * 8, lane);
+  d[0] = (uint32_t)piece | ((uint32_t)rot << 8) | ((uint32_t)x << 16) | ((uint32_t)y << 24);
+  d[1] = (d[1] & 0xFFFF0000u) | (uint32_t)val | (flags << 8);
   rng_store(r, p.rng + env, lane);
   if (lane == 0) {
-    p.reward[env] = reward;
-    p.terminated[env] = (uint8_t)terminated;
-    p.lines[env] = (uint8_t)lines;
-    if (p.episode) {
-      tg_episode_rec e = p.episode[env];
-      e.ret += reward;
-      e.len += 1;
-      if (terminated) { e.last_ret = e.ret; e.last_len = e.len; e.ret = 0.0f; e.len = 0; }
-      p.episode[env] = e;
+    uint32_t* rec_out = p.rec + env * 8u;
+    if (full_dirty) {
+      *reinterpret_cast<uint4*>(rec_out) = make_uint4(d[0], d[1], d[2], d[3]);
+      *reinterpret_cast<uint4*>(rec_out + 4) = make_uint4(d[4], d[5], d[6], d[7]);
+    } else {
+      *reinterpret_cast<uint2*>(rec_out) = make_uint2(d[0], d[1]);
     }
+    p.out[env] = make_uint2(__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8));
+    if (p.episode) {
+      tg_episode_rec ep = p.episode[env];
+      ep.ret += reward;
+      ep.len += 1;
+      if (terminated) { ep.last_ret = ep.ret; ep.last_len = ep.len; ep.ret = 0.0f; ep.len = 0; }
+      p.episode[env] = ep;
+    }
+  }
+}
+
+// Persistent launch: a fixed grid of waves, each walking envs  wave_id, wave_id + n_waves, ...  with the
+// next env's slab / record / action already in flight while the current one is processed (the loads of
+// env i+1 are issued before env i is touched).  Measured reason (profiles/r01_*): with one short-lived
+// wave per env the kernel was bound by wave launch rate and by the serial load→use chains of each
+// wave, with only half of the wave slots occupied on average.
+template <int W, int H, int RULESET>
+__global__ __launch_bounds__(kBlock) void step_kernel(const KParams p) {
+  using G = Geo<W, H>;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * G::LDS_SLAB];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = rfl((uint32_t)threadIdx.x) >> 6;
+  const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+  const uint32_t B = (uint32_t)p.batch;
+  uint32_t env = blockIdx.x * kWavesPerBlock + wave;
+  if (env >= B) return;
+  uint8_t* slab = lds + wave * G::LDS_SLAB;
+  uint32_t bv[G::DPL];
+  uint32_t recv;
+  load_env<W, H>(p, env, lane, bv, recv);
+  for (;;) {
+    const uint32_t nenv = env + n_waves;
+    const bool last = nenv >= B;
+    uint32_t nbv[G::DPL] = {};
+    uint32_t nrecv = 0;
+    if (!last) load_env<W, H>(p, nenv, lane, nbv, nrecv);  // prefetch the next env of this wave
+    process_env<W, H, RULESET>(p, env, lane, slab, bv, recv);
+    if (last) break;
+#pragma unroll
+    for (int k = 0; k < G::DPL; ++k) bv[k] = nbv[k];
+    recv = nrecv;
+    env = nenv;
+    wave_sync();
   }
 }
 
@@ -669,13 +887,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const KParams p) {
 template <int W, int H, int RULESET>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const ResetParams p) {
   using G = Geo<W, H>;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * G::SLAB];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * G::LDS_SLAB];
   const int lane = threadIdx.x & 63;
   const int wave = rfl((int)(threadIdx.x >> 6));
   const int env = blockIdx.x * kWavesPerBlock + wave;
   if (env >= p.batch) return;
   if (p.mask && rfl((int)p.mask[env]) == 0) return;
-  uint8_t* slab = lds + wave * G::SLAB;
+  uint8_t* slab = lds + wave * G::LDS_SLAB;
   uint32_t* slab_dw = reinterpret_cast<uint32_t*>(slab);
   EnvS s;
   rec_unpack(s, p.rec + (size_t)env * 8);
@@ -722,12 +940,12 @@ struct ObserveParams {
 template <int W, int H>
 __global__ __launch_bounds__(kBlock) void observe_kernel(const ObserveParams p) {
   using G = Geo<W, H>;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * G::SLAB];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * G::LDS_SLAB];
   const int lane = threadIdx.x & 63;
   const int wave = rfl((int)(threadIdx.x >> 6));
   const int env = blockIdx.x * kWavesPerBlock + wave;
   if (env >= p.batch) return;
-  uint8_t* slab = lds + wave * G::SLAB;
+  uint8_t* slab = lds + wave * G::LDS_SLAB;
   uint32_t* slab_dw = reinterpret_cast<uint32_t*>(slab);
   const uint32_t* gboard = reinterpret_cast<const uint32_t*>(p.board + (size_t)env * G::CELLS);
 #pragma unroll

@@ -20,7 +20,8 @@ class Engine:
     """
 
     def __init__(self, batch, width=10, height=20, *, ruleset=N.RULESET_NUMPY, gravity=True, queue_size=None,
-                 obs_mode=None, autoreset=N.AUTORESET_NONE, device=0, env_offset=0, padding=4):
+                 obs_mode=None, autoreset=N.AUTORESET_NONE, device=0, env_offset=0, padding=4, episode_stats=False,
+                 final_obs=False):
         self.lib = N.load()
         if queue_size is None:
             queue_size = 4 if ruleset == N.RULESET_NUMPY else 7
@@ -32,6 +33,7 @@ class Engine:
         cfg.gravity, cfg.ruleset, cfg.obs_mode, cfg.autoreset = int(bool(gravity)), ruleset, obs_mode, autoreset
         cfg.action_set, cfg.batch, cfg.device, cfg.env_offset = N.ACTIONS_BASE, batch, device, env_offset
         cfg.grouped_terminate_on_illegal = 1
+        cfg.flags = (N.FLAG_EPISODE_STATS if episode_stats else 0) | (N.FLAG_FINAL_OBS if final_obs else 0)
         self.cfg = cfg
         self.B, self.W, self.H, self.P, self.Q = batch, width, height, padding, queue_size
         self.Wp, self.Hp = width + 2 * padding, height + padding
@@ -88,13 +90,10 @@ class Engine:
         return self.fetch_outputs()
 
     def fetch_outputs(self):
-        rew = np.empty(self.B, np.float32)
-        term = np.empty(self.B, np.uint8)
-        lines = np.empty(self.B, np.uint8)
-        self._chk(self.lib.tg_fetch(self.h, N.BUF_REWARD, N.ptr(rew), rew.nbytes), "tg_fetch(reward)")
-        self._chk(self.lib.tg_fetch(self.h, N.BUF_TERMINATED, N.ptr(term), term.nbytes), "tg_fetch(terminated)")
-        self._chk(self.lib.tg_fetch(self.h, N.BUF_LINES, N.ptr(lines), lines.nbytes), "tg_fetch(lines)")
-        return rew, term, lines
+        out = np.empty(self.B, N.STEP_OUT)
+        self._chk(self.lib.tg_fetch(self.h, N.BUF_STEP_OUT, N.ptr(out), out.nbytes), "tg_fetch(step_out)")
+        return (np.ascontiguousarray(out["reward"]), np.ascontiguousarray(out["terminated"]),
+                np.ascontiguousarray(out["lines"]))
 
     # -- observations --------------------------------------------------------------------------
     def _fetch(self, which, arr):
