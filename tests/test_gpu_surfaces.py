@@ -1,0 +1,276 @@
+"""GPU tests of the three Python surfaces: the reference's own tests restated against the drop-in
+`Tetris` class and the functional `reset/step/batched_*`, plus the VectorEnv adapter against the oracle."""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+from tetris_gymnasium_amd import _native as N  # noqa: E402
+from tetris_gymnasium_amd.components.tetromino import make_tetromino  # noqa: E402
+from tetris_gymnasium_amd.envs import Tetris  # noqa: E402
+from tetris_gymnasium_amd.envs.tetris_fn import PRNGKey, batched_reset, batched_step, reset, step  # noqa: E402
+from tetris_gymnasium_amd.functional import TETROMINOES, EnvConfig  # noqa: E402
+from tetris_gymnasium_amd.mappings.actions import ActionsMapping  # noqa: E402
+from tetris_gymnasium_amd.mappings.rewards import RewardsMapping  # noqa: E402
+from tetris_gymnasium_amd.vector import TetrisVectorEnv  # noqa: E402
+
+
+@pytest.fixture
+def tetris_env():
+    env = Tetris(render_mode="ansi")
+    env.reset(seed=42)
+    yield env
+    env.close()
+
+
+@pytest.fixture
+def tetris_env_no_gravity():
+    env = Tetris(render_mode="ansi", gravity=False)
+    env.reset(seed=42)
+    yield env
+    env.close()
+
+
+def vertical_i():  # tests/conftest.py:37-42 (binary cell values!)
+    return make_tetromino(0, 1, 1)
+
+
+# ---------------- NumPy env: reference tests/test_base_env/** restated ----------------
+def test_reset_matches_reference_probe(tetris_env):
+    # SURVEY §8c probe: seed 42 ⇒ stream 3 2 6 4 1 5 0 | 3 6 ...; active = stream[0], queue = stream[1..4]
+    e = tetris_env
+    assert e.active_tetromino.id == 5 and list(e.queue.queue) == [2, 6, 4, 1]
+    assert (e.x, e.y) == (8, 0) and list(e.randomizer.bag) == [3, 2, 6, 4, 1, 5, 0] and e.randomizer.index == 5
+
+
+def test_observation_dict_shapes(tetris_env):  # test_base_env_general.py:13-36
+    obs, info = tetris_env.reset(seed=42)
+    assert set(obs) == {"board", "active_tetromino_mask", "holder", "queue"}
+    assert obs["board"].shape == (24, 18) and obs["holder"].shape == (4, 4) and obs["queue"].shape == (4, 16)
+    assert obs["active_tetromino_mask"].sum() == 9  # bounding box of a 3x3 matrix
+    assert (obs["holder"] == 1).all() and info == {"lines_cleared": 0}
+
+
+def test_movement(tetris_env, tetris_env_no_gravity):  # actions/test_base_env_movement.py
+    e = tetris_env
+    e.x = 5; e.step(ActionsMapping.move_right); assert e.x == 6
+    e.reset(seed=42); e.x = 5; e.step(ActionsMapping.move_left); assert e.x == 4
+    e.reset(seed=42); e.y = 5; e.step(ActionsMapping.move_down); assert e.y == 7  # move + gravity
+    e.reset(seed=42); e.x = e.width + e.padding - 1; e.step(ActionsMapping.move_right); assert e.x == e.width + e.padding - 1
+    e.reset(seed=42); e.x = e.padding; e.step(ActionsMapping.move_left); assert e.x == e.padding
+    e.reset(seed=42); e.x = 5; e.board[0:e.height, e.x + 1:e.x + 5] = 2; e.step(ActionsMapping.move_right); assert e.x == 5
+    e.reset(seed=42); e.y = 5; e.board[e.y + 1:e.y + 5, 0:e.width] = 2; e.step(ActionsMapping.move_down); assert e.y == 5
+    e.reset(seed=42); e.y = 0; e.step(ActionsMapping.no_op); assert e.y == 1
+    g = tetris_env_no_gravity
+    g.y = 5; g.step(ActionsMapping.move_down); assert g.y == 6
+    g.reset(seed=42); sx = g.width_padded // 2; g.x = sx
+    for _ in range(3):
+        g.step(ActionsMapping.move_left)
+    assert g.x == sx - 3
+
+
+def test_rotation(tetris_env, tetris_env_no_gravity):  # actions/test_base_env_rotation.py
+    e = tetris_env
+    m = np.copy(e.active_tetromino.matrix)
+    e.step(ActionsMapping.rotate_clockwise)
+    assert np.all(np.rot90(m) == e.active_tetromino.matrix)
+    e.reset(seed=42); m = np.copy(e.active_tetromino.matrix)
+    e.step(ActionsMapping.rotate_counterclockwise)
+    assert np.array_equal(np.rot90(m, -1), e.active_tetromino.matrix)
+    e.reset(seed=42); e.board[0:e.height, e.x:e.x + 4] = 2; t = copy.copy(e.active_tetromino)
+    e.step(ActionsMapping.rotate_clockwise)
+    assert np.array_equal(t.matrix, e.active_tetromino.matrix)
+    g = tetris_env_no_gravity
+    g.x = 0; t = copy.copy(g.active_tetromino); g.step(ActionsMapping.rotate_clockwise)
+    assert np.array_equal(t.matrix, g.active_tetromino.matrix)
+    g.reset(seed=42); m = np.copy(g.active_tetromino.matrix)
+    for _ in range(4):
+        g.step(ActionsMapping.rotate_clockwise)
+    assert np.array_equal(m, g.active_tetromino.matrix)
+
+
+def test_line_clear_rewards(tetris_env):  # reward/test_base_env_line_clear.py:9-89 (161 / 41 / 1)
+    e = tetris_env
+    cleared = np.copy(e.board)
+    vi = vertical_i()
+    e.board[e.height - vi.matrix.shape[0]:-e.padding, e.padding:-e.padding - 1] = 2
+    e.active_tetromino = vi
+    e.x = e.width + e.padding - 2
+    obs, reward, term, trunc, info = e.step(ActionsMapping.hard_drop)
+    assert np.array_equal(e.board, cleared) and reward == 161 and not term and not trunc and info["lines_cleared"] == 4
+    assert e.x == e.width_padded // 2 - e.active_tetromino.matrix.shape[0] // 2 and e.y == 0
+    e.reset(seed=42)
+    e.board[e.height - 2:e.height, e.padding:-e.padding - 2] = 2
+    e.active_tetromino = copy.deepcopy(e.tetrominoes[1]); e.x = e.width + e.padding - 2
+    _, reward, _, _, info = e.step(ActionsMapping.hard_drop)
+    assert info["lines_cleared"] == 2 and reward == 41
+    e.reset(seed=42)
+    _, reward, _, _, info = e.step(ActionsMapping.hard_drop)
+    assert info["lines_cleared"] == 0 and reward == RewardsMapping.alife
+
+
+def test_game_over(tetris_env):  # termination/test_base_env_game_over.py + reward/test_base_env_scoring.py:34-47
+    e = tetris_env
+    o = copy.deepcopy(Tetris.TETROMINOES[1])
+    e.board[2:e.height, e.padding:-(e.padding + 1)] = 2
+    e.active_tetromino = o; e.x = e.width_padded // 2 - 1; e.y = 0
+    _, reward, term, _, _ = e.step(ActionsMapping.hard_drop)
+    assert term and reward == RewardsMapping.game_over
+    e.reset(seed=42)
+    e.board[0:e.height, e.padding:-e.padding] = 2
+    _, reward, term, _, _ = e.step(ActionsMapping.hard_drop)
+    assert term and reward == 0 and e.game_over
+    obs, info = e.reset(seed=42)
+    assert not e.game_over and (e.board[:e.height, e.padding:-e.padding] == 0).all()
+    assert [e.score(n) for n in (1, 2, 3, 4)] == [10, 40, 90, 160]
+
+
+def test_swap(tetris_env, tetris_env_no_gravity):  # actions/test_base_env_swap.py
+    e = tetris_env
+    first = e.active_tetromino.id
+    assert len(e.holder.get_tetrominoes()) == 0
+    e.step(ActionsMapping.swap)
+    assert [t.id for t in e.holder.get_tetrominoes()] == [first] and e.has_swapped
+    after = e.active_tetromino.id
+    e.step(ActionsMapping.swap)
+    assert e.active_tetromino.id == after  # blocked
+    e.step(ActionsMapping.hard_drop)
+    assert not e.has_swapped
+    e.step(ActionsMapping.swap)
+    assert e.active_tetromino.id == first
+    g = tetris_env_no_gravity
+    g.y = 5; g.x = g.padding + 2; g.step(ActionsMapping.hard_drop); g.step(ActionsMapping.swap)
+    g.step(ActionsMapping.hard_drop); g.y = 5; g.x = g.padding + 3; g.step(ActionsMapping.swap)
+    assert g.x == g.width_padded // 2 - g.active_tetromino.matrix.shape[0] // 2 and g.y == 0
+
+
+def test_action_space_assert_and_state_clone(tetris_env):  # test_base_env_action_space.py + general.py:139-172
+    e = tetris_env
+    with pytest.raises(AssertionError):
+        e.step(8)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        e.step(int(rng.integers(0, 8)))
+    snap = e.get_state()
+    acts = [int(rng.integers(0, 8)) for _ in range(60)]
+    out1 = [e.step(a)[1:3] for a in acts]
+    b1 = e.board.copy()
+    e.set_state(snap)
+    out2 = [e.step(a)[1:3] for a in acts]
+    assert out1 == out2 and np.array_equal(b1, e.board)
+    assert isinstance(e.render(), str) and len(e.render().split("\n")) == 20
+
+
+def test_tetris_class_equals_oracle_trajectory():
+    e = Tetris(); o = po.OracleBatch(1)
+    e.reset(seed=7); o.reset(np.array([7], np.uint64))
+    rng = np.random.default_rng(1)
+    for t in range(400):
+        a = int(rng.integers(0, 8))
+        obs, r, term, _, info = e.step(a)
+        ro, to, lo = o.step(np.array([a]))
+        od = o.observe(po.OBS_DICT)
+        assert r == ro[0] and term == bool(to[0]) and info["lines_cleared"] == lo[0]
+        for k in od:
+            np.testing.assert_array_equal(obs[k], od[k][0], err_msg=f"{k} t={t}")
+        if term:
+            e.reset(); o.reset(mask=np.array([1], np.uint8))
+    e.close()
+
+
+# ---------------- functional surface ----------------
+CFG = EnvConfig(width=10, height=20, padding=4, queue_size=7, gravity_enabled=True)
+CFG_NG = EnvConfig(width=10, height=20, padding=4, queue_size=7, gravity_enabled=False)
+
+
+def test_fn_reset_step_contract():  # tests/test_functional/test_env/test_reset.py, test_step.py
+    key, state, obs = reset(TETROMINOES, PRNGKey(42), CFG)
+    assert key.shape == (2,) and obs.shape == (20, 10) and obs.dtype == np.int8 and (obs == -1).sum() == 4
+    assert state.board.shape == (24, 18) and state.board.dtype == np.int8 and int(state.x) == 7 and int(state.y) == 0
+    assert sorted(state.queue) == list(range(7)) and int(state.queue_index) == 1 and not bool(state.game_over)
+    _, state2, _ = reset(TETROMINOES, PRNGKey(42), CFG)
+    assert all(np.array_equal(getattr(state, f), getattr(state2, f)) for f in ("board", "queue", "rng_key"))
+    new_state, obs, reward, terminated, info = step(TETROMINOES, state, 5, CFG)
+    assert "lines_cleared" in info and float(reward) == float(new_state.score) - float(state.score)
+    assert int(new_state.y) == 1 and int(state.y) == 0  # input not mutated
+    over = state.replace(game_over=np.bool_(True))
+    ns, obs, reward, terminated, _ = step(TETROMINOES, over, 0, CFG)
+    assert bool(terminated) and float(reward) == 0.0 and np.array_equal(ns.board, over.board) and (obs == -1).sum() == 0
+    s4, *_ = step(TETROMINOES, state, 4, CFG_NG); assert int(s4.rotation) == 1   # test_rotation.py:9-19
+    s3, *_ = step(TETROMINOES, state, 3, CFG_NG); assert int(s3.rotation) == 3
+    hd, _, reward, _, _ = step(TETROMINOES, state, 6, CFG_NG)
+    assert int(hd.y) == 0 and float(reward) > 0 and (hd.board[:20, 4:14] > 0).sum() == 4
+
+
+def test_fn_batched_equals_sequential_and_oracle():  # tests/test_functional/test_batched.py:64-89
+    B = 4
+    keys = np.stack([PRNGKey(s) for s in (1, 2, 3, 4)])
+    _, states, obs = batched_reset(TETROMINOES, keys, config=CFG, batch_size=B)
+    assert obs.shape == (B, 20, 10) and states.board.shape == (B, 24, 18)
+    singles = [reset(TETROMINOES, k, CFG)[1] for k in keys]
+    o = po.OracleBatch(B, 10, 20, po.RULESET_FUNCTIONAL)
+    o.reset((keys[:, 0].astype(np.uint64) << np.uint64(32)) | keys[:, 1].astype(np.uint64))
+    rng = np.random.default_rng(0)
+    for t in range(60):
+        a = rng.integers(0, 7, B)
+        states, obs, rew, term, info = batched_step(TETROMINOES, states, a, config=CFG)
+        ro, to, lo = o.step(a)
+        np.testing.assert_array_equal(rew, ro); np.testing.assert_array_equal(term, to.astype(bool))
+        np.testing.assert_array_equal(obs, o.observe(po.OBS_FN))
+        for i in range(B):
+            singles[i], so, sr, st, si = step(TETROMINOES, singles[i], int(a[i]), CFG)
+            assert np.array_equal(so, obs[i]) and sr == rew[i] and st == term[i]
+            assert np.array_equal(singles[i].board, states.board[i]) and float(singles[i].score) == float(states.score[i])
+
+
+# ---------------- vector env ----------------
+@pytest.mark.parametrize("mode", ["next_step", "same_step"])
+def test_vector_env_matches_oracle(mode):
+    B = 192
+    env = TetrisVectorEnv(B, autoreset_mode=mode, devices=(0,))
+    obs, info = env.reset(seed=11)
+    o = po.OracleBatch(B)
+    o.reset(np.arange(11, 11 + B, dtype=np.uint64))
+    assert env.single_action_space.n == 8 and obs["board"].shape == (B, 24, 18)
+    rng = np.random.default_rng(3)
+    ar = po.AUTORESET_NEXT_STEP if mode == "next_step" else po.AUTORESET_SAME_STEP
+    ret = np.zeros(B); ln = np.zeros(B, int); n_eps = 0
+    for t in range(300):
+        a = rng.integers(0, 8, B)
+        obs, rew, term, trunc, infos = env.step(a)
+        ro, to, lo = o.step(a, autoreset=ar)
+        od = o.observe(po.OBS_DICT)
+        np.testing.assert_array_equal(rew, ro); np.testing.assert_array_equal(term, to.astype(bool))
+        np.testing.assert_array_equal(infos["lines_cleared"], lo); assert not trunc.any()
+        for k in od:
+            np.testing.assert_array_equal(obs[k], od[k], err_msg=f"{k} t={t}")
+        ret += rew; ln += 1
+        if term.any():
+            np.testing.assert_array_equal(infos["_episode"], term)
+            np.testing.assert_allclose(infos["episode"]["r"][term], ret[term])
+            np.testing.assert_array_equal(infos["episode"]["l"][term], ln[term])
+            n_eps += int(term.sum()); ret[term] = 0; ln[term] = 0
+    assert n_eps > B
+    env.close()
+
+
+def test_vector_env_sharding_is_transparent():
+    """Two shards on the same GPU (env_offset set) reproduce the unsharded batch: results are independent of the
+    number of devices."""
+    B = 256
+    one = TetrisVectorEnv(B, observation="board", autoreset_mode="same_step", devices=(0,))
+    two = TetrisVectorEnv(B, observation="board", autoreset_mode="same_step", devices=(0, 0))
+    assert two.ranges == [(0, 128), (128, 256)]
+    o1, _ = one.reset(seed=5); o2, _ = two.reset(seed=5)
+    np.testing.assert_array_equal(o1, o2)
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        a = rng.integers(0, 8, B)
+        r1, r2 = one.step(a), two.step(a)
+        for x, y in zip(r1[:4], r2[:4]):
+            np.testing.assert_array_equal(x, y)
+    one.close(); two.close()

@@ -1,0 +1,132 @@
+"""`TetrisVectorEnv`: a gymnasium.vector.VectorEnv adapter over the HIP engine (no reference counterpart —
+the reference only ever uses gymnasium's generic SyncVectorEnv: examples/train_ppo.py:185-190).
+
+All `num_envs` environments live on the GPU(s); `step(actions)` is one kernel launch per device.  With
+several devices the env batch is sharded by contiguous ranges (env i → device i // (num_envs / n_dev)), no
+collective: envs are independent.  Consumes/produces what the reference's trainers use: `reset(seed=...)`,
+`step(actions)` → (obs, rewards, terminations, truncations, infos) with `infos["lines_cleared"]`,
+`infos["episode"]` / `infos["_episode"]` (RecordEpisodeStatistics convention), `single_action_space`,
+`single_observation_space`.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _native as N
+from ._gym_compat import HAVE_GYMNASIUM, VectorEnvBase, spaces
+from .engine import Engine
+
+_OBS = {"dict": N.OBS_DICT, "board": N.OBS_BOARD, "functional": N.OBS_FN}
+_AUTORESET = {"next_step": N.AUTORESET_NEXT_STEP, "same_step": N.AUTORESET_SAME_STEP, "disabled": N.AUTORESET_NONE}
+
+
+def shard_ranges(num_envs: int, n_shards: int):
+    """Contiguous, balanced env ranges: shard k owns [lo_k, hi_k).  (env i → GPU i // (B/G))"""
+    base, extra = divmod(num_envs, n_shards)
+    out, lo = [], 0
+    for k in range(n_shards):
+        hi = lo + base + (1 if k < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def default_seeds(lo: int, hi: int, seed=None) -> np.ndarray:
+    """Env i gets seed `seed + i` (gymnasium vector convention); global index ⇒ results do not depend on
+    the number of devices.  seed=None → 1 + i."""
+    base = 1 if seed is None else int(seed)
+    return np.arange(base + lo, base + hi, dtype=np.uint64)
+
+
+class TetrisVectorEnv(VectorEnvBase):
+    metadata = {"render_modes": [], "autoreset_mode": "next_step"}
+
+    def __init__(self, num_envs: int, width: int = 10, height: int = 20, gravity: bool = True, *,
+                 ruleset: str = "numpy", observation: str = "dict", queue_size: int | None = None,
+                 autoreset_mode: str = "next_step", devices=(0,), episode_stats: bool = True):
+        self.num_envs = int(num_envs)
+        self.width, self.height = width, height
+        self.ruleset = N.RULESET_NUMPY if ruleset == "numpy" else N.RULESET_FUNCTIONAL
+        self.obs_kind = observation
+        self.autoreset_mode = autoreset_mode
+        self.metadata = dict(self.metadata, autoreset_mode=autoreset_mode)
+        if queue_size is None:
+            queue_size = 4 if self.ruleset == N.RULESET_NUMPY else 7
+        self.queue_size = queue_size
+        self.ranges = shard_ranges(self.num_envs, len(devices))
+        self.engines = [
+            Engine(hi - lo, width, height, ruleset=self.ruleset, gravity=gravity, queue_size=queue_size,
+                   obs_mode=_OBS[observation], autoreset=_AUTORESET[autoreset_mode], device=dev, env_offset=lo,
+                   episode_stats=episode_stats)
+            for (lo, hi), dev in zip(self.ranges, devices) if hi > lo
+        ]
+        self.ranges = [r for r in self.ranges if r[1] > r[0]]
+        self.episode_stats = episode_stats
+        n_act = 8 if self.ruleset == N.RULESET_NUMPY else 7
+        hp, wp, p = height + 4, width + 8, 4
+        self.single_action_space = spaces.Discrete(n_act)
+        if observation == "dict":
+            self.single_observation_space = spaces.Dict({
+                "board": spaces.Box(low=0, high=9, shape=(hp, wp), dtype=np.uint8),
+                "active_tetromino_mask": spaces.Box(low=0, high=1, shape=(hp, wp), dtype=np.uint8),
+                "holder": spaces.Box(low=0, high=9, shape=(p, p), dtype=np.uint8),
+                "queue": spaces.Box(low=0, high=9, shape=(p, p * queue_size), dtype=np.uint8),
+            })
+        elif observation == "board":
+            self.single_observation_space = spaces.Box(low=0, high=9, shape=(height, width), dtype=np.uint8)
+        else:
+            self.single_observation_space = spaces.Box(low=-1, high=1, shape=(height, width), dtype=np.int8)
+        if HAVE_GYMNASIUM:  # pragma: no cover - depends on the environment
+            from gymnasium.vector.utils import batch_space
+
+            self.action_space = batch_space(self.single_action_space, self.num_envs)
+            self.observation_space = batch_space(self.single_observation_space, self.num_envs)
+        else:
+            self.action_space = spaces.MultiDiscrete([n_act] * self.num_envs)
+            self.observation_space = None
+        self._prev_len = np.zeros(self.num_envs, np.uint32)
+
+    # ---- helpers --------------------------------------------------------------------------------
+    def _gather_obs(self):
+        parts = [e.observation() for e in self.engines]
+        if isinstance(parts[0], dict):
+            return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+        return np.concatenate(parts)
+
+    # ---- gymnasium.vector API ---------------------------------------------------------------------
+    def reset(self, *, seed=None, options=None):
+        mask = None if not options else options.get("reset_mask")
+        for e, (lo, hi) in zip(self.engines, self.ranges):
+            if isinstance(seed, (list, tuple, np.ndarray)):
+                seeds = np.asarray(seed, np.uint64)[lo:hi]
+            elif seed is None and self.ruleset == N.RULESET_NUMPY:
+                seeds = None  # keep running generators (never-seeded envs get 1 + global index)
+            else:
+                seeds = default_seeds(lo, hi, seed)
+            e.reset(seeds, None if mask is None else np.asarray(mask, np.uint8)[lo:hi])
+        self._prev_len[:] = 0
+        return self._gather_obs(), {"lines_cleared": np.zeros(self.num_envs, np.int32)}
+
+    def step(self, actions):
+        actions = np.asarray(actions, np.int32).reshape(self.num_envs)
+        for e, (lo, hi) in zip(self.engines, self.ranges):  # launch on every device first ...
+            e.step_async(actions[lo:hi])
+        outs = [e.fetch_outputs() for e in self.engines]   # ... then collect
+        rewards = np.concatenate([o[0] for o in outs]).astype(np.float64)
+        terminations = np.concatenate([o[1] for o in outs]).astype(bool)
+        lines = np.concatenate([o[2] for o in outs]).astype(np.int32)
+        infos = {"lines_cleared": lines, "_lines_cleared": np.ones(self.num_envs, bool)}
+        if self.episode_stats and terminations.any():
+            ep = np.concatenate([e.episode_stats() for e in self.engines])
+            infos["episode"] = {"r": np.where(terminations, ep["last_ret"], 0.0).astype(np.float64),
+                                "l": np.where(terminations, ep["last_len"], 0).astype(np.int32)}
+            infos["_episode"] = terminations.copy()
+        truncations = np.zeros(self.num_envs, bool)
+        return self._gather_obs(), rewards, terminations, truncations, infos
+
+    def close(self, **kwargs):
+        for e in self.engines:
+            e.close()
+        self.engines = []
+
+    close_extras = close
