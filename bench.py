@@ -40,8 +40,8 @@ def cpu_baseline(W, H, Q, budget_s=12.0):
     """The oracle's C restatement (kind "port") on this host's cores, bounded sample of the same workload."""
     from oracle import pyoracle as po
 
-    cores = os.cpu_count() or 1
-    B = 8192
+    cores = min(os.cpu_count() or 1, 64)  # OpenMP over envs; more threads than this only adds fork/join cost
+    B = 16384
     o = po.OracleBatch(B, W, H, po.RULESET_NUMPY, True, Q, nthreads=cores)
     o.reset(np.arange(1, B + 1, dtype=np.uint64))
     rng = np.random.default_rng(0)
@@ -61,6 +61,52 @@ def cpu_baseline(W, H, Q, budget_s=12.0):
             "sample": f"{B} envs x {n} steps of the same workload (C oracle, OpenMP over envs, incl. observation pack)"}
 
 
+class Dist:
+    """torch.distributed plumbing for N > 1 (one process per GPU): rendezvous, barrier, max-over-ranks.
+    No data-path collective exists — envs are independent shards."""
+
+    def __init__(self, backend="gloo"):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.pg = None
+        if self.world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+            self.pg = dist
+
+    def barrier(self):
+        if self.pg is not None:
+            self.pg.barrier()
+
+    def max(self, *values):
+        if self.pg is None:
+            return values
+        import torch
+
+        t = torch.tensor(values, dtype=torch.float64)
+        self.pg.all_reduce(t, op=self.pg.ReduceOp.MAX)
+        return tuple(float(v) for v in t)
+
+    def shard(self, envs_per_rank):
+        """Weak scaling: rank r owns global envs [r*B, (r+1)*B), seeds 1 + global index."""
+        lo = self.rank * envs_per_rank
+        return lo, lo + envs_per_rank, np.arange(1 + lo, 1 + lo + envs_per_rank, dtype=np.uint64)
+
+    def close(self):
+        if self.pg is not None:
+            self.pg.barrier()
+            self.pg.destroy_process_group()
+
+
+def throughput(world, envs_per_rank, steps, max_elapsed_s):
+    """Whole-job env steps/s: units all ranks processed / max-over-ranks time."""
+    return world * envs_per_rank * steps / max_elapsed_s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,28 +120,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # plumbing only: barrier + max of the timing
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    D = Dist()
+    rank, world, local = D.rank, D.world, D.local
+    barrier = D.barrier
 
     W, H, B = args.width, args.height, args.batch
     Q = 4
     ruleset = N.RULESET_NUMPY if args.ruleset == "numpy" else N.RULESET_FUNCTIONAL
     obs_mode = {"board": N.OBS_BOARD, "dict": N.OBS_DICT, "fn": N.OBS_FN, "none": N.OBS_NONE}[args.obs]
     n_act = 8 if ruleset == N.RULESET_NUMPY else 7
+    lo, hi, seeds = D.shard(B)
     e = Engine(B, W, H, ruleset=ruleset, queue_size=(Q if ruleset == N.RULESET_NUMPY else 7), obs_mode=obs_mode,
-               autoreset=N.AUTORESET_SAME_STEP, device=local, env_offset=rank * B)
-    e.reset(np.arange(1 + rank * B, 1 + (rank + 1) * B, dtype=np.uint64))
+               autoreset=N.AUTORESET_SAME_STEP, device=local, env_offset=lo)
+    e.reset(seeds)
 
     # pre-generated uniform random actions, uploaded once: [T][B] int8 resident in HBM
     T = min(args.warmup + args.steps, 512)
@@ -123,13 +160,7 @@ def main():
     e.sync()
     t1 = time.perf_counter()
     barrier()
-    elapsed = t1 - t0
-    if dist is not None:
-        import torch
-
-        tt = torch.tensor([elapsed, gpu_ms], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, gpu_ms = float(tt[0]), float(tt[1])
+    elapsed, gpu_ms = D.max(t1 - t0, gpu_ms)
 
     if rank == 0:
         bytes_alg = alg_bytes_per_step(W, H, args.obs)
@@ -144,7 +175,7 @@ def main():
                 traffic = None
         out = {
             "metric": "env steps/sec (whole node), 10x20 board, batch=65536 per GPU",
-            "value": world * B * args.steps / elapsed,
+            "value": throughput(world, B, args.steps, elapsed),
             "unit": "env steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -174,9 +205,7 @@ def main():
         print(json.dumps(out), flush=True)
     e.dev_free(d_acts)
     e.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.close()
 
 
 if __name__ == "__main__":

@@ -108,6 +108,8 @@ typedef struct tg_env_rec { /* 32 bytes */
 #define TG_F_GAME_OVER 0x01
 #define TG_F_HAS_SWAPPED 0x02
 #define TG_F_PENDING_RESET 0x04 /* NEXT_STEP autoreset: reset on the next step */
+#define TG_F_FULLROW 0x08       /* device-private: the stored board may hold an uncleared full row (only after
+                                   tg_set_state with such a board); stripped by tg_get_state */
 
 typedef struct tg_rng_rec { /* 48 bytes */
   /* NUMPY: numpy PCG64 bit-generator state (state, inc as 128-bit little-endian pairs) + the

@@ -239,6 +239,7 @@ def test_vector_env_matches_oracle(mode):
     rng = np.random.default_rng(3)
     ar = po.AUTORESET_NEXT_STEP if mode == "next_step" else po.AUTORESET_SAME_STEP
     ret = np.zeros(B); ln = np.zeros(B, int); n_eps = 0
+    prev = np.zeros(B, bool)  # next_step mode: the step after a terminal one is the reset step (belongs to no episode)
     for t in range(300):
         a = rng.integers(0, 8, B)
         obs, rew, term, trunc, infos = env.step(a)
@@ -248,7 +249,9 @@ def test_vector_env_matches_oracle(mode):
         np.testing.assert_array_equal(infos["lines_cleared"], lo); assert not trunc.any()
         for k in od:
             np.testing.assert_array_equal(obs[k], od[k], err_msg=f"{k} t={t}")
-        ret += rew; ln += 1
+        count = ~prev if mode == "next_step" else np.ones(B, bool)
+        ret[count] += rew[count]; ln[count] += 1
+        prev = term.copy()
         if term.any():
             np.testing.assert_array_equal(infos["_episode"], term)
             np.testing.assert_allclose(infos["episode"]["r"][term], ret[term])

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "tg_kernel_lanes.h"
 #include "tg_kernels.h"
 
 // ---- board sizes compiled in (W, H).  Extend the list and rebuild to support another size. ----
@@ -32,8 +33,24 @@ inline int grid_for(int batch) { return (batch + tg::kWavesPerBlock - 1) / tg::k
 
 int g_step_blocks = 0;  // persistent grid size (blocks); set once per process from the device's CU count
 
+// step kernel selection (TG_KERNEL): 4 = "quad": 16 envs per wave, 4 lanes per env (default); 1 = "lanes": 64 envs
+// per wave, one per lane (both tg_kernel_lanes.h); 0 = "wave": one env per wavefront (tg_kernels.h)
+int g_kernel_lanes = 4;
+
 template <int W, int H, int RS>
 void launch_step(const tg::KParams& p, hipStream_t s) {
+  if (g_kernel_lanes && !p.final_obs) {
+    if (g_kernel_lanes == 4) {
+      const int grid = (p.batch + 15) / 16;
+      const size_t lds = (((size_t)16 * W * H + 15) / 16) * 16 + 64;
+      hipLaunchKernelGGL((tg::step_kernel_lanes<W, H, RS, 4>), dim3(grid), dim3(64), lds, s, p);
+    } else {
+      const int grid = (p.batch + 63) / 64;
+      const size_t lds = (size_t)64 * W * H + 64;
+      hipLaunchKernelGGL((tg::step_kernel_lanes<W, H, RS, 1>), dim3(grid), dim3(64), lds, s, p);
+    }
+    return;
+  }
   int grid = grid_for(p.batch);
   if (g_step_blocks > 0 && grid > g_step_blocks) grid = g_step_blocks;
   hipLaunchKernelGGL((tg::step_kernel<W, H, RS>), dim3(grid), dim3(tg::kBlock), 0, s, p);
@@ -84,6 +101,7 @@ struct tg_handle {
   tg_rng_rec* d_new_rng = nullptr;
   uint8_t* d_reseed = nullptr;
   uint8_t* d_mask = nullptr;
+  void* dbg = nullptr;  // phase-timing buffer (TG_PHASE_TIMING builds)
   std::vector<uint8_t> rng_valid;
   std::vector<tg_rng_rec> h_new_rng;
   std::vector<uint8_t> h_reseed;
@@ -202,6 +220,7 @@ tg::KParams step_params(tg_handle* h) {
   p.autoreset = h->cfg.autoreset;
   p.obs_mode = h->cfg.obs_mode;
   p.queue_size = h->Q;
+  p.dbg = (unsigned long long*)h->dbg;
   return p;
 }
 
@@ -311,6 +330,8 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     // looping over its envs with the next env's loads in flight.
     int per_cu = 0;
     if (const char* e = getenv("TG_BLOCKS_PER_CU")) per_cu = atoi(e);
+    if (const char* k = getenv("TG_KERNEL"))
+      g_kernel_lanes = strcmp(k, "wave") == 0 ? 0 : (strcmp(k, "lanes") == 0 ? 1 : 4);
     g_step_blocks = per_cu > 0 ? prop.multiProcessorCount * per_cu : -1;
   }
   CRCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -332,6 +353,10 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   CRCHK(hipMalloc((void**)&h->d_new_rng, B * sizeof(tg_rng_rec)));
   CRCHK(hipMalloc((void**)&h->d_reseed, B));
   CRCHK(hipMalloc((void**)&h->d_mask, B));
+#ifdef TG_PHASE_TIMING
+  CRCHK(hipMalloc(&h->dbg, ((B + 63) / 64) * 16 * 8));
+  CRCHK(hipMemset(h->dbg, 0, ((B + 63) / 64) * 16 * 8));
+#endif
   // a valid (if arbitrary) initial record so that a step before the first reset cannot index out of range
   {
     std::vector<tg_env_rec> init(B);
@@ -478,6 +503,8 @@ int tg_get_state(tg_handle* h, uint8_t* board, tg_env_rec* rec, tg_rng_rec* rng)
   if (rec) HIPCHK(h, hipMemcpyAsync(rec, h->buf[TG_BUF_REC], B * sizeof(tg_env_rec), hipMemcpyDeviceToHost, h->stream));
   if (rng) HIPCHK(h, hipMemcpyAsync(rng, h->buf[TG_BUF_RNG], B * sizeof(tg_rng_rec), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (rec)
+    for (size_t i = 0; i < B; ++i) rec[i].flags &= (uint8_t)~TG_F_FULLROW;  // device-private bit
   return TG_OK;
 }
 
@@ -496,7 +523,30 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
         if (r.bag[k] > 6 || (k < h->Q && h->cfg.ruleset == TG_RULESET_NUMPY && r.queue[k] > 6))
           return fail(h, TG_EINVAL, "tg_set_state: record %zu holds a tetromino index > 6", i);
     }
-  if (board) HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_BOARD], board, B * h->cells, hipMemcpyHostToDevice, h->stream));
+  // The lane kernel looks for completed rows only among the rows a lock touched; a caller-provided board
+  // may already hold a full row (the reference would clear it at the next lock, envs/tetris.py:493-494), so
+  // such envs are marked for one full scan.
+  std::vector<tg_env_rec> tmp;
+  if (board) {
+    HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_BOARD], board, B * h->cells, hipMemcpyHostToDevice, h->stream));
+    tmp.resize(B);
+    if (rec) std::memcpy(tmp.data(), rec, B * sizeof(tg_env_rec));
+    else {
+      HIPCHK(h, hipMemcpyAsync(tmp.data(), h->buf[TG_BUF_REC], B * sizeof(tg_env_rec), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    for (size_t i = 0; i < B; ++i) {
+      bool any_full = false;
+      const uint8_t* b = board + i * h->cells;
+      for (int r = 0; r < h->H && !any_full; ++r) {
+        bool full = true;
+        for (int c = 0; c < h->W; ++c) full &= b[r * h->W + c] != 0;
+        any_full = full;
+      }
+      tmp[i].flags = (uint8_t)((tmp[i].flags & ~TG_F_FULLROW) | (any_full ? TG_F_FULLROW : 0));
+    }
+    rec = tmp.data();
+  }
   if (rec) HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_REC], rec, B * sizeof(tg_env_rec), hipMemcpyHostToDevice, h->stream));
   if (rng) {
     HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_RNG], rng, B * sizeof(tg_rng_rec), hipMemcpyHostToDevice, h->stream));
@@ -593,6 +643,14 @@ int tg_stream_copy_gbps(tg_handle* h, size_t bytes, int iters, float* gbps) {
   (void)hipFree(b);
   if (e != hipSuccess) return fail(h, TG_EHIP, "tg_stream_copy_gbps: %s", hipGetErrorString(e));
   *gbps = (float)(2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9);
+  return TG_OK;
+}
+
+// phase-timing buffer of the lane kernel (TG_PHASE_TIMING builds): u64 [waves][16] s_memtime stamps
+int tg_debug_phase_times(tg_handle* h, unsigned long long* out, size_t n_waves) {
+  if (!h || !h->dbg) return TG_EUNSUPPORTED;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->dbg, n_waves * 16 * 8, hipMemcpyDeviceToHost));
   return TG_OK;
 }
 

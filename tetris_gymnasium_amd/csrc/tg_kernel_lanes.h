@@ -1,0 +1,649 @@
+// tg_kernel_lanes.h — second step kernel: 64 envs per wavefront, ONE ENV PER LANE.
+//
+// Why it exists (measured, profiles/r01_*): the one-env-per-wavefront kernel (tg_kernels.h) executes the
+// rule logic of an env as ~250 mostly-scalar instructions issued ONCE PER ENV; a CU issues about one
+// instruction per SIMD per ~5 cycles for that stream, so 65 536 envs cost ≈36-40 µs per step (SALU-issue
+// bound, 0.14 of the HBM roofline) no matter how the loads are arranged.  Here the same rule logic runs
+// as vector instructions over 64 envs at once: every instruction is amortised over 64 envs, and the
+// wave-level operations that made the first kernel attractive are kept where they pay:
+//   * the 64 slabs of a wave are one contiguous 64*H*W-byte block: loaded/stored with fully coalesced
+//     16-byte-per-lane accesses and staged in LDS (the lane then addresses its own slab in LDS);
+//   * rare heavy operations are done COOPERATIVELY per env with wave-level primitives: row compaction
+//     after a line clear uses the row-per-lane ballot/popcount routine of tg_kernels.h on that env's slab;
+//   * divergent rare paths (bag reshuffle with PCG64, reset, swap) are entered with wave-uniform branches
+//     (`if (any lane needs it)`) and executed under lane predicates.
+// Board/reward/done/observation outputs are bit-identical to the first kernel and to the oracle.
+#pragma once
+#include "tg_kernels.h"
+
+namespace tg {
+
+#ifdef TG_PHASE_TIMING
+#define TG_STAMP(i) do { if (p.dbg && lane == 0) p.dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TG_STAMP(i) do {} while (0)
+#endif
+
+// piece cells as 4 nibbles (k << 2 | c) per (piece, rot): 4 rotations x 16 bit per piece
+struct CellTable {
+  uint64_t cells[7];
+};
+
+constexpr CellTable make_cell_table() {
+  CellTable t{};
+  const ShapeTable s = make_shape_table();
+  for (int p = 0; p < 7; ++p) {
+    uint64_t row = 0;
+    for (int r = 0; r < 4; ++r) {
+      uint64_t v = 0;
+      int n = 0;
+      for (int cell = 0; cell < 16; ++cell)
+        if ((s.mask[p][r] >> cell) & 1) {
+          v |= (uint64_t)cell << (4 * n);  // cell index = 4*k + c  → nibble holds (k << 2 | c)
+          ++n;
+        }
+      row |= v << (16 * r);
+    }
+    t.cells[p] = row;
+  }
+  return t;
+}
+
+__constant__ CellTable c_cells = make_cell_table();
+
+// per-lane generator state (numpy PCG64 + buffered half, or the jax key)
+struct LaneRng {
+  uint64_t s_lo, s_hi, i_lo, i_hi;
+  uint32_t uinteger, has32, k0, k1;
+};
+
+__device__ __forceinline__ uint32_t lane_pcg_next32(LaneRng& r) {
+  // divergent form of pcg_next32 (tg_kernels.h): every lane advances its own generator
+  constexpr uint64_t MLO = 0x4385DF649FCCF645ULL, MHI = 0x2360ED051FC65DA4ULL;
+  const bool buffered = r.has32 != 0;
+  const uint64_t lo = r.s_lo * MLO;
+  uint64_t hi = __umul64hi(r.s_lo, MLO) + r.s_lo * MHI + r.s_hi * MLO;
+  const uint64_t nlo = lo + r.i_lo;
+  hi = hi + r.i_hi + (nlo < lo ? 1ULL : 0ULL);
+  const uint64_t x = hi ^ nlo;
+  const unsigned rot = (unsigned)(hi >> 58);
+  const uint64_t out = (x >> rot) | (x << ((64u - rot) & 63u));
+  const uint32_t res = buffered ? r.uinteger : (uint32_t)out;
+  if (!buffered) {
+    r.s_lo = nlo;
+    r.s_hi = hi;
+    r.uinteger = (uint32_t)(out >> 32);
+  }
+  r.has32 = buffered ? 0u : 1u;
+  return res;
+}
+
+// Generator.shuffle of the 7-byte bag for the lanes in `need` (others untouched)
+__device__ __forceinline__ void lane_shuffle7(LaneRng& r, uint64_t& bag, const bool need) {
+  if (!__any(need)) return;
+  LaneRng t = r;
+  uint64_t b = bag;
+  for (int i = 6; i >= 1; --i) {
+    const uint32_t mask = i >= 4 ? 7u : (i >= 2 ? 3u : 1u);
+    uint32_t j = 0;
+    bool pending = need;
+    while (__any(pending)) {  // masked rejection (random_interval)
+      LaneRng u = t;
+      const uint32_t v = lane_pcg_next32(u) & mask;
+      if (pending) {
+        t = u;
+        j = v;
+        pending = v > (uint32_t)i;
+      }
+    }
+    const uint64_t bi = (b >> (8 * i)) & 0xFF, bj = (b >> (8 * j)) & 0xFF;
+    b &= ~((0xFFULL << (8 * i)) | (0xFFULL << (8 * j)));
+    b |= (bj << (8 * i)) | (bi << (8 * j));
+  }
+  if (need) {
+    r = t;
+    bag = b;
+  }
+}
+
+// per-lane env state
+struct LaneS {
+  int piece, rot, x, y, val, flags, hp, hr, hv, bidx;
+  uint64_t bag, queue;
+  float score;
+  uint32_t reserved;
+};
+
+__device__ __forceinline__ void lane_unpack(LaneS& s, const uint4 a, const uint4 b) {
+  s.piece = a.x & 0xFF; s.rot = (a.x >> 8) & 0xFF; s.x = (a.x >> 16) & 0xFF; s.y = a.x >> 24;
+  s.val = a.y & 0xFF; s.flags = (a.y >> 8) & 0xFF; s.hp = (a.y >> 16) & 0xFF; s.hr = a.y >> 24;
+  s.hv = a.z & 0xFF; s.bidx = (a.z >> 8) & 0xFF;
+  s.bag = (uint64_t)(a.z >> 16) | ((uint64_t)a.w << 16) | ((uint64_t)(b.x & 0xFF) << 48);
+  s.queue = (uint64_t)(b.x >> 8) | ((uint64_t)b.y << 24);
+  s.score = __uint_as_float(b.z);
+  s.reserved = b.w;
+}
+
+__device__ __forceinline__ void lane_pack(const LaneS& s, uint4& a, uint4& b) {
+  a.x = (uint32_t)s.piece | ((uint32_t)s.rot << 8) | ((uint32_t)s.x << 16) | ((uint32_t)s.y << 24);
+  a.y = (uint32_t)s.val | ((uint32_t)s.flags << 8) | ((uint32_t)s.hp << 16) | ((uint32_t)s.hr << 24);
+  a.z = (uint32_t)s.hv | ((uint32_t)s.bidx << 8) | ((uint32_t)(s.bag & 0xFFFF) << 16);
+  a.w = (uint32_t)(s.bag >> 16);
+  b.x = (uint32_t)((s.bag >> 48) & 0xFF) | ((uint32_t)(s.queue & 0xFFFFFF) << 8);
+  b.y = (uint32_t)(s.queue >> 24);
+  b.z = __float_as_uint(s.score);
+  b.w = s.reserved;
+}
+
+// BagRandomizer.get_next_tetromino for the lanes in `on` (eager reshuffle, tetromino_randomizer.py:65-85)
+__device__ __forceinline__ int lane_randomizer_next(LaneS& s, LaneRng& r, const bool on) {
+  const int t = (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
+  if (on) s.bidx += 1;
+  const bool sh = on && s.bidx >= 7;
+  lane_shuffle7(r, s.bag, sh);
+  if (sh) s.bidx = 0;
+  return t;
+}
+
+// TetrominoQueue.get_next_tetromino (tetromino_queue.py:35-42)
+__device__ __forceinline__ int lane_queue_pop(LaneS& s, LaneRng& r, const bool on, const int Q) {
+  const int t = (int)(s.queue & 0xFF);
+  const int nxt = lane_randomizer_next(s, r, on);
+  if (on) s.queue = (s.queue >> 8) | ((uint64_t)nxt << (8 * (Q - 1)));
+  return t;
+}
+
+// OR of a small bit-set over the L lanes that serve one env (L = 4: one DPP quad, two v_or_b32_dpp)
+template <int L>
+__device__ __forceinline__ uint32_t env_or(uint32_t x) {
+  if constexpr (L == 4) {
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  }
+  return x;
+}
+
+// One env's slab in LDS, addressed by the L lanes that serve the env: lane `sub` owns piece cell(s)
+// sub, sub+L, ... (L = 4: one cell per lane; L = 1: all four).
+template <int W, int H, int L>
+struct LaneBoard {
+  uint8_t* my;  // this env's slab in LDS
+  int sub;      // lane index within the env's lane group
+  // LDS byte offset of playfield cell (row, col) or -1 when it is implicit bedrock (envs/tetris.py:632-641)
+  static __device__ __forceinline__ int cell_addr(int row, int col) {
+    const bool inb = (unsigned)col < (unsigned)W && (unsigned)row < (unsigned)H;
+    return inb ? row * W + col : -1;
+  }
+  // N placements of the same 4 cells tested at once: all byte reads are issued before any is consumed;
+  // returns bit i = placement i collides
+  template <int N>
+  __device__ __forceinline__ uint32_t collide_n(uint32_t cells, const int (&xs)[N], const int (&ys)[N]) const {
+    constexpr int CPL = 4 / L;  // cells per lane
+    int addr[N][CPL];
+#pragma unroll
+    for (int jj = 0; jj < CPL; ++jj) {
+      const int j = L == 1 ? jj : sub;
+      const int k = (cells >> (4 * j + 2)) & 3, c = (cells >> (4 * j)) & 3;
+#pragma unroll
+      for (int i = 0; i < N; ++i) addr[i][jj] = cell_addr(ys[i] + k, xs[i] + c - 4);
+    }
+    uint8_t v[N][CPL];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int jj = 0; jj < CPL; ++jj) v[i][jj] = my[addr[i][jj] < 0 ? 0 : addr[i][jj]];
+    uint32_t hits = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      bool h = false;
+#pragma unroll
+      for (int jj = 0; jj < CPL; ++jj) h |= addr[i][jj] < 0 || v[i][jj] != 0;
+      hits |= (h ? 1u : 0u) << i;
+    }
+    return env_or<L>(hits);
+  }
+  __device__ __forceinline__ bool collide(uint32_t cells, int x, int y) const {
+    const int xs[1] = {x}, ys[1] = {y};
+    return collide_n<1>(cells, xs, ys) != 0;
+  }
+  // The reference's drop loop `while not collision(y + 1): y += 1` (envs/tetris.py:445-448,
+  // functional/core.py:243-249) for the envs in `go`, four rows per pass.
+  __device__ __forceinline__ int drop(uint32_t cells, int x, int y, bool go) const {
+    int yd = y;
+    while (__any(go)) {
+      const int xs[4] = {x, x, x, x}, ys[4] = {yd + 1, yd + 2, yd + 3, yd + 4};
+      const uint32_t hit = collide_n<4>(cells, xs, ys);
+      const int steps = hit ? (int)__builtin_ctz(hit) : 4;
+      yd += go ? steps : 0;
+      go = go && steps == 4;
+    }
+    return yd;
+  }
+  __device__ __forceinline__ void stamp(uint32_t cells, int x, int y, uint32_t val, bool add, bool on) const {
+    constexpr int CPL = 4 / L;
+    int addr[CPL];
+#pragma unroll
+    for (int jj = 0; jj < CPL; ++jj) {
+      const int j = L == 1 ? jj : sub;
+      const int k = (cells >> (4 * j + 2)) & 3, c = (cells >> (4 * j)) & 3;
+      addr[jj] = cell_addr(y + k, x + c - 4);
+    }
+    if (add) {
+      uint8_t old[CPL];
+#pragma unroll
+      for (int jj = 0; jj < CPL; ++jj) old[jj] = my[addr[jj] < 0 ? 0 : addr[jj]];
+#pragma unroll
+      for (int jj = 0; jj < CPL; ++jj)
+        if (on && addr[jj] >= 0) my[addr[jj]] = (uint8_t)(old[jj] + val);
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < CPL; ++jj)
+        if (on && addr[jj] >= 0) my[addr[jj]] = (uint8_t)val;
+    }
+  }
+  // is playfield row `row` completely filled?  (16-bit reads when W is even, all issued before use)
+  __device__ __forceinline__ bool row_full(int row) const {
+    const bool ok = (unsigned)row < (unsigned)H;
+    const int r = ok ? row : 0;
+    bool full = ok;
+    if constexpr (W % 2 == 0) {
+      uint16_t v[W / 2];
+      const uint16_t* rp = reinterpret_cast<const uint16_t*>(my + r * W);
+#pragma unroll
+      for (int c = 0; c < W / 2; ++c) v[c] = rp[c];
+#pragma unroll
+      for (int c = 0; c < W / 2; ++c) full &= (v[c] & 0xFF) != 0 && (v[c] >> 8) != 0;
+    } else {
+      uint8_t v[W];
+#pragma unroll
+      for (int c = 0; c < W; ++c) v[c] = my[r * W + c];
+#pragma unroll
+      for (int c = 0; c < W; ++c) full &= v[c] != 0;
+    }
+    return full;
+  }
+  // are any of the playfield rows y0 .. y0+3 completely filled?
+  __device__ __forceinline__ bool any_row_full4(int y0) const {
+    uint32_t any = 0;
+    if constexpr (L == 4) {
+      any = row_full(y0 + sub) ? 1u : 0u;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) any |= row_full(y0 + k) ? 1u : 0u;
+    }
+    return env_or<L>(any) != 0;
+  }
+};
+
+__device__ __forceinline__ uint32_t lane_cells(const uint64_t* tab, int piece, int rot) {
+  return (uint32_t)(tab[piece] >> (16 * rot)) & 0xFFFFu;
+}
+
+// ------------------------------------------------------------------------------------------------
+// L = lanes per env (1: 64 envs per wave; 4: 16 envs per wave, the four lanes of an env split the piece's
+// four cells and OR their results with DPP quad permutes; everything else is computed redundantly by the quad).
+// Measured (profiles/r01_*): with L = 1 there is exactly one wave per SIMD at batch 65 536, so nothing hides
+// LDS/VALU dependency latency and the load / compute / store phases of all waves run in lockstep; L = 4 gives
+// four waves per SIMD with a quarter of the per-wave work.
+template <int W, int H, int RULESET, int L>
+__global__ __launch_bounds__(64) void step_kernel_lanes(const KParams p) {
+  using G = Geo<W, H>;
+  constexpr int S = G::CELLS;  // per-env stride in LDS (bytes), same as in HBM: the wave's slabs are one block
+  constexpr int EPW = 64 / L;  // envs per wave
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint64_t* cell_tab = reinterpret_cast<uint64_t*>(lds + ((EPW * S + 15) / 16) * 16);  // 7 x 8 bytes behind the slabs
+  const int lane = threadIdx.x;
+  const int eidx = lane / L, sub = lane % L;
+  const uint32_t B = (uint32_t)p.batch;
+  const uint32_t base_env = blockIdx.x * (uint32_t)EPW;
+  const uint32_t nlive = B - base_env < (uint32_t)EPW ? B - base_env : (uint32_t)EPW;
+  const bool live = (uint32_t)eidx < nlive;
+  const uint32_t env = base_env + (live ? (uint32_t)eidx : nlive - 1u);  // dead lanes shadow the last live env
+  const bool leader = sub == 0;
+
+  TG_STAMP(0);
+  // ---- A: the wave's 64 slabs: one contiguous block, coalesced 16 B per lane → LDS ----
+  const uint32_t nbytes = nlive * (uint32_t)S;
+  const uint32_t nchunks = (nbytes + 15u) / 16u;
+  const uint4* gsrc = reinterpret_cast<const uint4*>(p.board + (size_t)base_env * S);
+  uint4* lds4 = reinterpret_cast<uint4*>(lds);
+  constexpr int NCH = (EPW * S + 15) / 16;        // 16-byte chunks of a full wave's block
+  constexpr int NIT = (NCH + 63) / 64;            // chunk passes
+  const bool full_wave = nlive == (uint32_t)EPW;
+  if (full_wave) {  // all loads in flight before the first LDS write (one latency, not NIT of them)
+    uint4 stage[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int c = lane + 64 * k;
+      stage[k] = gsrc[c < NCH ? c : NCH - 1];  // unconditional (clamped) so the staging array stays in registers
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int c = lane + 64 * k;
+      if (c < NCH) lds4[c] = stage[k];
+    }
+  } else {
+    for (uint32_t c = lane; c < nchunks; c += 64) lds4[c] = gsrc[c];
+  }
+  if (lane < 7) cell_tab[lane] = c_cells.cells[lane];
+
+  // ---- B: per-lane record, generator state, action ----
+  const uint4* rec4 = reinterpret_cast<const uint4*>(p.rec) + (size_t)env * 2;
+  const uint4 ra = rec4[0], rb = rec4[1];
+  const uint4* rng4 = reinterpret_cast<const uint4*>(p.rng + env);
+  const uint4 g0 = rng4[0], g1 = rng4[1], g2 = rng4[2];
+  const int action = p.act_i8 ? (int)reinterpret_cast<const int8_t*>(p.actions)[env]
+                              : reinterpret_cast<const int32_t*>(p.actions)[env];
+  LaneS s;
+  lane_unpack(s, ra, rb);
+  LaneRng r;
+  r.s_lo = (uint64_t)g0.x | ((uint64_t)g0.y << 32); r.s_hi = (uint64_t)g0.z | ((uint64_t)g0.w << 32);
+  r.i_lo = (uint64_t)g1.x | ((uint64_t)g1.y << 32); r.i_hi = (uint64_t)g1.z | ((uint64_t)g1.w << 32);
+  r.uinteger = g2.x; r.has32 = g2.y; r.k0 = g2.z; r.k1 = g2.w;
+  const LaneRng r_in = r;
+  const int Q = p.queue_size;
+  const int grav = p.gravity;
+  LaneBoard<W, H, L> bd;
+  bd.my = lds + eidx * S;
+  bd.sub = sub;
+  wave_sync();
+  TG_STAMP(1);
+
+  float reward = 0.0f;
+  int lines = 0;
+  bool board_dirty = false;
+  bool final_coll = false;
+
+  const bool pending = p.autoreset == TG_AUTORESET_NEXT_STEP && (s.flags & TG_F_PENDING_RESET);
+  const bool frozen = RULESET == TG_RULESET_FUNCTIONAL && (s.flags & TG_F_GAME_OVER);
+  const bool stepped = live && !pending && !frozen;
+
+  // ---- C: action → tentative placement (branch-free LUT, per lane) ----
+  uint32_t e;
+  if (RULESET == TG_RULESET_NUMPY) {
+    e = (uint32_t)(kActLutNumpy >> (8 * (action & 7))) & 0xFFu;
+  } else {
+    const int br = action < 0 ? 0 : (action > 6 ? 6 : action);
+    e = (uint32_t)(kActLutFn >> (8 * br)) & 0xFFu;
+  }
+  int tp = s.piece, tv = s.val;
+  int tx = s.x + (int)(e & 3u) - 1;
+  int ty = s.y + (int)((e >> 2) & 1u);
+  int tr = (s.rot + (int)((e >> 3) & 3u)) & 3;
+  const bool check = (e & 0x20u) != 0;
+  const bool hard = stepped && (e & 0x40u) != 0;
+  // swap (envs/tetris.py:242-252, components/tetromino_holder.py:31-49)
+  const bool swap_eff = RULESET == TG_RULESET_NUMPY && stepped && (e & 0x80u) && !(s.flags & TG_F_HAS_SWAPPED);
+  if (RULESET == TG_RULESET_NUMPY && __any(swap_eff)) {
+    const bool empty = swap_eff && s.hp == TG_NONE;
+    const int popped = lane_queue_pop(s, r, empty, Q);  // spawn_tetromino; its collision result is ignored
+    if (swap_eff) {
+      if (empty) { tp = popped; tr = 0; tv = popped + 2; }
+      else { tp = s.hp; tr = s.hr; tv = s.hv; }
+      s.hp = s.piece; s.hr = s.rot; s.hv = s.val;
+      s.flags |= TG_F_HAS_SWAPPED;
+      tx = np_spawn_x<W>(tp);
+      ty = 0;
+    }
+  }
+  TG_STAMP(2);
+  const uint32_t cellsC = lane_cells(cell_tab, s.piece, s.rot);
+  const uint32_t cellsT = lane_cells(cell_tab, tp, tr);
+
+  bool lock = false;
+  int drop_reward = 0;
+  uint32_t cells = cellsC;
+  if (RULESET == TG_RULESET_FUNCTIONAL && __any(hard)) {
+    // functional/core.py:230-251 hard_drop: step-wise, stops at the first blocked row below y
+    const int yd = bd.drop(cellsC, s.x, s.y, hard);
+    if (hard) {
+      drop_reward = 2 * (yd - s.y);
+      s.y = yd;
+      lock = grav || action == 6;  // blocked below by construction → should_lock iff gravity (tetris_fn.py:247-264)
+    }
+  }
+  {
+    bool cT, cT1, cC, cC1;
+    {
+      // tentative {here, below} and current {here, below}: all reads in flight before the first use
+      const int xa[2] = {tx, tx}, ya[2] = {ty, ty + 1}, xb[2] = {s.x, s.x}, yb[2] = {s.y, s.y + 1};
+      const uint32_t ha = bd.template collide_n<2>(cellsT, xa, ya);
+      const uint32_t hb = bd.template collide_n<2>(cellsC, xb, yb);
+      cT = ha & 1u; cT1 = (ha >> 1) & 1u; cC = hb & 1u; cC1 = (hb >> 1) & 1u;
+    }
+    const bool moving = stepped && !(RULESET == TG_RULESET_FUNCTIONAL && hard);
+    const bool accept = moving && (swap_eff || (check && !cT));
+    if (accept) { s.piece = tp; s.rot = tr; s.x = tx; s.y = ty; s.val = tv; cells = cellsT; }
+    const bool coll_here = accept ? cT : cC;
+    const bool coll_below = accept ? cT1 : cC1;
+    if (RULESET == TG_RULESET_FUNCTIONAL && accept && (e & 4u)) drop_reward = 1;  // soft drop (tetris_fn.py:183-190)
+    if (moving) {
+      if (RULESET == TG_RULESET_NUMPY) {
+        final_coll = coll_here;
+        lock = hard;
+        if (grav && !hard) {  // envs/tetris.py:259-264
+          if (!coll_below) { s.y += 1; final_coll = false; }
+          else lock = true;
+        }
+      } else if (grav) {  // functional/core.py:150-182 + tetris_fn.py:242-247
+        if (!coll_below) s.y += 1;
+        else lock = true;
+      }
+    }
+    TG_STAMP(3);
+    // ---- D: lock path ----
+    if (__any(lock)) {
+      bool place = lock;
+      if (RULESET == TG_RULESET_NUMPY) {  // envs/tetris.py:450-479 commit_active_tetromino
+        const bool dead = lock && coll_here;  // already colliding: game over, nothing placed (:461-463)
+        if (dead) { s.flags |= TG_F_GAME_OVER; reward = 0.0f; }
+        place = lock && !coll_here;
+        const int yd = bd.drop(cells, s.x, s.y, place && hard);  // :445-448 (only hard drops can still move)
+        if (place) s.y = yd;
+        bd.stamp(cells, s.x, s.y, (uint32_t)s.val, false, place);
+      } else {
+        bd.stamp(cells, s.x, s.y, (uint32_t)(s.piece + 2), true, place);  // functional/core.py:103-121
+      }
+      wave_sync();
+      TG_STAMP(4);
+      // full rows can only appear among the rows the piece touched (boards never hold a stale full row:
+      // see TG_F_FULLROW in tg_set_state); envs that need it are compacted cooperatively, one at a time
+      const bool any_full = bd.any_row_full4(s.y);
+      const bool scan = place && (any_full || (s.flags & TG_F_FULLROW));
+      uint64_t todo = __ballot(scan && leader);
+      while (todo) {
+        const int l = (int)__builtin_ctzll(todo) / L;  // env within the wave
+        todo &= todo - 1;
+        const int n = clear_rows<W, H, RULESET>(lds + l * S, lane);
+        if (eidx == l) lines = n;
+      }
+      if (place) {
+        s.flags &= ~TG_F_FULLROW;
+        board_dirty = true;
+      }
+      if (RULESET == TG_RULESET_FUNCTIONAL) {
+        // the jnp.take wrap copies old row 0 into the vacated rows: if that row was full, full rows remain
+        const bool stale = place && lines > 0 && bd.row_full(0);
+        if (stale) s.flags |= TG_F_FULLROW;
+      }
+      TG_STAMP(5);
+      // spawn the next piece
+      if (RULESET == TG_RULESET_NUMPY) {
+        const int np_ = lane_queue_pop(s, r, place, Q);  // envs/tetris.py:393-401
+        if (place) {
+          s.piece = np_; s.rot = 0; s.val = np_ + 2; s.x = np_spawn_x<W>(np_); s.y = 0;
+        }
+        const bool sc = bd.collide(lane_cells(cell_tab, s.piece, 0), s.x, 0);
+        if (place) {
+          reward = (float)(lines * lines * W + 1);  // score + rewards.alife
+          if (sc) { s.flags |= TG_F_GAME_OVER; reward = 0.0f; }
+          else s.flags &= ~TG_F_GAME_OVER;
+          s.flags &= ~TG_F_HAS_SWAPPED;
+          final_coll = sc;
+        }
+      } else {  // envs/tetris_fn.py:370-413 place_active_tetromino
+        uint32_t a0, a1, b0, b1;
+        threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);  // split(rng_key)[0]
+        const bool refill = place && s.bidx >= 7;
+        if (__any(refill)) {
+          threefry2x32(r.k0, r.k1, 0u, 1u, b0, b1);  // split(rng_key)[1] (functional/queue.py:59-67)
+          const uint64_t nb = jax_permutation7(b0, b1);
+          if (refill) { s.bag = nb; s.bidx = 0; }
+        }
+        if (place) {
+          s.piece = (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
+          s.bidx += 1;
+          r.k0 = a0; r.k1 = a1;
+          s.rot = 0; s.val = s.piece + 2; s.x = (W + 8) / 2 - 2; s.y = 0;
+        }
+        const bool sc = bd.collide(lane_cells(cell_tab, s.piece, 0), s.x, 0);
+        if (place && sc) s.flags |= TG_F_GAME_OVER;
+      }
+    }
+    if (RULESET == TG_RULESET_FUNCTIONAL && stepped) {
+      const int lock_reward = lock ? (lines == 4 ? 800 : (lines > 0 ? lines * 200 - 100 : 0)) : 0;  // core.py:124-146
+      const float old = s.score;
+      float t = old + (float)drop_reward;
+      t = t + (float)lock_reward;
+      s.score = t;
+      reward = t - old;  // tetris_fn.py:312
+    }
+  }
+
+  TG_STAMP(6);
+  // ---- E: termination / autoreset ----
+  const int terminated = (!pending && (s.flags & TG_F_GAME_OVER)) ? 1 : 0;
+  const bool do_reset = live && (pending || (terminated && p.autoreset == TG_AUTORESET_SAME_STEP));
+  if (terminated && p.autoreset == TG_AUTORESET_NEXT_STEP && !pending) s.flags |= TG_F_PENDING_RESET;
+  if (__any(do_reset)) {
+    // (final observation of the terminal state is not produced by this kernel; TG_FLAG_FINAL_OBS selects the other one)
+    uint32_t* myw = reinterpret_cast<uint32_t*>(bd.my);
+    if (do_reset)
+      for (int i = sub; i < S / 4; i += L) myw[i] = 0u;
+    if (RULESET == TG_RULESET_NUMPY) {
+      if (do_reset) { s.bag = 0x06050403020100ULL; s.queue = 0; }
+      lane_shuffle7(r, s.bag, do_reset);
+      if (do_reset) s.bidx = 0;
+      for (int i = 0; i < Q; ++i) {
+        const int t = lane_randomizer_next(s, r, do_reset);
+        if (do_reset) s.queue |= (uint64_t)t << (8 * i);
+      }
+      const int first = lane_queue_pop(s, r, do_reset, Q);
+      if (do_reset) { s.piece = first; s.x = np_spawn_x<W>(first); }
+    } else {
+      uint32_t a0, a1, b0, b1;
+      threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);
+      threefry2x32(r.k0, r.k1, 0u, 1u, b0, b1);
+      const uint64_t nb = jax_permutation7(a0, a1);
+      if (do_reset) {
+        s.bag = nb; s.queue = 0; s.piece = (int)(nb & 0xFF); s.bidx = 1;
+        r.k0 = b0; r.k1 = b1;
+        s.x = (W + 8) / 2 - 2;
+      }
+    }
+    if (do_reset) {
+      s.rot = 0; s.y = 0; s.val = s.piece + 2;
+      s.hp = TG_NONE; s.hr = 0; s.hv = 0;
+      s.flags = 0;
+      s.score = 0.0f;
+      board_dirty = true;
+      final_coll = false;
+    }
+  }
+  wave_sync();
+
+  TG_STAMP(7);
+  // ---- F: write back dirty slabs, pack observations, store records ----
+  {
+    const uint64_t dirty = __ballot(board_dirty && live && leader);  // bit L*e = env e of this wave
+    if (dirty) {  // chunk c covers bytes [16c, 16c+16): at most two envs
+      uint4* gdst = reinterpret_cast<uint4*>(p.board + (size_t)base_env * S);
+      if (full_wave) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const int c = lane + 64 * k;
+          const uint32_t e0 = ((uint32_t)c * 16u) / (uint32_t)S, e1 = ((uint32_t)c * 16u + 15u) / (uint32_t)S;
+          if (c < NCH && (((dirty >> ((e0 * L) & 63u)) | (dirty >> ((e1 < (uint32_t)EPW ? e1 : (uint32_t)EPW - 1u) * L))) & 1ULL))
+            gdst[c] = lds4[c];
+        }
+      } else {
+        for (uint32_t c = lane; c < nchunks; c += 64) {
+          const uint32_t e0 = (c * 16u) / (uint32_t)S, e1 = (c * 16u + 15u) / (uint32_t)S;
+          if (((dirty >> ((e0 * L) & 63u)) | (dirty >> ((e1 < (uint32_t)EPW ? e1 : (uint32_t)EPW - 1u) * L))) & 1ULL)
+            gdst[c] = lds4[c];
+        }
+      }
+    }
+  }
+  if (p.obs_mode == TG_OBS_BOARD || p.obs_mode == TG_OBS_FN) {
+    const bool show = live && (RULESET == TG_RULESET_NUMPY ? !final_coll : !(s.flags & TG_F_GAME_OVER));
+    bd.stamp(lane_cells(cell_tab, s.piece, s.rot), s.x, s.y, p.obs_mode == TG_OBS_FN ? 0xFFu : (uint32_t)s.val, false,
+             show);
+    wave_sync();
+    uint4* odst = reinterpret_cast<uint4*>(p.obs + (size_t)base_env * S);
+    const bool fn = p.obs_mode == TG_OBS_FN;
+    auto bin1 = [](uint32_t x) -> uint32_t {  // bytes: 0xFF (active) stays -1, other non-zero → 1  (tetris_fn.py:137-158)
+      const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+      const uint32_t ff = ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u;
+      return (nz >> 7) | ((ff >> 7) * 0xFFu);
+    };
+    auto binarize = [&](uint4 v) -> uint4 { return make_uint4(bin1(v.x), bin1(v.y), bin1(v.z), bin1(v.w)); };
+    if (full_wave) {
+      uint4 stage[NIT];
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int c = lane + 64 * k;
+        stage[k] = lds4[c < NCH ? c : NCH - 1];
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int c = lane + 64 * k;
+        if (c < NCH) {
+          odst[c] = fn ? binarize(stage[k]) : stage[k];
+        }
+      }
+    } else {
+      for (uint32_t c = lane; c < nchunks; c += 64) {
+        uint4 v = lds4[c];
+        if (fn) v = binarize(v);
+        if (c * 16u + 16u <= nbytes) {
+          odst[c] = v;
+        } else {  // ragged tail of a partial wave
+          const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+          for (uint32_t i = 0; c * 16u + i < nbytes; ++i)
+            p.obs[(size_t)base_env * S + c * 16u + i] = (uint8_t)(w4[i >> 2] >> (8 * (i & 3)));
+        }
+      }
+    }
+  }
+  TG_STAMP(8);
+  if (live && leader) {
+    uint4 oa, ob;
+    lane_pack(s, oa, ob);
+    uint4* rec_out = reinterpret_cast<uint4*>(p.rec) + (size_t)env * 2;
+    rec_out[0] = oa;
+    rec_out[1] = ob;
+    p.out[env] = make_uint2(__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8));
+    const bool rng_dirty = r.s_lo != r_in.s_lo || r.s_hi != r_in.s_hi || r.has32 != r_in.has32 ||
+                           r.uinteger != r_in.uinteger || r.k0 != r_in.k0 || r.k1 != r_in.k1;
+    if (rng_dirty) {
+      uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
+      rng_out[0] = make_uint4((uint32_t)r.s_lo, (uint32_t)(r.s_lo >> 32), (uint32_t)r.s_hi, (uint32_t)(r.s_hi >> 32));
+      rng_out[2] = make_uint4(r.uinteger, r.has32, r.k0, r.k1);
+    }
+    if (p.episode) {
+      tg_episode_rec ep = p.episode[env];
+      if (pending) {  // the NEXT_STEP reset step belongs to no episode (gymnasium RecordEpisodeStatistics)
+        ep.ret = 0.0f; ep.len = 0;
+      } else {
+        ep.ret += reward;
+        ep.len += 1;
+        if (terminated) { ep.last_ret = ep.ret; ep.last_len = ep.len; ep.ret = 0.0f; ep.len = 0; }
+      }
+      p.episode[env] = ep;
+    }
+  }
+  TG_STAMP(9);
+}
+
+}  // namespace tg

@@ -43,6 +43,7 @@ struct KParams {
   int obs_mode;
   int queue_size;
   int act_i8;
+  unsigned long long* dbg;  // optional phase-timing buffer (TG_PHASE_TIMING builds only)
 };
 
 struct ResetParams {
@@ -745,7 +746,7 @@ __device__ __forceinline__ void process_env(const KParams& p, const uint32_t env
             reward = (float)(lines * lines * W + 1);  // score + rewards.alife
             if (sc) { flags |= TG_F_GAME_OVER; reward = 0.0f; }
             else flags &= ~(uint32_t)TG_F_GAME_OVER;
-            flags &= ~(uint32_t)TG_F_HAS_SWAPPED;
+            flags &= ~(uint32_t)(TG_F_HAS_SWAPPED | TG_F_FULLROW);
             final_coll = sc;
             s.piece = piece; s.rot = 0; s.x = x; s.y = 0; s.val = val; s.flags = (int)flags;
             env_to_raw(s, d);
@@ -838,9 +839,13 @@ __device__ __forceinline__ void process_env(const KParams& p, const uint32_t env
     p.out[env] = make_uint2(__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8));
     if (p.episode) {
       tg_episode_rec ep = p.episode[env];
-      ep.ret += reward;
-      ep.len += 1;
-      if (terminated) { ep.last_ret = ep.ret; ep.last_len = ep.len; ep.ret = 0.0f; ep.len = 0; }
+      if (pending) {  // the NEXT_STEP reset step belongs to no episode (gymnasium RecordEpisodeStatistics)
+        ep.ret = 0.0f; ep.len = 0;
+      } else {
+        ep.ret += reward;
+        ep.len += 1;
+        if (terminated) { ep.last_ret = ep.ret; ep.last_len = ep.len; ep.ret = 0.0f; ep.len = 0; }
+      }
       p.episode[env] = ep;
     }
   }
