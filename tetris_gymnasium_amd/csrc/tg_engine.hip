@@ -42,11 +42,11 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
   if (g_kernel_lanes && !p.final_obs) {
     if (g_kernel_lanes == 4) {
       const int grid = (p.batch + 15) / 16;
-      const size_t lds = (((size_t)16 * W * H + 15) / 16) * 16 + 64;
+      const size_t lds = (((size_t)16 * W * H + 15) / 16) * 16 + 64 + 4 * W + 16;  // + cell table + drop-probe overrun
       hipLaunchKernelGGL((tg::step_kernel_lanes<W, H, RS, 4>), dim3(grid), dim3(64), lds, s, p);
     } else {
       const int grid = (p.batch + 63) / 64;
-      const size_t lds = (size_t)64 * W * H + 64;
+      const size_t lds = (size_t)64 * W * H + 64 + 4 * W + 16;
       hipLaunchKernelGGL((tg::step_kernel_lanes<W, H, RS, 1>), dim3(grid), dim3(64), lds, s, p);
     }
     return;
@@ -354,8 +354,8 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   CRCHK(hipMalloc((void**)&h->d_reseed, B));
   CRCHK(hipMalloc((void**)&h->d_mask, B));
 #ifdef TG_PHASE_TIMING
-  CRCHK(hipMalloc(&h->dbg, ((B + 63) / 64) * 16 * 8));
-  CRCHK(hipMemset(h->dbg, 0, ((B + 63) / 64) * 16 * 8));
+  CRCHK(hipMalloc(&h->dbg, ((B + 15) / 16) * 16 * 8));
+  CRCHK(hipMemset(h->dbg, 0, ((B + 15) / 16) * 16 * 8));
 #endif
   // a valid (if arbitrary) initial record so that a step before the first reset cannot index out of range
   {

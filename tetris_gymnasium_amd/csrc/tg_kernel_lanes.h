@@ -135,13 +135,20 @@ __device__ __forceinline__ void lane_pack(const LaneS& s, uint4& a, uint4& b) {
   b.w = s.reserved;
 }
 
-// BagRandomizer.get_next_tetromino for the lanes in `on` (eager reshuffle, tetromino_randomizer.py:65-85)
+// BagRandomizer (components/tetromino_randomizer.py:65-85).  The reference reshuffles EAGERLY when the 7th piece
+// is drawn; the shuffled bag is first needed by the env's NEXT draw, so inside a step the reshuffle is kept
+// pending (bidx == 7) and resolved (a) before a later draw of the same step, (b) together with the reset
+// shuffles, or (c) at the end of the step — one PCG64 shuffle invocation per wave-step in the common case
+// instead of one per call site.  Per env the generator is advanced in exactly the reference's order.
+__device__ __forceinline__ void lane_resolve_shuffle(LaneS& s, LaneRng& r, const bool need) {
+  lane_shuffle7(r, s.bag, need);
+  if (need) s.bidx = 0;
+}
+
 __device__ __forceinline__ int lane_randomizer_next(LaneS& s, LaneRng& r, const bool on) {
+  lane_resolve_shuffle(s, r, on && s.bidx >= 7);  // rare: a second draw in the same step after a wrap
   const int t = (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
   if (on) s.bidx += 1;
-  const bool sh = on && s.bidx >= 7;
-  lane_shuffle7(r, s.bag, sh);
-  if (sh) s.bidx = 0;
   return t;
 }
 
@@ -209,12 +216,44 @@ struct LaneBoard {
   // The reference's drop loop `while not collision(y + 1): y += 1` (envs/tetris.py:445-448,
   // functional/core.py:243-249) for the envs in `go`, four rows per pass.
   __device__ __forceinline__ int drop(uint32_t cells, int x, int y, bool go) const {
+    // per cell: LDS offset of its current position, rows left above the floor, column inside the playfield;
+    // the four probe rows of a pass are immediate offsets (W, 2W, 3W, 4W) from that position, so a pass costs
+    // 4 byte reads + a handful of compares per cell (reads may run a few rows past the slab: LDS is padded and
+    // those probes are masked by `lim`).
+    constexpr int CPL = 4 / L;
+    int cur[CPL], lim[CPL];
+    bool colok[CPL];
+#pragma unroll
+    for (int jj = 0; jj < CPL; ++jj) {
+      const int j = L == 1 ? jj : sub;
+      const int k = (cells >> (4 * j + 2)) & 3, c = (cells >> (4 * j)) & 3;
+      const int col = x + c - 4, row = y + k;
+      colok[jj] = (unsigned)col < (unsigned)W;
+      lim[jj] = H - row;  // probe t is inside the playfield iff t < lim
+      const int a = row * W + (colok[jj] ? col : 0);
+      cur[jj] = a < H * W ? a : H * W - 1;
+    }
     int yd = y;
     while (__any(go)) {
-      const int xs[4] = {x, x, x, x}, ys[4] = {yd + 1, yd + 2, yd + 3, yd + 4};
-      const uint32_t hit = collide_n<4>(cells, xs, ys);
+      uint8_t v[CPL][4];
+#pragma unroll
+      for (int jj = 0; jj < CPL; ++jj)
+#pragma unroll
+        for (int t = 1; t <= 4; ++t) v[jj][t - 1] = my[cur[jj] + t * W];
+      uint32_t hit = 0;
+#pragma unroll
+      for (int t = 1; t <= 4; ++t) {
+        bool h = false;
+#pragma unroll
+        for (int jj = 0; jj < CPL; ++jj) h |= !colok[jj] || t >= lim[jj] || v[jj][t - 1] != 0;
+        hit |= (h ? 1u : 0u) << (t - 1);
+      }
+      hit = env_or<L>(hit);
       const int steps = hit ? (int)__builtin_ctz(hit) : 4;
-      yd += go ? steps : 0;
+      const int adv = go ? steps : 0;
+      yd += adv;
+#pragma unroll
+      for (int jj = 0; jj < CPL; ++jj) { cur[jj] += adv * W; lim[jj] -= adv; }
       go = go && steps == 4;
     }
     return yd;
@@ -302,6 +341,13 @@ __global__ __launch_bounds__(64) void step_kernel_lanes(const KParams p) {
   const bool leader = sub == 0;
 
   TG_STAMP(0);
+  // ---- B (issued first: needed first): per-env record, generator state, action ----
+  const uint4* rec4 = reinterpret_cast<const uint4*>(p.rec) + (size_t)env * 2;
+  const uint4 ra = rec4[0], rb = rec4[1];
+  const uint4* rng4 = reinterpret_cast<const uint4*>(p.rng + env);
+  const uint4 g0 = rng4[0], g1 = rng4[1], g2 = rng4[2];
+  const int action = p.act_i8 ? (int)reinterpret_cast<const int8_t*>(p.actions)[env]
+                              : reinterpret_cast<const int32_t*>(p.actions)[env];
   // ---- A: the wave's 64 slabs: one contiguous block, coalesced 16 B per lane → LDS ----
   const uint32_t nbytes = nlive * (uint32_t)S;
   const uint32_t nchunks = (nbytes + 15u) / 16u;
@@ -327,13 +373,6 @@ __global__ __launch_bounds__(64) void step_kernel_lanes(const KParams p) {
   }
   if (lane < 7) cell_tab[lane] = c_cells.cells[lane];
 
-  // ---- B: per-lane record, generator state, action ----
-  const uint4* rec4 = reinterpret_cast<const uint4*>(p.rec) + (size_t)env * 2;
-  const uint4 ra = rec4[0], rb = rec4[1];
-  const uint4* rng4 = reinterpret_cast<const uint4*>(p.rng + env);
-  const uint4 g0 = rng4[0], g1 = rng4[1], g2 = rng4[2];
-  const int action = p.act_i8 ? (int)reinterpret_cast<const int8_t*>(p.actions)[env]
-                              : reinterpret_cast<const int32_t*>(p.actions)[env];
   LaneS s;
   lane_unpack(s, ra, rb);
   LaneRng r;
@@ -521,9 +560,9 @@ __global__ __launch_bounds__(64) void step_kernel_lanes(const KParams p) {
     if (do_reset)
       for (int i = sub; i < S / 4; i += L) myw[i] = 0u;
     if (RULESET == TG_RULESET_NUMPY) {
-      if (do_reset) { s.bag = 0x06050403020100ULL; s.queue = 0; }
-      lane_shuffle7(r, s.bag, do_reset);
-      if (do_reset) s.bidx = 0;
+      lane_resolve_shuffle(s, r, do_reset && s.bidx >= 7);  // rare: this step's spawn wrapped the bag, then game over
+      if (do_reset) { s.bag = 0x06050403020100ULL; s.queue = 0; s.bidx = 7; }
+      lane_resolve_shuffle(s, r, s.bidx >= 7);  // reset shuffles + pending spawn reshuffles of the other envs, at once
       for (int i = 0; i < Q; ++i) {
         const int t = lane_randomizer_next(s, r, do_reset);
         if (do_reset) s.queue |= (uint64_t)t << (8 * i);
@@ -616,6 +655,7 @@ __global__ __launch_bounds__(64) void step_kernel_lanes(const KParams p) {
       }
     }
   }
+  if (RULESET == TG_RULESET_NUMPY) lane_resolve_shuffle(s, r, s.bidx >= 7);  // pending reshuffle (no reset in this wave)
   TG_STAMP(8);
   if (live && leader) {
     uint4 oa, ob;

@@ -19,17 +19,18 @@ acts = rng.integers(0, 8, (80, B)).astype(np.int8)
 d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts)
 e.step_k_device(d, 79); e.sync()
 e.step_k_device(d + 79 * B, 1); e.sync()
-nw = B // 64
+EPW = 16 if os.environ.get("TG_KERNEL", "quad") == "quad" else 64
+nw = B // EPW
 buf = np.zeros((nw, 16), np.uint64)
 e.lib.tg_debug_phase_times.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 rc = e.lib.tg_debug_phase_times(e.h, buf.ctypes.data_as(C.c_void_p), nw)
 assert rc == 0, rc
 t = buf[:, :10].astype(np.int64)
-names = ["A load+stage", "B/C unpack+swap", "cells", "collide+decide", "drop+stamp", "rows+clear", "spawn(+shuffle)", "reset", "writeback+obs", "stores"]
+names = ["A load+stage", "unpack+LUT+swap", "cells+collide+decide", "lock: drop+stamp", "rows+clear loop", "spawn(+shuffle)", "E reset", "F writeback+obs", "rec/out stores", "-"]
 dt = np.diff(t, axis=1)
-print("per-wave mean ticks (s_memtime, 100 MHz → x10 ns):")
+print("per-wave mean shader cycles (s_memtime) per phase, kernel", os.environ.get("TG_KERNEL", "quad"))
 for i in range(9):
     col = dt[:, i]
     ok = (t[:, i] > 0) & (t[:, i + 1] > 0)
-    print(f"  {i}->{i+1} {names[i]:18s} mean {col[ok].mean():8.1f} ticks = {col[ok].mean()*10:8.0f} ns   (n={ok.sum()})")
-print("total mean", (t[:, 9] - t[:, 0]).mean() * 10, "ns; span of kernel", (t[:, 9].max() - t[:, 0].min()) * 10, "ns")
+    print(f"  {i}->{i+1} {names[i]:22s} mean {col[ok].mean():8.1f} cycles   (n={ok.sum()})")
+print("wave lifetime mean", (t[:, 9] - t[:, 0]).mean(), "cycles; kernel span", (t[:, 9].max() - t[:, 0].min()), "cycles")
