@@ -36,16 +36,27 @@ int g_step_blocks = 0;  // persistent grid size (blocks); set once per process f
 // step kernel selection (TG_KERNEL): 4 = "quad": 16 envs per wave, 4 lanes per env (default); 1 = "lanes": 64 envs
 // per wave, one per lane (both tg_kernel_lanes.h); 0 = "wave": one env per wavefront (tg_kernels.h)
 int g_kernel_lanes = 4;
+size_t g_lds_pad = 0;
+int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE (>1: each wave walks several groups)  // TG_LDS_PAD: extra dynamic LDS per wave = occupancy limiter (staggers the waves of a SIMD)
 
 template <int W, int H, int RS>
 void launch_step(const tg::KParams& p, hipStream_t s) {
   if (g_kernel_lanes && !p.final_obs) {
-    if (g_kernel_lanes == 4) {
-      const int grid = (p.batch + 15) / 16;
-      const size_t lds = (((size_t)16 * W * H + 15) / 16) * 16 + 64 + 4 * W + 16;  // + cell table + drop-probe overrun
+    // groups per wave: 2 when the batch divides evenly (software-pipelined loads/stores), else 1
+    auto grid_of = [&](int epw) {
+      const int groups = (p.batch + epw - 1) / epw;
+      return (g_groups_per_wave > 1 && groups % g_groups_per_wave == 0 && groups >= 2048) ? groups / g_groups_per_wave : groups;
+    };
+    if (g_kernel_lanes == 2) {
+      const int grid = grid_of(32);
+      const size_t lds = (((size_t)32 * W * H + 15) / 16) * 16 + 64 + 4 * W + 16;
+      hipLaunchKernelGGL((tg::step_kernel_lanes<W, H, RS, 2>), dim3(grid), dim3(64), lds, s, p);
+    } else if (g_kernel_lanes == 4) {
+      const int grid = grid_of(16);
+      const size_t lds = (((size_t)16 * W * H + 15) / 16) * 16 + 64 + 4 * W + 16 + g_lds_pad;  // + cell table + drop-probe overrun
       hipLaunchKernelGGL((tg::step_kernel_lanes<W, H, RS, 4>), dim3(grid), dim3(64), lds, s, p);
     } else {
-      const int grid = (p.batch + 63) / 64;
+      const int grid = grid_of(64);
       const size_t lds = (size_t)64 * W * H + 64 + 4 * W + 16;
       hipLaunchKernelGGL((tg::step_kernel_lanes<W, H, RS, 1>), dim3(grid), dim3(64), lds, s, p);
     }
@@ -330,8 +341,10 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     // looping over its envs with the next env's loads in flight.
     int per_cu = 0;
     if (const char* e = getenv("TG_BLOCKS_PER_CU")) per_cu = atoi(e);
+    if (const char* e2 = getenv("TG_LDS_PAD")) g_lds_pad = (size_t)atoi(e2);
+    if (const char* e3 = getenv("TG_GROUPS_PER_WAVE")) g_groups_per_wave = atoi(e3) > 0 ? atoi(e3) : 1;
     if (const char* k = getenv("TG_KERNEL"))
-      g_kernel_lanes = strcmp(k, "wave") == 0 ? 0 : (strcmp(k, "lanes") == 0 ? 1 : 4);
+      g_kernel_lanes = strcmp(k, "wave") == 0 ? 0 : (strcmp(k, "lanes") == 0 ? 1 : (strcmp(k, "pair") == 0 ? 2 : 4));
     g_step_blocks = per_cu > 0 ? prop.multiProcessorCount * per_cu : -1;
   }
   CRCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));

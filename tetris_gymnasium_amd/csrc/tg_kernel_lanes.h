@@ -55,7 +55,20 @@ __constant__ CellTable c_cells = make_cell_table();
 struct LaneRng {
   uint64_t s_lo, s_hi, i_lo, i_hi;
   uint32_t uinteger, has32, k0, k1;
+  const tg_rng_rec* src;  // this env's record in HBM
+  bool loaded;            // wave-uniform: the 48-byte records are fetched only by wave-steps that draw random numbers
+  bool dirty;             // per env
 };
+
+__device__ __forceinline__ void lane_rng_ensure(LaneRng& r) {
+  if (r.loaded) return;
+  const uint4* q = reinterpret_cast<const uint4*>(r.src);
+  const uint4 g0 = q[0], g1 = q[1], g2 = q[2];
+  r.s_lo = (uint64_t)g0.x | ((uint64_t)g0.y << 32); r.s_hi = (uint64_t)g0.z | ((uint64_t)g0.w << 32);
+  r.i_lo = (uint64_t)g1.x | ((uint64_t)g1.y << 32); r.i_hi = (uint64_t)g1.z | ((uint64_t)g1.w << 32);
+  r.uinteger = g2.x; r.has32 = g2.y; r.k0 = g2.z; r.k1 = g2.w;
+  r.loaded = true;
+}
 
 __device__ __forceinline__ uint32_t lane_pcg_next32(LaneRng& r) {
   // divergent form of pcg_next32 (tg_kernels.h): every lane advances its own generator
@@ -81,6 +94,7 @@ __device__ __forceinline__ uint32_t lane_pcg_next32(LaneRng& r) {
 // Generator.shuffle of the 7-byte bag for the lanes in `need` (others untouched)
 __device__ __forceinline__ void lane_shuffle7(LaneRng& r, uint64_t& bag, const bool need) {
   if (!__any(need)) return;
+  lane_rng_ensure(r);
   LaneRng t = r;
   uint64_t b = bag;
   for (int i = 6; i >= 1; --i) {
@@ -102,6 +116,7 @@ __device__ __forceinline__ void lane_shuffle7(LaneRng& r, uint64_t& bag, const b
   }
   if (need) {
     r = t;
+    r.dirty = true;
     bag = b;
   }
 }
@@ -163,10 +178,8 @@ __device__ __forceinline__ int lane_queue_pop(LaneS& s, LaneRng& r, const bool o
 // OR of a small bit-set over the L lanes that serve one env (L = 4: one DPP quad, two v_or_b32_dpp)
 template <int L>
 __device__ __forceinline__ uint32_t env_or(uint32_t x) {
-  if constexpr (L == 4) {
-    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
-  }
+  if constexpr (L >= 2) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  if constexpr (L == 4) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
   return x;
 }
 
@@ -189,7 +202,7 @@ struct LaneBoard {
     int addr[N][CPL];
 #pragma unroll
     for (int jj = 0; jj < CPL; ++jj) {
-      const int j = L == 1 ? jj : sub;
+      const int j = jj * L + sub;
       const int k = (cells >> (4 * j + 2)) & 3, c = (cells >> (4 * j)) & 3;
 #pragma unroll
       for (int i = 0; i < N; ++i) addr[i][jj] = cell_addr(ys[i] + k, xs[i] + c - 4);
@@ -225,7 +238,7 @@ struct LaneBoard {
     bool colok[CPL];
 #pragma unroll
     for (int jj = 0; jj < CPL; ++jj) {
-      const int j = L == 1 ? jj : sub;
+      const int j = jj * L + sub;
       const int k = (cells >> (4 * j + 2)) & 3, c = (cells >> (4 * j)) & 3;
       const int col = x + c - 4, row = y + k;
       colok[jj] = (unsigned)col < (unsigned)W;
@@ -263,7 +276,7 @@ struct LaneBoard {
     int addr[CPL];
 #pragma unroll
     for (int jj = 0; jj < CPL; ++jj) {
-      const int j = L == 1 ? jj : sub;
+      const int j = jj * L + sub;
       const int k = (cells >> (4 * j + 2)) & 3, c = (cells >> (4 * j)) & 3;
       addr[jj] = cell_addr(y + k, x + c - 4);
     }
@@ -304,12 +317,8 @@ struct LaneBoard {
   // are any of the playfield rows y0 .. y0+3 completely filled?
   __device__ __forceinline__ bool any_row_full4(int y0) const {
     uint32_t any = 0;
-    if constexpr (L == 4) {
-      any = row_full(y0 + sub) ? 1u : 0u;
-    } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) any |= row_full(y0 + k) ? 1u : 0u;
-    }
+    for (int kk = 0; kk < 4 / L; ++kk) any |= row_full(y0 + kk * L + sub) ? 1u : 0u;
     return env_or<L>(any) != 0;
   }
 };
@@ -324,62 +333,109 @@ __device__ __forceinline__ uint32_t lane_cells(const uint64_t* tab, int piece, i
 // Measured (profiles/r01_*): with L = 1 there is exactly one wave per SIMD at batch 65 536, so nothing hides
 // LDS/VALU dependency latency and the load / compute / store phases of all waves run in lockstep; L = 4 gives
 // four waves per SIMD with a quarter of the per-wave work.
+// ------------------------------------------------------------------------------------------------
+// L = lanes per env (1: 64 envs per wave; 4: 16 envs per wave, the four lanes of an env split the piece's
+// four cells and OR their results with DPP quad permutes; everything else is computed redundantly by the quad).
+// Measured (profiles/r01_*): with L = 1 there is exactly one wave per SIMD at batch 65 536, so nothing hides
+// LDS/VALU dependency latency and the load / compute / store phases of all waves run in lockstep; L = 4 gives
+// four waves per SIMD with a quarter of the per-wave work.
+// inputs of one group (= the 64/L envs a wave handles at a time), fetched ahead of their use
+template <int W, int H, int L>
+struct GroupIn {
+  static constexpr int NCH = ((64 / L) * W * H + 15) / 16;  // 16-byte chunks of a full group's block
+  static constexpr int NIT = (NCH + 63) / 64;               // chunk passes
+  uint4 stage[NIT];
+  uint4 ra, rb;
+  int action;
+};
+
+template <int W, int H, int L>
+__device__ __forceinline__ void lanes_load(const KParams& p, const uint32_t group, const int lane, GroupIn<W, H, L>& in) {
+  constexpr int S = W * H, EPW = 64 / L;
+  using GI = GroupIn<W, H, L>;
+  const uint32_t B = (uint32_t)p.batch;
+  const uint32_t base_env = group * (uint32_t)EPW;
+  const uint32_t nlive = B - base_env < (uint32_t)EPW ? B - base_env : (uint32_t)EPW;
+  const uint32_t eidx = (uint32_t)lane / L;
+  const uint32_t env = base_env + (eidx < nlive ? eidx : nlive - 1u);
+  // small per-env loads first (needed first): record, action
+  const uint4* rec4 = reinterpret_cast<const uint4*>(p.rec) + (size_t)env * 2;
+  in.ra = rec4[0];
+  in.rb = rec4[1];
+  in.action = p.act_i8 ? (int)reinterpret_cast<const int8_t*>(p.actions)[env]
+                       : reinterpret_cast<const int32_t*>(p.actions)[env];
+  // the group's slabs: one contiguous block, coalesced 16 B per lane (clamped, unconditional: stays in registers)
+  const uint32_t nchunks = (nlive * (uint32_t)S + 15u) / 16u;
+  const uint4* gsrc = reinterpret_cast<const uint4*>(p.board + (size_t)base_env * S);
+#pragma unroll
+  for (int k = 0; k < GI::NIT; ++k) {
+    const uint32_t c = (uint32_t)lane + 64u * k;
+    in.stage[k] = gsrc[c < nchunks ? c : nchunks - 1u];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// L = lanes per env (1: 64 envs per wave; 4: 16 envs per wave, the four lanes of an env split the piece's
+// four cells and OR their results with DPP quad permutes; everything else is computed redundantly by the quad).
+// Measured (profiles/r01_*): with L = 1 there is exactly one wave per SIMD at batch 65 536, so nothing hides
+// LDS/VALU dependency latency and the load / compute / store phases of all waves run in lockstep; L = 4 gives
+// four waves per SIMD with a quarter of the per-wave work.
 template <int W, int H, int RULESET, int L>
-__global__ __launch_bounds__(64) void step_kernel_lanes(const KParams p) {
+__device__ __forceinline__ void lanes_process(const KParams& p, const uint32_t group, const int lane, uint8_t* lds) {
   using G = Geo<W, H>;
   constexpr int S = G::CELLS;  // per-env stride in LDS (bytes), same as in HBM: the wave's slabs are one block
   constexpr int EPW = 64 / L;  // envs per wave
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  constexpr int NCH = (EPW * S + 15) / 16;  // 16-byte chunks of a full group's block
+  constexpr int NIT = (NCH + 63) / 64;      // chunk passes
   uint64_t* cell_tab = reinterpret_cast<uint64_t*>(lds + ((EPW * S + 15) / 16) * 16);  // 7 x 8 bytes behind the slabs
-  const int lane = threadIdx.x;
   const int eidx = lane / L, sub = lane % L;
   const uint32_t B = (uint32_t)p.batch;
-  const uint32_t base_env = blockIdx.x * (uint32_t)EPW;
+  const uint32_t base_env = group * (uint32_t)EPW;
   const uint32_t nlive = B - base_env < (uint32_t)EPW ? B - base_env : (uint32_t)EPW;
   const bool live = (uint32_t)eidx < nlive;
   const uint32_t env = base_env + (live ? (uint32_t)eidx : nlive - 1u);  // dead lanes shadow the last live env
   const bool leader = sub == 0;
 
+#ifdef TG_PHASE_TIMING
+  if (p.dbg && lane == 0)
+    for (int i = 1; i < 16; ++i) p.dbg[(size_t)blockIdx.x * 16 + i] = 0;
+#endif
   TG_STAMP(0);
-  // ---- B (issued first: needed first): per-env record, generator state, action ----
+  // ---- B (issued first: needed first): per-env record, action ----
   const uint4* rec4 = reinterpret_cast<const uint4*>(p.rec) + (size_t)env * 2;
   const uint4 ra = rec4[0], rb = rec4[1];
-  const uint4* rng4 = reinterpret_cast<const uint4*>(p.rng + env);
-  const uint4 g0 = rng4[0], g1 = rng4[1], g2 = rng4[2];
   const int action = p.act_i8 ? (int)reinterpret_cast<const int8_t*>(p.actions)[env]
                               : reinterpret_cast<const int32_t*>(p.actions)[env];
-  // ---- A: the wave's 64 slabs: one contiguous block, coalesced 16 B per lane → LDS ----
+  // ---- A: the group's slabs: one contiguous block, coalesced 16 B per lane → LDS; all loads are in flight
+  // before the first LDS write (one latency, not NIT of them; clamped + unconditional: stays in registers) ----
   const uint32_t nbytes = nlive * (uint32_t)S;
   const uint32_t nchunks = (nbytes + 15u) / 16u;
   const uint4* gsrc = reinterpret_cast<const uint4*>(p.board + (size_t)base_env * S);
   uint4* lds4 = reinterpret_cast<uint4*>(lds);
-  constexpr int NCH = (EPW * S + 15) / 16;        // 16-byte chunks of a full wave's block
-  constexpr int NIT = (NCH + 63) / 64;            // chunk passes
   const bool full_wave = nlive == (uint32_t)EPW;
-  if (full_wave) {  // all loads in flight before the first LDS write (one latency, not NIT of them)
+  {
     uint4 stage[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      const int c = lane + 64 * k;
-      stage[k] = gsrc[c < NCH ? c : NCH - 1];  // unconditional (clamped) so the staging array stays in registers
+      const uint32_t c = (uint32_t)lane + 64u * k;
+      stage[k] = gsrc[c < nchunks ? c : nchunks - 1u];
     }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      const int c = lane + 64 * k;
-      if (c < NCH) lds4[c] = stage[k];
+      const uint32_t c = (uint32_t)lane + 64u * k;
+      if (c < nchunks) lds4[c] = stage[k];
     }
-  } else {
-    for (uint32_t c = lane; c < nchunks; c += 64) lds4[c] = gsrc[c];
   }
   if (lane < 7) cell_tab[lane] = c_cells.cells[lane];
 
   LaneS s;
   lane_unpack(s, ra, rb);
   LaneRng r;
-  r.s_lo = (uint64_t)g0.x | ((uint64_t)g0.y << 32); r.s_hi = (uint64_t)g0.z | ((uint64_t)g0.w << 32);
-  r.i_lo = (uint64_t)g1.x | ((uint64_t)g1.y << 32); r.i_hi = (uint64_t)g1.z | ((uint64_t)g1.w << 32);
-  r.uinteger = g2.x; r.has32 = g2.y; r.k0 = g2.z; r.k1 = g2.w;
-  const LaneRng r_in = r;
+  r.s_lo = r.s_hi = r.i_lo = r.i_hi = 0;
+  r.uinteger = r.has32 = r.k0 = r.k1 = 0;
+  r.src = p.rng + env;
+  r.loaded = false;
+  r.dirty = false;
   const int Q = p.queue_size;
   const int grav = p.gravity;
   LaneBoard<W, H, L> bd;
@@ -521,6 +577,7 @@ __global__ __launch_bounds__(64) void step_kernel_lanes(const KParams p) {
           final_coll = sc;
         }
       } else {  // envs/tetris_fn.py:370-413 place_active_tetromino
+        lane_rng_ensure(r);
         uint32_t a0, a1, b0, b1;
         threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);  // split(rng_key)[0]
         const bool refill = place && s.bidx >= 7;
@@ -533,6 +590,7 @@ __global__ __launch_bounds__(64) void step_kernel_lanes(const KParams p) {
           s.piece = (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
           s.bidx += 1;
           r.k0 = a0; r.k1 = a1;
+          r.dirty = true;
           s.rot = 0; s.val = s.piece + 2; s.x = (W + 8) / 2 - 2; s.y = 0;
         }
         const bool sc = bd.collide(lane_cells(cell_tab, s.piece, 0), s.x, 0);
@@ -570,6 +628,7 @@ __global__ __launch_bounds__(64) void step_kernel_lanes(const KParams p) {
       const int first = lane_queue_pop(s, r, do_reset, Q);
       if (do_reset) { s.piece = first; s.x = np_spawn_x<W>(first); }
     } else {
+      lane_rng_ensure(r);
       uint32_t a0, a1, b0, b1;
       threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);
       threefry2x32(r.k0, r.k1, 0u, 1u, b0, b1);
@@ -577,6 +636,7 @@ __global__ __launch_bounds__(64) void step_kernel_lanes(const KParams p) {
       if (do_reset) {
         s.bag = nb; s.queue = 0; s.piece = (int)(nb & 0xFF); s.bidx = 1;
         r.k0 = b0; r.k1 = b1;
+        r.dirty = true;
         s.x = (W + 8) / 2 - 2;
       }
     }
@@ -664,9 +724,7 @@ __global__ __launch_bounds__(64) void step_kernel_lanes(const KParams p) {
     rec_out[0] = oa;
     rec_out[1] = ob;
     p.out[env] = make_uint2(__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8));
-    const bool rng_dirty = r.s_lo != r_in.s_lo || r.s_hi != r_in.s_hi || r.has32 != r_in.has32 ||
-                           r.uinteger != r_in.uinteger || r.k0 != r_in.k0 || r.k1 != r_in.k1;
-    if (rng_dirty) {
+    if (r.dirty) {
       uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
       rng_out[0] = make_uint4((uint32_t)r.s_lo, (uint32_t)(r.s_lo >> 32), (uint32_t)r.s_hi, (uint32_t)(r.s_hi >> 32));
       rng_out[2] = make_uint4(r.uinteger, r.has32, r.k0, r.k1);
@@ -684,6 +742,19 @@ __global__ __launch_bounds__(64) void step_kernel_lanes(const KParams p) {
     }
   }
   TG_STAMP(9);
+}
+
+// The kernel: a wave walks groups  g, g + gridDim.x, ...  (one group per wave by default)
+template <int W, int H, int RULESET, int L>
+__global__ __launch_bounds__(64) void step_kernel_lanes(const KParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  constexpr int EPW = 64 / L;
+  const int lane = threadIdx.x;
+  const uint32_t n_groups = ((uint32_t)p.batch + EPW - 1) / EPW;
+  for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    lanes_process<W, H, RULESET, L>(p, g, lane, lds);
+    wave_sync();
+  }
 }
 
 }  // namespace tg

@@ -26,6 +26,8 @@ e.lib.tg_debug_phase_times.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 rc = e.lib.tg_debug_phase_times(e.h, buf.ctypes.data_as(C.c_void_p), nw)
 assert rc == 0, rc
 t = buf[:, :10].astype(np.int64)
+for i in range(1, 10):  # stamps inside skipped blocks stay 0: forward-fill
+    t[:, i] = np.where(t[:, i] == 0, t[:, i - 1], t[:, i])
 names = ["A load+stage", "unpack+LUT+swap", "cells+collide+decide", "lock: drop+stamp", "rows+clear loop", "spawn(+shuffle)", "E reset", "F writeback+obs", "rec/out stores", "-"]
 dt = np.diff(t, axis=1)
 print("per-wave mean shader cycles (s_memtime) per phase, kernel", os.environ.get("TG_KERNEL", "quad"))
