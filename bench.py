@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--obs", choices=["board", "dict", "fn", "none"], default="board")
     ap.add_argument("--ruleset", choices=["numpy", "functional"], default="numpy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config5", action="store_true",
+                    help="BASELINE config 5: 20x40 board, queue_size 7, grouped hard-drop action set, legal actions sampled on device")
     args = ap.parse_args()
 
     D = Dist()
@@ -126,12 +128,14 @@ def main():
 
     W, H, B = args.width, args.height, args.batch
     Q = 4
+    if args.config5:
+        W, H, Q = 20, 40, 7
     ruleset = N.RULESET_NUMPY if args.ruleset == "numpy" else N.RULESET_FUNCTIONAL
     obs_mode = {"board": N.OBS_BOARD, "dict": N.OBS_DICT, "fn": N.OBS_FN, "none": N.OBS_NONE}[args.obs]
     n_act = 8 if ruleset == N.RULESET_NUMPY else 7
     lo, hi, seeds = D.shard(B)
     e = Engine(B, W, H, ruleset=ruleset, queue_size=(Q if ruleset == N.RULESET_NUMPY else 7), obs_mode=obs_mode,
-               autoreset=N.AUTORESET_SAME_STEP, device=local, env_offset=lo)
+               autoreset=N.AUTORESET_SAME_STEP, device=local, env_offset=lo, grouped=args.config5)
     e.reset(seeds)
 
     # pre-generated uniform random actions, uploaded once: [T][B] int8 resident in HBM
@@ -142,6 +146,11 @@ def main():
     e.dev_upload(d_acts, acts)
 
     def run(k0, k):
+        if args.config5:  # one pass = sample a legal placement per env on the device + the grouped step
+            for i in range(k):
+                e.sample_legal_actions(seed=rank + 1, counter=k0 + i, fetch=False)
+                e.step_sampled()
+            return
         done = 0
         while done < k:  # cycle through the resident action rows
             row = (k0 + done) % T
@@ -186,7 +195,10 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": f"Batch {B} envs/GPU, {W}x{H} board, {args.ruleset} rule-set, uniform random "
+            "config": {"workload": (f"Batch {B} envs/GPU, {W}x{H} board, queue_size 7, grouped action set (column*4+rotation "
+                                    f"→ teleport + hard drop), legal actions sampled on device, obs={args.obs}, same-step "
+                                    f"autoreset") if args.config5 else
+                                   f"Batch {B} envs/GPU, {W}x{H} board, {args.ruleset} rule-set, uniform random "
                                    f"actions (int8, resident in HBM), obs={args.obs}, same-step autoreset",
                        "envs_per_gpu": B, "total_envs": world * B, "parallelism": f"env-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -199,7 +211,7 @@ def main():
             out["hbm_copy_gbps"] = None
             out["hbm_copy_error"] = str(ex)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, H, Q)
+            out["cpu_baseline"] = cpu_baseline(W, H, Q) if not args.config5 else None
             out["cpu_baseline"]["reference_python_single_env"] = \
                 "~3.4k steps/s on one 2.6 GHz Xeon core, measured in the survey container, not on this host"
         print(json.dumps(out), flush=True)

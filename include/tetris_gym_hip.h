@@ -199,6 +199,11 @@ int tg_observe(tg_handle* h);
  * placement boards u8 [B][4W][Hp][Wp] there) for the current state (wrappers/grouped.py:124-207). */
 int tg_grouped_enumerate(tg_handle* h, uint8_t* boards_dev);
 
+/* Grouped action surface: draw one action per env uniformly from its legal mask into TG_BUF_ACTIONS (device-side
+ * random policy for benchmarks / epsilon-greedy exploration: examples/train_lin_grouped.py:284-285). Deterministic in
+ * (seed, counter, env). Step afterwards with tg_step(h, <TG_BUF_ACTIONS pointer>, TG_MEM_DEVICE). */
+int tg_grouped_sample(tg_handle* h, uint32_t seed, uint32_t counter);
+
 int tg_sync(tg_handle* h);
 
 /* Stream timing with HIP events recorded on the handle's own stream (bench.py). */

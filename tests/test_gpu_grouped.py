@@ -1,0 +1,86 @@
+"""GPU parity of the grouped action set (wrappers/grouped.py: column*4+rotation → teleport + hard drop) against
+reference-generated fixtures and the oracle."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import replay
+
+pytestmark = pytest.mark.gpu
+
+from tetris_gymnasium_amd import Engine, _native as N  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["grouped_10x20", "grouped_20x40", "grouped_clears_10x20"])
+def test_grouped_trace_against_reference_fixture(golden_dir, name):
+    fx = replay.load(golden_dir, name)
+    W, H, B, T, Q = int(fx["width"]), int(fx["height"]), int(fx["B"]), int(fx["T"]), int(fx["queue_size"])
+    init = fx["init_boards"] if "init_boards" in fx.files and fx["init_boards"].size else None
+    e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_BOARD, grouped=True)
+    e.reset(1 + np.arange(B, dtype=np.uint64))
+    if init is not None:
+        e.set_state(board=replay.crop(init))
+    np.testing.assert_array_equal(e.legal_mask(), fx["reset_mask"])
+    for t in range(T):
+        rew, term, lines = e.step(fx["actions"][t].astype(np.int32))
+        np.testing.assert_array_equal(rew, fx["reward"][t], err_msg=f"reward t={t}")  # -0.1f for illegal actions
+        np.testing.assert_array_equal(term, fx["done"][t], err_msg=f"t={t}")
+        np.testing.assert_array_equal(lines, fx["lines"][t])
+        np.testing.assert_array_equal(e.get_state()[0], replay.crop(fx["board_after"][t]), err_msg=f"board t={t}")
+        if term.any():
+            e.reset(mask=term)
+            if init is not None:
+                b = e.get_state()[0]
+                b[term.astype(bool)] = replay.crop(init)[term.astype(bool)]
+                e.set_state(board=b)
+        np.testing.assert_array_equal(e.legal_mask(), fx["masks"][t], err_msg=f"mask t={t}")
+
+
+@pytest.mark.parametrize("term_on_illegal", [True, False])
+@pytest.mark.parametrize("W,H,Q", [(10, 20, 4), (20, 40, 7)])
+@pytest.mark.parametrize("autoreset", [N.AUTORESET_NONE, N.AUTORESET_SAME_STEP, N.AUTORESET_NEXT_STEP])
+def test_grouped_engine_vs_oracle(W, H, Q, term_on_illegal, autoreset):
+    B, T = 256, 150
+    e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_BOARD, grouped=True, terminate_on_illegal=term_on_illegal,
+               autoreset=autoreset)
+    o = po.OracleBatch(B, W, H, queue_size=Q)
+    seeds = np.arange(7, 7 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(W + autoreset)
+    n_ill = 0
+    for t in range(T):
+        np.testing.assert_array_equal(e.legal_mask(), o.grouped_enumerate(), err_msg=f"mask t={t}")
+        a = rng.integers(0, 4 * W, B)  # uniformly over ALL actions: ~10 % illegal
+        re_, te, le = e.step(a)
+        ro, to, lo, ill = o.grouped_step(a, terminate_on_illegal=term_on_illegal, autoreset=autoreset)
+        np.testing.assert_array_equal(re_, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(te, to, err_msg=f"terminated t={t}")
+        np.testing.assert_array_equal(le, lo)
+        np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_BOARD), err_msg=f"obs t={t}")
+        n_ill += int(ill.sum())
+        if autoreset == N.AUTORESET_NONE and te.any():
+            e.reset(mask=te); o.reset(mask=te)
+    be, re2, _ = e.get_state(); bo, ro2, _ = o.get_state()
+    np.testing.assert_array_equal(be, bo)
+    for k in re2.dtype.names:
+        if k != "reserved":
+            np.testing.assert_array_equal(re2[k], ro2[k], err_msg=k)
+    assert n_ill > 0
+
+
+def test_device_side_legal_sampling():
+    B, W = 4096, 20
+    e = Engine(B, W, 40, queue_size=7, obs_mode=N.OBS_BOARD, grouped=True, autoreset=N.AUTORESET_SAME_STEP)
+    e.reset(np.arange(1, B + 1, dtype=np.uint64))
+    seen = np.zeros(4 * W, int)
+    for t in range(60):
+        mask = e.legal_mask()
+        a = e.sample_legal_actions(seed=123, counter=t)
+        assert mask[np.arange(B), a].all(), "sampled an illegal action"
+        seen += np.bincount(a, minlength=4 * W)
+        a2 = e.sample_legal_actions(seed=123, counter=t)
+        np.testing.assert_array_equal(a, a2)  # deterministic in (seed, counter, env)
+        e.step_sampled()
+        rew, term, lines = e.fetch_outputs()
+        assert (rew >= 0).all()  # never the -0.1 penalty
+    assert (seen > 0).sum() > 3 * W  # covers most of the action space

@@ -69,6 +69,7 @@ SYMBOLS = {
     "tg_set_state": (_i, [_vp, _vp, _vp, _vp]),
     "tg_observe": (_i, [_vp]),
     "tg_grouped_enumerate": (_i, [_vp, _vp]),
+    "tg_grouped_sample": (_i, [_vp, C.c_uint32, C.c_uint32]),
     "tg_sync": (_i, [_vp]),
     "tg_timer_start": (_i, [_vp]),
     "tg_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),

@@ -231,6 +231,8 @@ tg::KParams step_params(tg_handle* h) {
   p.autoreset = h->cfg.autoreset;
   p.obs_mode = h->cfg.obs_mode;
   p.queue_size = h->Q;
+  p.action_set = h->cfg.action_set;
+  p.grouped_term = h->cfg.grouped_terminate_on_illegal;
   p.dbg = (unsigned long long*)h->dbg;
   return p;
 }
@@ -301,8 +303,10 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
                 cfg->queue_size);
   if (cfg->obs_mode == TG_OBS_DICT && cfg->ruleset != TG_RULESET_NUMPY)
     return fail(nullptr, TG_EINVAL, "tg_create: TG_OBS_DICT is the NUMPY rule-set's observation");
-  if (cfg->action_set == TG_ACTIONS_GROUPED)
-    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: grouped action set not built yet");
+  if (cfg->action_set != TG_ACTIONS_BASE && cfg->action_set != TG_ACTIONS_GROUPED)
+    return fail(nullptr, TG_EINVAL, "tg_create: unknown action_set %d", cfg->action_set);
+  if (cfg->action_set == TG_ACTIONS_GROUPED && cfg->ruleset != TG_RULESET_NUMPY)
+    return fail(nullptr, TG_EINVAL, "tg_create: the grouped action set wraps the NUMPY rule-set (wrappers/grouped.py)");
   Launchers L{};
   if (!find_launchers(cfg->width, cfg->height, cfg->ruleset, &L))
     return fail(nullptr, TG_EUNSUPPORTED, "tg_create: board %dx%d not compiled in (built sizes: %s)", cfg->width,
@@ -356,7 +360,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   const size_t sizes[TG_BUF_COUNT] = {
       /*OBS*/ B * obs_bytes_per_env(cfg), /*STEP_OUT*/ B * sizeof(tg_step_out), /*ACTIONS*/ B * 4,
       /*BOARD*/ B * h->cells, /*REC*/ B * sizeof(tg_env_rec), /*RNG*/ B * sizeof(tg_rng_rec),
-      /*LEGAL_MASK*/ 0,
+      /*LEGAL_MASK*/ cfg->action_set == TG_ACTIONS_GROUPED ? B * 4 * (size_t)cfg->width : 0,
       /*FINAL_OBS*/ want_final ? B * h->cells : 0,
       /*EPISODE*/ (cfg->flags & TG_FLAG_EPISODE_STATS) ? B * sizeof(tg_episode_rec) : 0};
   for (int i = 0; i < TG_BUF_COUNT; ++i) {
@@ -576,9 +580,32 @@ int tg_observe(tg_handle* h) {
   return launch_observe_dict(h);
 }
 
+static int run_grouped(tg_handle* h, bool mask, bool sample, uint32_t seed, uint32_t counter) {
+  tg::GroupedParams g{};
+  g.rec = (const uint32_t*)h->buf[TG_BUF_REC];
+  g.mask = mask ? (uint8_t*)h->buf[TG_BUF_LEGAL_MASK] : nullptr;
+  g.actions = sample ? (int32_t*)h->buf[TG_BUF_ACTIONS] : nullptr;
+  const tg::KParams kp = step_params(h);
+  for (int i = 0; i < 7; ++i) g.shapes[i] = kp.shapes[i];
+  g.seed = seed; g.counter = counter; g.batch = h->B; g.width = h->W;
+  hipLaunchKernelGGL(tg::grouped_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, g);
+  HIPCHK(h, hipGetLastError());
+  return TG_OK;
+}
+
 int tg_grouped_enumerate(tg_handle* h, uint8_t* boards_dev) {
-  (void)boards_dev;
-  return h ? fail(h, TG_EUNSUPPORTED, "tg_grouped_enumerate: grouped action set not built yet") : TG_EINVAL;
+  if (!h) return TG_EINVAL;
+  if (h->cfg.action_set != TG_ACTIONS_GROUPED) return fail(h, TG_EINVAL, "tg_grouped_enumerate: handle was not created with TG_ACTIONS_GROUPED");
+  if (boards_dev) return fail(h, TG_EUNSUPPORTED, "tg_grouped_enumerate: placement boards are not built yet (legal mask only)");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  return run_grouped(h, true, false, 0, 0);
+}
+
+int tg_grouped_sample(tg_handle* h, uint32_t seed, uint32_t counter) {
+  if (!h) return TG_EINVAL;
+  if (h->cfg.action_set != TG_ACTIONS_GROUPED) return fail(h, TG_EINVAL, "tg_grouped_sample: handle was not created with TG_ACTIONS_GROUPED");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  return run_grouped(h, false, true, seed, counter);
 }
 
 int tg_sync(tg_handle* h) {

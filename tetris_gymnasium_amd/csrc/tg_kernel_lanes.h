@@ -404,8 +404,8 @@ __device__ __forceinline__ void lanes_process(const KParams& p, const uint32_t g
   // ---- B (issued first: needed first): per-env record, action ----
   const uint4* rec4 = reinterpret_cast<const uint4*>(p.rec) + (size_t)env * 2;
   const uint4 ra = rec4[0], rb = rec4[1];
-  const int action = p.act_i8 ? (int)reinterpret_cast<const int8_t*>(p.actions)[env]
-                              : reinterpret_cast<const int32_t*>(p.actions)[env];
+  const int action_in = p.act_i8 ? (int)reinterpret_cast<const int8_t*>(p.actions)[env]
+                                 : reinterpret_cast<const int32_t*>(p.actions)[env];
   // ---- A: the group's slabs: one contiguous block, coalesced 16 B per lane → LDS; all loads are in flight
   // before the first LDS write (one latency, not NIT of them; clamped + unconditional: stays in registers) ----
   const uint32_t nbytes = nlive * (uint32_t)S;
@@ -450,7 +450,23 @@ __device__ __forceinline__ void lanes_process(const KParams& p, const uint32_t g
   bool final_coll = false;
 
   const bool pending = p.autoreset == TG_AUTORESET_NEXT_STEP && (s.flags & TG_F_PENDING_RESET);
-  const bool frozen = RULESET == TG_RULESET_FUNCTIONAL && (s.flags & TG_F_GAME_OVER);
+  bool frozen = RULESET == TG_RULESET_FUNCTIONAL && (s.flags & TG_F_GAME_OVER);
+  // grouped action set (wrappers/grouped.py:209-269): action = column * 4 + rotations → teleport + hard drop; illegal
+  // iff a cell of the rotated piece lies outside the playfield columns (collision_with_frame, :104-122)
+  int action = action_in;
+  bool g_illegal = false;
+  if (RULESET == TG_RULESET_NUMPY && p.action_set == TG_ACTIONS_GROUPED) {
+    const int col = action_in >> 2, nrot = (s.rot + (action_in & 3)) & 3;
+    const int nx = col + 4 - (s.piece == 0 ? 2 : 1);  // x + padding - matrix.shape[1] // 2
+    const uint32_t cg = lane_cells(cell_tab, s.piece, nrot);
+    bool legal = (unsigned)action_in < (unsigned)(4 * W);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) legal = legal && (unsigned)(nx + (int)((cg >> (4 * j)) & 3) - 4) < (unsigned)W;
+    if (!pending) {
+      if (legal) { s.x = nx; s.rot = nrot; action = 5; }
+      else { g_illegal = true; action = 7; if (p.grouped_term) frozen = true; }
+    }
+  }
   const bool stepped = live && !pending && !frozen;
 
   // ---- C: action → tentative placement (branch-free LUT, per lane) ----
@@ -507,6 +523,7 @@ __device__ __forceinline__ void lanes_process(const KParams& p, const uint32_t g
       cT = ha & 1u; cT1 = (ha >> 1) & 1u; cC = hb & 1u; cC1 = (hb >> 1) & 1u;
     }
     const bool moving = stepped && !(RULESET == TG_RULESET_FUNCTIONAL && hard);
+    if (RULESET == TG_RULESET_NUMPY && !stepped) final_coll = cC;  // projection rule for an untouched env
     const bool accept = moving && (swap_eff || (check && !cT));
     if (accept) { s.piece = tp; s.rot = tr; s.x = tx; s.y = ty; s.val = tv; cells = cellsT; }
     const bool coll_here = accept ? cT : cC;
@@ -609,7 +626,8 @@ __device__ __forceinline__ void lanes_process(const KParams& p, const uint32_t g
 
   TG_STAMP(6);
   // ---- E: termination / autoreset ----
-  const int terminated = (!pending && (s.flags & TG_F_GAME_OVER)) ? 1 : 0;
+  if (g_illegal) reward = -0.1f;  // rewards.invalid_action
+  const int terminated = (!pending && ((s.flags & TG_F_GAME_OVER) || (g_illegal && p.grouped_term))) ? 1 : 0;
   const bool do_reset = live && (pending || (terminated && p.autoreset == TG_AUTORESET_SAME_STEP));
   if (terminated && p.autoreset == TG_AUTORESET_NEXT_STEP && !pending) s.flags |= TG_F_PENDING_RESET;
   if (__any(do_reset)) {

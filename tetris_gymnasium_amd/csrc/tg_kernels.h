@@ -43,6 +43,8 @@ struct KParams {
   int obs_mode;
   int queue_size;
   int act_i8;
+  int action_set;    // TG_ACTIONS_*
+  int grouped_term;  // wrappers/grouped.py:49 terminate_on_illegal_action
   unsigned long long* dbg;  // optional phase-timing buffer (TG_PHASE_TIMING builds only)
 };
 
@@ -511,7 +513,7 @@ __device__ __forceinline__ void process_env(const KParams& p, const uint32_t env
 #pragma unroll
   for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_readlane(recv, i);
   const uint32_t aword = __builtin_amdgcn_readlane(recv, 8);
-  const int action = p.act_i8 ? (int)(int8_t)(aword >> (8 * (env & 3))) : (int)aword;
+  const int action_in = p.act_i8 ? (int)(int8_t)(aword >> (8 * (env & 3))) : (int)aword;
   const tg_rng_rec* rp = p.rng + env;
   const int Q = p.queue_size;
   wave_sync();
@@ -525,13 +527,13 @@ __device__ __forceinline__ void process_env(const KParams& p, const uint32_t env
     const uint32_t fl = d[1] >> 8;  // flags in bits 0..7
     uint32_t e;
     if (RULESET == TG_RULESET_NUMPY) {
-      e = (uint32_t)(kActLutNumpy >> (8 * (action & 7)));
+      e = (uint32_t)(kActLutNumpy >> (8 * (action_in & 7)));
     } else {
-      const int br = action < 0 ? 0 : (action > 6 ? 6 : action);
+      const int br = action_in < 0 ? 0 : (action_in > 6 ? 6 : action_in);
       e = (uint32_t)(kActLutFn >> (8 * br));
     }
     const uint32_t swap_eff = (e >> 7) & ~(fl >> 1) & 1u;  // swap requested and not yet swapped (LUT bit 7: NUMPY only)
-    const uint32_t slow0 = (fl & (TG_F_GAME_OVER | TG_F_PENDING_RESET)) | (e & 0x40u) | swap_eff;
+    const uint32_t slow0 = (fl & (TG_F_GAME_OVER | TG_F_PENDING_RESET)) | (e & 0x40u) | swap_eff | (uint32_t)p.action_set;
     if (slow0 == 0) {
       const uint32_t piece = d[0] & 0xFFu, rot = (d[0] >> 8) & 0xFFu, x = (d[0] >> 16) & 0xFFu, y = d[0] >> 24;
       const uint64_t row = p.shapes[piece];
@@ -598,7 +600,30 @@ __device__ __forceinline__ void process_env(const KParams& p, const uint32_t env
   r.dirty = false;
 
   const bool pending = p.autoreset == TG_AUTORESET_NEXT_STEP && (flags & TG_F_PENDING_RESET);
-  const bool frozen = RULESET == TG_RULESET_FUNCTIONAL && (flags & TG_F_GAME_OVER);  // tetris_fn.py:284-289
+  bool frozen = RULESET == TG_RULESET_FUNCTIONAL && (flags & TG_F_GAME_OVER);  // tetris_fn.py:284-289
+  // grouped action set (wrappers/grouped.py:209-269): action = column * 4 + rotations → teleport + hard drop.
+  // The wrapper's legal mask only looks at the frame (collision_with_frame, :104-122): a placement is illegal iff
+  // one of the rotated piece's cells lies outside the playfield columns — a function of piece/rotation/column.
+  int action = action_in;
+  bool g_illegal = false;
+  if (RULESET == TG_RULESET_NUMPY && p.action_set == TG_ACTIONS_GROUPED && !pending) {
+    const int col = action_in >> 2, nrot = (rot + (action_in & 3)) & 3;
+    const int nx = col + 4 - (piece == 0 ? 2 : 1);  // x + padding - matrix.shape[1] // 2
+    const uint32_t sh = (uint32_t)(p.shapes[piece] >> (16 * nrot)) & 0xFFFFu;
+    bool legal = (unsigned)action_in < (unsigned)(4 * W);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (sh & (0x1111u << c)) legal = legal && (unsigned)(nx + c - 4) < (unsigned)W;
+    if (legal) { x = nx; rot = nrot; action = 5; }
+    else {
+      g_illegal = true;
+      action = 7;
+      if (p.grouped_term) {
+        frozen = true;
+        final_coll = test1<W, H>(slab, lane, (uint32_t)(p.shapes[piece] >> (16 * rot)) & 0xFFFFu, x, y);
+      }
+    }
+  }
   if (pending) {
     EnvS s;
     raw_to_env(s, d);
@@ -788,7 +813,8 @@ __device__ __forceinline__ void process_env(const KParams& p, const uint32_t env
     }
   }
 
-  const int terminated = (flags & TG_F_GAME_OVER) ? 1 : 0;
+  if (g_illegal) reward = -0.1f;  // rewards.invalid_action
+  const int terminated = ((flags & TG_F_GAME_OVER) || (g_illegal && p.grouped_term)) ? 1 : 0;
   if (terminated && p.autoreset != TG_AUTORESET_NONE) {
     if (p.autoreset == TG_AUTORESET_SAME_STEP) {
       if (p.final_obs) {
@@ -1014,6 +1040,59 @@ __global__ __launch_bounds__(kBlock) void observe_kernel(const ObserveParams p) 
     const int t = (int)((s.queue >> (8 * q)) & 0xFF);
     const uint32_t m = c_shapes.mask[t < 7 ? t : 0][0];
     o_queue[i] = ((m >> (4 * row + c)) & 1u) ? (uint8_t)(t + 2) : (uint8_t)0;
+  }
+}
+
+// ---- grouped action surface (wrappers/grouped.py:124-207): the legal mask depends only on the active piece,
+// its rotation and the column (frame collisions only) → one thread per env ----
+struct GroupedParams {
+  const uint32_t* rec;
+  uint8_t* mask;      // [B][4W] or null
+  int32_t* actions;   // [B] or null: sample one legal action per env (uniform, counter-based hash)
+  uint64_t shapes[7];
+  uint32_t seed, counter;
+  int batch, width;
+};
+
+__device__ __forceinline__ bool grouped_legal(const uint64_t* shapes, int piece, int rot, int a, int W) {
+  const int col = a >> 2, nrot = (rot + (a & 3)) & 3;
+  const int nx = col + 4 - (piece == 0 ? 2 : 1);
+  const uint32_t sh = (uint32_t)(shapes[piece] >> (16 * nrot)) & 0xFFFFu;
+  bool legal = true;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (sh & (0x1111u << c)) legal = legal && (unsigned)(nx + c - 4) < (unsigned)W;
+  return legal;
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {  // murmur3 finaliser
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void grouped_kernel(const GroupedParams p) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= p.batch) return;
+  const uint32_t d0 = p.rec[(size_t)env * 8];
+  const int piece = d0 & 0xFF, rot = (d0 >> 8) & 3;
+  const int NA = 4 * p.width;
+  int n_legal = 0;
+  for (int a = 0; a < NA; ++a) {
+    const bool l = grouped_legal(p.shapes, piece, rot, a, p.width);
+    if (p.mask) p.mask[(size_t)env * NA + a] = l ? 1 : 0;
+    n_legal += l ? 1 : 0;
+  }
+  if (p.actions) {
+    int pick = 0;
+    if (n_legal > 0) {
+      int k = (int)(mix32(mix32(p.seed ^ (uint32_t)env * 0x9E3779B9u) + p.counter) % (uint32_t)n_legal);
+      for (int a = 0; a < NA; ++a)
+        if (grouped_legal(p.shapes, piece, rot, a, p.width)) {
+          if (k == 0) { pick = a; break; }
+          --k;
+        }
+    }
+    p.actions[env] = pick;
   }
 }
 

@@ -21,7 +21,7 @@ class Engine:
 
     def __init__(self, batch, width=10, height=20, *, ruleset=N.RULESET_NUMPY, gravity=True, queue_size=None,
                  obs_mode=None, autoreset=N.AUTORESET_NONE, device=0, env_offset=0, padding=4, episode_stats=False,
-                 final_obs=False):
+                 final_obs=False, grouped=False, terminate_on_illegal=True):
         self.lib = N.load()
         if queue_size is None:
             queue_size = 4 if ruleset == N.RULESET_NUMPY else 7
@@ -31,8 +31,9 @@ class Engine:
         cfg.struct_size = C.sizeof(N.TgConfig)
         cfg.width, cfg.height, cfg.padding, cfg.queue_size = width, height, padding, queue_size
         cfg.gravity, cfg.ruleset, cfg.obs_mode, cfg.autoreset = int(bool(gravity)), ruleset, obs_mode, autoreset
-        cfg.action_set, cfg.batch, cfg.device, cfg.env_offset = N.ACTIONS_BASE, batch, device, env_offset
-        cfg.grouped_terminate_on_illegal = 1
+        cfg.action_set = N.ACTIONS_GROUPED if grouped else N.ACTIONS_BASE
+        cfg.batch, cfg.device, cfg.env_offset = batch, device, env_offset
+        cfg.grouped_terminate_on_illegal = int(bool(terminate_on_illegal))
         cfg.flags = (N.FLAG_EPISODE_STATS if episode_stats else 0) | (N.FLAG_FINAL_OBS if final_obs else 0)
         self.cfg = cfg
         self.B, self.W, self.H, self.P, self.Q = batch, width, height, padding, queue_size
@@ -116,6 +117,23 @@ class Engine:
             queue = flat[o:o + B * pp * self.Q].reshape(B, self.P, self.P * self.Q)
             return {"board": board, "active_tetromino_mask": mask, "holder": holder, "queue": queue}
         raise EngineError("engine was created with obs_mode NONE")
+
+    # -- grouped action surface (wrappers/grouped.py) ---------------------------------------------
+    def legal_mask(self):
+        """u8 [B, 4*W]: 1 = legal placement (column*4 + rotations) for the current active pieces."""
+        self._chk(self.lib.tg_grouped_enumerate(self.h, None), "tg_grouped_enumerate")
+        return self._fetch(N.BUF_LEGAL_MASK, np.empty((self.B, 4 * self.W), np.uint8))
+
+    def sample_legal_actions(self, seed=0, counter=0, fetch=True):
+        """Draw one legal action per env on the device into the actions buffer (uniform over the mask)."""
+        self._chk(self.lib.tg_grouped_sample(self.h, int(seed) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF), "tg_grouped_sample")
+        if fetch:
+            return self._fetch(N.BUF_ACTIONS, np.empty(self.B, np.int32))
+
+    def step_sampled(self):
+        """Step with the actions left in the device actions buffer by sample_legal_actions()."""
+        ptr, _ = self.device_ptr(N.BUF_ACTIONS)
+        self.step_device(ptr)
 
     def final_observation(self):
         return self.observation(N.BUF_FINAL_OBS)

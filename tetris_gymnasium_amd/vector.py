@@ -43,7 +43,8 @@ class TetrisVectorEnv(VectorEnvBase):
 
     def __init__(self, num_envs: int, width: int = 10, height: int = 20, gravity: bool = True, *,
                  ruleset: str = "numpy", observation: str = "dict", queue_size: int | None = None,
-                 autoreset_mode: str = "next_step", devices=(0,), episode_stats: bool = True):
+                 autoreset_mode: str = "next_step", devices=(0,), episode_stats: bool = True,
+                 grouped: bool = False, terminate_on_illegal_action: bool = True):
         self.num_envs = int(num_envs)
         self.width, self.height = width, height
         self.ruleset = N.RULESET_NUMPY if ruleset == "numpy" else N.RULESET_FUNCTIONAL
@@ -57,12 +58,13 @@ class TetrisVectorEnv(VectorEnvBase):
         self.engines = [
             Engine(hi - lo, width, height, ruleset=self.ruleset, gravity=gravity, queue_size=queue_size,
                    obs_mode=_OBS[observation], autoreset=_AUTORESET[autoreset_mode], device=dev, env_offset=lo,
-                   episode_stats=episode_stats)
+                   episode_stats=episode_stats, grouped=grouped, terminate_on_illegal=terminate_on_illegal_action)
             for (lo, hi), dev in zip(self.ranges, devices) if hi > lo
         ]
         self.ranges = [r for r in self.ranges if r[1] > r[0]]
         self.episode_stats = episode_stats
-        n_act = 8 if self.ruleset == N.RULESET_NUMPY else 7
+        self.grouped = grouped  # wrappers/grouped.py action set: column * 4 + rotations, infos["action_mask"]
+        n_act = 4 * width if grouped else (8 if self.ruleset == N.RULESET_NUMPY else 7)
         hp, wp, p = height + 4, width + 8, 4
         self.single_action_space = spaces.Discrete(n_act)
         if observation == "dict":
@@ -105,7 +107,10 @@ class TetrisVectorEnv(VectorEnvBase):
                 seeds = default_seeds(lo, hi, seed)
             e.reset(seeds, None if mask is None else np.asarray(mask, np.uint8)[lo:hi])
         self._prev_len[:] = 0
-        return self._gather_obs(), {"lines_cleared": np.zeros(self.num_envs, np.int32)}
+        info = {"lines_cleared": np.zeros(self.num_envs, np.int32)}
+        if self.grouped:
+            info["action_mask"] = np.concatenate([e.legal_mask() for e in self.engines])
+        return self._gather_obs(), info
 
     def step(self, actions):
         actions = np.asarray(actions, np.int32).reshape(self.num_envs)
@@ -121,6 +126,10 @@ class TetrisVectorEnv(VectorEnvBase):
             infos["episode"] = {"r": np.where(terminations, ep["last_ret"], 0.0).astype(np.float64),
                                 "l": np.where(terminations, ep["last_len"], 0).astype(np.int32)}
             infos["_episode"] = terminations.copy()
+        if self.grouped:  # the mask the NEXT action must be drawn from (wrappers/grouped.py:266-267)
+            infos["action_mask"] = np.concatenate([e.legal_mask() for e in self.engines])
+            illegal = np.concatenate([o[0] for o in outs]) < 0
+            rewards[illegal] = -0.1  # rewards.invalid_action as a Python float, not float32(-0.1)
         truncations = np.zeros(self.num_envs, bool)
         return self._gather_obs(), rewards, terminations, truncations, infos
 
