@@ -211,9 +211,10 @@ def main():
             out["hbm_copy_gbps"] = None
             out["hbm_copy_error"] = str(ex)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, H, Q) if not args.config5 else None
-            out["cpu_baseline"]["reference_python_single_env"] = \
-                "~3.4k steps/s on one 2.6 GHz Xeon core, measured in the survey container, not on this host"
+            if not args.config5:
+                out["cpu_baseline"] = cpu_baseline(W, H, Q)
+                out["cpu_baseline"]["reference_python_single_env"] = \
+                    "~3.4k steps/s on one 2.6 GHz Xeon core, measured in the survey container, not on this host"
         print(json.dumps(out), flush=True)
     e.dev_free(d_acts)
     e.close()

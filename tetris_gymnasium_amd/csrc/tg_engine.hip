@@ -37,29 +37,26 @@ int g_step_blocks = 0;  // persistent grid size (blocks); set once per process f
 // per wave, one per lane (both tg_kernel_lanes.h); 0 = "wave": one env per wavefront (tg_kernels.h)
 int g_kernel_lanes = 4;
 size_t g_lds_pad = 0;
-int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE (>1: each wave walks several groups)  // TG_LDS_PAD: extra dynamic LDS per wave = occupancy limiter (staggers the waves of a SIMD)
+int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = experimental pipelined pair of groups per wave (measured slower: the prefetched inputs spill), 1 = off  // TG_LDS_PAD: extra dynamic LDS per wave = occupancy limiter (staggers the waves of a SIMD)
 
 template <int W, int H, int RS>
 void launch_step(const tg::KParams& p, hipStream_t s) {
   if (g_kernel_lanes && !p.final_obs) {
-    // groups per wave: 2 when the batch divides evenly (software-pipelined loads/stores), else 1
-    auto grid_of = [&](int epw) {
+    // two groups per wave (software-pipelined inputs) when the batch is large enough to keep >= 2 waves per SIMD
+    auto launch = [&](auto kern1, auto kern2, int epw) {
       const int groups = (p.batch + epw - 1) / epw;
-      return (g_groups_per_wave > 1 && groups % g_groups_per_wave == 0 && groups >= 2048) ? groups / g_groups_per_wave : groups;
+      const size_t lds = (((size_t)epw * W * H + 15) / 16) * 16 + 64 + 4 * W + 16 + g_lds_pad;  // + cell table + drop-probe overrun
+      if (g_groups_per_wave > 1 && groups >= 4096)
+        hipLaunchKernelGGL(kern2, dim3((groups + 1) / 2), dim3(64), lds, s, p);
+      else
+        hipLaunchKernelGGL(kern1, dim3(groups), dim3(64), lds, s, p);
     };
-    if (g_kernel_lanes == 2) {
-      const int grid = grid_of(32);
-      const size_t lds = (((size_t)32 * W * H + 15) / 16) * 16 + 64 + 4 * W + 16;
-      hipLaunchKernelGGL((tg::step_kernel_lanes<W, H, RS, 2>), dim3(grid), dim3(64), lds, s, p);
-    } else if (g_kernel_lanes == 4) {
-      const int grid = grid_of(16);
-      const size_t lds = (((size_t)16 * W * H + 15) / 16) * 16 + 64 + 4 * W + 16 + g_lds_pad;  // + cell table + drop-probe overrun
-      hipLaunchKernelGGL((tg::step_kernel_lanes<W, H, RS, 4>), dim3(grid), dim3(64), lds, s, p);
-    } else {
-      const int grid = grid_of(64);
-      const size_t lds = (size_t)64 * W * H + 64 + 4 * W + 16;
-      hipLaunchKernelGGL((tg::step_kernel_lanes<W, H, RS, 1>), dim3(grid), dim3(64), lds, s, p);
-    }
+    if (g_kernel_lanes == 2)
+      launch(tg::step_kernel_lanes<W, H, RS, 2, false>, tg::step_kernel_lanes<W, H, RS, 2, true>, 32);
+    else if (g_kernel_lanes == 4)
+      launch(tg::step_kernel_lanes<W, H, RS, 4, false>, tg::step_kernel_lanes<W, H, RS, 4, true>, 16);
+    else
+      launch(tg::step_kernel_lanes<W, H, RS, 1, false>, tg::step_kernel_lanes<W, H, RS, 1, false>, 64);
     return;
   }
   int grid = grid_for(p.batch);
@@ -490,9 +487,12 @@ int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K) {
   for (int k = 0; k < K; ++k) {
     p.actions = actions_dev + (size_t)k * h->B;
     h->L.step(p, h->stream);
+    if (h->cfg.obs_mode == TG_OBS_DICT) {  // the DICT surface is packed by its own kernel after every transition
+      int rc = launch_observe_dict(h);
+      if (rc != TG_OK) return rc;
+    }
   }
   HIPCHK(h, hipGetLastError());
-  if (h->cfg.obs_mode == TG_OBS_DICT) return launch_observe_dict(h);
   return TG_OK;
 }
 

@@ -327,18 +327,6 @@ __device__ __forceinline__ uint32_t lane_cells(const uint64_t* tab, int piece, i
   return (uint32_t)(tab[piece] >> (16 * rot)) & 0xFFFFu;
 }
 
-// ------------------------------------------------------------------------------------------------
-// L = lanes per env (1: 64 envs per wave; 4: 16 envs per wave, the four lanes of an env split the piece's
-// four cells and OR their results with DPP quad permutes; everything else is computed redundantly by the quad).
-// Measured (profiles/r01_*): with L = 1 there is exactly one wave per SIMD at batch 65 536, so nothing hides
-// LDS/VALU dependency latency and the load / compute / store phases of all waves run in lockstep; L = 4 gives
-// four waves per SIMD with a quarter of the per-wave work.
-// ------------------------------------------------------------------------------------------------
-// L = lanes per env (1: 64 envs per wave; 4: 16 envs per wave, the four lanes of an env split the piece's
-// four cells and OR their results with DPP quad permutes; everything else is computed redundantly by the quad).
-// Measured (profiles/r01_*): with L = 1 there is exactly one wave per SIMD at batch 65 536, so nothing hides
-// LDS/VALU dependency latency and the load / compute / store phases of all waves run in lockstep; L = 4 gives
-// four waves per SIMD with a quarter of the per-wave work.
 // inputs of one group (= the 64/L envs a wave handles at a time), fetched ahead of their use
 template <int W, int H, int L>
 struct GroupIn {
@@ -364,7 +352,8 @@ __device__ __forceinline__ void lanes_load(const KParams& p, const uint32_t grou
   in.rb = rec4[1];
   in.action = p.act_i8 ? (int)reinterpret_cast<const int8_t*>(p.actions)[env]
                        : reinterpret_cast<const int32_t*>(p.actions)[env];
-  // the group's slabs: one contiguous block, coalesced 16 B per lane (clamped, unconditional: stays in registers)
+  // the group's slabs: one contiguous block, coalesced 16 B per lane; all loads in flight before the first LDS
+  // write (one latency, not NIT of them; clamped + unconditional so the staging array stays in registers)
   const uint32_t nchunks = (nlive * (uint32_t)S + 15u) / 16u;
   const uint4* gsrc = reinterpret_cast<const uint4*>(p.board + (size_t)base_env * S);
 #pragma unroll
@@ -381,7 +370,8 @@ __device__ __forceinline__ void lanes_load(const KParams& p, const uint32_t grou
 // LDS/VALU dependency latency and the load / compute / store phases of all waves run in lockstep; L = 4 gives
 // four waves per SIMD with a quarter of the per-wave work.
 template <int W, int H, int RULESET, int L>
-__device__ __forceinline__ void lanes_process(const KParams& p, const uint32_t group, const int lane, uint8_t* lds) {
+__device__ __forceinline__ void lanes_process(const KParams& p, const uint32_t group, const int lane, uint8_t* lds,
+                                              const GroupIn<W, H, L>& in) {
   using G = Geo<W, H>;
   constexpr int S = G::CELLS;  // per-env stride in LDS (bytes), same as in HBM: the wave's slabs are one block
   constexpr int EPW = 64 / L;  // envs per wave
@@ -401,30 +391,17 @@ __device__ __forceinline__ void lanes_process(const KParams& p, const uint32_t g
     for (int i = 1; i < 16; ++i) p.dbg[(size_t)blockIdx.x * 16 + i] = 0;
 #endif
   TG_STAMP(0);
-  // ---- B (issued first: needed first): per-env record, action ----
-  const uint4* rec4 = reinterpret_cast<const uint4*>(p.rec) + (size_t)env * 2;
-  const uint4 ra = rec4[0], rb = rec4[1];
-  const int action_in = p.act_i8 ? (int)reinterpret_cast<const int8_t*>(p.actions)[env]
-                                 : reinterpret_cast<const int32_t*>(p.actions)[env];
-  // ---- A: the group's slabs: one contiguous block, coalesced 16 B per lane → LDS; all loads are in flight
-  // before the first LDS write (one latency, not NIT of them; clamped + unconditional: stays in registers) ----
+  const uint4 ra = in.ra, rb = in.rb;
+  const int action_in = in.action;
+  // ---- A: stage the group's slabs in LDS ----
   const uint32_t nbytes = nlive * (uint32_t)S;
   const uint32_t nchunks = (nbytes + 15u) / 16u;
-  const uint4* gsrc = reinterpret_cast<const uint4*>(p.board + (size_t)base_env * S);
   uint4* lds4 = reinterpret_cast<uint4*>(lds);
   const bool full_wave = nlive == (uint32_t)EPW;
-  {
-    uint4 stage[NIT];
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const uint32_t c = (uint32_t)lane + 64u * k;
-      stage[k] = gsrc[c < nchunks ? c : nchunks - 1u];
-    }
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const uint32_t c = (uint32_t)lane + 64u * k;
-      if (c < nchunks) lds4[c] = stage[k];
-    }
+  for (int k = 0; k < NIT; ++k) {
+    const uint32_t c = (uint32_t)lane + 64u * k;
+    if (c < nchunks) lds4[c] = in.stage[k];
   }
   if (lane < 7) cell_tab[lane] = c_cells.cells[lane];
 
@@ -762,16 +739,31 @@ __device__ __forceinline__ void lanes_process(const KParams& p, const uint32_t g
   TG_STAMP(9);
 }
 
-// The kernel: a wave walks groups  g, g + gridDim.x, ...  (one group per wave by default)
-template <int W, int H, int RULESET, int L>
-__global__ __launch_bounds__(64) void step_kernel_lanes(const KParams p) {
+// The kernel.  PIPE = false: one group per wave.  PIPE = true: two groups per wave (g and g + gridDim.x); the
+// second group's inputs are requested before the first group is processed, so that half of the loads and half
+// of the stores overlap compute instead of every wave loading, computing and storing in lockstep.
+template <int W, int H, int RULESET, int L, bool PIPE>
+__global__ __launch_bounds__(64, 4) void step_kernel_lanes(const KParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr int EPW = 64 / L;
   const int lane = threadIdx.x;
   const uint32_t n_groups = ((uint32_t)p.batch + EPW - 1) / EPW;
-  for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    lanes_process<W, H, RULESET, L>(p, g, lane, lds);
-    wave_sync();
+  const uint32_t g0 = blockIdx.x;
+  if (g0 >= n_groups) return;
+  GroupIn<W, H, L> a;
+  lanes_load<W, H, L>(p, g0, lane, a);
+  if constexpr (PIPE) {
+    const uint32_t g1 = g0 + gridDim.x;
+    const bool two = g1 < n_groups;
+    GroupIn<W, H, L> b;
+    lanes_load<W, H, L>(p, two ? g1 : g0, lane, b);  // (a harmless re-read when this wave has a single group)
+    lanes_process<W, H, RULESET, L>(p, g0, lane, lds, a);
+    if (two) {
+      wave_sync();
+      lanes_process<W, H, RULESET, L>(p, g1, lane, lds, b);
+    }
+  } else {
+    lanes_process<W, H, RULESET, L>(p, g0, lane, lds, a);
   }
 }
 
