@@ -40,7 +40,17 @@ def cpu_baseline(W, H, Q, budget_s=12.0):
     """The oracle's C restatement (kind "port") on this host's cores, bounded sample of the same workload."""
     from oracle import pyoracle as po
 
-    cores = min(os.cpu_count() or 1, 64)  # OpenMP over envs; more threads than this only adds fork/join cost
+    try:
+        avail = len(os.sched_getaffinity(0))  # cores this process may actually use (cgroup/affinity), not the box total
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    try:  # cgroup v2 CPU quota of the container (e.g. "1600000 100000" = 16 cores on a 256-CPU host)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            avail = min(avail, max(1, int(q) // int(per)))
+    except Exception:
+        pass
+    cores = max(1, min(avail, 64))  # OpenMP over envs
     B = 16384
     o = po.OracleBatch(B, W, H, po.RULESET_NUMPY, True, Q, nthreads=cores)
     o.reset(np.arange(1, B + 1, dtype=np.uint64))
@@ -57,7 +67,7 @@ def cpu_baseline(W, H, Q, budget_s=12.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": B * n / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
+    return {"value": B * n / dt, "unit": "env steps/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{B} envs x {n} steps of the same workload (C oracle, OpenMP over envs, incl. observation pack)"}
 
 
