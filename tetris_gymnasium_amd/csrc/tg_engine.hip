@@ -36,6 +36,7 @@ int g_step_blocks = 0;  // persistent grid size (blocks); set once per process f
 // step kernel selection (TG_KERNEL): 4 = "quad": 16 envs per wave, 4 lanes per env (default); 1 = "lanes": 64 envs
 // per wave, one per lane (both tg_kernel_lanes.h); 0 = "wave": one env per wavefront (tg_kernels.h)
 int g_kernel_lanes = 4;
+int g_stagger = 0;  // TG_STAGGER: odd waves of the lane kernels start this many x64 cycles late
 size_t g_lds_pad = 0;
 int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = experimental pipelined pair of groups per wave (measured slower: the prefetched inputs spill), 1 = off  // TG_LDS_PAD: extra dynamic LDS per wave = occupancy limiter (staggers the waves of a SIMD)
 
@@ -230,6 +231,7 @@ tg::KParams step_params(tg_handle* h) {
   p.queue_size = h->Q;
   p.action_set = h->cfg.action_set;
   p.grouped_term = h->cfg.grouped_terminate_on_illegal;
+  p.stagger = g_stagger;
   p.dbg = (unsigned long long*)h->dbg;
   return p;
 }
@@ -343,6 +345,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     int per_cu = 0;
     if (const char* e = getenv("TG_BLOCKS_PER_CU")) per_cu = atoi(e);
     if (const char* e2 = getenv("TG_LDS_PAD")) g_lds_pad = (size_t)atoi(e2);
+    if (const char* e4 = getenv("TG_STAGGER")) g_stagger = atoi(e4);
     if (const char* e3 = getenv("TG_GROUPS_PER_WAVE")) g_groups_per_wave = atoi(e3) > 0 ? atoi(e3) : 1;
     if (const char* k = getenv("TG_KERNEL"))
       g_kernel_lanes = strcmp(k, "wave") == 0 ? 0 : (strcmp(k, "lanes") == 0 ? 1 : (strcmp(k, "pair") == 0 ? 2 : 4));

@@ -750,6 +750,11 @@ __global__ __launch_bounds__(64, 4) void step_kernel_lanes(const KParams p) {
   const uint32_t n_groups = ((uint32_t)p.batch + EPW - 1) / EPW;
   const uint32_t g0 = blockIdx.x;
   if (g0 >= n_groups) return;
+  if (p.stagger > 0 && (blockIdx.x & 1)) {
+    // All waves of a launch would otherwise load, compute and store in lockstep (three serial bursts).  Starting
+    // every other wave late lets its loads run under the early waves' compute and its compute under their stores.
+    for (int i = 0; i < p.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
+  }
   GroupIn<W, H, L> a;
   lanes_load<W, H, L>(p, g0, lane, a);
   if constexpr (PIPE) {

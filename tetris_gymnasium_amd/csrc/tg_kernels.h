@@ -45,6 +45,7 @@ struct KParams {
   int act_i8;
   int action_set;    // TG_ACTIONS_*
   int grouped_term;  // wrappers/grouped.py:49 terminate_on_illegal_action
+  int stagger;       // lane kernels: odd waves start this many x64 cycles late (de-phases load/compute/store bursts)
   unsigned long long* dbg;  // optional phase-timing buffer (TG_PHASE_TIMING builds only)
 };
 
