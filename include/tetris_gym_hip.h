@@ -57,6 +57,7 @@ extern "C" {
 /* ---- tg_config.flags ---- */
 #define TG_FLAG_EPISODE_STATS 1 /* keep device-side episode return/length (RecordEpisodeStatistics) */
 #define TG_FLAG_FINAL_OBS 2     /* SAME_STEP autoreset: also write the terminal observation to TG_BUF_FINAL_OBS */
+#define TG_FLAG_FEATURES 4      /* allocate the feature buffers used by tg_features */
 
 /* ---- error codes ---- */
 #define TG_OK 0
@@ -132,7 +133,9 @@ typedef struct tg_rng_rec { /* 48 bytes */
 #define TG_BUF_LEGAL_MASK 6 /* u8 [B][4*W]  grouped legal-action mask (TG_ACTIONS_GROUPED) */
 #define TG_BUF_FINAL_OBS 7  /* SAME_STEP autoreset: observation of the terminal state (valid where terminated) */
 #define TG_BUF_EPISODE 8    /* tg_episode_rec [B] (TG_FLAG_EPISODE_STATS) */
-#define TG_BUF_COUNT 9
+#define TG_BUF_PLACEMENT_FEATS 9 /* u8 [B][4W][W+3] (TG_FLAG_FEATURES): per-placement feature vectors, see tg_features */
+#define TG_BUF_FEATS 10     /* u8 [B][W+3] (TG_FLAG_FEATURES): FeatureVectorObservation of the current observation */
+#define TG_BUF_COUNT 11
 
 typedef struct tg_step_out { /* 8 bytes, written by the step kernel with one store per env */
   float reward;        /* NUMPY rewards are integer-valued (envs/tetris.py:468-474); grouped illegal = -0.1f */
@@ -203,6 +206,13 @@ int tg_grouped_enumerate(tg_handle* h, uint8_t* boards_dev);
  * random policy for benchmarks / epsilon-greedy exploration: examples/train_lin_grouped.py:284-285). Deterministic in
  * (seed, counter, env). Step afterwards with tg_step(h, <TG_BUF_ACTIONS pointer>, TG_MEM_DEVICE). */
 int tg_grouped_sample(tg_handle* h, uint32_t seed, uint32_t counter);
+
+/* Feature observations of the current state (NUMPY rule-set), written to TG_BUF_PLACEMENT_FEATS / TG_BUF_FEATS:
+ *  - per placement (column*4 + rotations): heights[W], max height, holes, bumpiness of the board that placement
+ *    produces, i.e. GroupedActionsObservations(env, observation_wrappers=[FeatureVectorObservation(env)])
+ *    (wrappers/grouped.py:124-207 + wrappers/observation.py:236-278) — without building the 4W boards;
+ *  - the same 13-entry vector for the current observation (info["board"] of the wrapper). */
+int tg_features(tg_handle* h);
 
 int tg_sync(tg_handle* h);
 

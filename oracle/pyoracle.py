@@ -66,6 +66,8 @@ def lib() -> C.CDLL:
         L.tgo_grouped_step.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32]
         L.tgo_grouped_enumerate.argtypes = [vp, vp, vp, i32]
         L.tgo_observe.argtypes = [vp, i32, vp, i32]
+        L.tgo_grouped_features.argtypes = [vp, vp, i32]
+        L.tgo_features.argtypes = [vp, vp, i32]
         L.tgo_get_state.argtypes = [vp, vp, vp, vp]
         L.tgo_set_state.argtypes = [vp, vp, vp, vp]
         L.tgo_get_padded_boards.argtypes = [vp, vp]
@@ -143,6 +145,16 @@ class OracleBatch:
         bo = np.empty((self.B, 4 * self.W, self.Hp, self.Wp), np.uint8) if boards else None
         self.L.tgo_grouped_enumerate(self.h, _p(mask), _p(bo), self.nthreads)
         return (mask, bo) if boards else mask
+
+    def grouped_features(self):
+        out = np.empty((self.B, 4 * self.W, self.W + 3), np.uint8)
+        self.L.tgo_grouped_features(self.h, _p(out), self.nthreads)
+        return out
+
+    def features(self):
+        out = np.empty((self.B, self.W + 3), np.uint8)
+        self.L.tgo_features(self.h, _p(out), self.nthreads)
+        return out
 
     def observe(self, mode):
         if mode == OBS_BOARD:

@@ -12,6 +12,7 @@ Fixtures (all NumPy rule-set, i.e. envs/tetris.py — the graded oracle of BASEL
   clears_<cfg>.npz       line-clear-dense traces from pre-filled boards
   grouped_<cfg>.npz      grouped wrapper: legal masks, placement boards, traces (grouped_clears_*: on dense stacks)
   features.npz           FeatureVectorObservation outputs on trace states
+  grouped_features_*.npz per-placement feature tensors [4W][W+3] (grouped wrapper + FeatureVectorObservation)
   ref_tests_grouped.npz  the reference tests' own mock board / CSV board / 40-entry mask (data only)
 """
 from __future__ import annotations
@@ -282,6 +283,44 @@ def gen_grouped(ref, name, width, height, queue_size, B, T, seed, n_enum, init_b
           f"lines={int(lines.sum())} enums={ne} illegal={(reward<0).sum()}")
 
 
+def gen_grouped_features(ref, name, width, height, queue_size, n_states, seed, dense=False):
+    """GroupedActionsObservations(env, observation_wrappers=[FeatureVectorObservation(env)]) — the observation
+    examples/train_lin_grouped.py trains on: for each of the 4W placements the 13-entry feature vector of the
+    resulting board (wrappers/grouped.py:124-207 + wrappers/observation.py:236-278), plus info["board"]."""
+    rng = np.random.default_rng(seed)
+    NA, Hp, Wp = 4 * width, height + 4, width + 8
+    boards = np.zeros((n_states, Hp, Wp), np.uint8)
+    pieces = np.zeros(n_states, np.uint8)
+    mats = np.zeros((n_states, 16), np.uint8)
+    feats = np.zeros((n_states, NA, width + 3), np.uint8)
+    cur_feats = np.zeros((n_states, width + 3), np.uint8)
+    masks = np.zeros((n_states, NA), np.uint8)
+    base = make_env(ref, width, height, True, queue_size)
+    env = ref.GroupedActionsObservations(base, observation_wrappers=[ref.FeatureVectorObservation(base)])
+    dense_boards_, _ = dense_boards(width, height, 64, seed + 1)
+    obs, info = env.reset(seed=seed)
+    k = 0
+    while k < n_states:
+        if dense and rng.random() < 0.3:
+            base.board = dense_boards_[int(rng.integers(0, 64))].copy()
+            obs = env.observation(base._get_obs())
+            info = {"board": ref.FeatureVectorObservation(base).observation(base._get_obs())}
+        boards[k] = base.board
+        pieces[k] = base.active_tetromino.id - 2
+        mats[k] = matrix16(base.active_tetromino)
+        feats[k] = obs
+        masks[k] = env.legal_actions_mask
+        cur_feats[k] = info["board"]
+        k += 1
+        legal = np.flatnonzero(env.legal_actions_mask == 1)
+        obs, r, d, _, info = env.step(int(rng.choice(legal)))
+        if d:
+            obs, info = env.reset()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), width=width, height=height, queue_size=queue_size,
+                        boards=boards, pieces=pieces, mats=mats, feats=feats, masks=masks, cur_feats=cur_feats)
+    print(f"{name}: {n_states} states, feature tensors {feats.shape}, max feature {feats.max()}")
+
+
 def gen_ref_tests_grouped(ref):
     """Data held by the reference's own grouped tests: the mock board (tests/helpers/mock.py:5-47 applied to
     a fresh env), the CSV board after action 21 (tests/test_grouped_env/expected_result_i_placement.csv) and
@@ -367,6 +406,8 @@ def main():
         "grouped_20x40": lambda: gen_grouped(ref, "grouped_20x40", 20, 40, 7, 4, 64, 32, 12),
         "grouped_clears_10x20": lambda: gen_grouped(ref, "grouped_clears_10x20", 10, 20, 4, 16, 96, 33, 16,
                                                     init_boards=dense_boards(10, 20, 16, 8)[0]),
+        "grouped_features_10x20": lambda: gen_grouped_features(ref, "grouped_features_10x20", 10, 20, 4, 192, 41, dense=True),
+        "grouped_features_20x40": lambda: gen_grouped_features(ref, "grouped_features_20x40", 20, 40, 7, 24, 42, dense=True),
         "ref_tests_grouped": lambda: gen_ref_tests_grouped(ref),
         "features": lambda: gen_features(ref),
     }

@@ -919,6 +919,38 @@ void tgo_grouped_enumerate(tgo_batch* b, uint8_t* legal_mask, uint8_t* boards, i
   }
 }
 
+/* per-placement feature tensors u8 [B][4W][W+3]: GroupedActionsObservations(observation_wrappers=[FeatureVectorObservation])
+ * (wrappers/grouped.py:185-205: every placement board is wrapped with an all-zero active_tetromino_mask) */
+void tgo_grouped_features(tgo_batch* b, uint8_t* feats, int nthreads) {
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+#endif
+  for (int i = 0; i < b->batch; ++i) {
+    const env_t* e = &b->e[i];
+    const int NA = 4 * e->W, cells = e->Hp * e->Wp, NF = e->W + 3;
+    uint8_t legal[4 * 32];
+    uint8_t* boards = (uint8_t*)malloc((size_t)NA * cells);
+    uint8_t* zero = (uint8_t*)calloc((size_t)cells, 1);
+    grouped_enumerate(e, legal, boards);
+    for (int a = 0; a < NA; ++a)
+      tgo_feature_vector(boards + (size_t)a * cells, zero, e->W, e->H, e->P, feats + ((size_t)i * NA + a) * NF);
+    free(boards);
+    free(zero);
+  }
+}
+
+/* FeatureVectorObservation of the current observation u8 [B][W+3] (wrappers/observation.py:236-278) */
+void tgo_features(tgo_batch* b, uint8_t* feats, int nthreads) {
+  (void)nthreads;
+  for (int i = 0; i < b->batch; ++i) {
+    const env_t* e = &b->e[i];
+    uint8_t board[MAXCELLS], mask[MAXCELLS];
+    np_obs_dict(e, board, mask, NULL, NULL);
+    tgo_feature_vector(board, mask, e->W, e->H, e->P, feats + (size_t)i * (e->W + 3));
+  }
+}
+
 void tgo_observe(tgo_batch* b, int obs_mode, void* out, int nthreads) {
   (void)nthreads;
   const env_t* e0 = &b->e[0];

@@ -40,6 +40,11 @@ void tgo_grouped_step(tgo_batch* b, const int32_t* actions, float* reward, uint8
 /* legal mask u8 [B][4W]; boards (optional) u8 [B][4W][Hp][Wp]  (wrappers/grouped.py:124-207) */
 void tgo_grouped_enumerate(tgo_batch* b, uint8_t* legal_mask, uint8_t* boards, int nthreads);
 
+/* per-placement feature tensors u8 [B][4W][W+3] and current-state features u8 [B][W+3]
+ * (wrappers/grouped.py:185-205 with observation_wrappers=[FeatureVectorObservation], wrappers/observation.py:236-278) */
+void tgo_grouped_features(tgo_batch* b, uint8_t* feats, int nthreads);
+void tgo_features(tgo_batch* b, uint8_t* feats, int nthreads);
+
 /* observation pack, layouts as TG_OBS_* */
 void tgo_observe(tgo_batch* b, int obs_mode, void* out, int nthreads);
 

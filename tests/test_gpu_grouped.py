@@ -84,3 +84,45 @@ def test_device_side_legal_sampling():
         rew, term, lines = e.fetch_outputs()
         assert (rew >= 0).all()  # never the -0.1 penalty
     assert (seen > 0).sum() > 3 * W  # covers most of the action space
+
+
+@pytest.mark.parametrize("name", ["grouped_features_10x20", "grouped_features_20x40"])
+def test_placement_features_against_reference_fixture(golden_dir, name):
+    """[4W][W+3] feature tensor of GroupedActionsObservations + FeatureVectorObservation, computed on bit masks."""
+    fx = replay.load(golden_dir, name)
+    W, H, Q, n = int(fx["width"]), int(fx["height"]), int(fx["queue_size"]), fx["boards"].shape[0]
+    e = Engine(n, W, H, queue_size=Q, obs_mode=N.OBS_BOARD, grouped=True, features=True)
+    e.reset(1 + np.arange(n, dtype=np.uint64))
+    _, rec, _ = e.get_state()
+    for i in range(n):
+        val = int(fx["mats"][i].max())
+        rec["rot"][i] = next(r for r in range(4) if np.array_equal(replay.matrix16(fx["pieces"][i], r, val), fx["mats"][i]))
+        rec["piece"][i], rec["val"][i] = fx["pieces"][i], val
+    rec["x"] = (W + 8) // 2 - np.where(fx["pieces"] == 0, 2, 1)
+    rec["y"] = 0
+    e.set_state(board=replay.crop(fx["boards"]), rec=rec)
+    pf, cf = e.features()
+    np.testing.assert_array_equal(pf, fx["feats"])
+    np.testing.assert_array_equal(cf, fx["cur_feats"])
+    np.testing.assert_array_equal(e.legal_mask(), fx["masks"])
+
+
+def test_placement_features_engine_vs_oracle_random_states():
+    B, W, H = 512, 10, 20
+    e = Engine(B, W, H, obs_mode=N.OBS_BOARD, grouped=True, features=True, autoreset=N.AUTORESET_SAME_STEP)
+    o = po.OracleBatch(B, W, H)
+    seeds = np.arange(3, 3 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(0)
+    for t in range(40):
+        if t % 8 == 0:  # dense stacks: placements that clear 1-4 rows
+            b = rng.integers(2, 9, (B, H, W)).astype(np.uint8)
+            b[:, : rng.integers(8, 16)] = 0
+            for i in range(B):
+                g = rng.integers(0, W - 3); b[i, :, g:g + rng.integers(1, 4)] = 0
+            e.set_state(board=b); o.set_state(board=b)
+        pf, cf = e.features()
+        np.testing.assert_array_equal(pf, o.grouped_features(), err_msg=f"placement features t={t}")
+        np.testing.assert_array_equal(cf, o.features(), err_msg=f"current features t={t}")
+        a = e.sample_legal_actions(seed=5, counter=t)
+        e.step_sampled(); o.grouped_step(a, autoreset=po.AUTORESET_SAME_STEP)

@@ -277,3 +277,23 @@ def test_vector_env_sharding_is_transparent():
         for x, y in zip(r1[:4], r2[:4]):
             np.testing.assert_array_equal(x, y)
     one.close(); two.close()
+
+
+def test_vector_env_grouped_placement_features():
+    """The reference's train_lin_grouped.py loop: obs = [4W, 13] features per env, infos["action_mask"], infos["board"]."""
+    B = 64
+    env = TetrisVectorEnv(B, observation="placement_features", grouped=True, autoreset_mode="same_step")
+    obs, info = env.reset(seed=3)
+    o = po.OracleBatch(B)
+    o.reset(np.arange(3, 3 + B, dtype=np.uint64))
+    assert obs.shape == (B, 40, 13) and env.single_action_space.n == 40
+    rng = np.random.default_rng(0)
+    for t in range(60):
+        np.testing.assert_array_equal(obs, o.grouped_features())
+        np.testing.assert_array_equal(info["action_mask"], o.grouped_enumerate())
+        np.testing.assert_array_equal(info["board"], o.features())
+        a = np.array([rng.choice(np.flatnonzero(m)) for m in info["action_mask"]])
+        obs, rew, term, trunc, info = env.step(a)
+        ro, to, lo, _ = o.grouped_step(a, autoreset=po.AUTORESET_SAME_STEP)
+        np.testing.assert_array_equal(rew, ro); np.testing.assert_array_equal(term, to.astype(bool))
+    env.close()

@@ -80,3 +80,20 @@ def test_feature_vector(golden_dir):
     # tests/helpers/mock.py:35-39 known answers (mask all-zero → only row 0 is wiped)
     f = po.feature_vector(g["mock_board"], np.zeros_like(g["mock_board"]), 10, 20)
     assert list(f[:10]) == list(g["heights"]) and f[10] == 11 and f[11] == 3 and f[12] == 14
+
+
+@pytest.mark.parametrize("name", ["grouped_features_10x20", "grouped_features_20x40"])
+def test_grouped_placement_features(golden_dir, name):
+    """What examples/train_lin_grouped.py trains on: [4W][W+3] feature tensor per state + info["board"]."""
+    fx = replay.load(golden_dir, name)
+    n = fx["boards"].shape[0]
+    o = po.OracleBatch(n, int(fx["width"]), int(fx["height"]), queue_size=int(fx["queue_size"]))
+    o.reset(seeds=1 + np.arange(n, dtype=np.uint64))
+    _state_from_matrix(o, fx["boards"], fx["pieces"], fx["mats"])
+    _, rec, _ = o.get_state()
+    rec["x"] = (int(fx["width"]) + 8) // 2 - np.where(fx["pieces"] == 0, 2, 1)  # states were recorded right after a spawn
+    rec["y"] = 0
+    o.set_state(rec=rec)
+    np.testing.assert_array_equal(o.grouped_enumerate(), fx["masks"])
+    np.testing.assert_array_equal(o.grouped_features(), fx["feats"])
+    np.testing.assert_array_equal(o.features(), fx["cur_feats"])

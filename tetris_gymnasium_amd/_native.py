@@ -19,8 +19,8 @@ AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = 0, 1, 2
 ACTIONS_BASE, ACTIONS_GROUPED = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 (BUF_OBS, BUF_STEP_OUT, BUF_ACTIONS, BUF_BOARD, BUF_REC, BUF_RNG, BUF_LEGAL_MASK, BUF_FINAL_OBS,
- BUF_EPISODE) = range(9)
-FLAG_EPISODE_STATS, FLAG_FINAL_OBS = 1, 2
+ BUF_EPISODE, BUF_PLACEMENT_FEATS, BUF_FEATS) = range(11)
+FLAG_EPISODE_STATS, FLAG_FINAL_OBS, FLAG_FEATURES = 1, 2, 4
 NONE = 0xFF
 F_GAME_OVER, F_HAS_SWAPPED, F_PENDING_RESET = 1, 2, 4
 
@@ -70,6 +70,7 @@ SYMBOLS = {
     "tg_observe": (_i, [_vp]),
     "tg_grouped_enumerate": (_i, [_vp, _vp]),
     "tg_grouped_sample": (_i, [_vp, C.c_uint32, C.c_uint32]),
+    "tg_features": (_i, [_vp]),
     "tg_sync": (_i, [_vp]),
     "tg_timer_start": (_i, [_vp]),
     "tg_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "tg_kernel_features.h"
 #include "tg_kernel_lanes.h"
 #include "tg_kernels.h"
 
@@ -24,6 +25,7 @@ namespace {
 thread_local std::string g_create_err;
 
 struct Launchers {
+  void (*features)(const tg::FeatureParams&, hipStream_t);
   void (*step)(const tg::KParams&, hipStream_t);
   void (*reset)(const tg::ResetParams&, hipStream_t);
   void (*observe)(const tg::ObserveParams&, hipStream_t);
@@ -69,6 +71,10 @@ void launch_reset(const tg::ResetParams& p, hipStream_t s) {
   hipLaunchKernelGGL((tg::reset_kernel<W, H, RS>), dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p);
 }
 template <int W, int H>
+void launch_features(const tg::FeatureParams& p, hipStream_t s) {
+  hipLaunchKernelGGL((tg::features_kernel<W, H>), dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p);
+}
+template <int W, int H>
 void launch_observe(const tg::ObserveParams& p, hipStream_t s) {
   hipLaunchKernelGGL((tg::observe_kernel<W, H>), dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p);
 }
@@ -77,9 +83,9 @@ bool find_launchers(int W, int H, int ruleset, Launchers* out) {
 #define X(w, h)                                                                                     \
   if (W == w && H == h) {                                                                           \
     if (ruleset == TG_RULESET_NUMPY)                                                                \
-      *out = {launch_step<w, h, TG_RULESET_NUMPY>, launch_reset<w, h, TG_RULESET_NUMPY>, launch_observe<w, h>}; \
+      *out = {launch_features<w, h>, launch_step<w, h, TG_RULESET_NUMPY>, launch_reset<w, h, TG_RULESET_NUMPY>, launch_observe<w, h>}; \
     else                                                                                            \
-      *out = {launch_step<w, h, TG_RULESET_FUNCTIONAL>, launch_reset<w, h, TG_RULESET_FUNCTIONAL>,  \
+      *out = {launch_features<w, h>, launch_step<w, h, TG_RULESET_FUNCTIONAL>, launch_reset<w, h, TG_RULESET_FUNCTIONAL>,  \
               launch_observe<w, h>};                                                                \
     return true;                                                                                    \
   }
@@ -362,7 +368,9 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
       /*BOARD*/ B * h->cells, /*REC*/ B * sizeof(tg_env_rec), /*RNG*/ B * sizeof(tg_rng_rec),
       /*LEGAL_MASK*/ cfg->action_set == TG_ACTIONS_GROUPED ? B * 4 * (size_t)cfg->width : 0,
       /*FINAL_OBS*/ want_final ? B * h->cells : 0,
-      /*EPISODE*/ (cfg->flags & TG_FLAG_EPISODE_STATS) ? B * sizeof(tg_episode_rec) : 0};
+      /*EPISODE*/ (cfg->flags & TG_FLAG_EPISODE_STATS) ? B * sizeof(tg_episode_rec) : 0,
+      /*PLACEMENT_FEATS*/ (cfg->flags & TG_FLAG_FEATURES) ? B * 4 * (size_t)cfg->width * (size_t)(cfg->width + 3) : 0,
+      /*FEATS*/ (cfg->flags & TG_FLAG_FEATURES) ? B * (size_t)(cfg->width + 3) : 0};
   for (int i = 0; i < TG_BUF_COUNT; ++i) {
     int rc = alloc_buf(h, i, sizes[i]);
     if (rc != TG_OK) return bail(rc);
@@ -609,6 +617,22 @@ int tg_grouped_sample(tg_handle* h, uint32_t seed, uint32_t counter) {
   if (h->cfg.action_set != TG_ACTIONS_GROUPED) return fail(h, TG_EINVAL, "tg_grouped_sample: handle was not created with TG_ACTIONS_GROUPED");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   return run_grouped(h, false, true, seed, counter);
+}
+
+int tg_features(tg_handle* h) {
+  if (!h) return TG_EINVAL;
+  if (!(h->cfg.flags & TG_FLAG_FEATURES)) return fail(h, TG_EINVAL, "tg_features: handle was created without TG_FLAG_FEATURES");
+  if (h->cfg.ruleset != TG_RULESET_NUMPY) return fail(h, TG_EINVAL, "tg_features: NUMPY rule-set only (wrappers/observation.py wraps envs/tetris.py)");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  tg::FeatureParams f{};
+  f.board = (const uint8_t*)h->buf[TG_BUF_BOARD];
+  f.rec = (const uint32_t*)h->buf[TG_BUF_REC];
+  f.placement_feats = (uint8_t*)h->buf[TG_BUF_PLACEMENT_FEATS];
+  f.feats = (uint8_t*)h->buf[TG_BUF_FEATS];
+  f.batch = h->B;
+  h->L.features(f, h->stream);
+  HIPCHK(h, hipGetLastError());
+  return TG_OK;
 }
 
 int tg_sync(tg_handle* h) {

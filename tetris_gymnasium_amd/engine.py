@@ -21,7 +21,7 @@ class Engine:
 
     def __init__(self, batch, width=10, height=20, *, ruleset=N.RULESET_NUMPY, gravity=True, queue_size=None,
                  obs_mode=None, autoreset=N.AUTORESET_NONE, device=0, env_offset=0, padding=4, episode_stats=False,
-                 final_obs=False, grouped=False, terminate_on_illegal=True):
+                 final_obs=False, grouped=False, terminate_on_illegal=True, features=False):
         self.lib = N.load()
         if queue_size is None:
             queue_size = 4 if ruleset == N.RULESET_NUMPY else 7
@@ -34,7 +34,8 @@ class Engine:
         cfg.action_set = N.ACTIONS_GROUPED if grouped else N.ACTIONS_BASE
         cfg.batch, cfg.device, cfg.env_offset = batch, device, env_offset
         cfg.grouped_terminate_on_illegal = int(bool(terminate_on_illegal))
-        cfg.flags = (N.FLAG_EPISODE_STATS if episode_stats else 0) | (N.FLAG_FINAL_OBS if final_obs else 0)
+        cfg.flags = ((N.FLAG_EPISODE_STATS if episode_stats else 0) | (N.FLAG_FINAL_OBS if final_obs else 0)
+                     | (N.FLAG_FEATURES if features else 0))
         self.cfg = cfg
         self.B, self.W, self.H, self.P, self.Q = batch, width, height, padding, queue_size
         self.Wp, self.Hp = width + 2 * padding, height + padding
@@ -134,6 +135,14 @@ class Engine:
         """Step with the actions left in the device actions buffer by sample_legal_actions()."""
         ptr, _ = self.device_ptr(N.BUF_ACTIONS)
         self.step_device(ptr)
+
+    def features(self):
+        """(placement_features u8 [B, 4W, W+3], current_features u8 [B, W+3]) — the observations of
+        GroupedActionsObservations(env, observation_wrappers=[FeatureVectorObservation(env)]) and its info["board"]."""
+        self._chk(self.lib.tg_features(self.h), "tg_features")
+        pf = self._fetch(N.BUF_PLACEMENT_FEATS, np.empty((self.B, 4 * self.W, self.W + 3), np.uint8))
+        cf = self._fetch(N.BUF_FEATS, np.empty((self.B, self.W + 3), np.uint8))
+        return pf, cf
 
     def final_observation(self):
         return self.observation(N.BUF_FINAL_OBS)

@@ -16,7 +16,7 @@ from . import _native as N
 from ._gym_compat import HAVE_GYMNASIUM, VectorEnvBase, spaces
 from .engine import Engine
 
-_OBS = {"dict": N.OBS_DICT, "board": N.OBS_BOARD, "functional": N.OBS_FN}
+_OBS = {"dict": N.OBS_DICT, "board": N.OBS_BOARD, "functional": N.OBS_FN, "placement_features": N.OBS_NONE}
 _AUTORESET = {"next_step": N.AUTORESET_NEXT_STEP, "same_step": N.AUTORESET_SAME_STEP, "disabled": N.AUTORESET_NONE}
 
 
@@ -58,7 +58,8 @@ class TetrisVectorEnv(VectorEnvBase):
         self.engines = [
             Engine(hi - lo, width, height, ruleset=self.ruleset, gravity=gravity, queue_size=queue_size,
                    obs_mode=_OBS[observation], autoreset=_AUTORESET[autoreset_mode], device=dev, env_offset=lo,
-                   episode_stats=episode_stats, grouped=grouped, terminate_on_illegal=terminate_on_illegal_action)
+                   episode_stats=episode_stats, grouped=grouped, terminate_on_illegal=terminate_on_illegal_action,
+                   features=(observation == "placement_features"))
             for (lo, hi), dev in zip(self.ranges, devices) if hi > lo
         ]
         self.ranges = [r for r in self.ranges if r[1] > r[0]]
@@ -76,6 +77,11 @@ class TetrisVectorEnv(VectorEnvBase):
             })
         elif observation == "board":
             self.single_observation_space = spaces.Box(low=0, high=9, shape=(height, width), dtype=np.uint8)
+        elif observation == "placement_features":
+            # GroupedActionsObservations(env, observation_wrappers=[FeatureVectorObservation(env)]) (train_lin_grouped.py)
+            if not grouped:
+                raise ValueError("observation='placement_features' needs grouped=True")
+            self.single_observation_space = spaces.Box(low=0, high=255, shape=(4 * width, width + 3), dtype=np.uint8)
         else:
             self.single_observation_space = spaces.Box(low=-1, high=1, shape=(height, width), dtype=np.int8)
         if HAVE_GYMNASIUM:  # pragma: no cover - depends on the environment
@@ -90,6 +96,10 @@ class TetrisVectorEnv(VectorEnvBase):
 
     # ---- helpers --------------------------------------------------------------------------------
     def _gather_obs(self):
+        if self.obs_kind == "placement_features":
+            parts = [e.features() for e in self.engines]
+            self._cur_feats = np.concatenate([p[1] for p in parts])
+            return np.concatenate([p[0] for p in parts])
         parts = [e.observation() for e in self.engines]
         if isinstance(parts[0], dict):
             return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
@@ -110,7 +120,10 @@ class TetrisVectorEnv(VectorEnvBase):
         info = {"lines_cleared": np.zeros(self.num_envs, np.int32)}
         if self.grouped:
             info["action_mask"] = np.concatenate([e.legal_mask() for e in self.engines])
-        return self._gather_obs(), info
+        obs = self._gather_obs()
+        if self.obs_kind == "placement_features":
+            info["board"] = self._cur_feats
+        return obs, info
 
     def step(self, actions):
         actions = np.asarray(actions, np.int32).reshape(self.num_envs)
@@ -131,7 +144,10 @@ class TetrisVectorEnv(VectorEnvBase):
             illegal = np.concatenate([o[0] for o in outs]) < 0
             rewards[illegal] = -0.1  # rewards.invalid_action as a Python float, not float32(-0.1)
         truncations = np.zeros(self.num_envs, bool)
-        return self._gather_obs(), rewards, terminations, truncations, infos
+        obs = self._gather_obs()
+        if self.obs_kind == "placement_features":
+            infos["board"] = self._cur_feats  # wrappers/grouped.py:261-264 info["board"]
+        return obs, rewards, terminations, truncations, infos
 
     def close(self, **kwargs):
         for e in self.engines:
