@@ -363,64 +363,28 @@ __device__ __forceinline__ void lanes_load(const KParams& p, const uint32_t grou
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// L = lanes per env (1: 64 envs per wave; 4: 16 envs per wave, the four lanes of an env split the piece's
-// four cells and OR their results with DPP quad permutes; everything else is computed redundantly by the quad).
-// Measured (profiles/r01_*): with L = 1 there is exactly one wave per SIMD at batch 65 536, so nothing hides
-// LDS/VALU dependency latency and the load / compute / store phases of all waves run in lockstep; L = 4 gives
-// four waves per SIMD with a quarter of the per-wave work.
+// what one env's transition produced (besides its updated state `s`, generator `r` and LDS slab)
+struct LaneOut {
+  float reward;
+  int lines, terminated;
+  bool board_dirty;  // the slab changed (lock / clear / reset)
+  bool final_coll;   // NUMPY projection rule: the active piece collides where it stands → not drawn
+  bool pending;      // this step was a NEXT_STEP-autoreset step
+};
+
+// The rule logic of one transition for the env served by this lane group (L lanes), on its slab in LDS.  Callable
+// with any assignment of envs to lane groups (`slab_off` = byte offset of the env's slab inside `slabs`); the rare
+// heavy paths are entered by wave-uniform any() branches and the line-clear compaction is cooperative.
 template <int W, int H, int RULESET, int L>
-__device__ __forceinline__ void lanes_process(const KParams& p, const uint32_t group, const int lane, uint8_t* lds,
-                                              const GroupIn<W, H, L>& in) {
+__device__ __forceinline__ void lanes_logic(const KParams& p, LaneS& s, LaneRng& r, const LaneBoard<W, H, L>& bd,
+                                            uint8_t* slabs, const uint64_t* cell_tab, const int action_in,
+                                            const bool live, const int slab_off, const int lane, LaneOut& out) {
   using G = Geo<W, H>;
-  constexpr int S = G::CELLS;  // per-env stride in LDS (bytes), same as in HBM: the wave's slabs are one block
-  constexpr int EPW = 64 / L;  // envs per wave
-  constexpr int NCH = (EPW * S + 15) / 16;  // 16-byte chunks of a full group's block
-  constexpr int NIT = (NCH + 63) / 64;      // chunk passes
-  uint64_t* cell_tab = reinterpret_cast<uint64_t*>(lds + ((EPW * S + 15) / 16) * 16);  // 7 x 8 bytes behind the slabs
-  const int eidx = lane / L, sub = lane % L;
-  const uint32_t B = (uint32_t)p.batch;
-  const uint32_t base_env = group * (uint32_t)EPW;
-  const uint32_t nlive = B - base_env < (uint32_t)EPW ? B - base_env : (uint32_t)EPW;
-  const bool live = (uint32_t)eidx < nlive;
-  const uint32_t env = base_env + (live ? (uint32_t)eidx : nlive - 1u);  // dead lanes shadow the last live env
+  constexpr int S = G::CELLS;
+  const int sub = lane % L;
   const bool leader = sub == 0;
-
-#ifdef TG_PHASE_TIMING
-  if (p.dbg && lane == 0)
-    for (int i = 1; i < 16; ++i) p.dbg[(size_t)blockIdx.x * 16 + i] = 0;
-#endif
-  TG_STAMP(0);
-  const uint4 ra = in.ra, rb = in.rb;
-  const int action_in = in.action;
-  // ---- A: stage the group's slabs in LDS ----
-  const uint32_t nbytes = nlive * (uint32_t)S;
-  const uint32_t nchunks = (nbytes + 15u) / 16u;
-  uint4* lds4 = reinterpret_cast<uint4*>(lds);
-  const bool full_wave = nlive == (uint32_t)EPW;
-#pragma unroll
-  for (int k = 0; k < NIT; ++k) {
-    const uint32_t c = (uint32_t)lane + 64u * k;
-    if (c < nchunks) lds4[c] = in.stage[k];
-  }
-  if (lane < 7) cell_tab[lane] = c_cells.cells[lane];
-
-  LaneS s;
-  lane_unpack(s, ra, rb);
-  LaneRng r;
-  r.s_lo = r.s_hi = r.i_lo = r.i_hi = 0;
-  r.uinteger = r.has32 = r.k0 = r.k1 = 0;
-  r.src = p.rng + env;
-  r.loaded = false;
-  r.dirty = false;
   const int Q = p.queue_size;
   const int grav = p.gravity;
-  LaneBoard<W, H, L> bd;
-  bd.my = lds + eidx * S;
-  bd.sub = sub;
-  wave_sync();
-  TG_STAMP(1);
-
   float reward = 0.0f;
   int lines = 0;
   bool board_dirty = false;
@@ -444,7 +408,7 @@ __device__ __forceinline__ void lanes_process(const KParams& p, const uint32_t g
       else { g_illegal = true; action = 7; if (p.grouped_term) frozen = true; }
     }
   }
-  const bool stepped = live && !pending && !frozen;
+  const bool stepped = live && !pending && !frozen && p.stagger != -1;  // (stagger == -1: measurement skeleton, no env steps)
 
   // ---- C: action → tentative placement (branch-free LUT, per lane) ----
   uint32_t e;
@@ -543,8 +507,8 @@ __device__ __forceinline__ void lanes_process(const KParams& p, const uint32_t g
       while (todo) {
         const int l = (int)__builtin_ctzll(todo) / L;  // env within the wave
         todo &= todo - 1;
-        const int n = clear_rows<W, H, RULESET>(lds + l * S, lane);
-        if (eidx == l) lines = n;
+        const int n = clear_rows<W, H, RULESET>(slabs + __shfl(slab_off, l * L), lane);
+        if (lane / L == l) lines = n;
       }
       if (place) {
         s.flags &= ~TG_F_FULLROW;
@@ -645,6 +609,75 @@ __device__ __forceinline__ void lanes_process(const KParams& p, const uint32_t g
     }
   }
   wave_sync();
+  out.reward = reward;
+  out.lines = lines;
+  out.terminated = terminated;
+  out.board_dirty = board_dirty;
+  out.final_coll = final_coll;
+  out.pending = pending;
+}
+
+// ------------------------------------------------------------------------------------------------
+// L = lanes per env (1: 64 envs per wave; 4: 16 envs per wave, the four lanes of an env split the piece's
+// four cells and OR their results with DPP quad permutes; everything else is computed redundantly by the quad).
+// Measured (profiles/r01_*): with L = 1 there is exactly one wave per SIMD at batch 65 536, so nothing hides
+// LDS/VALU dependency latency and the load / compute / store phases of all waves run in lockstep; L = 4 gives
+// four waves per SIMD with a quarter of the per-wave work.
+template <int W, int H, int RULESET, int L>
+__device__ __forceinline__ void lanes_process(const KParams& p, const uint32_t group, const int lane, uint8_t* lds,
+                                              const GroupIn<W, H, L>& in) {
+  using G = Geo<W, H>;
+  constexpr int S = G::CELLS;  // per-env stride in LDS (bytes), same as in HBM: the wave's slabs are one block
+  constexpr int EPW = 64 / L;  // envs per wave
+  constexpr int NCH = (EPW * S + 15) / 16;  // 16-byte chunks of a full group's block
+  constexpr int NIT = (NCH + 63) / 64;      // chunk passes
+  uint64_t* cell_tab = reinterpret_cast<uint64_t*>(lds + ((EPW * S + 15) / 16) * 16);  // 7 x 8 bytes behind the slabs
+  const int eidx = lane / L, sub = lane % L;
+  const uint32_t B = (uint32_t)p.batch;
+  const uint32_t base_env = group * (uint32_t)EPW;
+  const uint32_t nlive = B - base_env < (uint32_t)EPW ? B - base_env : (uint32_t)EPW;
+  const bool live = (uint32_t)eidx < nlive;
+  const uint32_t env = base_env + (live ? (uint32_t)eidx : nlive - 1u);  // dead lanes shadow the last live env
+  const bool leader = sub == 0;
+
+#ifdef TG_PHASE_TIMING
+  if (p.dbg && lane == 0)
+    for (int i = 1; i < 16; ++i) p.dbg[(size_t)blockIdx.x * 16 + i] = 0;
+#endif
+  TG_STAMP(0);
+  const uint4 ra = in.ra, rb = in.rb;
+  const int action_in = in.action;
+  // ---- A: stage the group's slabs in LDS ----
+  const uint32_t nbytes = nlive * (uint32_t)S;
+  const uint32_t nchunks = (nbytes + 15u) / 16u;
+  uint4* lds4 = reinterpret_cast<uint4*>(lds);
+  const bool full_wave = nlive == (uint32_t)EPW;
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const uint32_t c = (uint32_t)lane + 64u * k;
+    if (c < nchunks) lds4[c] = in.stage[k];
+  }
+  if (lane < 7) cell_tab[lane] = c_cells.cells[lane];
+
+  LaneS s;
+  lane_unpack(s, ra, rb);
+  LaneRng r;
+  r.s_lo = r.s_hi = r.i_lo = r.i_hi = 0;
+  r.uinteger = r.has32 = r.k0 = r.k1 = 0;
+  r.src = p.rng + env;
+  r.loaded = false;
+  r.dirty = false;
+  LaneBoard<W, H, L> bd;
+  bd.my = lds + eidx * S;
+  bd.sub = sub;
+  wave_sync();
+  TG_STAMP(1);
+
+  LaneOut lo;
+  lanes_logic<W, H, RULESET, L>(p, s, r, bd, lds, cell_tab, action_in, live, eidx * S, lane, lo);
+  const float reward = lo.reward;
+  const int lines = lo.lines, terminated = lo.terminated;
+  const bool board_dirty = lo.board_dirty, final_coll = lo.final_coll, pending = lo.pending;
 
   TG_STAMP(7);
   // ---- F: write back dirty slabs, pack observations, store records ----
