@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "tg_kernel_block.h"
 #include "tg_kernel_features.h"
 #include "tg_kernel_lanes.h"
 #include "tg_kernels.h"
@@ -35,15 +36,27 @@ inline int grid_for(int batch) { return (batch + tg::kWavesPerBlock - 1) / tg::k
 
 int g_step_blocks = 0;  // persistent grid size (blocks); set once per process from the device's CU count
 
-// step kernel selection (TG_KERNEL): 4 = "quad": 16 envs per wave, 4 lanes per env (default); 1 = "lanes": 64 envs
+// step kernel selection (TG_KERNEL): 8 = "block": two-phase workgroup kernel (default, tg_kernel_block.h);
+// 4 = "quad": 16 envs per wave, 4 lanes per env; 1 = "lanes": 64 envs
 // per wave, one per lane (both tg_kernel_lanes.h); 0 = "wave": one env per wavefront (tg_kernels.h)
-int g_kernel_lanes = 4;
+int g_kernel_lanes = 8;
+int g_block_waves = 4;  // TG_BLOCK_WAVES: waves per workgroup of the block kernel (4 → 64 envs, 8 → 128 envs)
 int g_stagger = 0;  // TG_STAGGER: odd waves of the lane kernels start this many x64 cycles late
 size_t g_lds_pad = 0;
 int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = experimental pipelined pair of groups per wave (measured slower: the prefetched inputs spill), 1 = off  // TG_LDS_PAD: extra dynamic LDS per wave = occupancy limiter (staggers the waves of a SIMD)
 
 template <int W, int H, int RS>
 void launch_step(const tg::KParams& p, hipStream_t s) {
+  if (g_kernel_lanes == 8 && !p.final_obs) {  // "block": two-phase kernel with workgroup-level slow-path compaction
+    if (g_block_waves == 8) {
+      using BG = tg::BlockGeo<W, H, 8>;
+      hipLaunchKernelGGL((tg::step_kernel_block<W, H, RS, 8>), dim3((p.batch + BG::EPB - 1) / BG::EPB), dim3(BG::NT), BG::BYTES, s, p);
+    } else {
+      using BG = tg::BlockGeo<W, H, 4>;
+      hipLaunchKernelGGL((tg::step_kernel_block<W, H, RS, 4>), dim3((p.batch + BG::EPB - 1) / BG::EPB), dim3(BG::NT), BG::BYTES, s, p);
+    }
+    return;
+  }
   if (g_kernel_lanes && !p.final_obs) {
     // two groups per wave (software-pipelined inputs) when the batch is large enough to keep >= 2 waves per SIMD
     auto launch = [&](auto kern1, auto kern2, int epw) {
@@ -354,7 +367,8 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     if (const char* e4 = getenv("TG_STAGGER")) g_stagger = atoi(e4);
     if (const char* e3 = getenv("TG_GROUPS_PER_WAVE")) g_groups_per_wave = atoi(e3) > 0 ? atoi(e3) : 1;
     if (const char* k = getenv("TG_KERNEL"))
-      g_kernel_lanes = strcmp(k, "wave") == 0 ? 0 : (strcmp(k, "lanes") == 0 ? 1 : (strcmp(k, "pair") == 0 ? 2 : 4));
+      g_kernel_lanes = strcmp(k, "wave") == 0 ? 0 : (strcmp(k, "lanes") == 0 ? 1 : (strcmp(k, "pair") == 0 ? 2 : (strcmp(k, "quad") == 0 ? 4 : 8)));
+    if (const char* bw = getenv("TG_BLOCK_WAVES")) g_block_waves = atoi(bw) == 8 ? 8 : 4;
     g_step_blocks = per_cu > 0 ? prop.multiProcessorCount * per_cu : -1;
   }
   CRCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));

@@ -70,52 +70,70 @@ __device__ __forceinline__ void lane_rng_ensure(LaneRng& r) {
   r.loaded = true;
 }
 
-__device__ __forceinline__ uint32_t lane_pcg_next32(LaneRng& r) {
-  // divergent form of pcg_next32 (tg_kernels.h): every lane advances its own generator
+// one PCG64 step (state = state * M + inc, XSL-RR output of the NEW state) from 32/64-bit pieces: 10 multiplies
+__device__ __forceinline__ void lane_pcg_step(const uint64_t s_lo, const uint64_t s_hi, const uint64_t i_lo,
+                                              const uint64_t i_hi, uint64_t& n_lo, uint64_t& n_hi, uint64_t& out) {
   constexpr uint64_t MLO = 0x4385DF649FCCF645ULL, MHI = 0x2360ED051FC65DA4ULL;
-  const bool buffered = r.has32 != 0;
-  const uint64_t lo = r.s_lo * MLO;
-  uint64_t hi = __umul64hi(r.s_lo, MLO) + r.s_lo * MHI + r.s_hi * MLO;
-  const uint64_t nlo = lo + r.i_lo;
-  hi = hi + r.i_hi + (nlo < lo ? 1ULL : 0ULL);
-  const uint64_t x = hi ^ nlo;
-  const unsigned rot = (unsigned)(hi >> 58);
-  const uint64_t out = (x >> rot) | (x << ((64u - rot) & 63u));
-  const uint32_t res = buffered ? r.uinteger : (uint32_t)out;
-  if (!buffered) {
-    r.s_lo = nlo;
-    r.s_hi = hi;
-    r.uinteger = (uint32_t)(out >> 32);
-  }
-  r.has32 = buffered ? 0u : 1u;
-  return res;
+  constexpr uint32_t b0 = (uint32_t)MLO, b1 = (uint32_t)(MLO >> 32);
+  const uint32_t a0 = (uint32_t)s_lo, a1 = (uint32_t)(s_lo >> 32);
+  const uint64_t p0 = (uint64_t)a0 * b0, p1 = (uint64_t)a0 * b1, p2 = (uint64_t)a1 * b0, p3 = (uint64_t)a1 * b1;
+  const uint64_t mid = (p0 >> 32) + (uint32_t)p1 + (uint32_t)p2;
+  const uint64_t lo = (uint64_t)(uint32_t)p0 | (mid << 32);
+  uint64_t hi = p3 + (p1 >> 32) + (p2 >> 32) + (mid >> 32);  // high half of s_lo * MLO
+  hi += s_lo * MHI + s_hi * MLO;
+  n_lo = lo + i_lo;
+  n_hi = hi + i_hi + (n_lo < lo ? 1ULL : 0ULL);
+  const uint64_t x = n_hi ^ n_lo;
+  const unsigned rot = (unsigned)(n_hi >> 58);
+  out = (x >> rot) | (x << ((64u - rot) & 63u));
 }
 
-// Generator.shuffle of the 7-byte bag for the lanes in `need` (others untouched)
+// Generator.shuffle of the 7-byte bag for the lanes in `need` (others untouched).
+// numpy: for i = 6..1: j = masked-rejection draw in [0, i] from 32-bit outputs (low half of a 64-bit output first,
+// the high half is buffered); swap(bag[i], bag[j]).  Every lane runs its OWN position i: one wave-level trip =
+// one PCG64 step (the expensive part: 10 quarter-rate multiplies) + two draw attempts (low half, high half), so the
+// trip count is the maximum over lanes of ceil(total attempts / 2) (≈ 5-7) instead of the sum over the six draws of
+// the per-draw maximum.  (Profiled: the previous per-draw loop was 6 of the 16.7 µs of a 65 536-env step.)
 __device__ __forceinline__ void lane_shuffle7(LaneRng& r, uint64_t& bag, const bool need) {
   if (!__any(need)) return;
+#ifdef TG_EXPERIMENT_NO_SHUFFLE
+  return;  // measurement only: breaks parity
+#endif
   lane_rng_ensure(r);
-  LaneRng t = r;
-  uint64_t b = bag;
-  for (int i = 6; i >= 1; --i) {
+  uint64_t s_lo = r.s_lo, s_hi = r.s_hi, b = bag;
+  uint32_t uinteger = r.uinteger, has32 = r.has32;
+  int i = 6;
+  bool run = need;
+  auto attempt = [&](const uint32_t val, const bool on) {
     const uint32_t mask = i >= 4 ? 7u : (i >= 2 ? 3u : 1u);
-    uint32_t j = 0;
-    bool pending = need;
-    while (__any(pending)) {  // masked rejection (random_interval)
-      LaneRng u = t;
-      const uint32_t v = lane_pcg_next32(u) & mask;
-      if (pending) {
-        t = u;
-        j = v;
-        pending = v > (uint32_t)i;
-      }
+    const uint32_t j = val & mask;
+    if (on && j <= (uint32_t)i) {
+      const uint64_t bi = (b >> (8 * i)) & 0xFF, bj = (b >> (8 * j)) & 0xFF;
+      b &= ~((0xFFULL << (8 * i)) | (0xFFULL << (8 * j)));
+      b |= (bj << (8 * i)) | (bi << (8 * j));
+      i -= 1;
     }
-    const uint64_t bi = (b >> (8 * i)) & 0xFF, bj = (b >> (8 * j)) & 0xFF;
-    b &= ~((0xFFULL << (8 * i)) | (0xFFULL << (8 * j)));
-    b |= (bj << (8 * i)) | (bi << (8 * j));
+  };
+  // lanes that hold a buffered high half consume it first; afterwards every running lane is in phase
+  {
+    const bool on = run && has32 != 0;
+    attempt(uinteger, on);
+    if (on) has32 = 0;
+    run = run && i >= 1;
+  }
+  while (__any(run)) {
+    uint64_t n_lo, n_hi, out;
+    lane_pcg_step(s_lo, s_hi, r.i_lo, r.i_hi, n_lo, n_hi, out);
+    if (run) { s_lo = n_lo; s_hi = n_hi; uinteger = (uint32_t)(out >> 32); has32 = 1; }  // low half taken, high half buffered
+    attempt((uint32_t)out, run);
+    run = run && i >= 1;
+    attempt(uinteger, run);
+    if (run) has32 = 0;
+    run = run && i >= 1;
   }
   if (need) {
-    r = t;
+    r.s_lo = s_lo; r.s_hi = s_hi;
+    r.uinteger = uinteger; r.has32 = has32;
     r.dirty = true;
     bag = b;
   }
@@ -571,6 +589,7 @@ __device__ __forceinline__ void lanes_logic(const KParams& p, LaneS& s, LaneRng&
   const int terminated = (!pending && ((s.flags & TG_F_GAME_OVER) || (g_illegal && p.grouped_term))) ? 1 : 0;
   const bool do_reset = live && (pending || (terminated && p.autoreset == TG_AUTORESET_SAME_STEP));
   if (terminated && p.autoreset == TG_AUTORESET_NEXT_STEP && !pending) s.flags |= TG_F_PENDING_RESET;
+  TG_STAMP(7);
   if (__any(do_reset)) {
     // (final observation of the terminal state is not produced by this kernel; TG_FLAG_FINAL_OBS selects the other one)
     uint32_t* myw = reinterpret_cast<uint32_t*>(bd.my);
@@ -579,7 +598,9 @@ __device__ __forceinline__ void lanes_logic(const KParams& p, LaneS& s, LaneRng&
     if (RULESET == TG_RULESET_NUMPY) {
       lane_resolve_shuffle(s, r, do_reset && s.bidx >= 7);  // rare: this step's spawn wrapped the bag, then game over
       if (do_reset) { s.bag = 0x06050403020100ULL; s.queue = 0; s.bidx = 7; }
+      TG_STAMP(8);
       lane_resolve_shuffle(s, r, s.bidx >= 7);  // reset shuffles + pending spawn reshuffles of the other envs, at once
+      TG_STAMP(9);
       for (int i = 0; i < Q; ++i) {
         const int t = lane_randomizer_next(s, r, do_reset);
         if (do_reset) s.queue |= (uint64_t)t << (8 * i);
