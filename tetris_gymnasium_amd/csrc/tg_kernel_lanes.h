@@ -100,17 +100,21 @@ __device__ __forceinline__ void lane_shuffle7(LaneRng& r, uint64_t& bag, const b
   return;  // measurement only: breaks parity
 #endif
   lane_rng_ensure(r);
-  uint64_t s_lo = r.s_lo, s_hi = r.s_hi, b = bag;
+  uint64_t s_lo = r.s_lo, s_hi = r.s_hi;
   uint32_t uinteger = r.uinteger, has32 = r.has32;
+  // the bag as seven nibbles of one 32-bit word: every swap is full-rate 32-bit shift/mask work
+  uint32_t nb = 0;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) nb |= (uint32_t)((bag >> (8 * k)) & 0xF) << (4 * k);
   int i = 6;
   bool run = need;
   auto attempt = [&](const uint32_t val, const bool on) {
-    const uint32_t mask = i >= 4 ? 7u : (i >= 2 ? 3u : 1u);
+    const uint32_t mask = (0x7773310u >> (4 * i)) & 7u;  // i >= 4 ? 7 : (i >= 2 ? 3 : 1)
     const uint32_t j = val & mask;
     if (on && j <= (uint32_t)i) {
-      const uint64_t bi = (b >> (8 * i)) & 0xFF, bj = (b >> (8 * j)) & 0xFF;
-      b &= ~((0xFFULL << (8 * i)) | (0xFFULL << (8 * j)));
-      b |= (bj << (8 * i)) | (bi << (8 * j));
+      const uint32_t bi = (nb >> (4 * i)) & 0xFu, bj = (nb >> (4 * j)) & 0xFu;
+      nb &= ~((0xFu << (4 * i)) | (0xFu << (4 * j)));
+      nb |= (bj << (4 * i)) | (bi << (4 * j));
       i -= 1;
     }
   };
@@ -135,6 +139,9 @@ __device__ __forceinline__ void lane_shuffle7(LaneRng& r, uint64_t& bag, const b
     r.s_lo = s_lo; r.s_hi = s_hi;
     r.uinteger = uinteger; r.has32 = has32;
     r.dirty = true;
+    uint64_t b = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) b |= (uint64_t)((nb >> (4 * k)) & 0xFu) << (8 * k);
     bag = b;
   }
 }
