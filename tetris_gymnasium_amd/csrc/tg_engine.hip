@@ -13,13 +13,16 @@
 #include <string>
 #include <vector>
 
+#include "tg_kernel_bits.h"
 #include "tg_kernel_block.h"
 #include "tg_kernel_features.h"
 #include "tg_kernel_lanes.h"
 #include "tg_kernels.h"
 
 // ---- board sizes compiled in (W, H).  Extend the list and rebuild to support another size. ----
+#ifndef TG_FOR_EACH_SIZE
 #define TG_FOR_EACH_SIZE(X) X(10, 20) X(20, 40) X(6, 12) X(8, 16) X(10, 24) X(12, 24)
+#endif
 
 namespace {
 
@@ -30,16 +33,18 @@ struct Launchers {
   void (*step)(const tg::KParams&, hipStream_t);
   void (*reset)(const tg::ResetParams&, hipStream_t);
   void (*observe)(const tg::ObserveParams&, hipStream_t);
+  void (*prepare)(const tg::PrepareParams&, hipStream_t);
+  size_t cols_bytes;  // per env: column masks of the bits kernel
 };
 
 inline int grid_for(int batch) { return (batch + tg::kWavesPerBlock - 1) / tg::kWavesPerBlock; }
 
 int g_step_blocks = 0;  // persistent grid size (blocks); set once per process from the device's CU count
 
-// step kernel selection (TG_KERNEL): 8 = "block": two-phase workgroup kernel (default, tg_kernel_block.h);
-// 4 = "quad": 16 envs per wave, 4 lanes per env; 1 = "lanes": 64 envs
-// per wave, one per lane (both tg_kernel_lanes.h); 0 = "wave": one env per wavefront (tg_kernels.h)
-int g_kernel_lanes = 8;
+// step kernel selection (TG_KERNEL): 16 = "bits": column-bitmask logic, one env per lane (default, tg_kernel_bits.h);
+// 8 = "block": two-phase workgroup kernel (tg_kernel_block.h); 4 = "quad": 16 envs per wave, 4 lanes per env;
+// 1 = "lanes": 64 envs per wave, one per lane (both tg_kernel_lanes.h); 0 = "wave": one env per wavefront (tg_kernels.h)
+int g_kernel_lanes = 16;
 int g_block_waves = 4;  // TG_BLOCK_WAVES: waves per workgroup of the block kernel (4 → 64 envs, 8 → 128 envs)
 int g_stagger = 0;  // TG_STAGGER: odd waves of the lane kernels start this many x64 cycles late
 size_t g_lds_pad = 0;
@@ -47,6 +52,12 @@ int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = experimental pipelined pa
 
 template <int W, int H, int RS>
 void launch_step(const tg::KParams& p, hipStream_t s) {
+  if (p.cols && !p.final_obs) {  // "bits": the handle carries the column masks / look-ahead permutations
+    using BG = tg::BitsGeo<W, H>;
+    const tg::BitsParams bp{p.cols, p.ahead};
+    hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS>), dim3((p.batch + BG::EPW - 1) / BG::EPW), dim3(64), BG::BYTES, s, p, bp);
+    return;
+  }
   if (g_kernel_lanes == 8 && !p.final_obs) {  // "block": two-phase kernel with workgroup-level slow-path compaction
     if (g_block_waves == 8) {
       using BG = tg::BlockGeo<W, H, 8>;
@@ -88,6 +99,10 @@ void launch_features(const tg::FeatureParams& p, hipStream_t s) {
   hipLaunchKernelGGL((tg::features_kernel<W, H>), dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p);
 }
 template <int W, int H>
+void launch_prepare(const tg::PrepareParams& p, hipStream_t s) {
+  hipLaunchKernelGGL((tg::bits_prepare_kernel<W, H>), dim3((p.batch + 255) / 256), dim3(256), 0, s, p);
+}
+template <int W, int H>
 void launch_observe(const tg::ObserveParams& p, hipStream_t s) {
   hipLaunchKernelGGL((tg::observe_kernel<W, H>), dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p);
 }
@@ -96,10 +111,11 @@ bool find_launchers(int W, int H, int ruleset, Launchers* out) {
 #define X(w, h)                                                                                     \
   if (W == w && H == h) {                                                                           \
     if (ruleset == TG_RULESET_NUMPY)                                                                \
-      *out = {launch_features<w, h>, launch_step<w, h, TG_RULESET_NUMPY>, launch_reset<w, h, TG_RULESET_NUMPY>, launch_observe<w, h>}; \
+      *out = {launch_features<w, h>, launch_step<w, h, TG_RULESET_NUMPY>, launch_reset<w, h, TG_RULESET_NUMPY>, launch_observe<w, h>, \
+              launch_prepare<w, h>, tg::bits_cols_bytes<w, h>()};                                   \
     else                                                                                            \
       *out = {launch_features<w, h>, launch_step<w, h, TG_RULESET_FUNCTIONAL>, launch_reset<w, h, TG_RULESET_FUNCTIONAL>,  \
-              launch_observe<w, h>};                                                                \
+              launch_observe<w, h>, launch_prepare<w, h>, tg::bits_cols_bytes<w, h>()};             \
     return true;                                                                                    \
   }
   TG_FOR_EACH_SIZE(X)
@@ -130,6 +146,8 @@ struct tg_handle {
   uint8_t* d_reseed = nullptr;
   uint8_t* d_mask = nullptr;
   void* dbg = nullptr;  // phase-timing buffer (TG_PHASE_TIMING builds)
+  void* d_cols = nullptr;   // bits kernel: column masks [B][W] (device-private acceleration state)
+  uint4* d_ahead = nullptr; // bits kernel: generator state after the look-ahead shuffle [B][2]
   std::vector<uint8_t> rng_valid;
   std::vector<tg_rng_rec> h_new_rng;
   std::vector<uint8_t> h_reseed;
@@ -252,6 +270,8 @@ tg::KParams step_params(tg_handle* h) {
   p.grouped_term = h->cfg.grouped_terminate_on_illegal;
   p.stagger = g_stagger;
   p.dbg = (unsigned long long*)h->dbg;
+  p.cols = h->d_cols;
+  p.ahead = h->d_ahead;
   return p;
 }
 
@@ -265,6 +285,24 @@ int launch_observe_dict(tg_handle* h) {
   o.queue_size = h->Q;
   o.ruleset = h->cfg.ruleset;
   h->L.observe(o, h->stream);
+  HIPCHK(h, hipGetLastError());
+  return TG_OK;
+}
+
+// bits kernel: rebuild column masks + look-ahead permutations from the reference-defined state
+int launch_prepare_bits(tg_handle* h, const uint8_t* d_mask, int force) {
+  if (!h->d_cols) return TG_OK;
+  tg::PrepareParams q{};
+  q.board = (const uint8_t*)h->buf[TG_BUF_BOARD];
+  q.rec = (uint32_t*)h->buf[TG_BUF_REC];
+  q.rng = (tg_rng_rec*)h->buf[TG_BUF_RNG];
+  q.cols = h->d_cols;
+  q.ahead = h->d_ahead;
+  q.mask = d_mask;
+  q.batch = h->B;
+  q.ruleset = h->cfg.ruleset;
+  q.force = force;
+  h->L.prepare(q, h->stream);
   HIPCHK(h, hipGetLastError());
   return TG_OK;
 }
@@ -367,7 +405,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     if (const char* e4 = getenv("TG_STAGGER")) g_stagger = atoi(e4);
     if (const char* e3 = getenv("TG_GROUPS_PER_WAVE")) g_groups_per_wave = atoi(e3) > 0 ? atoi(e3) : 1;
     if (const char* k = getenv("TG_KERNEL"))
-      g_kernel_lanes = strcmp(k, "wave") == 0 ? 0 : (strcmp(k, "lanes") == 0 ? 1 : (strcmp(k, "pair") == 0 ? 2 : (strcmp(k, "quad") == 0 ? 4 : 8)));
+      g_kernel_lanes = strcmp(k, "wave") == 0 ? 0 : (strcmp(k, "lanes") == 0 ? 1 : (strcmp(k, "pair") == 0 ? 2 : (strcmp(k, "quad") == 0 ? 4 : (strcmp(k, "block") == 0 ? 8 : 16))));
     if (const char* bw = getenv("TG_BLOCK_WAVES")) g_block_waves = atoi(bw) == 8 ? 8 : 4;
     g_step_blocks = per_cu > 0 ? prop.multiProcessorCount * per_cu : -1;
   }
@@ -392,6 +430,12 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   CRCHK(hipMalloc((void**)&h->d_new_rng, B * sizeof(tg_rng_rec)));
   CRCHK(hipMalloc((void**)&h->d_reseed, B));
   CRCHK(hipMalloc((void**)&h->d_mask, B));
+  if (g_kernel_lanes == 16 && !want_final) {
+    CRCHK(hipMalloc(&h->d_cols, B * L.cols_bytes + kTailPad));
+    CRCHK(hipMemsetAsync(h->d_cols, 0, B * L.cols_bytes + kTailPad, h->stream));
+    CRCHK(hipMalloc((void**)&h->d_ahead, B * 32 + kTailPad));
+    CRCHK(hipMemsetAsync(h->d_ahead, 0, B * 32 + kTailPad, h->stream));
+  }
 #ifdef TG_PHASE_TIMING
   CRCHK(hipMalloc(&h->dbg, ((B + 15) / 16) * 16 * 8));
   CRCHK(hipMemset(h->dbg, 0, ((B + 15) / 16) * 16 * 8));
@@ -419,6 +463,8 @@ void tg_destroy(tg_handle* h) {
   if (h->d_new_rng) (void)hipFree(h->d_new_rng);
   if (h->d_reseed) (void)hipFree(h->d_reseed);
   if (h->d_mask) (void)hipFree(h->d_mask);
+  if (h->d_cols) (void)hipFree(h->d_cols);
+  if (h->d_ahead) (void)hipFree(h->d_ahead);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -472,6 +518,10 @@ int tg_reset(tg_handle* h, const uint64_t* seeds, const uint8_t* mask) {
   }
   h->L.reset(p, h->stream);
   HIPCHK(h, hipGetLastError());
+  {
+    int rc = launch_prepare_bits(h, p.mask, 0);
+    if (rc != TG_OK) return rc;
+  }
   if (h->cfg.obs_mode == TG_OBS_DICT) {
     int rc = launch_observe_dict(h);
     if (rc != TG_OK) return rc;
@@ -546,7 +596,10 @@ int tg_get_state(tg_handle* h, uint8_t* board, tg_env_rec* rec, tg_rng_rec* rng)
   if (rng) HIPCHK(h, hipMemcpyAsync(rng, h->buf[TG_BUF_RNG], B * sizeof(tg_rng_rec), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (rec)
-    for (size_t i = 0; i < B; ++i) rec[i].flags &= (uint8_t)~TG_F_FULLROW;  // device-private bit
+    for (size_t i = 0; i < B; ++i) {  // device-private: full-row hint, look-ahead permutation
+      rec[i].flags &= (uint8_t)~TG_F_FULLROW;
+      rec[i].reserved = 0;
+    }
   return TG_OK;
 }
 
@@ -593,6 +646,10 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
   if (rng) {
     HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_RNG], rng, B * sizeof(tg_rng_rec), hipMemcpyHostToDevice, h->stream));
     h->rng_valid.assign(B, 1);
+  }
+  {
+    int rc = launch_prepare_bits(h, nullptr, 1);
+    if (rc != TG_OK) return rc;
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return TG_OK;

@@ -1,0 +1,823 @@
+// tg_kernel_bits.h — fifth formulation of the step kernel: rule logic on per-env COLUMN BITMASKS, one env per lane.
+//
+// Why (measured, profiles/r01/block1_*): at batch 65 536 every workgroup of a launch is resident at once, so the
+// launch time is the critical path of ONE workgroup, not a throughput; 78 % of the wave cycles of the byte-probing
+// kernels are waits on dependent LDS byte reads (collision probes, the step-wise drop loop, row scans) and on the
+// PCG64 bag shuffle (128-bit multiplies in a rejection loop, behind a dependent HBM load of the generator).  Here:
+//   * besides the uint8 playfield (the state the reference defines, envs/tetris.py:632-641) every env carries an
+//     acceleration structure: one bitmask per playfield column (bit r = cell (r, c) is filled), W words per env in
+//     HBM (40 B at 10x20), kept consistent by this kernel and rebuilt by bits_prepare_kernel after reset/set_state;
+//   * ONE LDS round trip fetches the six columns around the piece; every collision test of the step (tentative
+//     here/below, current here/below), the hard drop (the reference's step-wise loop == first set bit of the
+//     "piece at row r collides" mask below y) and the lock are register ALU on those six words;
+//   * full rows = AND over the W columns (the reference's whole-board scan, envs/tetris.py:493-494), the spawn
+//     collision reads the same registers; line-clear compaction of the masks is bit arithmetic (rare path);
+//   * the uint8 slab is only the payload: it streams HBM → LDS → HBM while the logic runs, receives the locked
+//     cells / cleared rows / resets afterwards and leaves as the observation (coalesced 16-byte accesses);
+//   * numpy's Generator.shuffle draws do not depend on the array being shuffled (Fisher-Yates positions only), so
+//     the NEXT bag permutation is computed one shuffle ahead and kept in the env record (7 nibbles): using it is a
+//     nibble gather; the PCG64 loop that refreshes it runs at the END of the step, after all stores were issued.
+//     The generator state the reference would hold (tg_get_state) stays in tg_rng_rec; the state after the
+//     look-ahead shuffle lives in a device-private buffer and is promoted when the permutation is consumed.
+// Bit-identical to the other four step kernels and to the oracle (tests/test_gpu_*.py run against all of them).
+#pragma once
+#include <type_traits>
+
+#include "tg_kernel_lanes.h"
+
+namespace tg {
+
+// per (piece, rot): four column nibbles — nibble c holds, as bits k, the filled cells (k, c) of the 4x4 box
+// (the transpose of ShapeTable.mask)
+struct ColTable {
+  uint64_t cols[7];
+};
+
+constexpr ColTable make_col_table() {
+  ColTable t{};
+  const ShapeTable s = make_shape_table();
+  for (int p = 0; p < 7; ++p) {
+    uint64_t row = 0;
+    for (int r = 0; r < 4; ++r) {
+      uint64_t v = 0;
+      for (int k = 0; k < 4; ++k)
+        for (int c = 0; c < 4; ++c)
+          if ((s.mask[p][r] >> (4 * k + c)) & 1) v |= 1ULL << (4 * c + k);
+      row |= v << (16 * r);
+    }
+    t.cols[p] = row;
+  }
+  return t;
+}
+
+__constant__ ColTable c_colmasks = make_col_table();
+
+template <int H>
+using ColT = std::conditional_t<(H + 6 <= 32), uint32_t, uint64_t>;
+
+__device__ __forceinline__ int ctz_t(uint32_t v) { return (int)__builtin_ctz(v); }
+__device__ __forceinline__ int ctz_t(uint64_t v) { return (int)__builtin_ctzll(v); }
+__device__ __forceinline__ int popc_t(uint32_t v) { return (int)__popc(v); }
+__device__ __forceinline__ int popc_t(uint64_t v) { return (int)__popcll(v); }
+
+// bytes per env of the column-mask buffer
+template <int W, int H>
+constexpr size_t bits_cols_bytes() { return (size_t)W * sizeof(ColT<H>); }
+
+// dynamic LDS of one wave of step_kernel_bits.  EPW envs per wave (one per lane; on large boards fewer than 64 so that
+// the wave's slab block still fits the staging registers — the idle lanes only help streaming the slabs)
+template <int W, int H>
+struct BitsGeo {
+  using T = ColT<H>;
+  static constexpr int S = W * H;
+  static constexpr int EPW = S <= 320 ? 64 : (S <= 640 ? 32 : 16);
+  static constexpr int SLABS = ((EPW * S + 15) / 16) * 16;
+  static constexpr int NCH = SLABS / 16;
+  static constexpr int NIT = (NCH + 63) / 64;
+  static constexpr int OFF_TAB = SLABS;             // cell table (7 x 8 B), column table (7 x 8 B)
+  static constexpr int OFF_COLS = OFF_TAB + 128;    // T [EPW][CST]: [0] bedrock, [1..W] playfield columns, [W+1] bedrock
+  static constexpr int CST = (W + 2) | 1;           // odd stride: conflict-free for same-index accesses of the 64 lanes
+  static constexpr int BYTES = OFF_COLS + EPW * CST * (int)sizeof(T);
+  static_assert(W % 2 == 0, "column masks are moved as 8-byte pairs");
+};
+
+// look-ahead generator context of one lane (NUMPY rule-set)
+struct BitsRng {
+  uint64_t s_lo, s_hi, i_lo, i_hi;  // frontier state (after the last COMPUTED shuffle) and the stream increment
+  uint32_t uinteger, has32;
+  bool loaded;                      // per lane: only lanes that shuffle fetch their generator
+};
+
+// Fisher-Yates positions of Generator.shuffle on a 7-array (numpy/random/_generator.pyx shuffle → random_interval,
+// masked rejection on 32-bit draws; components/tetromino_randomizer.py:42-46, 84) for the lanes in `need`, run on the
+// identity: the result P (7 nibbles) is the permutation with  shuffled[k] = original[P[k]]  for ANY original array.
+// Same vector loop as lane_shuffle7 (tg_kernel_lanes.h): one PCG64 step + two draw attempts per trip.
+__device__ __forceinline__ void bits_shuffle_perm(BitsRng& g, uint32_t& sig, const bool need) {
+  uint64_t s_lo = g.s_lo, s_hi = g.s_hi;
+  uint32_t uinteger = g.uinteger, has32 = g.has32;
+  uint32_t nb = 0x6543210u;
+  int i = 6;
+  bool run = need;
+  auto attempt = [&](const uint32_t val, const bool on) {
+    const uint32_t mask = (0x7773310u >> (4 * i)) & 7u;  // i >= 4 ? 7 : (i >= 2 ? 3 : 1)
+    const uint32_t j = val & mask;
+    if (on && j <= (uint32_t)i) {
+      const uint32_t bi = (nb >> (4 * i)) & 0xFu, bj = (nb >> (4 * j)) & 0xFu;
+      nb &= ~((0xFu << (4 * i)) | (0xFu << (4 * j)));
+      nb |= (bj << (4 * i)) | (bi << (4 * j));
+      i -= 1;
+    }
+  };
+  {
+    const bool on = run && has32 != 0;  // a buffered high half is consumed first
+    attempt(uinteger, on);
+    if (on) has32 = 0;
+    run = run && i >= 1;
+  }
+  while (__any(run)) {
+    uint64_t n_lo, n_hi, out;
+    lane_pcg_step(s_lo, s_hi, g.i_lo, g.i_hi, n_lo, n_hi, out);
+    if (run) { s_lo = n_lo; s_hi = n_hi; uinteger = (uint32_t)(out >> 32); has32 = 1; }
+    attempt((uint32_t)out, run);
+    run = run && i >= 1;
+    attempt(uinteger, run);
+    if (run) has32 = 0;
+    run = run && i >= 1;
+  }
+  if (need) {
+    g.s_lo = s_lo; g.s_hi = s_hi;
+    g.uinteger = uinteger; g.has32 = has32;
+    sig = nb;
+  }
+}
+
+// shuffled[k] = src[P[k]]  on 7-byte arrays packed in a 64-bit word
+__device__ __forceinline__ uint64_t bits_apply_perm(const uint32_t sig, const uint64_t src) {
+  uint64_t out = 0;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const uint32_t pk = (sig >> (4 * k)) & 7u;
+    out |= ((src >> (8 * pk)) & 0xFFULL) << (8 * k);
+  }
+  return out;
+}
+
+struct BitsParams {
+  void* cols;    // ColT [B][W]
+  uint4* ahead;  // [B][2]: {state_lo, state_hi as 4 dwords} {uinteger, has32, 0, 0} after the look-ahead shuffle
+};
+
+constexpr uint32_t kSigValid = 0x80000000u;
+
+// native 16-byte vector for the slab stream: HIP's uint4 is a struct whose copies become memcpy intrinsics, which
+// kept the staging array in scratch memory (and made the kernel wait for every slab load right after issuing it)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// streaming stores: L2 is per XCD and written back at the end of every kernel; data no wave of THIS launch reads again
+// (observations, outputs) leaves with the nontemporal hint so that it drains while the kernel still computes
+template <typename V>
+__device__ __forceinline__ void st_stream(V* dst, const V v) {
+#ifdef TG_NO_NT
+  *dst = v;
+#else
+  __builtin_nontemporal_store(v, dst);
+#endif
+}
+
+// state that the NEXT launch reads again (board, records): TG_NT_STATE also streams it
+#ifdef TG_NT_STATE
+#define TG_ST_STATE(ptr, val) st_stream(ptr, val)
+#else
+#define TG_ST_STATE(ptr, val) (*(ptr) = (val))
+#endif
+
+template <int W, int H, int RULESET>
+__global__ __launch_bounds__(64, 1) void step_kernel_bits(const KParams p, const BitsParams bp) {
+  using BG = BitsGeo<W, H>;
+  using T = ColT<H>;
+  constexpr int S = BG::S, EPW = BG::EPW, NCH = BG::NCH, NIT = BG::NIT, CST = BG::CST;
+  constexpr T ONES = ~T(0);
+  constexpr T FLOOR = (T)(ONES << H);  // rows >= H are bedrock (envs/tetris.py:632-641)
+  constexpr T PLAY = (T)~FLOOR;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  u32x4* lds4 = reinterpret_cast<u32x4*>(lds);
+  uint64_t* cell_tab = reinterpret_cast<uint64_t*>(lds + BG::OFF_TAB);
+  uint64_t* col_tab = cell_tab + 8;
+  const int lane = threadIdx.x;
+
+  const uint32_t B = (uint32_t)p.batch;
+  const uint32_t base_env = blockIdx.x * (uint32_t)EPW;
+  const uint32_t nlive = B - base_env < (uint32_t)EPW ? B - base_env : (uint32_t)EPW;
+  const bool live = (uint32_t)lane < nlive;
+  const int slot = live ? lane : (int)nlive - 1;  // dead lanes shadow the last live env (identical, benign LDS writes)
+  const uint32_t env = base_env + (uint32_t)slot;
+  T* colsL = reinterpret_cast<T*>(lds + BG::OFF_COLS) + slot * CST;
+  const bool full_wave = nlive == (uint32_t)EPW;
+  const uint32_t nbytes = nlive * (uint32_t)S;
+  const uint32_t nchunks = (nbytes + 15u) / 16u;
+
+#ifdef TG_PHASE_TIMING
+  unsigned long long tstamp[10];  // kept in SGPRs and written at the very end: a store per stamp would itself be waited on
+#define TG_BITS_STAMP(i) tstamp[i] = __builtin_amdgcn_s_memtime()
+#else
+#define TG_BITS_STAMP(i) do {} while (0)
+#endif
+  TG_BITS_STAMP(0);
+  // ---- A: all loads in flight: tables, record, action, column masks (small, needed first), then the slab block.
+  // vmcnt counts in issue order: the logic may only wait for the small loads if they are issued FIRST and nothing else
+  // is loaded before the slabs are consumed (sched_barrier keeps the compiler from interleaving the two groups) ----
+  uint64_t tab_cells = 0, tab_cols = 0;
+  if (lane < 7) { tab_cells = c_cells.cells[lane]; tab_cols = c_colmasks.cols[lane]; }
+  const uint4* rec4 = reinterpret_cast<const uint4*>(p.rec) + (size_t)env * 2;
+  const uint4 ra = rec4[0], rb = rec4[1];
+  const int action_in = p.act_i8 ? (int)reinterpret_cast<const int8_t*>(p.actions)[env]
+                                 : reinterpret_cast<const int32_t*>(p.actions)[env];
+  T cv[W];
+  {
+    constexpr int NP = (int)(W * sizeof(T) / 8);
+    const uint2* gc = reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(bp.cols) + (size_t)env * W);
+    uint2 raw[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) raw[k] = gc[k];
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      if constexpr (sizeof(T) == 4) cv[c] = (c & 1) ? raw[c / 2].y : raw[c / 2].x;
+      else cv[c] = (T)raw[c].x | ((T)raw[c].y << 32);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const bool need_slab = p.obs_mode == TG_OBS_BOARD || p.obs_mode == TG_OBS_FN;
+  u32x4 stage[NIT];
+  {
+    const u32x4* gsrc = reinterpret_cast<const u32x4*>(p.board + (size_t)base_env * S);
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const uint32_t c = (uint32_t)lane + 64u * k;
+      stage[k] = gsrc[c < nchunks ? c : nchunks - 1u];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (lane < 7) { cell_tab[lane] = tab_cells; col_tab[lane] = tab_cols; }
+  colsL[0] = ONES;
+  colsL[W + 1] = ONES;
+#pragma unroll
+  for (int c = 0; c < W; ++c) colsL[1 + c] = (T)(cv[c] | FLOOR);
+  wave_sync();
+  TG_BITS_STAMP(1);
+
+  // ---- B: rule logic (per lane, branch-free except wave-uniform any() branches) ----
+  LaneS s;
+  lane_unpack(s, ra, rb);
+  const int Q = p.queue_size;
+  const int grav = p.gravity;
+  float reward = 0.0f;
+  int lines = 0;
+  bool final_coll = false;
+  // look-ahead permutation (NUMPY)
+  uint32_t sig = s.reserved & 0x0FFFFFFFu;
+  bool sig_ok = RULESET == TG_RULESET_NUMPY && (s.reserved & kSigValid) != 0;
+  const bool sig_valid0 = sig_ok;
+  bool consumed = false;
+  BitsRng g;
+  g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
+  g.uinteger = g.has32 = 0;
+  g.loaded = false;
+  const uint4* rng4 = reinterpret_cast<const uint4*>(p.rng + env);
+  auto rng_ensure = [&](const bool need) {
+    const bool go = need && !g.loaded;
+    if (!__any(go)) return;
+    if (go) {
+      // frontier = state after the look-ahead shuffle (valid permutation) or the generator state itself (none yet)
+      const uint4* a4 = bp.ahead + (size_t)env * 2;
+      const uint4 f0 = sig_valid0 ? a4[0] : rng4[0];
+      const uint4 f1 = sig_valid0 ? a4[1] : rng4[2];
+      const uint4 gi = rng4[1];
+      g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
+      g.i_lo = (uint64_t)gi.x | ((uint64_t)gi.y << 32); g.i_hi = (uint64_t)gi.z | ((uint64_t)gi.w << 32);
+      g.uinteger = f1.x; g.has32 = f1.y;
+      g.loaded = true;
+    }
+  };
+  // BagRandomizer reshuffle (components/tetromino_randomizer.py:42-46, 84) / reset shuffle (:87-91) for the lanes in `need`
+  auto consume_perm = [&](const bool need, const bool from_identity) {
+    if (!__any(need)) return;
+    if (__any(need && !sig_ok)) {  // rare: a second shuffle in one step (this load also waits for the slab loads)
+      rng_ensure(need && !sig_ok);
+      bits_shuffle_perm(g, sig, need && !sig_ok);
+    }
+    const uint64_t nb = bits_apply_perm(sig, from_identity ? 0x06050403020100ULL : s.bag);
+    if (need) { s.bag = nb; s.bidx = 0; sig_ok = false; consumed = true; }
+  };
+  // BagRandomizer.get_next_tetromino (:65-85): eager reshuffle when the 7th piece is drawn
+  auto randomizer_next = [&](const bool on) -> int {
+    const int t = (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
+    if (on) s.bidx += 1;
+    consume_perm(on && s.bidx >= 7, false);
+    return t;
+  };
+  // TetrominoQueue.get_next_tetromino (components/tetromino_queue.py:35-42)
+  auto queue_pop = [&](const bool on) -> int {
+    const int t = (int)(s.queue & 0xFF);
+    const int nxt = randomizer_next(on);
+    if (on) s.queue = (s.queue >> 8) | ((uint64_t)nxt << (8 * (Q - 1)));
+    return t;
+  };
+  LaneRng r;  // FUNCTIONAL: the jax key (in-line threefry)
+  r.s_lo = r.s_hi = r.i_lo = r.i_hi = 0;
+  r.uinteger = r.has32 = r.k0 = r.k1 = 0;
+  r.src = p.rng + env;
+  r.loaded = false;
+  r.dirty = false;
+
+  const bool pending = p.autoreset == TG_AUTORESET_NEXT_STEP && (s.flags & TG_F_PENDING_RESET);
+  bool frozen = RULESET == TG_RULESET_FUNCTIONAL && (s.flags & TG_F_GAME_OVER);
+  auto colmask = [&](int piece, int rot) -> uint32_t { return (uint32_t)(col_tab[piece] >> (16 * rot)) & 0xFFFFu; };
+  // grouped action set (wrappers/grouped.py:209-269): action = column * 4 + rotations → teleport + hard drop; illegal
+  // iff a cell of the rotated piece lies outside the playfield columns (collision_with_frame, :104-122)
+  int action = action_in;
+  bool g_illegal = false;
+  if (RULESET == TG_RULESET_NUMPY && p.action_set == TG_ACTIONS_GROUPED) {
+    const int col = action_in >> 2, nrot = (s.rot + (action_in & 3)) & 3;
+    const int nx = col + 4 - (s.piece == 0 ? 2 : 1);  // x + padding - matrix.shape[1] // 2
+    const uint32_t cg = colmask(s.piece, nrot);
+    bool legal = (unsigned)action_in < (unsigned)(4 * W);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      legal = legal && (((cg >> (4 * c)) & 0xFu) == 0 || (unsigned)(nx + c - 4) < (unsigned)W);
+    if (!pending) {
+      if (legal) { s.x = nx; s.rot = nrot; action = 5; }
+      else { g_illegal = true; action = 7; if (p.grouped_term) frozen = true; }
+    }
+  }
+  const bool stepped = live && !pending && !frozen;
+
+  // action → tentative placement (branch-free LUT)
+  uint32_t e;
+  if (RULESET == TG_RULESET_NUMPY) {
+    e = (uint32_t)(kActLutNumpy >> (8 * (action & 7))) & 0xFFu;
+  } else {
+    const int br = action < 0 ? 0 : (action > 6 ? 6 : action);
+    e = (uint32_t)(kActLutFn >> (8 * br)) & 0xFFu;
+  }
+  int tp = s.piece, tv = s.val;
+  int tx = s.x + (int)(e & 3u) - 1;
+  int ty = s.y + (int)((e >> 2) & 1u);
+  int tr = (s.rot + (int)((e >> 3) & 3u)) & 3;
+  const bool check = (e & 0x20u) != 0;
+  const bool hard = stepped && (e & 0x40u) != 0;
+  // swap (envs/tetris.py:242-252, components/tetromino_holder.py:31-49)
+  const bool swap_eff = RULESET == TG_RULESET_NUMPY && stepped && (e & 0x80u) && !(s.flags & TG_F_HAS_SWAPPED);
+  if (RULESET == TG_RULESET_NUMPY && __any(swap_eff)) {
+    const bool empty = swap_eff && s.hp == TG_NONE;
+    const int popped = queue_pop(empty);  // spawn_tetromino; its collision result is ignored
+    if (swap_eff) {
+      if (empty) { tp = popped; tr = 0; tv = popped + 2; }
+      else { tp = s.hp; tr = s.hr; tv = s.hv; }
+      s.hp = s.piece; s.hr = s.rot; s.hv = s.val;
+      s.flags |= TG_F_HAS_SWAPPED;
+      tx = np_spawn_x<W>(tp);
+      ty = 0;
+    }
+  }
+
+  // the six columns around the piece: padded columns wb .. wb+5 (the current piece spans wb+1 .. wb+4, a tentative
+  // one wb+dxT .. wb+dxT+3 with dxT in 0..2).  An out-of-range position (only by tg_set_state) collides everywhere.
+  const int wb = (swap_eff ? tx : s.x) - 1;
+  const bool oob = (unsigned)wb > (unsigned)(W + 2) || (unsigned)s.y > (unsigned)H;
+  T w[6];
+  int widx[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int j = wb + i - 3;  // padded column → LDS index: playfield column c sits at 1 + c, bedrock at 0 and W + 1
+    widx[i] = j < 0 ? 0 : (j > W + 1 ? W + 1 : j);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) w[i] = colsL[widx[i]];
+  if (oob) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) w[i] = ONES;
+  }
+  TG_BITS_STAMP(2);
+  const uint32_t mC = colmask(s.piece, s.rot), mT = colmask(tp, tr);
+  const int dxT = tx - wb;                 // 0..2 (1 after a swap)
+  const uint32_t PT = mT << (4 * dxT);     // nibble i = the tentative piece's cells in window column i
+  const uint32_t PC = mC << 4;
+  bool cT, cT1, cC, cC1;
+  {
+    T hT = 0, hT1 = 0, hC = 0, hC1 = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const T a = (T)((PT >> (4 * i)) & 0xFu) << ty;
+      hT |= w[i] & a;
+      hT1 |= w[i] & (T)(a << 1);
+      if (i >= 1 && i <= 4) {
+        const T b = (T)((PC >> (4 * i)) & 0xFu) << s.y;
+        hC |= w[i] & b;
+        hC1 |= w[i] & (T)(b << 1);
+      }
+    }
+    cT = hT != 0; cT1 = hT1 != 0; cC = hC != 0; cC1 = hC1 != 0;
+  }
+  // "piece at row r collides" for every r at once: OR over the piece's cells (k, i) of (column i >> k); the
+  // reference's drop loop `while not collision(y + 1): y += 1` (envs/tetris.py:445-448, functional/core.py:243-249)
+  // ends at the first blocked row below y
+  auto drop_row_of = [&](const uint32_t P, const int y) -> int {
+    T bm = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const uint32_t n = (P >> (4 * i)) & 0xFu;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bm |= ((n >> k) & 1u) ? (T)(w[i] >> k) : T(0);
+    }
+    const int sh = y + 1 < (int)(8 * sizeof(T)) - 1 ? y + 1 : (int)(8 * sizeof(T)) - 1;
+    return y + ctz_t((T)((bm | (T(1) << (8 * sizeof(T) - 1))) >> sh));
+  };
+
+  bool lock = false;
+  int drop_reward = 0;
+  uint32_t PF = PC;                 // window-spread column masks of the piece as it ends the move
+  int fpiece = s.piece, frot = s.rot;  // ... and its identity (for the uint8 stamp)
+  if (RULESET == TG_RULESET_FUNCTIONAL && __any(hard)) {
+    // functional/core.py:230-251 hard_drop: step-wise, stops at the first blocked row below y
+    const int yd = drop_row_of(PC, s.y);
+    if (hard) {
+      drop_reward = 2 * (yd - s.y);
+      s.y = yd;
+      lock = grav || action == 6;  // blocked below by construction → should_lock iff gravity (tetris_fn.py:247-264)
+    }
+  }
+  const bool moving = stepped && !(RULESET == TG_RULESET_FUNCTIONAL && hard);
+  if (RULESET == TG_RULESET_NUMPY && !stepped) final_coll = cC;  // projection rule for an untouched env
+  const bool accept = moving && (swap_eff || (check && !cT));
+  if (accept) { s.piece = tp; s.rot = tr; s.x = tx; s.y = ty; s.val = tv; PF = PT; fpiece = tp; frot = tr; }
+  const bool coll_here = accept ? cT : cC;
+  const bool coll_below = accept ? cT1 : cC1;
+  if (RULESET == TG_RULESET_FUNCTIONAL && accept && (e & 4u)) drop_reward = 1;  // soft drop (tetris_fn.py:183-190)
+  if (moving) {
+    if (RULESET == TG_RULESET_NUMPY) {
+      final_coll = coll_here;
+      lock = hard;
+      if (grav && !hard) {  // envs/tetris.py:259-264
+        if (!coll_below) { s.y += 1; final_coll = false; }
+        else lock = true;
+      }
+    } else if (grav) {  // functional/core.py:150-182 + tetris_fn.py:242-247
+      if (!coll_below) s.y += 1;
+      else lock = true;
+    }
+  }
+
+  TG_BITS_STAMP(3);
+  // ---- lock path ----
+  bool place = false;
+  uint32_t lock_cells = 0;
+  int lock_x = 0, lock_y = 0, lock_val = 0;
+  bool do_clear = false;
+  if (__any(lock)) {
+    place = lock;
+    if (RULESET == TG_RULESET_NUMPY) {  // envs/tetris.py:450-479 commit_active_tetromino
+      const bool dead = lock && coll_here;  // already colliding: game over, nothing placed (:461-463)
+      if (dead) { s.flags |= TG_F_GAME_OVER; reward = 0.0f; }
+      place = lock && !coll_here;
+      if (__any(place && hard)) {
+        const int yd = drop_row_of(PF, s.y);  // :445-448 (only hard drops can still move)
+        if (place && hard) s.y = yd;
+      }
+    }
+    lock_cells = lane_cells(cell_tab, fpiece, frot);
+    lock_x = s.x; lock_y = s.y;
+    lock_val = RULESET == TG_RULESET_NUMPY ? s.val : s.piece + 2;  // functional/core.py:103-121 adds piece id
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const uint32_t n = (PF >> (4 * i)) & 0xFu;
+      if (place && n != 0 && !oob) colsL[widx[i]] = (T)(w[i] | ((T)n << s.y));
+    }
+    wave_sync();
+    // full rows: AND over the playfield columns (whole-board scan, envs/tetris.py:493-494, functional/core.py:198-201)
+    T v[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) v[c] = colsL[1 + c];
+    T full = PLAY;
+#pragma unroll
+    for (int c = 0; c < W; ++c) full &= v[c];
+    if (!place) full = 0;
+    lines = popc_t(full);
+    do_clear = lines > 0;
+    if (__any(do_clear)) {
+      // compaction of the masks: delete the full rows top-down (rows above move down by one each time);
+      // NUMPY (envs/tetris.py:500-510): vacated top rows are empty; FUNCTIONAL (functional/core.py:203-214): the
+      // gather index -H of a cleared row wraps to row 0 of the pre-compaction board → copies of old row 0
+#pragma unroll
+      for (int c = 0; c < W; ++c) {
+        T x = (T)(v[c] & PLAY);
+        const T top = (RULESET == TG_RULESET_FUNCTIONAL && (x & 1)) ? (T)((T(1) << lines) - 1) : T(0);
+        T f = full;
+        while (f) {
+          const int rr = ctz_t(f);
+          f &= (T)(f - 1);
+          const T lowm = (T)((T(1) << rr) - 1);
+          x = (T)((x & (T)~((lowm << 1) | 1)) | ((x & lowm) << 1));
+        }
+        x |= top;
+        if (do_clear) { v[c] = (T)(x | FLOOR); colsL[1 + c] = v[c]; }
+      }
+    }
+    if (place) s.flags &= ~TG_F_FULLROW;
+    // spawn the next piece
+    if (RULESET == TG_RULESET_NUMPY) {
+      const int np_ = queue_pop(place);  // envs/tetris.py:393-401
+      if (place) {
+        s.piece = np_; s.rot = 0; s.val = np_ + 2; s.x = np_spawn_x<W>(np_); s.y = 0;
+      }
+    } else {  // envs/tetris_fn.py:370-413 place_active_tetromino
+      lane_rng_ensure(r);
+      uint32_t a0, a1, b0, b1;
+      threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);  // split(rng_key)[0]
+      const bool refill = place && s.bidx >= 7;
+      if (__any(refill)) {
+        threefry2x32(r.k0, r.k1, 0u, 1u, b0, b1);  // split(rng_key)[1] (functional/queue.py:59-67)
+        const uint64_t nb = jax_permutation7(b0, b1);
+        if (refill) { s.bag = nb; s.bidx = 0; }
+      }
+      if (place) {
+        s.piece = (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
+        s.bidx += 1;
+        r.k0 = a0; r.k1 = a1;
+        r.dirty = true;
+        s.rot = 0; s.val = s.piece + 2; s.x = (W + 8) / 2 - 2; s.y = 0;
+      }
+    }
+    // collision of the new piece at its spawn position (rows 0..3 of the columns it spans; static columns)
+    bool sc;
+    {
+      constexpr int X0 = (W + 8) / 2 - 2;  // I (and every functional piece) spawns at X0, the others at X0 + 1
+      const uint32_t ms = colmask(s.piece, 0);
+      const bool at0 = s.x == X0;
+      T hs = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const T col = at0 ? v[X0 - 4 + c] : v[X0 - 3 + c];
+        hs |= col & (T)((ms >> (4 * c)) & 0xFu);
+      }
+      sc = hs != 0;
+    }
+    if (RULESET == TG_RULESET_NUMPY) {
+      if (place) {
+        reward = (float)(lines * lines * W + 1);  // score + rewards.alife
+        if (sc) { s.flags |= TG_F_GAME_OVER; reward = 0.0f; }
+        else s.flags &= ~TG_F_GAME_OVER;
+        s.flags &= ~TG_F_HAS_SWAPPED;
+        final_coll = sc;
+      }
+    } else {
+      if (place && sc) s.flags |= TG_F_GAME_OVER;
+    }
+  }
+  if (RULESET == TG_RULESET_FUNCTIONAL && stepped) {
+    const int lock_reward = lock ? (lines == 4 ? 800 : (lines > 0 ? lines * 200 - 100 : 0)) : 0;  // core.py:124-146
+    const float old = s.score;
+    float t = old + (float)drop_reward;
+    t = t + (float)lock_reward;
+    s.score = t;
+    reward = t - old;  // tetris_fn.py:312
+  }
+
+  TG_BITS_STAMP(4);
+  // ---- termination / autoreset ----
+  if (g_illegal) reward = -0.1f;  // rewards.invalid_action
+  const int terminated = (!pending && ((s.flags & TG_F_GAME_OVER) || (g_illegal && p.grouped_term))) ? 1 : 0;
+  const bool do_reset = live && (pending || (terminated && p.autoreset == TG_AUTORESET_SAME_STEP));
+  if (terminated && p.autoreset == TG_AUTORESET_NEXT_STEP && !pending) s.flags |= TG_F_PENDING_RESET;
+  if (__any(do_reset)) {
+    if (do_reset) {
+#pragma unroll
+      for (int c = 0; c < W; ++c) colsL[1 + c] = FLOOR;
+    }
+    if (RULESET == TG_RULESET_NUMPY) {  // envs/tetris.py:274-307, tetromino_queue.py:23-33, tetromino_randomizer.py:87-91
+      consume_perm(do_reset, true);
+      if (do_reset) s.queue = 0;
+      for (int i = 0; i < Q; ++i) {
+        const int t = randomizer_next(do_reset);
+        if (do_reset) s.queue |= (uint64_t)t << (8 * i);
+      }
+      const int first = queue_pop(do_reset);
+      if (do_reset) { s.piece = first; s.x = np_spawn_x<W>(first); }
+    } else {  // envs/tetris_fn.py:318-367
+      lane_rng_ensure(r);
+      uint32_t a0, a1, b0, b1;
+      threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);
+      threefry2x32(r.k0, r.k1, 0u, 1u, b0, b1);
+      const uint64_t nb = jax_permutation7(a0, a1);
+      if (do_reset) {
+        s.bag = nb; s.queue = 0; s.piece = (int)(nb & 0xFF); s.bidx = 1;
+        r.k0 = b0; r.k1 = b1;
+        r.dirty = true;
+        s.x = (W + 8) / 2 - 2;
+      }
+    }
+    if (do_reset) {
+      s.rot = 0; s.y = 0; s.val = s.piece + 2;
+      s.hp = TG_NONE; s.hr = 0; s.hv = 0;
+      s.flags = 0;
+      s.score = 0.0f;
+      final_coll = false;
+    }
+  }
+  const bool cols_dirty = live && (place || do_reset);
+  TG_BITS_STAMP(5);
+
+  // ---- C: the uint8 payload: stage the slab block, apply lock / clear / reset, write back, observation ----
+  const bool any_dirty = __any(cols_dirty);
+  __builtin_amdgcn_sched_barrier(0);
+  if (need_slab || any_dirty) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const uint32_t c = (uint32_t)lane + 64u * k;
+      if (c < nchunks) lds4[c] = stage[k];
+    }
+    wave_sync();
+    __builtin_amdgcn_sched_barrier(0);
+    // the slabs have landed: now fetch the generators of the lanes whose permutation was consumed (used in E)
+    if (RULESET == TG_RULESET_NUMPY) rng_ensure(live && !sig_ok);
+    LaneBoard<W, H, 1> bd;
+    bd.my = lds + slot * S;
+    bd.sub = 0;
+    if (any_dirty) {
+      bd.stamp(lock_cells, lock_x, lock_y, (uint32_t)lock_val, RULESET == TG_RULESET_FUNCTIONAL, live && place);
+      wave_sync();
+      uint64_t todo = __ballot(live && do_clear);
+      while (todo) {  // cooperative row compaction of the uint8 slab, one env at a time (rare)
+        const int l = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        (void)clear_rows<W, H, RULESET>(lds + l * S, lane);
+      }
+      todo = __ballot(do_reset);
+      while (todo) {  // cooperative zero of a reset env's slab
+        const int l = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        uint32_t* sw = reinterpret_cast<uint32_t*>(lds + l * S);
+        for (int i = lane; i < S / 4; i += 64) sw[i] = 0u;
+      }
+      wave_sync();
+      const uint64_t dirty = __ballot(cols_dirty);
+      u32x4* gdst = reinterpret_cast<u32x4*>(p.board + (size_t)base_env * S);
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {  // chunk c covers bytes [16c, 16c+16): at most two envs
+        const uint32_t c = (uint32_t)lane + 64u * k;
+        const uint32_t e0 = (c * 16u) / (uint32_t)S, e1 = (c * 16u + 15u) / (uint32_t)S;
+        if (c < nchunks && (((dirty >> (e0 & 63u)) | (dirty >> (e1 < (uint32_t)EPW ? e1 : (uint32_t)EPW - 1u))) & 1ULL))
+          TG_ST_STATE(&gdst[c], lds4[c]);
+      }
+    }
+    TG_BITS_STAMP(6);
+    if (need_slab) {
+      const bool show = live && (RULESET == TG_RULESET_NUMPY ? !final_coll : !(s.flags & TG_F_GAME_OVER));
+      bd.stamp(lane_cells(cell_tab, s.piece, s.rot), s.x, s.y, p.obs_mode == TG_OBS_FN ? 0xFFu : (uint32_t)s.val, false,
+               show);
+      wave_sync();
+      u32x4* odst = reinterpret_cast<u32x4*>(p.obs + (size_t)base_env * S);
+      const bool fn = p.obs_mode == TG_OBS_FN;
+      auto bin1 = [](uint32_t x) -> uint32_t {  // bytes: 0xFF (active) stays -1, other non-zero → 1  (tetris_fn.py:137-158)
+        const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+        const uint32_t ff = ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u;
+        return (nz >> 7) | ((ff >> 7) * 0xFFu);
+      };
+      if (full_wave) {
+        u32x4 o[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const int c = lane + 64 * k;
+          o[k] = lds4[c < NCH ? c : NCH - 1];
+        }
+        if (fn) {
+#pragma unroll
+          for (int k = 0; k < NIT; ++k) o[k] = u32x4{bin1(o[k].x), bin1(o[k].y), bin1(o[k].z), bin1(o[k].w)};
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const int c = lane + 64 * k;
+          if (c < NCH) st_stream(&odst[c], o[k]);
+        }
+      } else {
+        for (uint32_t c = lane; c < nchunks; c += 64) {
+          u32x4 vv = lds4[c];
+          if (fn) vv = u32x4{bin1(vv.x), bin1(vv.y), bin1(vv.z), bin1(vv.w)};
+          if (c * 16u + 16u <= nbytes) {
+            odst[c] = vv;
+          } else {  // ragged tail of a partial wave
+            const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
+            for (uint32_t i = 0; c * 16u + i < nbytes; ++i)
+              p.obs[(size_t)base_env * S + c * 16u + i] = (uint8_t)(w4[i >> 2] >> (8 * (i & 3)));
+          }
+        }
+      }
+    }
+  }
+
+  TG_BITS_STAMP(7);
+  // ---- D: per-env stores: outputs, first record half, column masks ----
+  uint4 oa, ob;
+  lane_pack(s, oa, ob);
+  uint4* rec_out = reinterpret_cast<uint4*>(p.rec) + (size_t)env * 2;
+  if (live) {
+    TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out), (u32x4{oa.x, oa.y, oa.z, oa.w}));
+    st_stream(reinterpret_cast<u32x2*>(p.out + env), u32x2{__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8)});
+    if (p.episode) {
+      tg_episode_rec ep = p.episode[env];
+      if (pending) {  // the NEXT_STEP reset step belongs to no episode (gymnasium RecordEpisodeStatistics)
+        ep.ret = 0.0f; ep.len = 0;
+      } else {
+        ep.ret += reward;
+        ep.len += 1;
+        if (terminated) { ep.last_ret = ep.ret; ep.last_len = ep.len; ep.ret = 0.0f; ep.len = 0; }
+      }
+      p.episode[env] = ep;
+    }
+  }
+  if (__any(cols_dirty)) {
+    T nv[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) nv[c] = (T)(colsL[1 + c] & PLAY);
+    if (cols_dirty) {
+      uint2* gc = reinterpret_cast<uint2*>(reinterpret_cast<T*>(bp.cols) + (size_t)env * W);
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int k = 0; k < W / 2; ++k) gc[k] = make_uint2((uint32_t)nv[2 * k], (uint32_t)nv[2 * k + 1]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < W; ++c) gc[c] = make_uint2((uint32_t)nv[c], (uint32_t)((uint64_t)nv[c] >> 32));
+      }
+    }
+  }
+
+  TG_BITS_STAMP(8);
+  // ---- E: generator upkeep, off the critical path (every other store of this wave is already in flight) ----
+  if (RULESET == TG_RULESET_NUMPY) {
+    const bool refresh = live && !sig_ok;
+    if (__any(refresh)) {
+      rng_ensure(refresh);
+      uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
+      if (refresh && consumed) {  // the look-ahead state becomes the generator state the reference would hold
+        rng_out[0] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
+        *reinterpret_cast<uint2*>(rng_out + 2) = make_uint2(g.uinteger, g.has32);
+      }
+      bits_shuffle_perm(g, sig, refresh);
+      if (refresh) {
+        uint4* a4 = bp.ahead + (size_t)env * 2;
+        a4[0] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
+        a4[1] = make_uint4(g.uinteger, g.has32, 0u, 0u);
+        ob.w = sig | kSigValid;
+      }
+    }
+  } else if (live && r.dirty) {
+    uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
+    rng_out[2] = make_uint4(r.uinteger, r.has32, r.k0, r.k1);
+  }
+  TG_BITS_STAMP(9);
+#ifdef TG_PHASE_TIMING
+  if (p.dbg && lane == 0)
+    for (int i = 0; i < 10; ++i) p.dbg[(size_t)blockIdx.x * 16 + i] = tstamp[i];
+#endif
+  if (live && (ob.x != rb.x || ob.y != rb.y || ob.z != rb.z || ob.w != rb.w))
+    TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out + 1), (u32x4{ob.x, ob.y, ob.z, ob.w}));
+}
+
+// ------------------------------------------------------------------------------------------------
+// bits_prepare_kernel: (re)build the acceleration state of the bits kernel from the reference-defined state —
+// column masks from the uint8 board, the look-ahead permutation from the generator.  Runs after tg_reset /
+// tg_set_state (not hot).  One thread per env.
+// ------------------------------------------------------------------------------------------------
+struct PrepareParams {
+  const uint8_t* board;
+  uint32_t* rec;
+  tg_rng_rec* rng;
+  void* cols;
+  uint4* ahead;
+  const uint8_t* mask;  // [B] or null: envs whose generator moved (their permutation is recomputed)
+  int batch;
+  int ruleset;
+  int force;            // recompute every permutation
+};
+
+template <int W, int H>
+__global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p) {
+  using T = ColT<H>;
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= p.batch) return;
+  const uint8_t* b = p.board + (size_t)env * W * H;
+  T* gc = reinterpret_cast<T*>(p.cols) + (size_t)env * W;
+  for (int c = 0; c < W; ++c) {
+    T v = 0;
+    for (int rr = 0; rr < H; ++rr) v |= (T)(b[rr * W + c] != 0 ? 1 : 0) << rr;
+    gc[c] = v;
+  }
+  if (p.ruleset != TG_RULESET_NUMPY) return;
+  uint32_t* rec = p.rec + (size_t)env * 8;
+  const bool moved = p.force || (p.mask ? p.mask[env] != 0 : true);
+  if (!moved && (rec[7] & kSigValid)) return;
+  Rng r;
+  r.loaded = false;
+  r.dirty = false;
+  rng_load(r, p.rng + env);
+  // a record uploaded with bag_index 7 holds a reshuffle the reference has already done (eager, :84)
+  const uint32_t d2 = rec[2];
+  if (((d2 >> 8) & 0xFF) >= 7) {
+    const uint32_t d3 = rec[3], d4 = rec[4];
+    uint64_t bag = (uint64_t)(d2 >> 16) | ((uint64_t)d3 << 16) | ((uint64_t)(d4 & 0xFF) << 48);
+    bag = pcg_shuffle7(r, bag);
+    rec[2] = (d2 & 0x000000FFu) | ((uint32_t)(bag & 0xFFFF) << 16);
+    rec[3] = (uint32_t)(bag >> 16);
+    rec[4] = (d4 & 0xFFFFFF00u) | (uint32_t)((bag >> 48) & 0xFF);
+    rng_store(r, p.rng + env, 0);
+  }
+  const uint64_t perm = pcg_shuffle7(r, 0x06050403020100ULL);
+  uint32_t sig = 0;
+  for (int k = 0; k < 7; ++k) sig |= (uint32_t)((perm >> (8 * k)) & 0xF) << (4 * k);
+  rec[7] = sig | kSigValid;
+  uint4* a4 = p.ahead + (size_t)env * 2;
+  a4[0] = make_uint4((uint32_t)r.s_lo, (uint32_t)(r.s_lo >> 32), (uint32_t)r.s_hi, (uint32_t)(r.s_hi >> 32));
+  a4[1] = make_uint4(r.uinteger, r.has32, 0u, 0u);
+}
+
+}  // namespace tg

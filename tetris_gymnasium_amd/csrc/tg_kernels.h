@@ -47,6 +47,8 @@ struct KParams {
   int grouped_term;  // wrappers/grouped.py:49 terminate_on_illegal_action
   int stagger;       // lane kernels: odd waves start this many x64 cycles late (de-phases load/compute/store bursts)
   unsigned long long* dbg;  // optional phase-timing buffer (TG_PHASE_TIMING builds only)
+  void* cols;               // bits kernel only: column masks [B][W] (tg_kernel_bits.h); null otherwise
+  uint4* ahead;             // bits kernel only: generator state after the look-ahead shuffle [B][2]
 };
 
 struct ResetParams {

@@ -5,11 +5,11 @@ TAG=${1:-run}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 if [[ " $* " != *" notest "* ]]; then
-  for K in block quad lanes wave; do
+  for K in ${TG_KERNELS:-bits block quad lanes wave}; do
     TG_KERNEL=$K timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu_$K.log 2>&1; echo "pytest[$K] rc=$?"; tail -3 $OUT/pytest_gpu_$K.log
   done
 fi
-for K in block quad lanes wave; do
+for K in ${TG_KERNELS:-bits block quad lanes wave}; do
   TG_KERNEL=$K timeout 600 python bench.py --steps 512 --warmup 64 --no-cpu-baseline > $OUT/bench_$K.json 2> $OUT/bench_$K.err; echo "bench[$K] rc=$?"; cut -c1-330 $OUT/bench_$K.json
 done
 if [[ " $* " != *" nopmc "* ]]; then

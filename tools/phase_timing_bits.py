@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Runs ON THE GPU BOX: s_memtime phase stamps of the bits kernel (one wave = 64 envs per workgroup)."""
+import ctypes as C, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+src = os.path.join(ROOT, "tetris_gymnasium_amd", "csrc", "tg_engine.hip")
+out = "/tmp/libtg_phase.so"
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DTG_PHASE_TIMING",
+                       "-DTG_FOR_EACH_SIZE(X)=X(10,20)", *sys.argv[1:], "-shared", "-o", out, src])
+from tetris_gymnasium_amd import _native as N
+N.LIB_PATH = out
+from tetris_gymnasium_amd import Engine
+B = 65536
+e = Engine(B, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP)
+e.reset(np.arange(1, B + 1, dtype=np.uint64))
+acts = np.random.default_rng(0).integers(0, 8, (80, B)).astype(np.int8)
+d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts)
+e.step_k_device(d, 79); e.sync(); e.step_k_device(d + 79 * B, 1); e.sync()
+nb = B // 64
+buf = np.zeros((B // 16, 16), np.uint64)
+e.lib.tg_debug_phase_times.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+assert e.lib.tg_debug_phase_times(e.h, buf.ctypes.data_as(C.c_void_p), B // 16) == 0
+t = buf[:nb, 0:10].astype(np.int64)
+names = ["A loads + cols->LDS", "B0 unpack/swap + window read", "B1 tests/decide", "B2 lock path", "B3 reset path",
+         "C0 stage slab, lock stamp, write-back", "C1 obs stamp + obs stores", "D rec/out/cols stores", "E refresh (PCG)"]
+dd = np.diff(t, axis=1)
+for i, nm in enumerate(names):
+    print(f"  {nm:40s} mean {dd[:, i].mean():8.1f}   p50 {np.median(dd[:, i]):8.1f}   max {dd[:, i].max():8.1f}")
+for x in range(8):  # workgroups are dealt round-robin to the 8 XCDs; each XCD has its own counter
+    tx = t[x::8]
+    print(f"  XCD {x}: first start → last end {tx[:, 9].max() - tx[:, 0].min():8d}   start spread {tx[:, 0].max() - tx[:, 0].min():6d}   end spread {tx[:, 9].max() - tx[:, 9].min():6d}")
+life = t[:, 9] - t[:, 0]
+print("wave lifetime (stamps 0..9): mean", life.mean(), "p50", np.median(life), "max", life.max())
