@@ -55,7 +55,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
   if (p.cols && !p.final_obs) {  // "bits": the handle carries the column masks / look-ahead permutations
     using BG = tg::BitsGeo<W, H>;
     const tg::BitsParams bp{p.cols, p.ahead};
-    hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS>), dim3((p.batch + BG::EPW - 1) / BG::EPW), dim3(64), BG::BYTES, s, p, bp);
+    hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS>), dim3((p.batch + BG::EPW - 1) / BG::EPW), dim3(128), BG::BYTES, s, p, bp);
     return;
   }
   if (g_kernel_lanes == 8 && !p.final_obs) {  // "block": two-phase kernel with workgroup-level slow-path compaction

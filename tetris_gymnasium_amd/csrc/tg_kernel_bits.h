@@ -74,8 +74,9 @@ struct BitsGeo {
   static constexpr int SLABS = ((EPW * S + 15) / 16) * 16;
   static constexpr int NCH = SLABS / 16;
   static constexpr int NIT = (NCH + 63) / 64;
-  static constexpr int OFF_TAB = SLABS;             // cell table (7 x 8 B), column table (7 x 8 B)
-  static constexpr int OFF_COLS = OFF_TAB + 128;    // T [EPW][CST]: [0] bedrock, [1..W] playfield columns, [W+1] bedrock
+  static constexpr int OFF_TAB = SLABS;             // cell table, column table, cell table (logic wave's copy): 3 x 64 B
+  static constexpr int OFF_POST = OFF_TAB + 192;    // uint4 [EPW]: what the stream wave has to do per env
+  static constexpr int OFF_COLS = OFF_POST + EPW * 16;  // T [EPW][CST]: [0] bedrock, [1..W] playfield columns, [W+1] bedrock
   static constexpr int CST = (W + 2) | 1;           // odd stride: conflict-free for same-index accesses of the 64 lanes
   static constexpr int BYTES = OFF_COLS + EPW * CST * (int)sizeof(T);
   static_assert(W % 2 == 0, "column masks are moved as 8-byte pairs");
@@ -173,7 +174,7 @@ __device__ __forceinline__ void st_stream(V* dst, const V v) {
 #endif
 
 template <int W, int H, int RULESET>
-__global__ __launch_bounds__(64, 1) void step_kernel_bits(const KParams p, const BitsParams bp) {
+__global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, const BitsParams bp) {
   using BG = BitsGeo<W, H>;
   using T = ColT<H>;
   constexpr int S = BG::S, EPW = BG::EPW, NCH = BG::NCH, NIT = BG::NIT, CST = BG::CST;
@@ -184,7 +185,9 @@ __global__ __launch_bounds__(64, 1) void step_kernel_bits(const KParams p, const
   u32x4* lds4 = reinterpret_cast<u32x4*>(lds);
   uint64_t* cell_tab = reinterpret_cast<uint64_t*>(lds + BG::OFF_TAB);
   uint64_t* col_tab = cell_tab + 8;
-  const int lane = threadIdx.x;
+  uint4* post = reinterpret_cast<uint4*>(lds + BG::OFF_POST);
+  const int lane = threadIdx.x & 63;
+  const int wave = rfl((int)(threadIdx.x >> 6));
 
   const uint32_t B = (uint32_t)p.batch;
   const uint32_t base_env = blockIdx.x * (uint32_t)EPW;
@@ -192,21 +195,151 @@ __global__ __launch_bounds__(64, 1) void step_kernel_bits(const KParams p, const
   const bool live = (uint32_t)lane < nlive;
   const int slot = live ? lane : (int)nlive - 1;  // dead lanes shadow the last live env (identical, benign LDS writes)
   const uint32_t env = base_env + (uint32_t)slot;
-  T* colsL = reinterpret_cast<T*>(lds + BG::OFF_COLS) + slot * CST;
-  const bool full_wave = nlive == (uint32_t)EPW;
-  const uint32_t nbytes = nlive * (uint32_t)S;
-  const uint32_t nchunks = (nbytes + 15u) / 16u;
+  const bool need_slab = p.obs_mode == TG_OBS_BOARD || p.obs_mode == TG_OBS_FN;
 
 #ifdef TG_PHASE_TIMING
-  unsigned long long tstamp[10];  // kept in SGPRs and written at the very end: a store per stamp would itself be waited on
+  unsigned long long tstamp[8];  // kept in SGPRs and written at the very end: a store per stamp would itself be waited on
 #define TG_BITS_STAMP(i) tstamp[i] = __builtin_amdgcn_s_memtime()
 #else
 #define TG_BITS_STAMP(i) do {} while (0)
 #endif
   TG_BITS_STAMP(0);
-  // ---- A: all loads in flight: tables, record, action, column masks (small, needed first), then the slab block.
-  // vmcnt counts in issue order: the logic may only wait for the small loads if they are issued FIRST and nothing else
-  // is loaded before the slabs are consumed (sched_barrier keeps the compiler from interleaving the two groups) ----
+
+  if (wave == 1) {
+    // =====================================================================================================
+    // STREAM WAVE: the uint8 payload.  Slab block HBM → LDS while the logic wave decides; afterwards the locked
+    // cells / cleared rows / resets are applied, changed slabs go back to the board, and the observation leaves.
+    // =====================================================================================================
+    const bool full_wave = nlive == (uint32_t)EPW;
+    const uint32_t nbytes = nlive * (uint32_t)S;
+    const uint32_t nchunks = (nbytes + 15u) / 16u;
+    uint64_t tab_cells = 0;
+    if (lane < 7) tab_cells = c_cells.cells[lane];
+    u32x4 stage[NIT];
+    {
+      const u32x4* gsrc = reinterpret_cast<const u32x4*>(p.board + (size_t)base_env * S);
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const uint32_t c = (uint32_t)lane + 64u * k;
+        stage[k] = gsrc[c < nchunks ? c : nchunks - 1u];
+      }
+    }
+    if (lane < 7) cell_tab[lane] = tab_cells;
+    if (full_wave) {
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int c = lane + 64 * k;
+        if (c < NCH) lds4[c] = stage[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const uint32_t c = (uint32_t)lane + 64u * k;
+        if (c < nchunks) lds4[c] = stage[k];
+      }
+    }
+    TG_BITS_STAMP(1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();  // the logic wave has published what happened to every env
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    TG_BITS_STAMP(2);
+    // post record of this lane's env: x = lock {cells | val << 16 | place << 24 | clear << 25 | reset << 26},
+    // y = lock {x | y << 8}, z = observation {cells | val << 16 | show << 24}, w = observation {x | y << 8}
+    const uint4 po = post[slot];
+    const bool place = live && ((po.x >> 24) & 1u), do_clear = live && ((po.x >> 25) & 1u), do_reset = live && ((po.x >> 26) & 1u);
+    const bool dirty = place || do_reset;
+    LaneBoard<W, H, 1> bd;
+    bd.my = lds + slot * S;
+    bd.sub = 0;
+    if (__any(dirty)) {
+      bd.stamp(po.x & 0xFFFFu, (int)(po.y & 0xFFu), (int)((po.y >> 8) & 0xFFu), (po.x >> 16) & 0xFFu,
+               RULESET == TG_RULESET_FUNCTIONAL, place);
+      wave_sync();
+      uint64_t todo = __ballot(do_clear);
+      while (todo) {  // cooperative row compaction of the uint8 slab, one env at a time (rare)
+        const int l = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        (void)clear_rows<W, H, RULESET>(lds + l * S, lane);
+      }
+      todo = __ballot(do_reset);
+      while (todo) {  // cooperative zero of a reset env's slab
+        const int l = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        uint32_t* sw = reinterpret_cast<uint32_t*>(lds + l * S);
+        for (int i = lane; i < S / 4; i += 64) sw[i] = 0u;
+      }
+      wave_sync();
+      // board write-back: every changed env's lane copies its own slab (8-byte aligned in LDS and in HBM)
+      if (dirty) {
+        const u32x2* src = reinterpret_cast<const u32x2*>(bd.my);
+        u32x2* dst = reinterpret_cast<u32x2*>(p.board + (size_t)env * S);
+        constexpr int NU = S / 8, UB = NU <= 32 ? NU : 20;  // batches: all reads of a batch in flight before its stores
+        static_assert(S % 8 == 0, "slabs are copied in 8-byte units");
+#pragma unroll 1
+        for (int u0 = 0; u0 < NU; u0 += UB) {
+          u32x2 t2[UB];
+#pragma unroll
+          for (int u = 0; u < UB; ++u) t2[u] = src[u0 + u < NU ? u0 + u : NU - 1];
+#pragma unroll
+          for (int u = 0; u < UB; ++u)
+            if (u0 + u < NU) dst[u0 + u] = t2[u];
+        }
+      }
+    }
+    TG_BITS_STAMP(3);
+    if (need_slab) {
+      bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu),
+               p.obs_mode == TG_OBS_FN ? 0xFFu : ((po.z >> 16) & 0xFFu), false, live && ((po.z >> 24) & 1u));
+      wave_sync();
+      u32x4* odst = reinterpret_cast<u32x4*>(p.obs + (size_t)base_env * S);
+      const bool fn = p.obs_mode == TG_OBS_FN;
+      auto bin1 = [](uint32_t x) -> uint32_t {  // bytes: 0xFF (active) stays -1, other non-zero → 1  (tetris_fn.py:137-158)
+        const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+        const uint32_t ff = ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u;
+        return (nz >> 7) | ((ff >> 7) * 0xFFu);
+      };
+      if (full_wave) {
+        u32x4 o[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const int c = lane + 64 * k;
+          o[k] = lds4[c < NCH ? c : NCH - 1];
+        }
+        if (fn) {
+#pragma unroll
+          for (int k = 0; k < NIT; ++k) o[k] = u32x4{bin1(o[k].x), bin1(o[k].y), bin1(o[k].z), bin1(o[k].w)};
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const int c = lane + 64 * k;
+          if (c < NCH) st_stream(&odst[c], o[k]);
+        }
+      } else {
+        for (uint32_t c = lane; c < nchunks; c += 64) {
+          u32x4 vv = lds4[c];
+          if (fn) vv = u32x4{bin1(vv.x), bin1(vv.y), bin1(vv.z), bin1(vv.w)};
+          if (c * 16u + 16u <= nbytes) {
+            odst[c] = vv;
+          } else {  // ragged tail of a partial wave
+            const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
+            for (uint32_t i = 0; c * 16u + i < nbytes; ++i)
+              p.obs[(size_t)base_env * S + c * 16u + i] = (uint8_t)(w4[i >> 2] >> (8 * (i & 3)));
+          }
+        }
+      }
+    }
+    TG_BITS_STAMP(4);
+#ifdef TG_PHASE_TIMING
+    if (p.dbg && lane == 0)
+      for (int i = 0; i < 5; ++i) p.dbg[(size_t)blockIdx.x * 16 + 8 + i] = tstamp[i];
+#endif
+    return;
+  }
+
+  // =======================================================================================================
+  // LOGIC WAVE: one env per lane on column bitmasks
+  // =======================================================================================================
+  T* colsL = reinterpret_cast<T*>(lds + BG::OFF_COLS) + slot * CST;
   uint64_t tab_cells = 0, tab_cols = 0;
   if (lane < 7) { tab_cells = c_cells.cells[lane]; tab_cols = c_colmasks.cols[lane]; }
   const uint4* rec4 = reinterpret_cast<const uint4*>(p.rec) + (size_t)env * 2;
@@ -226,19 +359,9 @@ __global__ __launch_bounds__(64, 1) void step_kernel_bits(const KParams p, const
       else cv[c] = (T)raw[c].x | ((T)raw[c].y << 32);
     }
   }
-  __builtin_amdgcn_sched_barrier(0);
-  const bool need_slab = p.obs_mode == TG_OBS_BOARD || p.obs_mode == TG_OBS_FN;
-  u32x4 stage[NIT];
-  {
-    const u32x4* gsrc = reinterpret_cast<const u32x4*>(p.board + (size_t)base_env * S);
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const uint32_t c = (uint32_t)lane + 64u * k;
-      stage[k] = gsrc[c < nchunks ? c : nchunks - 1u];
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  if (lane < 7) { cell_tab[lane] = tab_cells; col_tab[lane] = tab_cols; }
+  // private copies of the two piece tables for this wave (the stream wave fills cell_tab for itself after its loads)
+  uint64_t* cell_tab_l = col_tab + 8;
+  if (lane < 7) { cell_tab_l[lane] = tab_cells; col_tab[lane] = tab_cols; }
   colsL[0] = ONES;
   colsL[W + 1] = ONES;
 #pragma unroll
@@ -465,7 +588,7 @@ __global__ __launch_bounds__(64, 1) void step_kernel_bits(const KParams p, const
         if (place && hard) s.y = yd;
       }
     }
-    lock_cells = lane_cells(cell_tab, fpiece, frot);
+    lock_cells = lane_cells(cell_tab_l, fpiece, frot);
     lock_x = s.x; lock_y = s.y;
     lock_val = RULESET == TG_RULESET_NUMPY ? s.val : s.piece + 2;  // functional/core.py:103-121 adds piece id
 #pragma unroll
@@ -605,97 +728,21 @@ __global__ __launch_bounds__(64, 1) void step_kernel_bits(const KParams p, const
     }
   }
   const bool cols_dirty = live && (place || do_reset);
-  TG_BITS_STAMP(5);
-
-  // ---- C: the uint8 payload: stage the slab block, apply lock / clear / reset, write back, observation ----
-  const bool any_dirty = __any(cols_dirty);
-  __builtin_amdgcn_sched_barrier(0);
-  if (need_slab || any_dirty) {
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const uint32_t c = (uint32_t)lane + 64u * k;
-      if (c < nchunks) lds4[c] = stage[k];
-    }
-    wave_sync();
-    __builtin_amdgcn_sched_barrier(0);
-    // the slabs have landed: now fetch the generators of the lanes whose permutation was consumed (used in E)
-    if (RULESET == TG_RULESET_NUMPY) rng_ensure(live && !sig_ok);
-    LaneBoard<W, H, 1> bd;
-    bd.my = lds + slot * S;
-    bd.sub = 0;
-    if (any_dirty) {
-      bd.stamp(lock_cells, lock_x, lock_y, (uint32_t)lock_val, RULESET == TG_RULESET_FUNCTIONAL, live && place);
-      wave_sync();
-      uint64_t todo = __ballot(live && do_clear);
-      while (todo) {  // cooperative row compaction of the uint8 slab, one env at a time (rare)
-        const int l = (int)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        (void)clear_rows<W, H, RULESET>(lds + l * S, lane);
-      }
-      todo = __ballot(do_reset);
-      while (todo) {  // cooperative zero of a reset env's slab
-        const int l = (int)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        uint32_t* sw = reinterpret_cast<uint32_t*>(lds + l * S);
-        for (int i = lane; i < S / 4; i += 64) sw[i] = 0u;
-      }
-      wave_sync();
-      const uint64_t dirty = __ballot(cols_dirty);
-      u32x4* gdst = reinterpret_cast<u32x4*>(p.board + (size_t)base_env * S);
-#pragma unroll
-      for (int k = 0; k < NIT; ++k) {  // chunk c covers bytes [16c, 16c+16): at most two envs
-        const uint32_t c = (uint32_t)lane + 64u * k;
-        const uint32_t e0 = (c * 16u) / (uint32_t)S, e1 = (c * 16u + 15u) / (uint32_t)S;
-        if (c < nchunks && (((dirty >> (e0 & 63u)) | (dirty >> (e1 < (uint32_t)EPW ? e1 : (uint32_t)EPW - 1u))) & 1ULL))
-          TG_ST_STATE(&gdst[c], lds4[c]);
-      }
-    }
-    TG_BITS_STAMP(6);
-    if (need_slab) {
-      const bool show = live && (RULESET == TG_RULESET_NUMPY ? !final_coll : !(s.flags & TG_F_GAME_OVER));
-      bd.stamp(lane_cells(cell_tab, s.piece, s.rot), s.x, s.y, p.obs_mode == TG_OBS_FN ? 0xFFu : (uint32_t)s.val, false,
-               show);
-      wave_sync();
-      u32x4* odst = reinterpret_cast<u32x4*>(p.obs + (size_t)base_env * S);
-      const bool fn = p.obs_mode == TG_OBS_FN;
-      auto bin1 = [](uint32_t x) -> uint32_t {  // bytes: 0xFF (active) stays -1, other non-zero → 1  (tetris_fn.py:137-158)
-        const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
-        const uint32_t ff = ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u;
-        return (nz >> 7) | ((ff >> 7) * 0xFFu);
-      };
-      if (full_wave) {
-        u32x4 o[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-          const int c = lane + 64 * k;
-          o[k] = lds4[c < NCH ? c : NCH - 1];
-        }
-        if (fn) {
-#pragma unroll
-          for (int k = 0; k < NIT; ++k) o[k] = u32x4{bin1(o[k].x), bin1(o[k].y), bin1(o[k].z), bin1(o[k].w)};
-        }
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-          const int c = lane + 64 * k;
-          if (c < NCH) st_stream(&odst[c], o[k]);
-        }
-      } else {
-        for (uint32_t c = lane; c < nchunks; c += 64) {
-          u32x4 vv = lds4[c];
-          if (fn) vv = u32x4{bin1(vv.x), bin1(vv.y), bin1(vv.z), bin1(vv.w)};
-          if (c * 16u + 16u <= nbytes) {
-            odst[c] = vv;
-          } else {  // ragged tail of a partial wave
-            const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
-            for (uint32_t i = 0; c * 16u + i < nbytes; ++i)
-              p.obs[(size_t)base_env * S + c * 16u + i] = (uint8_t)(w4[i >> 2] >> (8 * (i & 3)));
-          }
-        }
-      }
-    }
+  // publish the payload work of this lane's env to the stream wave
+  {
+    const bool show = live && (RULESET == TG_RULESET_NUMPY ? !final_coll : !(s.flags & TG_F_GAME_OVER));
+    const uint32_t ocells = lane_cells(cell_tab_l, s.piece, s.rot);
+    if (live) post[slot] = make_uint4(lock_cells | ((uint32_t)(lock_val & 0xFF) << 16) | ((place ? 1u : 0u) << 24) |
+                                ((do_clear ? 1u : 0u) << 25) | ((do_reset ? 1u : 0u) << 26),
+                            (uint32_t)(lock_x & 0xFF) | ((uint32_t)(lock_y & 0xFF) << 8),
+                            ocells | ((uint32_t)(s.val & 0xFF) << 16) | ((show ? 1u : 0u) << 24),
+                            (uint32_t)(s.x & 0xFF) | ((uint32_t)(s.y & 0xFF) << 8));
   }
+  TG_BITS_STAMP(5);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  if (RULESET == TG_RULESET_NUMPY) rng_ensure(live && !sig_ok);  // generators of the lanes whose permutation was consumed (used in E)
 
-  TG_BITS_STAMP(7);
   // ---- D: per-env stores: outputs, first record half, column masks ----
   uint4 oa, ob;
   lane_pack(s, oa, ob);
@@ -731,7 +778,7 @@ __global__ __launch_bounds__(64, 1) void step_kernel_bits(const KParams p, const
     }
   }
 
-  TG_BITS_STAMP(8);
+  TG_BITS_STAMP(6);
   // ---- E: generator upkeep, off the critical path (every other store of this wave is already in flight) ----
   if (RULESET == TG_RULESET_NUMPY) {
     const bool refresh = live && !sig_ok;
@@ -754,10 +801,10 @@ __global__ __launch_bounds__(64, 1) void step_kernel_bits(const KParams p, const
     uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
     rng_out[2] = make_uint4(r.uinteger, r.has32, r.k0, r.k1);
   }
-  TG_BITS_STAMP(9);
+  TG_BITS_STAMP(7);
 #ifdef TG_PHASE_TIMING
   if (p.dbg && lane == 0)
-    for (int i = 0; i < 10; ++i) p.dbg[(size_t)blockIdx.x * 16 + i] = tstamp[i];
+    for (int i = 0; i < 8; ++i) p.dbg[(size_t)blockIdx.x * 16 + i] = tstamp[i];
 #endif
   if (live && (ob.x != rb.x || ob.y != rb.y || ob.z != rb.z || ob.w != rb.w))
     TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out + 1), (u32x4{ob.x, ob.y, ob.z, ob.w}));

@@ -21,14 +21,17 @@ nb = B // 64
 buf = np.zeros((B // 16, 16), np.uint64)
 e.lib.tg_debug_phase_times.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 assert e.lib.tg_debug_phase_times(e.h, buf.ctypes.data_as(C.c_void_p), B // 16) == 0
-t = buf[:nb, 0:10].astype(np.int64)
-names = ["A loads + cols->LDS", "B0 unpack/swap + window read", "B1 tests/decide", "B2 lock path", "B3 reset path",
-         "C0 stage slab, lock stamp, write-back", "C1 obs stamp + obs stores", "D rec/out/cols stores", "E refresh (PCG)"]
-dd = np.diff(t, axis=1)
-for i, nm in enumerate(names):
-    print(f"  {nm:40s} mean {dd[:, i].mean():8.1f}   p50 {np.median(dd[:, i]):8.1f}   max {dd[:, i].max():8.1f}")
-for x in range(8):  # workgroups are dealt round-robin to the 8 XCDs; each XCD has its own counter
-    tx = t[x::8]
-    print(f"  XCD {x}: first start → last end {tx[:, 9].max() - tx[:, 0].min():8d}   start spread {tx[:, 0].max() - tx[:, 0].min():6d}   end spread {tx[:, 9].max() - tx[:, 9].min():6d}")
-life = t[:, 9] - t[:, 0]
-print("wave lifetime (stamps 0..9): mean", life.mean(), "p50", np.median(life), "max", life.max())
+tl = buf[:nb, 0:8].astype(np.int64)    # logic wave
+ts = buf[:nb, 8:13].astype(np.int64)   # stream wave
+def show(t, names):
+    dd = np.diff(t, axis=1)
+    for i, nm in enumerate(names):
+        print(f"  {nm:44s} mean {dd[:, i].mean():8.1f}   p50 {np.median(dd[:, i]):8.1f}   max {dd[:, i].max():8.1f}")
+print("logic wave:")
+show(tl, ["A small loads + cols->LDS", "B0 unpack/swap + window read", "B1 tests/decide", "B2 lock path",
+          "B3 reset path + publish", "barrier + D rec/out/cols stores", "E refresh (PCG)"])
+print("stream wave:")
+show(ts, ["slab loads -> LDS", "wait for logic (barrier)", "lock stamp / clear / reset / write-back", "obs stamp + obs stores"])
+ll, ls = tl[:, 7] - tl[:, 0], ts[:, 4] - ts[:, 0]
+print("logic wave lifetime: mean", ll.mean(), "p50", np.median(ll), "max", ll.max())
+print("stream wave lifetime: mean", ls.mean(), "p50", np.median(ls), "max", ls.max())
