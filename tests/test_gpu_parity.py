@@ -254,3 +254,50 @@ def test_full_size_determinism_and_invariants():
     for t in range(T):
         o.step(acts[t][idx], autoreset=po.AUTORESET_SAME_STEP)
     np.testing.assert_array_equal(o.get_state()[0], board[idx])
+
+
+@pytest.mark.parametrize("ruleset,B", [(N.RULESET_NUMPY, 20000), (N.RULESET_NUMPY, 33000), (N.RULESET_FUNCTIONAL, 20000)])
+def test_sharded_streams_engine_vs_oracle(ruleset, B, monkeypatch):
+    """Batches large enough for the engine to spread a transition over several streams (contiguous env shards, one
+    launch each, ragged last shard) must give exactly the single-launch result: host actions, device int8 action
+    rows through tg_step_k, masked resets in between, state and generator compared at the end."""
+    monkeypatch.setenv("TG_STREAMS", "4")  # read by tg_create (off by default: see DESIGN.md)
+    W, H, T = 10, 20, 60
+    numpy_rules = ruleset == N.RULESET_NUMPY
+    obs = N.OBS_BOARD if numpy_rules else N.OBS_FN
+    po_obs = po.OBS_BOARD if numpy_rules else po.OBS_FN
+    na = 8 if numpy_rules else 7
+    e = Engine(B, W, H, ruleset=ruleset, obs_mode=obs, autoreset=N.AUTORESET_NONE, episode_stats=True)
+    o = po.OracleBatch(B, W, H, ruleset)
+    seeds = np.arange(5, 5 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(B)
+    for t in range(T):
+        a = rng.integers(0, na, B)
+        re_, te, le = e.step(a)
+        ro, to, lo = o.step(a, autoreset=po.AUTORESET_NONE)
+        np.testing.assert_array_equal(re_, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(te, to, err_msg=f"terminated t={t}")
+        np.testing.assert_array_equal(le, lo, err_msg=f"lines t={t}")
+        if t % 10 == 0:
+            np.testing.assert_array_equal(e.observation(), o.observe(po_obs), err_msg=f"obs t={t}")
+        if te.any():
+            e.reset(mask=te); o.reset(mask=te)
+    # device-resident int8 action rows (the bench path): K launches per shard without host round trips
+    K = 24
+    acts = rng.integers(0, na, (K, B)).astype(np.int8)
+    # (no env may terminate un-reset in a rollout without autoreset: NUMPY rules keep stepping a dead env, as the oracle)
+    d = e.dev_alloc(acts.nbytes)
+    e.dev_upload(d, acts)
+    e.step_k_device(d, K)
+    for k in range(K):
+        ro, to, lo = o.step(acts[k].astype(np.int32), autoreset=po.AUTORESET_NONE)
+    np.testing.assert_array_equal(e.observation(), o.observe(po_obs))
+    got = e.fetch_outputs()
+    np.testing.assert_array_equal(got[0], ro); np.testing.assert_array_equal(got[1], to); np.testing.assert_array_equal(got[2], lo)
+    ge, go = _cmp_state(e, o, "end")
+    if numpy_rules:
+        for k in ("state_lo", "state_hi", "inc_lo", "inc_hi", "uinteger", "has_uint32"):
+            np.testing.assert_array_equal(ge[k], go[k], err_msg=f"rng.{k}")
+    e.dev_free(d)
+    e.close()

@@ -54,8 +54,9 @@ template <int W, int H, int RS>
 void launch_step(const tg::KParams& p, hipStream_t s) {
   if (p.cols && !p.final_obs) {  // "bits": the handle carries the column masks / look-ahead permutations
     using BG = tg::BitsGeo<W, H>;
-    const tg::BitsParams bp{p.cols, p.ahead};
-    hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS>), dim3((p.batch + BG::EPW - 1) / BG::EPW), dim3(128), BG::BYTES, s, p, bp);
+    const int nrb = RS == TG_RULESET_NUMPY ? (p.batch + 127) / 128 : 0;  // leading RNG workgroups (tg_kernel_bits.h)
+    const tg::BitsParams bp{p.cols, p.ahead, p.ring, p.hbuf, p.ring_cur, nrb, p.ring_stride};
+    hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS>), dim3(nrb + (p.batch + BG::EPW - 1) / BG::EPW), dim3(128), BG::BYTES, s, p, bp);
     return;
   }
   if (g_kernel_lanes == 8 && !p.final_obs) {  // "block": two-phase kernel with workgroup-level slow-path compaction
@@ -147,7 +148,21 @@ struct tg_handle {
   uint8_t* d_mask = nullptr;
   void* dbg = nullptr;  // phase-timing buffer (TG_PHASE_TIMING builds)
   void* d_cols = nullptr;   // bits kernel: column masks [B][W] (device-private acceleration state)
-  uint4* d_ahead = nullptr; // bits kernel: generator state after the look-ahead shuffle [B][2]
+  uint4* d_ahead = nullptr; // bits kernel: generator states after the ring's shuffles [B][2 slots][2]
+  uint64_t* d_ring = nullptr;  // bits kernel: permutation rings, double-buffered by launch parity [2][B]
+  uint8_t* d_hbuf = nullptr;   // bits kernel: consumed counters [2][B]
+  int ring_cur = 0;            // parity the next step launch reads
+  // TG_STREAMS=n (default 1) spreads the step launches of one transition over n streams (contiguous env shards).
+  // Kept as a tested knob, off by default — measured on MI355X: every launch costs ≈2.8-3.4 µs of
+  // command-processor time whichever stream it is on, so n shards cost n launch floors per transition (8.3 µs →
+  // 9.3 µs at n = 2, 13.8 µs at n = 4, also when the launches are replayed from a HIP graph).
+  // Every other operation joins the shards into `stream` first.
+  int n_shards = 1;
+  std::vector<hipStream_t> sh_stream;
+  std::vector<hipEvent_t> sh_event;
+  std::vector<int> sh_off, sh_cnt;
+  hipEvent_t fork_ev = nullptr;
+  bool forked = false;
   std::vector<uint8_t> rng_valid;
   std::vector<tg_rng_rec> h_new_rng;
   std::vector<uint8_t> h_reseed;
@@ -272,6 +287,11 @@ tg::KParams step_params(tg_handle* h) {
   p.dbg = (unsigned long long*)h->dbg;
   p.cols = h->d_cols;
   p.ahead = h->d_ahead;
+  p.ring = h->d_ring;
+  p.hbuf = h->d_hbuf;
+  p.ring_cur = h->ring_cur;
+  p.ring_stride = (uint32_t)h->B;
+  p.cols_bytes = (uint32_t)h->L.cols_bytes;
   return p;
 }
 
@@ -289,6 +309,54 @@ int launch_observe_dict(tg_handle* h) {
   return TG_OK;
 }
 
+// ---- shards: fork (step launches) / join (everything else) ----
+int join_shards(tg_handle* h) {
+  if (!h->forked) return TG_OK;
+  for (int i = 0; i < h->n_shards; ++i) {
+    HIPCHK(h, hipEventRecord(h->sh_event[i], h->sh_stream[i]));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->sh_event[i], 0));
+  }
+  h->forked = false;
+  return TG_OK;
+}
+
+int fork_shards(tg_handle* h) {
+  if (h->forked) return TG_OK;
+  HIPCHK(h, hipEventRecord(h->fork_ev, h->stream));
+  for (int i = 0; i < h->n_shards; ++i) HIPCHK(h, hipStreamWaitEvent(h->sh_stream[i], h->fork_ev, 0));
+  h->forked = true;
+  return TG_OK;
+}
+
+// one transition: a single launch on the handle's stream, or one launch per shard
+int launch_step_all(tg_handle* h, const tg::KParams& p) {
+  if (h->n_shards <= 1) {
+    h->L.step(p, h->stream);
+    return TG_OK;
+  }
+  int rc = fork_shards(h);
+  if (rc != TG_OK) return rc;
+  const size_t S = h->cells;
+  for (int i = 0; i < h->n_shards; ++i) {
+    const size_t o = (size_t)h->sh_off[i];
+    tg::KParams q = p;
+    q.batch = h->sh_cnt[i];
+    q.board = p.board + o * S;
+    q.rec = p.rec + o * 8;
+    q.rng = p.rng + o;
+    q.actions = p.act_i8 ? (const void*)((const int8_t*)p.actions + o) : (const void*)((const int32_t*)p.actions + o);
+    if (p.obs) q.obs = p.obs + o * obs_bytes_per_env(&h->cfg);
+    q.out = p.out + o;
+    if (p.episode) q.episode = p.episode + o;
+    if (p.cols) q.cols = (uint8_t*)p.cols + o * p.cols_bytes;
+    if (p.ahead) q.ahead = p.ahead + o * 4;
+    if (p.ring) q.ring = p.ring + o;
+    if (p.hbuf) q.hbuf = p.hbuf + o;
+    h->L.step(q, h->sh_stream[i]);
+  }
+  return TG_OK;
+}
+
 // bits kernel: rebuild column masks + look-ahead permutations from the reference-defined state
 int launch_prepare_bits(tg_handle* h, const uint8_t* d_mask, int force) {
   if (!h->d_cols) return TG_OK;
@@ -298,6 +366,9 @@ int launch_prepare_bits(tg_handle* h, const uint8_t* d_mask, int force) {
   q.rng = (tg_rng_rec*)h->buf[TG_BUF_RNG];
   q.cols = h->d_cols;
   q.ahead = h->d_ahead;
+  q.ring = h->d_ring;
+  q.hbuf = h->d_hbuf;
+  q.cur = h->ring_cur;
   q.mask = d_mask;
   q.batch = h->B;
   q.ruleset = h->cfg.ruleset;
@@ -433,8 +504,12 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   if (g_kernel_lanes == 16 && !want_final) {
     CRCHK(hipMalloc(&h->d_cols, B * L.cols_bytes + kTailPad));
     CRCHK(hipMemsetAsync(h->d_cols, 0, B * L.cols_bytes + kTailPad, h->stream));
-    CRCHK(hipMalloc((void**)&h->d_ahead, B * 32 + kTailPad));
-    CRCHK(hipMemsetAsync(h->d_ahead, 0, B * 32 + kTailPad, h->stream));
+    CRCHK(hipMalloc((void**)&h->d_ahead, B * 64 + kTailPad));
+    CRCHK(hipMemsetAsync(h->d_ahead, 0, B * 64 + kTailPad, h->stream));
+    CRCHK(hipMalloc((void**)&h->d_ring, 2 * B * 8 + kTailPad));
+    CRCHK(hipMemsetAsync(h->d_ring, 0, 2 * B * 8 + kTailPad, h->stream));
+    CRCHK(hipMalloc((void**)&h->d_hbuf, 2 * B + kTailPad));
+    CRCHK(hipMemsetAsync(h->d_hbuf, 0, 2 * B + kTailPad, h->stream));
   }
 #ifdef TG_PHASE_TIMING
   CRCHK(hipMalloc(&h->dbg, ((B + 15) / 16) * 16 * 8));
@@ -448,6 +523,28 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     CRCHK(hipMemcpyAsync(h->buf[TG_BUF_REC], init.data(), B * sizeof(tg_env_rec), hipMemcpyHostToDevice, h->stream));
     CRCHK(hipStreamSynchronize(h->stream));
   }
+  {
+    // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
+    int want = 1;
+    if (const char* e = getenv("TG_STREAMS")) want = atoi(e);
+    if (!h->d_cols || cfg->obs_mode == TG_OBS_DICT || (cfg->flags & TG_FLAG_FINAL_OBS)) want = 1;
+    while (want > 1 && (B + want - 1) / want < 8192) --want;  // small shards only add launches
+    if (want > 1) {
+      const int chunk = (int)(((B + want - 1) / want + 127) / 128 * 128);  // RNG workgroups own 128-env ranges
+      for (int o = 0; o < (int)B; o += chunk) {
+        h->sh_off.push_back(o);
+        h->sh_cnt.push_back((int)B - o < chunk ? (int)B - o : chunk);
+      }
+      h->n_shards = (int)h->sh_off.size();
+      h->sh_stream.assign(h->n_shards, nullptr);
+      h->sh_event.assign(h->n_shards, nullptr);
+      for (int i = 0; i < h->n_shards; ++i) {
+        CRCHK(hipStreamCreateWithFlags(&h->sh_stream[i], hipStreamNonBlocking));
+        CRCHK(hipEventCreateWithFlags(&h->sh_event[i], hipEventDisableTiming));
+      }
+      CRCHK(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+    }
+  }
 #undef CRCHK
   h->rng_valid.assign(B, 0);
   *out = h;
@@ -457,6 +554,11 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
 void tg_destroy(tg_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->cfg.device);
+  for (hipStream_t st : h->sh_stream)
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  for (hipEvent_t ev : h->sh_event)
+    if (ev) (void)hipEventDestroy(ev);
+  if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (int i = 0; i < TG_BUF_COUNT; ++i)
     if (h->buf[i]) (void)hipFree(h->buf[i]);
@@ -465,6 +567,8 @@ void tg_destroy(tg_handle* h) {
   if (h->d_mask) (void)hipFree(h->d_mask);
   if (h->d_cols) (void)hipFree(h->d_cols);
   if (h->d_ahead) (void)hipFree(h->d_ahead);
+  if (h->d_ring) (void)hipFree(h->d_ring);
+  if (h->d_hbuf) (void)hipFree(h->d_hbuf);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -474,6 +578,7 @@ void tg_destroy(tg_handle* h) {
 int tg_reset(tg_handle* h, const uint64_t* seeds, const uint8_t* mask) {
   if (!h) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   const size_t B = (size_t)h->B;
   bool any_reseed = false;
   h->h_new_rng.resize(B);
@@ -536,6 +641,8 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind) {
   HIPCHK(h, hipSetDevice(h->cfg.device));
   tg::KParams p = step_params(h);
   if (kind == TG_MEM_HOST) {
+    int rcj = join_shards(h);  // the staging copy runs on the handle's stream, behind the previous transition
+    if (rcj != TG_OK) return rcj;
     const int na = tg_num_actions(&h->cfg);
     for (int i = 0; i < h->B; ++i)  // envs/tetris.py:215-217: the reference asserts action_space.contains(action)
       if (h->cfg.ruleset == TG_RULESET_NUMPY && (actions[i] < 0 || actions[i] >= na))
@@ -547,7 +654,11 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind) {
   } else {
     return fail(h, TG_EINVAL, "tg_step: unknown memory kind %d", kind);
   }
-  h->L.step(p, h->stream);
+  {
+    int rc = launch_step_all(h, p);
+    if (rc != TG_OK) return rc;
+  }
+  h->ring_cur ^= 1;
   HIPCHK(h, hipGetLastError());
   if (h->cfg.obs_mode == TG_OBS_DICT) return launch_observe_dict(h);
   return TG_OK;
@@ -556,17 +667,25 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind) {
 int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K) {
   if (!h || !actions_dev || K <= 0) return h ? fail(h, TG_EINVAL, "tg_step_k: bad arguments") : TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
-  tg::KParams p = step_params(h);
   if (h->B % 4 != 0) return fail(h, TG_EINVAL, "tg_step_k: batch must be a multiple of 4 (packed int8 action rows)");
-  p.act_i8 = 1;
-  for (int k = 0; k < K; ++k) {
-    p.actions = actions_dev + (size_t)k * h->B;
-    h->L.step(p, h->stream);
-    if (h->cfg.obs_mode == TG_OBS_DICT) {  // the DICT surface is packed by its own kernel after every transition
-      int rc = launch_observe_dict(h);
+  auto enqueue = [&]() -> int {  // K transitions, one launch each (per shard)
+    tg::KParams p = step_params(h);
+    p.act_i8 = 1;
+    for (int k = 0; k < K; ++k) {
+      p.actions = actions_dev + (size_t)k * h->B;
+      p.ring_cur = h->ring_cur;
+      int rc = launch_step_all(h, p);
       if (rc != TG_OK) return rc;
+      h->ring_cur ^= 1;
+      if (h->cfg.obs_mode == TG_OBS_DICT) {  // the DICT surface is packed by its own kernel after every transition
+        rc = launch_observe_dict(h);
+        if (rc != TG_OK) return rc;
+      }
     }
-  }
+    return TG_OK;
+  };
+  int rc = enqueue();
+  if (rc != TG_OK) return rc;
   HIPCHK(h, hipGetLastError());
   return TG_OK;
 }
@@ -582,6 +701,7 @@ int tg_fetch(tg_handle* h, int which, void* host_dst, size_t bytes) {
   if (!h || which < 0 || which >= TG_BUF_COUNT || !host_dst) return h ? fail(h, TG_EINVAL, "tg_fetch: bad arguments") : TG_EINVAL;
   if (bytes > h->bytes[which]) return fail(h, TG_EINVAL, "tg_fetch: %zu bytes requested, buffer %d holds %zu", bytes, which, h->bytes[which]);
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   if (bytes) HIPCHK(h, hipMemcpyAsync(host_dst, h->buf[which], bytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return TG_OK;
@@ -590,6 +710,7 @@ int tg_fetch(tg_handle* h, int which, void* host_dst, size_t bytes) {
 int tg_get_state(tg_handle* h, uint8_t* board, tg_env_rec* rec, tg_rng_rec* rng) {
   if (!h) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   const size_t B = (size_t)h->B;
   if (board) HIPCHK(h, hipMemcpyAsync(board, h->buf[TG_BUF_BOARD], B * h->cells, hipMemcpyDeviceToHost, h->stream));
   if (rec) HIPCHK(h, hipMemcpyAsync(rec, h->buf[TG_BUF_REC], B * sizeof(tg_env_rec), hipMemcpyDeviceToHost, h->stream));
@@ -606,6 +727,7 @@ int tg_get_state(tg_handle* h, uint8_t* board, tg_env_rec* rec, tg_rng_rec* rng)
 int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, const tg_rng_rec* rng) {
   if (!h) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   const size_t B = (size_t)h->B;
   if (rec)
     for (size_t i = 0; i < B; ++i) {
@@ -658,6 +780,7 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
 int tg_observe(tg_handle* h) {
   if (!h) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   if (h->cfg.obs_mode == TG_OBS_NONE) return TG_OK;
   return launch_observe_dict(h);
 }
@@ -680,6 +803,7 @@ int tg_grouped_enumerate(tg_handle* h, uint8_t* boards_dev) {
   if (h->cfg.action_set != TG_ACTIONS_GROUPED) return fail(h, TG_EINVAL, "tg_grouped_enumerate: handle was not created with TG_ACTIONS_GROUPED");
   if (boards_dev) return fail(h, TG_EUNSUPPORTED, "tg_grouped_enumerate: placement boards are not built yet (legal mask only)");
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   return run_grouped(h, true, false, 0, 0);
 }
 
@@ -687,6 +811,7 @@ int tg_grouped_sample(tg_handle* h, uint32_t seed, uint32_t counter) {
   if (!h) return TG_EINVAL;
   if (h->cfg.action_set != TG_ACTIONS_GROUPED) return fail(h, TG_EINVAL, "tg_grouped_sample: handle was not created with TG_ACTIONS_GROUPED");
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   return run_grouped(h, false, true, seed, counter);
 }
 
@@ -695,6 +820,7 @@ int tg_features(tg_handle* h) {
   if (!(h->cfg.flags & TG_FLAG_FEATURES)) return fail(h, TG_EINVAL, "tg_features: handle was created without TG_FLAG_FEATURES");
   if (h->cfg.ruleset != TG_RULESET_NUMPY) return fail(h, TG_EINVAL, "tg_features: NUMPY rule-set only (wrappers/observation.py wraps envs/tetris.py)");
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   tg::FeatureParams f{};
   f.board = (const uint8_t*)h->buf[TG_BUF_BOARD];
   f.rec = (const uint32_t*)h->buf[TG_BUF_REC];
@@ -709,6 +835,7 @@ int tg_features(tg_handle* h) {
 int tg_sync(tg_handle* h) {
   if (!h) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return TG_OK;
 }
@@ -716,6 +843,7 @@ int tg_sync(tg_handle* h) {
 int tg_timer_start(tg_handle* h) {
   if (!h) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   return TG_OK;
 }
@@ -723,6 +851,7 @@ int tg_timer_start(tg_handle* h) {
 int tg_timer_stop(tg_handle* h, float* elapsed_ms) {
   if (!h || !elapsed_ms) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipEventSynchronize(h->ev1));
   HIPCHK(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
@@ -739,6 +868,7 @@ int tg_dev_alloc(tg_handle* h, size_t bytes, void** ptr) {
 int tg_dev_free(tg_handle* h, void* ptr) {
   if (!h) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipFree(ptr));
   return TG_OK;
@@ -747,6 +877,7 @@ int tg_dev_free(tg_handle* h, void* ptr) {
 int tg_dev_upload(tg_handle* h, void* dst_dev, const void* src_host, size_t bytes) {
   if (!h || !dst_dev || !src_host) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   HIPCHK(h, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return TG_OK;
@@ -755,6 +886,7 @@ int tg_dev_upload(tg_handle* h, void* dst_dev, const void* src_host, size_t byte
 int tg_dev_download(tg_handle* h, void* dst_host, const void* src_dev, size_t bytes) {
   if (!h || !dst_host || !src_dev) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   HIPCHK(h, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return TG_OK;
@@ -763,6 +895,7 @@ int tg_dev_download(tg_handle* h, void* dst_host, const void* src_dev, size_t by
 int tg_stream_copy_gbps(tg_handle* h, size_t bytes, int iters, float* gbps) {
   if (!h || !gbps || iters <= 0) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   bytes &= ~(size_t)15;
   void *a = nullptr, *b = nullptr;
   HIPCHK(h, hipMalloc(&a, bytes));
@@ -787,6 +920,7 @@ int tg_stream_copy_gbps(tg_handle* h, size_t bytes, int iters, float* gbps) {
 // phase-timing buffer of the lane kernel (TG_PHASE_TIMING builds): u64 [waves][16] s_memtime stamps
 int tg_debug_phase_times(tg_handle* h, unsigned long long* out, size_t n_waves) {
   if (!h || !h->dbg) return TG_EUNSUPPORTED;
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, h->dbg, n_waves * 16 * 8, hipMemcpyDeviceToHost));
   return TG_OK;

@@ -143,12 +143,21 @@ __device__ __forceinline__ uint64_t bits_apply_perm(const uint32_t sig, const ui
   return out;
 }
 
+// The bag permutations of an env are produced ahead of their use by separate RNG workgroups of the same launch
+// (role split by blockIdx) and consumed by the logic wave: a two-entry ring per env with monotonic 8-bit counters,
+// T = permutations produced (owned by the RNG role), H = permutations consumed (owned by the logic wave).  Entry i
+// lives in slot i & 1.  Everything one role reads from the other is double-buffered by launch parity (`cur`), so
+// both roles work on the snapshot of the previous launch boundary and never on each other's stores of this launch
+// (L2 is per XCD; cross-workgroup visibility inside a launch is not guaranteed).
 struct BitsParams {
-  void* cols;    // ColT [B][W]
-  uint4* ahead;  // [B][2]: {state_lo, state_hi as 4 dwords} {uinteger, has32, 0, 0} after the look-ahead shuffle
+  void* cols;      // ColT [B][W]
+  uint4* ahead;    // [B][2 slots][2]: generator state AFTER the slot's shuffle {state_lo, state_hi} {uinteger, has32, 0, 0}
+  uint64_t* ring;  // [2 parities][B]: bits 0..27 permutation of slot 0, 28..55 slot 1 (7 nibbles each), 56..63 T
+  uint8_t* hbuf;   // [2 parities][B]: H
+  int cur;         // parity this launch reads; it writes 1 - cur
+  int nrb;         // number of leading RNG workgroups (128 envs each)
+  uint32_t pstride;  // elements between the two parities of ring / hbuf (the handle's whole batch)
 };
-
-constexpr uint32_t kSigValid = 0x80000000u;
 
 // native 16-byte vector for the slab stream: HIP's uint4 is a struct whose copies become memcpy intrinsics, which
 // kept the staging array in scratch memory (and made the kernel wait for every slab load right after issuing it)
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   const int wave = rfl((int)(threadIdx.x >> 6));
 
   const uint32_t B = (uint32_t)p.batch;
-  const uint32_t base_env = blockIdx.x * (uint32_t)EPW;
+  const uint32_t base_env = (blockIdx.x - (uint32_t)bp.nrb) * (uint32_t)EPW;  // (meaningless in the RNG role)
   const uint32_t nlive = B - base_env < (uint32_t)EPW ? B - base_env : (uint32_t)EPW;
   const bool live = (uint32_t)lane < nlive;
   const int slot = live ? lane : (int)nlive - 1;  // dead lanes shadow the last live env (identical, benign LDS writes)
@@ -203,6 +212,45 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
 #else
 #define TG_BITS_STAMP(i) do {} while (0)
 #endif
+  if ((int)blockIdx.x < bp.nrb) {
+    // =====================================================================================================
+    // RNG ROLE (leading workgroups, 128 envs each): append one permutation to every ring that holds fewer than two.
+    // Generator.shuffle on the 7-bag = numpy PCG64 + masked rejection (components/tetromino_randomizer.py:42-46, 84).
+    // =====================================================================================================
+    if (RULESET != TG_RULESET_NUMPY) return;
+    const uint32_t e = blockIdx.x * 128u + threadIdx.x;
+    const bool on = e < B;
+    const uint32_t ee = on ? e : B - 1u;
+    uint64_t ring = bp.ring[(size_t)bp.cur * bp.pstride + ee];
+    const int Hn = bp.hbuf[(size_t)bp.cur * bp.pstride + ee];
+    const int Tn = (int)(ring >> 56);
+    const bool need = on && (int)(int8_t)(uint8_t)(Tn - Hn) < 2;
+    if (__any(need)) {
+      BitsRng g;
+      g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
+      g.uinteger = g.has32 = 0;
+      g.loaded = false;
+      uint4* a4 = bp.ahead + (size_t)ee * 4;
+      if (need) {  // frontier = state after entry T - 1
+        const uint4 f0 = a4[2 * ((Tn - 1) & 1)], f1 = a4[2 * ((Tn - 1) & 1) + 1];
+        const uint4 gi = reinterpret_cast<const uint4*>(p.rng + ee)[1];
+        g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
+        g.i_lo = (uint64_t)gi.x | ((uint64_t)gi.y << 32); g.i_hi = (uint64_t)gi.z | ((uint64_t)gi.w << 32);
+        g.uinteger = f1.x; g.has32 = f1.y;
+      }
+      uint32_t sig = 0;
+      bits_shuffle_perm(g, sig, need);
+      if (need) {
+        const int sl = Tn & 1;
+        a4[2 * sl] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
+        a4[2 * sl + 1] = make_uint4(g.uinteger, g.has32, 0u, 0u);
+        ring &= ~((0x0FFFFFFFULL << (28 * sl)) | (0xFFULL << 56));
+        ring |= ((uint64_t)sig << (28 * sl)) | ((uint64_t)((Tn + 1) & 0xFF) << 56);
+      }
+    }
+    if (on) bp.ring[(size_t)(1 - bp.cur) * bp.pstride + e] = ring;
+    return;
+  }
   TG_BITS_STAMP(0);
 
   if (wave == 1) {
@@ -215,6 +263,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
     const uint32_t nchunks = (nbytes + 15u) / 16u;
     uint64_t tab_cells = 0;
     if (lane < 7) tab_cells = c_cells.cells[lane];
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);  // TG_STAGGER: let the logic waves' small loads go first
     u32x4 stage[NIT];
     {
       const u32x4* gsrc = reinterpret_cast<const u32x4*>(p.board + (size_t)base_env * S);
@@ -331,7 +380,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
     TG_BITS_STAMP(4);
 #ifdef TG_PHASE_TIMING
     if (p.dbg && lane == 0)
-      for (int i = 0; i < 5; ++i) p.dbg[(size_t)blockIdx.x * 16 + 8 + i] = tstamp[i];
+      for (int i = 0; i < 5; ++i) p.dbg[(size_t)(blockIdx.x - bp.nrb) * 16 + 8 + i] = tstamp[i];
 #endif
     return;
   }
@@ -346,6 +395,12 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   const uint4 ra = rec4[0], rb = rec4[1];
   const int action_in = p.act_i8 ? (int)reinterpret_cast<const int8_t*>(p.actions)[env]
                                  : reinterpret_cast<const int32_t*>(p.actions)[env];
+  uint64_t ring = 0;
+  int Hc = 0;
+  if (RULESET == TG_RULESET_NUMPY) {
+    ring = bp.ring[(size_t)bp.cur * bp.pstride + env];
+    Hc = bp.hbuf[(size_t)bp.cur * bp.pstride + env];
+  }
   T cv[W];
   {
     constexpr int NP = (int)(W * sizeof(T) / 8);
@@ -377,40 +432,47 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   float reward = 0.0f;
   int lines = 0;
   bool final_coll = false;
-  // look-ahead permutation (NUMPY)
-  uint32_t sig = s.reserved & 0x0FFFFFFFu;
-  bool sig_ok = RULESET == TG_RULESET_NUMPY && (s.reserved & kSigValid) != 0;
-  const bool sig_valid0 = sig_ok;
+  // consumer side of the permutation ring (NUMPY).  g = the generator state the reference would hold after the
+  // shuffles consumed so far in this step (loaded lazily: from the ring slot's state on a consumption, from tg_rng_rec
+  // for the rare in-line shuffle)
+  const int ringT = (int)(ring >> 56);
   bool consumed = false;
   BitsRng g;
   g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
   g.uinteger = g.has32 = 0;
   g.loaded = false;
+  bool inc_loaded = false;
   const uint4* rng4 = reinterpret_cast<const uint4*>(p.rng + env);
-  auto rng_ensure = [&](const bool need) {
-    const bool go = need && !g.loaded;
-    if (!__any(go)) return;
-    if (go) {
-      // frontier = state after the look-ahead shuffle (valid permutation) or the generator state itself (none yet)
-      const uint4* a4 = bp.ahead + (size_t)env * 2;
-      const uint4 f0 = sig_valid0 ? a4[0] : rng4[0];
-      const uint4 f1 = sig_valid0 ? a4[1] : rng4[2];
-      const uint4 gi = rng4[1];
-      g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
-      g.i_lo = (uint64_t)gi.x | ((uint64_t)gi.y << 32); g.i_hi = (uint64_t)gi.z | ((uint64_t)gi.w << 32);
-      g.uinteger = f1.x; g.has32 = f1.y;
-      g.loaded = true;
-    }
-  };
   // BagRandomizer reshuffle (components/tetromino_randomizer.py:42-46, 84) / reset shuffle (:87-91) for the lanes in `need`
   auto consume_perm = [&](const bool need, const bool from_identity) {
     if (!__any(need)) return;
-    if (__any(need && !sig_ok)) {  // rare: a second shuffle in one step (this load also waits for the slab loads)
-      rng_ensure(need && !sig_ok);
-      bits_shuffle_perm(g, sig, need && !sig_ok);
+    const int av = (int)(int8_t)(uint8_t)(ringT - Hc);  // entries left for this lane
+    const bool from_ring = need && av > 0;
+    const bool fb = need && av <= 0;
+    uint32_t sig = (uint32_t)(ring >> (28 * (Hc & 1))) & 0x0FFFFFFFu;
+    if (__any(fb)) {  // rare: ring exhausted (three shuffles within two steps) → shuffle in-line
+      if (fb && !g.loaded) {
+        const uint4 f0 = rng4[0], f1 = rng4[2];
+        g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
+        g.uinteger = f1.x; g.has32 = f1.y;
+        g.loaded = true;
+      }
+      if (fb && !inc_loaded) {
+        const uint4 gi = rng4[1];
+        g.i_lo = (uint64_t)gi.x | ((uint64_t)gi.y << 32); g.i_hi = (uint64_t)gi.z | ((uint64_t)gi.w << 32);
+        inc_loaded = true;
+      }
+      bits_shuffle_perm(g, sig, fb);
+    }
+    if (from_ring) {  // the slot's state becomes the generator state (stored in D; nothing waits for this load before)
+      const uint4* a4 = bp.ahead + (size_t)env * 4 + 2 * (Hc & 1);
+      const uint4 f0 = a4[0], f1 = a4[1];
+      g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
+      g.uinteger = f1.x; g.has32 = f1.y;
+      g.loaded = true;
     }
     const uint64_t nb = bits_apply_perm(sig, from_identity ? 0x06050403020100ULL : s.bag);
-    if (need) { s.bag = nb; s.bidx = 0; sig_ok = false; consumed = true; }
+    if (need) { s.bag = nb; s.bidx = 0; Hc = (Hc + 1) & 0xFF; consumed = true; }
   };
   // BagRandomizer.get_next_tetromino (:65-85): eager reshuffle when the 7th piece is drawn
   auto randomizer_next = [&](const bool on) -> int {
@@ -699,13 +761,23 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
     }
     if (RULESET == TG_RULESET_NUMPY) {  // envs/tetris.py:274-307, tetromino_queue.py:23-33, tetromino_randomizer.py:87-91
       consume_perm(do_reset, true);
-      if (do_reset) s.queue = 0;
-      for (int i = 0; i < Q; ++i) {
-        const int t = randomizer_next(do_reset);
-        if (do_reset) s.queue |= (uint64_t)t << (8 * i);
+      if (Q <= 5) {
+        // Q draws fill the queue, the pop takes its head and draws one more: Q + 1 <= 6 draws never wrap the fresh bag
+        if (do_reset) {
+          s.piece = (int)(s.bag & 0xFF);
+          s.queue = (s.bag >> 8) & ((1ULL << (8 * Q)) - 1ULL);
+          s.bidx = Q + 1;
+          s.x = np_spawn_x<W>(s.piece);
+        }
+      } else {
+        if (do_reset) s.queue = 0;
+        for (int i = 0; i < Q; ++i) {
+          const int t = randomizer_next(do_reset);
+          if (do_reset) s.queue |= (uint64_t)t << (8 * i);
+        }
+        const int first = queue_pop(do_reset);
+        if (do_reset) { s.piece = first; s.x = np_spawn_x<W>(first); }
       }
-      const int first = queue_pop(do_reset);
-      if (do_reset) { s.piece = first; s.x = np_spawn_x<W>(first); }
     } else {  // envs/tetris_fn.py:318-367
       lane_rng_ensure(r);
       uint32_t a0, a1, b0, b1;
@@ -741,8 +813,6 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   TG_BITS_STAMP(5);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
-  if (RULESET == TG_RULESET_NUMPY) rng_ensure(live && !sig_ok);  // generators of the lanes whose permutation was consumed (used in E)
-
   // ---- D: per-env stores: outputs, first record half, column masks ----
   uint4 oa, ob;
   lane_pack(s, oa, ob);
@@ -779,23 +849,13 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   }
 
   TG_BITS_STAMP(6);
-  // ---- E: generator upkeep, off the critical path (every other store of this wave is already in flight) ----
+  // ---- E: generator bookkeeping: the consumed shuffles' end state is what the reference's generator now holds ----
   if (RULESET == TG_RULESET_NUMPY) {
-    const bool refresh = live && !sig_ok;
-    if (__any(refresh)) {
-      rng_ensure(refresh);
+    if (live) bp.hbuf[(size_t)(1 - bp.cur) * bp.pstride + env] = (uint8_t)Hc;
+    if (live && consumed) {
       uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
-      if (refresh && consumed) {  // the look-ahead state becomes the generator state the reference would hold
-        rng_out[0] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
-        *reinterpret_cast<uint2*>(rng_out + 2) = make_uint2(g.uinteger, g.has32);
-      }
-      bits_shuffle_perm(g, sig, refresh);
-      if (refresh) {
-        uint4* a4 = bp.ahead + (size_t)env * 2;
-        a4[0] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
-        a4[1] = make_uint4(g.uinteger, g.has32, 0u, 0u);
-        ob.w = sig | kSigValid;
-      }
+      rng_out[0] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
+      *reinterpret_cast<uint2*>(rng_out + 2) = make_uint2(g.uinteger, g.has32);
     }
   } else if (live && r.dirty) {
     uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
@@ -804,7 +864,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   TG_BITS_STAMP(7);
 #ifdef TG_PHASE_TIMING
   if (p.dbg && lane == 0)
-    for (int i = 0; i < 8; ++i) p.dbg[(size_t)blockIdx.x * 16 + i] = tstamp[i];
+    for (int i = 0; i < 8; ++i) p.dbg[(size_t)(blockIdx.x - bp.nrb) * 16 + i] = tstamp[i];
 #endif
   if (live && (ob.x != rb.x || ob.y != rb.y || ob.z != rb.z || ob.w != rb.w))
     TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out + 1), (u32x4{ob.x, ob.y, ob.z, ob.w}));
@@ -821,10 +881,13 @@ struct PrepareParams {
   tg_rng_rec* rng;
   void* cols;
   uint4* ahead;
-  const uint8_t* mask;  // [B] or null: envs whose generator moved (their permutation is recomputed)
+  uint64_t* ring;       // [2][B]
+  uint8_t* hbuf;        // [2][B]
+  const uint8_t* mask;  // [B] or null: envs whose generator moved (their ring is refilled)
   int batch;
   int ruleset;
-  int force;            // recompute every permutation
+  int force;            // refill every ring
+  int cur;              // parity the next launch reads
 };
 
 template <int W, int H>
@@ -840,9 +903,14 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
     gc[c] = v;
   }
   if (p.ruleset != TG_RULESET_NUMPY) return;
-  uint32_t* rec = p.rec + (size_t)env * 8;
+  const size_t B = (size_t)p.batch;
   const bool moved = p.force || (p.mask ? p.mask[env] != 0 : true);
-  if (!moved && (rec[7] & kSigValid)) return;
+  if (!moved) {  // ring untouched: make both parities agree with the one the next launch reads
+    p.ring[(size_t)(1 - p.cur) * B + env] = p.ring[(size_t)p.cur * B + env];
+    p.hbuf[(size_t)(1 - p.cur) * B + env] = p.hbuf[(size_t)p.cur * B + env];
+    return;
+  }
+  uint32_t* rec = p.rec + (size_t)env * 8;
   Rng r;
   r.loaded = false;
   r.dirty = false;
@@ -858,13 +926,21 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
     rec[4] = (d4 & 0xFFFFFF00u) | (uint32_t)((bag >> 48) & 0xFF);
     rng_store(r, p.rng + env, 0);
   }
-  const uint64_t perm = pcg_shuffle7(r, 0x06050403020100ULL);
-  uint32_t sig = 0;
-  for (int k = 0; k < 7; ++k) sig |= (uint32_t)((perm >> (8 * k)) & 0xF) << (4 * k);
-  rec[7] = sig | kSigValid;
-  uint4* a4 = p.ahead + (size_t)env * 2;
-  a4[0] = make_uint4((uint32_t)r.s_lo, (uint32_t)(r.s_lo >> 32), (uint32_t)r.s_hi, (uint32_t)(r.s_hi >> 32));
-  a4[1] = make_uint4(r.uinteger, r.has32, 0u, 0u);
+  rec[7] = 0;
+  uint64_t ring = 2ULL << 56;  // T = 2, H = 0: entries 0 and 1
+  uint4* a4 = p.ahead + (size_t)env * 4;
+  for (int sl = 0; sl < 2; ++sl) {
+    const uint64_t perm = pcg_shuffle7(r, 0x06050403020100ULL);
+    uint64_t sig = 0;
+    for (int k = 0; k < 7; ++k) sig |= ((perm >> (8 * k)) & 0xF) << (4 * k);
+    ring |= sig << (28 * sl);
+    a4[2 * sl] = make_uint4((uint32_t)r.s_lo, (uint32_t)(r.s_lo >> 32), (uint32_t)r.s_hi, (uint32_t)(r.s_hi >> 32));
+    a4[2 * sl + 1] = make_uint4(r.uinteger, r.has32, 0u, 0u);
+  }
+  p.ring[env] = ring;
+  p.ring[B + env] = ring;
+  p.hbuf[env] = 0;
+  p.hbuf[B + env] = 0;
 }
 
 }  // namespace tg

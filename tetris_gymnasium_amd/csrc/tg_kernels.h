@@ -48,7 +48,12 @@ struct KParams {
   int stagger;       // lane kernels: odd waves start this many x64 cycles late (de-phases load/compute/store bursts)
   unsigned long long* dbg;  // optional phase-timing buffer (TG_PHASE_TIMING builds only)
   void* cols;               // bits kernel only: column masks [B][W] (tg_kernel_bits.h); null otherwise
-  uint4* ahead;             // bits kernel only: generator state after the look-ahead shuffle [B][2]
+  uint4* ahead;             // bits kernel only: generator states of the permutation ring [B][2][2]
+  uint64_t* ring;           // bits kernel only: permutation rings [2][B]
+  uint8_t* hbuf;            // bits kernel only: consumed counters [2][B]
+  int ring_cur;             // bits kernel only: launch parity
+  uint32_t ring_stride;     // bits kernel only: elements between the parities of ring / hbuf
+  uint32_t cols_bytes;      // bits kernel only: bytes per env of `cols` (host-side shard offsets)
 };
 
 struct ResetParams {
