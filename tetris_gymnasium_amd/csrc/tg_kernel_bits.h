@@ -163,6 +163,7 @@ struct BitsParams {
 // kept the staging array in scratch memory (and made the kernel wait for every slab load right after issuing it)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x4 __attribute__((aligned(8))) u32x4_a8;  // 16-byte access at 8-byte alignment (env slabs: S % 8 == 0)
 
 // streaming stores: L2 is per XCD and written back at the end of every kernel; data no wave of THIS launch reads again
 // (observations, outputs) leaves with the nontemporal hint so that it drains while the kernel still computes
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
     // STREAM WAVE: the uint8 payload.  Slab block HBM → LDS while the logic wave decides; afterwards the locked
     // cells / cleared rows / resets are applied, changed slabs go back to the board, and the observation leaves.
     // =====================================================================================================
+    __builtin_amdgcn_s_setprio(1);
     const bool full_wave = nlive == (uint32_t)EPW;
     const uint32_t nbytes = nlive * (uint32_t)S;
     const uint32_t nchunks = (nbytes + 15u) / 16u;
@@ -291,6 +293,9 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();  // the logic wave has published what happened to every env
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#ifndef TG_NO_PRIO_SWAP
+    __builtin_amdgcn_s_setprio(3);  // from here on this wave is the workgroup's critical path
+#endif
     TG_BITS_STAMP(2);
     // post record of this lane's env: x = lock {cells | val << 16 | place << 24 | clear << 25 | reset << 26},
     // y = lock {x | y << 8}, z = observation {cells | val << 16 | show << 24}, w = observation {x | y << 8}
@@ -321,17 +326,21 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
       // board write-back: every changed env's lane copies its own slab (8-byte aligned in LDS and in HBM)
       if (dirty) {
         const u32x2* src = reinterpret_cast<const u32x2*>(bd.my);
-        u32x2* dst = reinterpret_cast<u32x2*>(p.board + (size_t)env * S);
+        uint8_t* dst = p.board + (size_t)env * S;
         constexpr int NU = S / 8, UB = NU <= 32 ? NU : 20;  // batches: all reads of a batch in flight before its stores
-        static_assert(S % 8 == 0, "slabs are copied in 8-byte units");
+        static_assert(S % 8 == 0, "slabs are copied in 8-byte units, stored in pairs");
 #pragma unroll 1
         for (int u0 = 0; u0 < NU; u0 += UB) {
           u32x2 t2[UB];
 #pragma unroll
           for (int u = 0; u < UB; ++u) t2[u] = src[u0 + u < NU ? u0 + u : NU - 1];
 #pragma unroll
-          for (int u = 0; u < UB; ++u)
-            if (u0 + u < NU) dst[u0 + u] = t2[u];
+          for (int u = 0; u + 1 < UB; u += 2)  // 16-byte stores at 8-byte alignment
+            if (u0 + u + 1 < NU)
+              *reinterpret_cast<u32x4_a8*>(dst + 8 * (u0 + u)) = u32x4{t2[u].x, t2[u].y, t2[u + 1].x, t2[u + 1].y};
+            else if (u0 + u < NU)
+              *reinterpret_cast<u32x2*>(dst + 8 * (u0 + u)) = t2[u];
+          if (UB % 2 == 1 && u0 + UB - 1 < NU) *reinterpret_cast<u32x2*>(dst + 8 * (u0 + UB - 1)) = t2[UB - 1];
         }
       }
     }
@@ -388,6 +397,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   // =======================================================================================================
   // LOGIC WAVE: one env per lane on column bitmasks
   // =======================================================================================================
+  __builtin_amdgcn_s_setprio(3);  // the decision logic is the critical path of the workgroup: it wins VALU arbitration
   T* colsL = reinterpret_cast<T*>(lds + BG::OFF_COLS) + slot * CST;
   uint64_t tab_cells = 0, tab_cols = 0;
   if (lane < 7) { tab_cells = c_cells.cells[lane]; tab_cols = c_colmasks.cols[lane]; }
@@ -813,6 +823,9 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   TG_BITS_STAMP(5);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
+#ifndef TG_NO_PRIO_SWAP
+  __builtin_amdgcn_s_setprio(0);
+#endif
   // ---- D: per-env stores: outputs, first record half, column masks ----
   uint4 oa, ob;
   lane_pack(s, oa, ob);
