@@ -126,3 +126,64 @@ def test_placement_features_engine_vs_oracle_random_states():
         np.testing.assert_array_equal(cf, o.features(), err_msg=f"current features t={t}")
         a = e.sample_legal_actions(seed=5, counter=t)
         e.step_sampled(); o.grouped_step(a, autoreset=po.AUTORESET_SAME_STEP)
+
+
+def _poke_piece(e, pieces, mats):
+    _, rec, _ = e.get_state()
+    for i in range(len(pieces)):
+        val = int(mats[i].max())
+        rec["rot"][i] = next(r for r in range(4) if np.array_equal(replay.matrix16(pieces[i], r, val), mats[i]))
+        rec["piece"][i], rec["val"][i] = pieces[i], val
+    return rec
+
+
+@pytest.mark.parametrize("name", ["grouped_10x20", "grouped_20x40", "grouped_clears_10x20"])
+def test_placement_boards_against_reference_fixture(golden_dir, name):
+    """The wrapper's observation tensor [4W][Hp][Wp] (wrappers/grouped.py:124-207) built on the device, against the
+    boards the reference produced for recorded states (illegal → ones, game-over placement → zeros, row clears)."""
+    fx = replay.load(golden_dir, name)
+    n = fx["enum_mask"].shape[0]
+    W, H = int(fx["width"]), int(fx["height"])
+    e = Engine(n, W, H, queue_size=int(fx["queue_size"]), obs_mode=N.OBS_BOARD, grouped=True)
+    e.reset(1 + np.arange(n, dtype=np.uint64))
+    e.set_state(board=replay.crop(fx["enum_state_board"]), rec=_poke_piece(e, fx["enum_piece"], fx["enum_matrix"]))
+    mask, boards = e.placement_boards()
+    np.testing.assert_array_equal(mask, fx["enum_mask"])
+    np.testing.assert_array_equal(boards, fx["enum_boards"])
+
+
+def test_placement_boards_reference_csv(golden_dir):
+    """The reference's only golden file: tests/test_grouped_env/expected_result_i_placement.csv = board of action 5*4+1
+    on the mock board with a vertical I (values 1), and its 40 placement boards."""
+    fx = replay.load(golden_dir, "ref_tests_grouped")
+    e = Engine(1, 10, 20, obs_mode=N.OBS_BOARD, grouped=True)
+    e.reset(np.array([42], np.uint64))
+    vi = np.zeros((4, 4), np.uint8); vi[:4, :4] = np.rot90(replay.NATIVE[0])
+    e.set_state(board=replay.crop(fx["mock_board"][None]), rec=_poke_piece(e, np.array([0]), vi.reshape(1, 16)))
+    mask, boards = e.placement_boards()
+    np.testing.assert_array_equal(mask[0], fx["mask"])
+    np.testing.assert_array_equal(boards[0], fx["boards40"])
+    np.testing.assert_array_equal(boards[0, 5 * 4 + 1], fx["csv_board"])
+
+
+@pytest.mark.parametrize("W,H,Q", [(10, 20, 4), (20, 40, 7), (10, 24, 4), (6, 12, 2)])
+def test_placement_boards_engine_vs_oracle_random_states(W, H, Q):
+    B = 384
+    e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_BOARD, grouped=True, autoreset=N.AUTORESET_SAME_STEP)
+    o = po.OracleBatch(B, W, H, queue_size=Q)
+    seeds = np.arange(11, 11 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(W)
+    for t in range(24):
+        if t % 6 == 0:  # dense stacks: placements that clear 1-4 rows, and stacks reaching the spawn rows
+            b = rng.integers(2, 9, (B, H, W)).astype(np.uint8)
+            b[:, : rng.integers(1, H - 4)] = 0
+            for i in range(B):
+                g = rng.integers(0, W - 3); b[i, :, g:g + rng.integers(1, 4)] = 0
+            e.set_state(board=b); o.set_state(board=b)
+        mask, boards = e.placement_boards()
+        om, ob = o.grouped_enumerate(boards=True)
+        np.testing.assert_array_equal(mask, om, err_msg=f"mask t={t}")
+        np.testing.assert_array_equal(boards, ob, err_msg=f"boards t={t}")
+        a = e.sample_legal_actions(seed=9, counter=t)
+        e.step_sampled(); o.grouped_step(a, autoreset=po.AUTORESET_SAME_STEP)

@@ -17,6 +17,7 @@
 #include "tg_kernel_block.h"
 #include "tg_kernel_features.h"
 #include "tg_kernel_lanes.h"
+#include "tg_kernel_placements.h"
 #include "tg_kernels.h"
 
 // ---- board sizes compiled in (W, H).  Extend the list and rebuild to support another size. ----
@@ -34,6 +35,7 @@ struct Launchers {
   void (*reset)(const tg::ResetParams&, hipStream_t);
   void (*observe)(const tg::ObserveParams&, hipStream_t);
   void (*prepare)(const tg::PrepareParams&, hipStream_t);
+  void (*placements)(const tg::PlacementParams&, hipStream_t);
   size_t cols_bytes;  // per env: column masks of the bits kernel
 };
 
@@ -104,6 +106,10 @@ void launch_prepare(const tg::PrepareParams& p, hipStream_t s) {
   hipLaunchKernelGGL((tg::bits_prepare_kernel<W, H>), dim3((p.batch + 255) / 256), dim3(256), 0, s, p);
 }
 template <int W, int H>
+void launch_placements(const tg::PlacementParams& p, hipStream_t s) {
+  hipLaunchKernelGGL((tg::placements_kernel<W, H>), dim3(grid_for(p.batch)), dim3(tg::kBlock), (tg::placements_lds_bytes<W, H>()), s, p);
+}
+template <int W, int H>
 void launch_observe(const tg::ObserveParams& p, hipStream_t s) {
   hipLaunchKernelGGL((tg::observe_kernel<W, H>), dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p);
 }
@@ -113,10 +119,10 @@ bool find_launchers(int W, int H, int ruleset, Launchers* out) {
   if (W == w && H == h) {                                                                           \
     if (ruleset == TG_RULESET_NUMPY)                                                                \
       *out = {launch_features<w, h>, launch_step<w, h, TG_RULESET_NUMPY>, launch_reset<w, h, TG_RULESET_NUMPY>, launch_observe<w, h>, \
-              launch_prepare<w, h>, tg::bits_cols_bytes<w, h>()};                                   \
+              launch_prepare<w, h>, launch_placements<w, h>, tg::bits_cols_bytes<w, h>()};          \
     else                                                                                            \
       *out = {launch_features<w, h>, launch_step<w, h, TG_RULESET_FUNCTIONAL>, launch_reset<w, h, TG_RULESET_FUNCTIONAL>,  \
-              launch_observe<w, h>, launch_prepare<w, h>, tg::bits_cols_bytes<w, h>()};             \
+              launch_observe<w, h>, launch_prepare<w, h>, launch_placements<w, h>, tg::bits_cols_bytes<w, h>()}; \
     return true;                                                                                    \
   }
   TG_FOR_EACH_SIZE(X)
@@ -801,10 +807,18 @@ static int run_grouped(tg_handle* h, bool mask, bool sample, uint32_t seed, uint
 int tg_grouped_enumerate(tg_handle* h, uint8_t* boards_dev) {
   if (!h) return TG_EINVAL;
   if (h->cfg.action_set != TG_ACTIONS_GROUPED) return fail(h, TG_EINVAL, "tg_grouped_enumerate: handle was not created with TG_ACTIONS_GROUPED");
-  if (boards_dev) return fail(h, TG_EUNSUPPORTED, "tg_grouped_enumerate: placement boards are not built yet (legal mask only)");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
-  return run_grouped(h, true, false, 0, 0);
+  int rc = run_grouped(h, true, false, 0, 0);
+  if (rc != TG_OK || !boards_dev) return rc;
+  tg::PlacementParams q{};
+  q.board = (const uint8_t*)h->buf[TG_BUF_BOARD];
+  q.rec = (const uint32_t*)h->buf[TG_BUF_REC];
+  q.boards = boards_dev;
+  q.batch = h->B;
+  h->L.placements(q, h->stream);
+  HIPCHK(h, hipGetLastError());
+  return TG_OK;
 }
 
 int tg_grouped_sample(tg_handle* h, uint32_t seed, uint32_t counter) {

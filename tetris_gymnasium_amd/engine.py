@@ -125,6 +125,23 @@ class Engine:
         self._chk(self.lib.tg_grouped_enumerate(self.h, None), "tg_grouped_enumerate")
         return self._fetch(N.BUF_LEGAL_MASK, np.empty((self.B, 4 * self.W), np.uint8))
 
+    def placement_boards(self):
+        """(legal mask u8[B][4W], boards u8[B][4W][H+p][W+2p]): the observation of GroupedActionsObservations
+        (wrappers/grouped.py:124-207) for the current state, built on the device."""
+        n = self.B * 4 * self.W * self.Hp * self.Wp
+        d = self.dev_alloc(n)
+        try:
+            self._chk(self.lib.tg_grouped_enumerate(self.h, C.c_void_p(d)), "tg_grouped_enumerate(boards)")
+            boards = np.empty((self.B, 4 * self.W, self.Hp, self.Wp), np.uint8)
+            self._chk(self.lib.tg_dev_download(self.h, N.ptr(boards), C.c_void_p(d), n), "tg_dev_download")
+        finally:
+            self.dev_free(d)
+        return self._fetch(N.BUF_LEGAL_MASK, np.empty((self.B, 4 * self.W), np.uint8)), boards
+
+    def placement_boards_device(self, boards_dev_ptr):
+        """Same, into a caller-owned device buffer (asynchronous on the engine's stream)."""
+        self._chk(self.lib.tg_grouped_enumerate(self.h, C.c_void_p(boards_dev_ptr)), "tg_grouped_enumerate(boards)")
+
     def sample_legal_actions(self, seed=0, counter=0, fetch=True):
         """Draw one legal action per env on the device into the actions buffer (uniform over the mask)."""
         self._chk(self.lib.tg_grouped_sample(self.h, int(seed) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF), "tg_grouped_sample")
