@@ -38,6 +38,9 @@ extern "C" {
 #define TG_OBS_DICT 2  /* NUMPY only. u8 board[B][Hp][Wp] | mask[B][Hp][Wp] | holder[B][p][p] |
                           queue[B][p][p*Q]  (envs/tetris.py:566-615) */
 #define TG_OBS_FN 3    /* i8 [B][H][W] in {-1,0,1} (envs/tetris_fn.py:137-158) */
+#define TG_OBS_RGB 4   /* NUMPY only. u8 [B][Hp][Wp + p*max(1,Q)][3]: RgbObservation — board left, queue strip top
+                          right, holder bottom right, through the pixel colour table
+                          (wrappers/observation.py:38-74, envs/tetris.py:45-75) */
 
 /* ---- autoreset ---- */
 #define TG_AUTORESET_NONE 0      /* caller resets via tg_reset(mask) — reference behaviour */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libtg_oracle.so")
 
 RULESET_NUMPY, RULESET_FUNCTIONAL = 0, 1
-OBS_NONE, OBS_BOARD, OBS_DICT, OBS_FN = 0, 1, 2, 3
+OBS_NONE, OBS_BOARD, OBS_DICT, OBS_FN, OBS_RGB = 0, 1, 2, 3, 4
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = 0, 1, 2
 NONE = 0xFF
 F_GAME_OVER, F_HAS_SWAPPED, F_PENDING_RESET = 1, 2, 4
@@ -170,6 +170,10 @@ class OracleBatch:
             flat = np.empty(self.B * (2 * cells + pp + pp * self.Q), np.uint8)
             self.L.tgo_observe(self.h, mode, _p(flat), self.nthreads)
             return split_dict_obs(flat, self.B, self.Hp, self.Wp, self.P, self.Q)
+        if mode == OBS_RGB:
+            out = np.empty((self.B, self.Hp, self.Wp + self.P * max(1, self.Q), 3), np.uint8)
+            self.L.tgo_observe(self.h, mode, _p(out), self.nthreads)
+            return out
         raise ValueError(mode)
 
     def get_state(self):

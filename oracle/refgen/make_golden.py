@@ -14,6 +14,7 @@ Fixtures (all NumPy rule-set, i.e. envs/tetris.py — the graded oracle of BASEL
   features.npz           FeatureVectorObservation outputs on trace states
   grouped_features_*.npz per-placement feature tensors [4W][W+3] (grouped wrapper + FeatureVectorObservation)
   ref_tests_grouped.npz  the reference tests' own mock board / CSV board / 40-entry mask (data only)
+  rgb_<cfg>.npz          RgbObservation frames (wrappers/observation.py:38-74) along random traces incl. hold swaps
 """
 from __future__ import annotations
 
@@ -321,6 +322,35 @@ def gen_grouped_features(ref, name, width, height, queue_size, n_states, seed, d
     print(f"{name}: {n_states} states, feature tensors {feats.shape}, max feature {feats.max()}")
 
 
+def gen_rgb(ref, name, width, height, queue_size, B, T, seed):
+    """RgbObservation (board | queue on top, holder at the bottom, colour LUT) along random-policy traces.  The
+    wrapper is driven exactly as a user would: env = RgbObservation(Tetris(...)); frames of reset() and every step()."""
+    rng = np.random.default_rng(seed)
+    # uniform over the 8 actions with extra weight on swap (6) so that the holder strip changes often
+    p = np.array([1, 1, 1, 1, 1, 1, 2.5, 0.5]); p /= p.sum()
+    actions = rng.choice(8, size=(T, B), p=p).astype(np.int8)
+    Hp, Wp = height + 4, width + 8 + 4 * max(1, queue_size)
+    frames = np.zeros((T, B, Hp, Wp, 3), np.uint8)
+    reset_frames = np.zeros((T, B, Hp, Wp, 3), np.uint8)
+    first = np.zeros((B, Hp, Wp, 3), np.uint8)
+    done = np.zeros((T, B), np.uint8)
+    for i in range(B):
+        base = make_env(ref, width, height, True, queue_size)
+        env = ref.RgbObservation(base)
+        obs, _ = env.reset(seed=1 + i)
+        assert obs.shape == (Hp, Wp, 3) and obs.dtype == np.uint8, (obs.shape, obs.dtype)
+        first[i] = obs
+        for t in range(T):
+            obs, r, d, _, info = env.step(int(actions[t, i]))
+            frames[t, i], done[t, i] = obs, int(d)
+            if d:
+                obs, _ = env.reset()
+                reset_frames[t, i] = obs
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), width=width, height=height, queue_size=queue_size, B=B, T=T,
+                        actions=actions, frames=frames, reset_frames=reset_frames, first=first, done=done)
+    print(f"{name}: {B*T} frames, episodes={int(done.sum())}, swaps={(actions == 6).sum()}")
+
+
 def gen_ref_tests_grouped(ref):
     """Data held by the reference's own grouped tests: the mock board (tests/helpers/mock.py:5-47 applied to
     a fresh env), the CSV board after action 21 (tests/test_grouped_env/expected_result_i_placement.csv) and
@@ -410,6 +440,8 @@ def main():
         "grouped_features_20x40": lambda: gen_grouped_features(ref, "grouped_features_20x40", 20, 40, 7, 24, 42, dense=True),
         "ref_tests_grouped": lambda: gen_ref_tests_grouped(ref),
         "features": lambda: gen_features(ref),
+        "rgb_10x20": lambda: gen_rgb(ref, "rgb_10x20", 10, 20, 4, 8, 160, 51),
+        "rgb_20x40": lambda: gen_rgb(ref, "rgb_20x40", 20, 40, 7, 2, 200, 52),
     }
     for name, fn in jobs.items():
         if args.only and args.only != name:

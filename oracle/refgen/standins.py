@@ -185,7 +185,7 @@ def import_reference() -> types.SimpleNamespace:
     from tetris_gymnasium.mappings.actions import ActionsMapping
     from tetris_gymnasium.mappings.rewards import RewardsMapping
     from tetris_gymnasium.wrappers.grouped import GroupedActionsObservations
-    from tetris_gymnasium.wrappers.observation import FeatureVectorObservation
+    from tetris_gymnasium.wrappers.observation import FeatureVectorObservation, RgbObservation
     from tetris_gymnasium.components.tetromino import Tetromino
 
     return types.SimpleNamespace(
@@ -194,5 +194,6 @@ def import_reference() -> types.SimpleNamespace:
         RewardsMapping=RewardsMapping,
         GroupedActionsObservations=GroupedActionsObservations,
         FeatureVectorObservation=FeatureVectorObservation,
+        RgbObservation=RgbObservation,
         Tetromino=Tetromino,
     )

@@ -974,6 +974,27 @@ void tgo_observe(tgo_batch* b, int obs_mode, void* out, int nthreads) {
                   base + 2 * B * cells + B * (size_t)(P * P) + (size_t)i * (size_t)(P * P * Q));
     } else if (obs_mode == TG_OBS_FN) {
       fn_obs(e, (int8_t*)out + (size_t)i * (size_t)(H * W));
+    } else if (obs_mode == TG_OBS_RGB) {
+      /* wrappers/observation.py:38-74: stack = hstack(board, vstack(queue, ones, holder)); rgb = colors[stack];
+       * colours = BASE_PIXELS + tetromino colours (envs/tetris.py:45-75) */
+      static const uint8_t LUT[9][3] = {{0, 0, 0},   {128, 128, 128}, {0, 240, 240}, {240, 240, 0}, {160, 0, 240},
+                                        {0, 240, 0}, {240, 0, 0},     {0, 0, 240},   {240, 160, 0}};
+      uint8_t board[MAXCELLS], holder[16], queue[16 * 7];
+      np_obs_dict(e, board, NULL, holder, queue);
+      const int ML = P * (Q > 1 ? Q : 1), WS = Wp + ML;
+      uint8_t* o = (uint8_t*)out + (size_t)i * (size_t)(Hp * WS * 3);
+      for (int R = 0; R < Hp; ++R)
+        for (int C = 0; C < WS; ++C) {
+          int id;
+          if (C < Wp) id = board[R * Wp + C];
+          else {
+            const int cc = C - Wp;
+            if (R < P) id = cc < P * Q ? queue[R * (P * Q) + cc] : 1;
+            else if (R >= Hp - P) id = cc < P ? holder[(R - (Hp - P)) * P + cc] : 1;
+            else id = 1;
+          }
+          memcpy(o + (R * WS + C) * 3, LUT[id <= 8 ? id : 8], 3);
+        }
     }
   }
 }

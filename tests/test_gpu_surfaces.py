@@ -9,7 +9,7 @@ from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
 
-from tetris_gymnasium_amd import _native as N  # noqa: E402
+from tetris_gymnasium_amd import Engine, _native as N  # noqa: E402
 from tetris_gymnasium_amd.components.tetromino import make_tetromino  # noqa: E402
 from tetris_gymnasium_amd.envs import Tetris  # noqa: E402
 from tetris_gymnasium_amd.envs.tetris_fn import PRNGKey, batched_reset, batched_step, reset, step  # noqa: E402
@@ -296,4 +296,73 @@ def test_vector_env_grouped_placement_features():
         obs, rew, term, trunc, info = env.step(a)
         ro, to, lo, _ = o.grouped_step(a, autoreset=po.AUTORESET_SAME_STEP)
         np.testing.assert_array_equal(rew, ro); np.testing.assert_array_equal(term, to.astype(bool))
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["rgb_10x20", "rgb_20x40"])
+def test_rgb_observation_against_reference_frames(golden_dir, name):
+    """TG_OBS_RGB = RgbObservation (wrappers/observation.py:38-74): frames the reference produced along random traces
+    with many hold swaps, replayed on the device."""
+    from tests import replay
+    fx = replay.load(golden_dir, name)
+    W, H, Q, B, T = (int(fx[k]) for k in ("width", "height", "queue_size", "B", "T"))
+    e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_RGB)
+    e.reset(1 + np.arange(B, dtype=np.uint64))
+    np.testing.assert_array_equal(e.observation(), fx["first"])
+    for t in range(T):
+        _, term, _ = e.step(fx["actions"][t].astype(np.int32))
+        np.testing.assert_array_equal(term, fx["done"][t], err_msg=f"t={t}")
+        np.testing.assert_array_equal(e.observation(), fx["frames"][t], err_msg=f"frame t={t}")
+        if term.any():
+            e.reset(mask=term)
+            m = term.astype(bool)
+            np.testing.assert_array_equal(e.observation()[m], fx["reset_frames"][t][m], err_msg=f"reset frame t={t}")
+
+
+@pytest.mark.parametrize("W,H,Q", [(10, 20, 4), (20, 40, 7), (6, 12, 1), (12, 24, 2)])
+def test_rgb_observation_engine_vs_oracle(W, H, Q):
+    B, T = 300, 120
+    e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_RGB, autoreset=N.AUTORESET_SAME_STEP)
+    o = po.OracleBatch(B, W, H, queue_size=Q)
+    seeds = np.arange(21, 21 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(Q)
+    for t in range(T):
+        a = rng.integers(0, 8, B)
+        re_, te, le = e.step(a)
+        ro, to, lo = o.step(a, autoreset=po.AUTORESET_SAME_STEP)
+        np.testing.assert_array_equal(te, to)
+        if t % 4 == 0 or t == T - 1:
+            np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_RGB), err_msg=f"rgb t={t}")
+
+
+def test_vector_env_rgb_and_placement_boards():
+    """The two image observations of the reference's wrappers through the VectorEnv adapter."""
+    B = 96
+    seeds = 1 + np.arange(B, dtype=np.uint64)
+    env = TetrisVectorEnv(B, observation="rgb", autoreset_mode="same_step")
+    o = po.OracleBatch(B, 10, 20)
+    obs, _ = env.reset(seed=1)
+    o.reset(seeds)
+    assert obs.shape == (B, 24, 34, 3) and obs.dtype == np.uint8  # tests/test_wrappers: RGB shape (24, 34, 3)
+    np.testing.assert_array_equal(obs, o.observe(po.OBS_RGB))
+    rng = np.random.default_rng(2)
+    for t in range(40):
+        a = rng.integers(0, 8, B)
+        obs, *_ = env.step(a)
+        o.step(a, autoreset=po.AUTORESET_SAME_STEP)
+        np.testing.assert_array_equal(obs, o.observe(po.OBS_RGB))
+    env.close()
+    env = TetrisVectorEnv(B, observation="placement_boards", grouped=True, autoreset_mode="same_step")
+    o = po.OracleBatch(B, 10, 20)
+    obs, info = env.reset(seed=1)
+    o.reset(seeds)
+    assert obs.shape == (B, 40, 24, 18)  # tests/test_grouped_env/observation: (40, 24, 18)
+    for t in range(20):
+        om, ob = o.grouped_enumerate(boards=True)
+        np.testing.assert_array_equal(obs, ob)
+        np.testing.assert_array_equal(info["action_mask"], om)
+        a = np.array([rng.choice(np.flatnonzero(m)) for m in om])
+        obs, rew, term, trunc, info = env.step(a)
+        o.grouped_step(a, autoreset=po.AUTORESET_SAME_STEP)
     env.close()

@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libtetris_gym_hip.so")
 
 RULESET_NUMPY, RULESET_FUNCTIONAL = 0, 1
-OBS_NONE, OBS_BOARD, OBS_DICT, OBS_FN = 0, 1, 2, 3
+OBS_NONE, OBS_BOARD, OBS_DICT, OBS_FN, OBS_RGB = 0, 1, 2, 3, 4
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = 0, 1, 2
 ACTIONS_BASE, ACTIONS_GROUPED = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1

@@ -201,6 +201,7 @@ size_t obs_bytes_per_env(const tg_config* c) {
     case TG_OBS_BOARD:
     case TG_OBS_FN: return cells;
     case TG_OBS_DICT: return 2 * pc + 16 + 16 * (size_t)c->queue_size;
+    case TG_OBS_RGB: return 3 * (size_t)(c->height + 4) * (size_t)(c->width + 8 + 4 * (c->queue_size > 1 ? c->queue_size : 1));
     default: return 0;
   }
 }
@@ -425,7 +426,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     return fail(nullptr, TG_EINVAL, "tg_create: batch*width*height must stay below 2^31 (32-bit slab offsets)");
   if (cfg->ruleset != TG_RULESET_NUMPY && cfg->ruleset != TG_RULESET_FUNCTIONAL)
     return fail(nullptr, TG_EINVAL, "tg_create: unknown ruleset %d", cfg->ruleset);
-  if (cfg->obs_mode < TG_OBS_NONE || cfg->obs_mode > TG_OBS_FN)
+  if (cfg->obs_mode < TG_OBS_NONE || cfg->obs_mode > TG_OBS_RGB)
     return fail(nullptr, TG_EINVAL, "tg_create: unknown obs_mode %d", cfg->obs_mode);
   if (cfg->autoreset < TG_AUTORESET_NONE || cfg->autoreset > TG_AUTORESET_NEXT_STEP)
     return fail(nullptr, TG_EINVAL, "tg_create: unknown autoreset mode %d", cfg->autoreset);
@@ -434,8 +435,8 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   if (cfg->ruleset == TG_RULESET_FUNCTIONAL && cfg->queue_size != 7)
     return fail(nullptr, TG_EUNSUPPORTED, "tg_create: FUNCTIONAL rule-set needs queue_size 7 (the 7-bag), got %d",
                 cfg->queue_size);
-  if (cfg->obs_mode == TG_OBS_DICT && cfg->ruleset != TG_RULESET_NUMPY)
-    return fail(nullptr, TG_EINVAL, "tg_create: TG_OBS_DICT is the NUMPY rule-set's observation");
+  if ((cfg->obs_mode == TG_OBS_DICT || cfg->obs_mode == TG_OBS_RGB) && cfg->ruleset != TG_RULESET_NUMPY)
+    return fail(nullptr, TG_EINVAL, "tg_create: TG_OBS_DICT / TG_OBS_RGB are observations of the NUMPY rule-set");
   if (cfg->action_set != TG_ACTIONS_BASE && cfg->action_set != TG_ACTIONS_GROUPED)
     return fail(nullptr, TG_EINVAL, "tg_create: unknown action_set %d", cfg->action_set);
   if (cfg->action_set == TG_ACTIONS_GROUPED && cfg->ruleset != TG_RULESET_NUMPY)
@@ -533,7 +534,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
     int want = 1;
     if (const char* e = getenv("TG_STREAMS")) want = atoi(e);
-    if (!h->d_cols || cfg->obs_mode == TG_OBS_DICT || (cfg->flags & TG_FLAG_FINAL_OBS)) want = 1;
+    if (!h->d_cols || cfg->obs_mode == TG_OBS_DICT || cfg->obs_mode == TG_OBS_RGB || (cfg->flags & TG_FLAG_FINAL_OBS)) want = 1;
     while (want > 1 && (B + want - 1) / want < 8192) --want;  // small shards only add launches
     if (want > 1) {
       const int chunk = (int)(((B + want - 1) / want + 127) / 128 * 128);  // RNG workgroups own 128-env ranges
@@ -633,7 +634,7 @@ int tg_reset(tg_handle* h, const uint64_t* seeds, const uint8_t* mask) {
     int rc = launch_prepare_bits(h, p.mask, 0);
     if (rc != TG_OK) return rc;
   }
-  if (h->cfg.obs_mode == TG_OBS_DICT) {
+  if (h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) {
     int rc = launch_observe_dict(h);
     if (rc != TG_OK) return rc;
   }
@@ -666,7 +667,7 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind) {
   }
   h->ring_cur ^= 1;
   HIPCHK(h, hipGetLastError());
-  if (h->cfg.obs_mode == TG_OBS_DICT) return launch_observe_dict(h);
+  if (h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) return launch_observe_dict(h);
   return TG_OK;
 }
 
@@ -683,7 +684,7 @@ int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K) {
       int rc = launch_step_all(h, p);
       if (rc != TG_OK) return rc;
       h->ring_cur ^= 1;
-      if (h->cfg.obs_mode == TG_OBS_DICT) {  // the DICT surface is packed by its own kernel after every transition
+      if (h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) {  // packed by its own kernel after every transition
         rc = launch_observe_dict(h);
         if (rc != TG_OK) return rc;
       }

@@ -976,15 +976,21 @@ struct ObserveParams {
   int ruleset;
 };
 
+// pixel colour table of the reference (envs/tetris.py:45-75: BASE_PIXELS + tetromino colours), r | g << 8 | b << 16
+__constant__ uint32_t c_rgb_lut[9] = {0x000000u, 0x808080u, 0xF0F000u, 0x00F0F0u, 0xF000A0u,
+                                      0x00F000u, 0x0000F0u, 0xF00000u, 0x00A0F0u};
+
 template <int W, int H>
 __global__ __launch_bounds__(kBlock) void observe_kernel(const ObserveParams p) {
   using G = Geo<W, H>;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * G::LDS_SLAB];
+  constexpr int IDS = ((G::HP * (G::WP + 28) + 15) / 16) * 16;  // RGB surface: pixel ids of board | queue/holder strip
+  constexpr int PER_WAVE = G::LDS_SLAB + IDS + 64;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * PER_WAVE];
   const int lane = threadIdx.x & 63;
   const int wave = rfl((int)(threadIdx.x >> 6));
   const int env = blockIdx.x * kWavesPerBlock + wave;
   if (env >= p.batch) return;
-  uint8_t* slab = lds + wave * G::LDS_SLAB;
+  uint8_t* slab = lds + wave * PER_WAVE;
   uint32_t* slab_dw = reinterpret_cast<uint32_t*>(slab);
   const uint32_t* gboard = reinterpret_cast<const uint32_t*>(p.board + (size_t)env * G::CELLS);
 #pragma unroll
@@ -1000,6 +1006,52 @@ __global__ __launch_bounds__(kBlock) void observe_kernel(const ObserveParams p) 
   if (p.obs_mode == TG_OBS_BOARD || p.obs_mode == TG_OBS_FN) {
     const bool show = p.ruleset == TG_RULESET_NUMPY ? !coll : !(s.flags & TG_F_GAME_OVER);
     emit_obs<W, H>(slab, lane, p.obs + (size_t)env * G::CELLS, p.obs_mode, show, shape, s.x, s.y, s.val);
+    return;
+  }
+  if (p.obs_mode == TG_OBS_RGB) {
+    // RgbObservation (wrappers/observation.py:38-74): stack = hstack(board_obs, vstack(queue_obs, ones, holder_obs))
+    // with the strip as wide as the queue; rgb = colours[stack].  Pixel ids are staged in LDS, then the image leaves
+    // as dwords (3 bytes per pixel, coalesced).
+    constexpr int WP = G::WP, HP = G::HP;
+    const int Q = p.queue_size;
+    const int ML = 4 * (Q > 1 ? Q : 1), WS = WP + ML, NPX = HP * WS;
+    uint8_t* ids = slab + G::LDS_SLAB;
+    uint32_t* lut = reinterpret_cast<uint32_t*>(ids + IDS);
+    if (lane < 9) lut[lane] = c_rgb_lut[lane];
+    for (int i = lane; i < NPX; i += 64) {
+      const int R = i / WS, C = i - R * WS;
+      uint32_t id = 1;
+      if (C < WP) {
+        const int col = C - 4;
+        const bool inb = (unsigned)col < (unsigned)W && R < H;
+        id = inb ? (uint32_t)slab[inb ? R * W + col : 0] : 1u;
+        const int k = R - s.y, c = C - s.x;
+        if (!coll && (unsigned)k < 4u && (unsigned)c < 4u && ((shape >> (4 * k + c)) & 1u)) id = (id + (uint32_t)s.val) & 0xFFu;
+      } else {
+        const int cc = C - WP;
+        if (R < 4) {  // queue strip: next pieces at rotation 0, values id + 2
+          const int q = cc >> 2, c = cc & 3;
+          if (q < Q) {
+            const int t = (int)((s.queue >> (8 * q)) & 0xFF);
+            id = ((c_shapes.mask[t < 7 ? t : 0][0] >> (4 * R + c)) & 1u) ? (uint32_t)(t + 2) : 0u;
+          }
+        } else if (R >= HP - 4 && cc < 4) {  // holder: ones when empty, else the held matrix (keeps rotation and values)
+          if (s.hp != TG_NONE) id = ((c_shapes.mask[s.hp][s.hr] >> (4 * (R - (HP - 4)) + cc)) & 1u) ? (uint32_t)s.hv : 0u;
+        }
+      }
+      ids[i] = (uint8_t)(id <= 8 ? id : 8);
+    }
+    wave_sync();
+    uint32_t* dst = reinterpret_cast<uint32_t*>(p.obs + (size_t)env * (size_t)NPX * 3);
+    for (int j = lane; j < NPX * 3 / 4; j += 64) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int b = 4 * j + t, px = b / 3, ch = b - 3 * px;
+        v |= ((lut[ids[px]] >> (8 * ch)) & 0xFFu) << (8 * t);
+      }
+      dst[j] = v;
+    }
     return;
   }
   if (p.obs_mode != TG_OBS_DICT) return;

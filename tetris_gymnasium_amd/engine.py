@@ -117,6 +117,8 @@ class Engine:
             holder = flat[o:o + B * pp].reshape(B, self.P, self.P); o += B * pp
             queue = flat[o:o + B * pp * self.Q].reshape(B, self.P, self.P * self.Q)
             return {"board": board, "active_tetromino_mask": mask, "holder": holder, "queue": queue}
+        if self.obs_mode == N.OBS_RGB:
+            return self._fetch(which, np.empty((self.B, self.Hp, self.Wp + self.P * max(1, self.Q), 3), np.uint8))
         raise EngineError("engine was created with obs_mode NONE")
 
     # -- grouped action surface (wrappers/grouped.py) ---------------------------------------------

@@ -16,7 +16,8 @@ from . import _native as N
 from ._gym_compat import HAVE_GYMNASIUM, VectorEnvBase, spaces
 from .engine import Engine
 
-_OBS = {"dict": N.OBS_DICT, "board": N.OBS_BOARD, "functional": N.OBS_FN, "placement_features": N.OBS_NONE}
+_OBS = {"dict": N.OBS_DICT, "board": N.OBS_BOARD, "functional": N.OBS_FN, "placement_features": N.OBS_NONE,
+        "rgb": N.OBS_RGB, "placement_boards": N.OBS_NONE}
 _AUTORESET = {"next_step": N.AUTORESET_NEXT_STEP, "same_step": N.AUTORESET_SAME_STEP, "disabled": N.AUTORESET_NONE}
 
 
@@ -82,6 +83,15 @@ class TetrisVectorEnv(VectorEnvBase):
             if not grouped:
                 raise ValueError("observation='placement_features' needs grouped=True")
             self.single_observation_space = spaces.Box(low=0, high=255, shape=(4 * width, width + 3), dtype=np.uint8)
+        elif observation == "rgb":
+            # RgbObservation(env) (wrappers/observation.py:11-74; examples/train_ppo.py:96-110)
+            self.single_observation_space = spaces.Box(low=0, high=255, shape=(hp, wp + p * max(1, queue_size), 3),
+                                                       dtype=np.uint8)
+        elif observation == "placement_boards":
+            # GroupedActionsObservations(env) without observation wrappers (wrappers/grouped.py:76-84, 124-207)
+            if not grouped:
+                raise ValueError("observation='placement_boards' needs grouped=True")
+            self.single_observation_space = spaces.Box(low=0, high=9, shape=(4 * width, hp, wp), dtype=np.uint8)
         else:
             self.single_observation_space = spaces.Box(low=-1, high=1, shape=(height, width), dtype=np.int8)
         if HAVE_GYMNASIUM:  # pragma: no cover - depends on the environment
@@ -100,6 +110,8 @@ class TetrisVectorEnv(VectorEnvBase):
             parts = [e.features() for e in self.engines]
             self._cur_feats = np.concatenate([p[1] for p in parts])
             return np.concatenate([p[0] for p in parts])
+        if self.obs_kind == "placement_boards":
+            return np.concatenate([e.placement_boards()[1] for e in self.engines])
         parts = [e.observation() for e in self.engines]
         if isinstance(parts[0], dict):
             return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
