@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--width", type=int, default=10)
     ap.add_argument("--height", type=int, default=20)
-    ap.add_argument("--obs", choices=["board", "dict", "fn", "none"], default="board")
+    ap.add_argument("--obs", choices=["board", "dict", "fn", "none", "rgb"], default="board")
     ap.add_argument("--ruleset", choices=["numpy", "functional"], default="numpy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config5", action="store_true",
@@ -141,7 +141,7 @@ def main():
     if args.config5:
         W, H, Q = 20, 40, 7
     ruleset = N.RULESET_NUMPY if args.ruleset == "numpy" else N.RULESET_FUNCTIONAL
-    obs_mode = {"board": N.OBS_BOARD, "dict": N.OBS_DICT, "fn": N.OBS_FN, "none": N.OBS_NONE}[args.obs]
+    obs_mode = {"board": N.OBS_BOARD, "dict": N.OBS_DICT, "fn": N.OBS_FN, "none": N.OBS_NONE, "rgb": N.OBS_RGB}[args.obs]
     n_act = 8 if ruleset == N.RULESET_NUMPY else 7
     lo, hi, seeds = D.shard(B)
     e = Engine(B, W, H, ruleset=ruleset, queue_size=(Q if ruleset == N.RULESET_NUMPY else 7), obs_mode=obs_mode,

@@ -201,8 +201,10 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
 /* Re-pack the observation buffer from the current state without stepping (after tg_set_state). */
 int tg_observe(tg_handle* h);
 
-/* Grouped action surface: recompute TG_BUF_LEGAL_MASK (and, if boards_dev != NULL, write all 4*W
- * placement boards u8 [B][4W][Hp][Wp] there) for the current state (wrappers/grouped.py:124-207). */
+/* Grouped action surface: recompute TG_BUF_LEGAL_MASK and, if boards_dev != NULL, write the wrapper's observation —
+ * all 4*W placement boards u8 [B][4W][Hp][Wp] (rotate, centre, hard drop from y = 0, project, clear rows; illegal
+ * placement = all ones, game-over placement = all zeros) — into that caller-owned DEVICE buffer, for the current
+ * state (wrappers/grouped.py:124-207).  HBM-write bound: 4W*Hp*Wp bytes per env (17 280 B at 10x20). */
 int tg_grouped_enumerate(tg_handle* h, uint8_t* boards_dev);
 
 /* Grouped action surface: draw one action per env uniformly from its legal mask into TG_BUF_ACTIONS (device-side

@@ -111,7 +111,8 @@ void launch_placements(const tg::PlacementParams& p, hipStream_t s) {
 }
 template <int W, int H>
 void launch_observe(const tg::ObserveParams& p, hipStream_t s) {
-  hipLaunchKernelGGL((tg::observe_kernel<W, H>), dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p);
+  const int per_block = tg::kWavesPerBlock * tg::kObserveEnvsPerWave;
+  hipLaunchKernelGGL((tg::observe_kernel<W, H>), dim3((p.batch + per_block - 1) / per_block), dim3(tg::kBlock), 0, s, p);
 }
 
 bool find_launchers(int W, int H, int ruleset, Launchers* out) {

@@ -980,27 +980,22 @@ struct ObserveParams {
 __constant__ uint32_t c_rgb_lut[9] = {0x000000u, 0x808080u, 0xF0F000u, 0x00F0F0u, 0xF000A0u,
                                       0x00F000u, 0x0000F0u, 0xF00000u, 0x00A0F0u};
 
+constexpr int kObserveEnvsPerWave = 4;  // envs a wave handles back to back, all their loads issued up front
+
 template <int W, int H>
-__global__ __launch_bounds__(kBlock) void observe_kernel(const ObserveParams p) {
+struct ObserveGeo {
   using G = Geo<W, H>;
-  constexpr int IDS = ((G::HP * (G::WP + 28) + 15) / 16) * 16;  // RGB surface: pixel ids of board | queue/holder strip
-  constexpr int PER_WAVE = G::LDS_SLAB + IDS + 64;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * PER_WAVE];
-  const int lane = threadIdx.x & 63;
-  const int wave = rfl((int)(threadIdx.x >> 6));
-  const int env = blockIdx.x * kWavesPerBlock + wave;
-  if (env >= p.batch) return;
-  uint8_t* slab = lds + wave * PER_WAVE;
-  uint32_t* slab_dw = reinterpret_cast<uint32_t*>(slab);
-  const uint32_t* gboard = reinterpret_cast<const uint32_t*>(p.board + (size_t)env * G::CELLS);
-#pragma unroll
-  for (int k = 0; k < G::DPL; ++k) {
-    const int idx = lane + 64 * k;
-    if (idx < G::NDW) slab_dw[idx] = gboard[idx];
-  }
-  EnvS s;
-  rec_unpack(s, p.rec + (size_t)env * 8);
-  wave_sync();
+  static constexpr int IDS = ((G::HP * (G::WP + 28) + 15) / 16) * 16;  // image ids: padded board (+ RGB: queue/holder strip)
+  static constexpr int MSK = ((G::HP * G::WP + 15) / 16) * 16;         // DICT: active_tetromino_mask
+  static constexpr int PER_WAVE = G::LDS_SLAB + IDS + MSK + 64;
+};
+
+// one env's observation from its slab (already staged in LDS) and record
+template <int W, int H>
+__device__ __forceinline__ void observe_env(const ObserveParams& p, const int env, const int lane, uint8_t* slab,
+                                            const EnvS& s) {
+  using G = Geo<W, H>;
+  constexpr int IDS = ObserveGeo<W, H>::IDS, MSK = ObserveGeo<W, H>::MSK;
   const uint32_t shape = c_shapes.mask[s.piece][s.rot];
   const bool coll = test1<W, H>(slab, lane, shape, s.x, s.y);
   if (p.obs_mode == TG_OBS_BOARD || p.obs_mode == TG_OBS_FN) {
@@ -1008,85 +1003,82 @@ __global__ __launch_bounds__(kBlock) void observe_kernel(const ObserveParams p) 
     emit_obs<W, H>(slab, lane, p.obs + (size_t)env * G::CELLS, p.obs_mode, show, shape, s.x, s.y, s.val);
     return;
   }
-  if (p.obs_mode == TG_OBS_RGB) {
-    // RgbObservation (wrappers/observation.py:38-74): stack = hstack(board_obs, vstack(queue_obs, ones, holder_obs))
-    // with the strip as wide as the queue; rgb = colours[stack].  Pixel ids are staged in LDS, then the image leaves
-    // as dwords (3 bytes per pixel, coalesced).
-    constexpr int WP = G::WP, HP = G::HP;
-    const int Q = p.queue_size;
-    const int ML = 4 * (Q > 1 ? Q : 1), WS = WP + ML, NPX = HP * WS;
-    uint8_t* ids = slab + G::LDS_SLAB;
-    uint32_t* lut = reinterpret_cast<uint32_t*>(ids + IDS);
-    if (lane < 9) lut[lane] = c_rgb_lut[lane];
-    for (int i = lane; i < NPX; i += 64) {
-      const int R = i / WS, C = i - R * WS;
-      uint32_t id = 1;
-      if (C < WP) {
-        const int col = C - 4;
-        const bool inb = (unsigned)col < (unsigned)W && R < H;
-        id = inb ? (uint32_t)slab[inb ? R * W + col : 0] : 1u;
-        const int k = R - s.y, c = C - s.x;
-        if (!coll && (unsigned)k < 4u && (unsigned)c < 4u && ((shape >> (4 * k + c)) & 1u)) id = (id + (uint32_t)s.val) & 0xFFu;
-      } else {
-        const int cc = C - WP;
-        if (R < 4) {  // queue strip: next pieces at rotation 0, values id + 2
-          const int q = cc >> 2, c = cc & 3;
-          if (q < Q) {
-            const int t = (int)((s.queue >> (8 * q)) & 0xFF);
-            id = ((c_shapes.mask[t < 7 ? t : 0][0] >> (4 * R + c)) & 1u) ? (uint32_t)(t + 2) : 0u;
-          }
-        } else if (R >= HP - 4 && cc < 4) {  // holder: ones when empty, else the held matrix (keeps rotation and values)
-          if (s.hp != TG_NONE) id = ((c_shapes.mask[s.hp][s.hr] >> (4 * (R - (HP - 4)) + cc)) & 1u) ? (uint32_t)s.hv : 0u;
-        }
-      }
-      ids[i] = (uint8_t)(id <= 8 ? id : 8);
+  if (p.obs_mode != TG_OBS_RGB && p.obs_mode != TG_OBS_DICT) return;
+  // Both image surfaces start from the padded board with the projected piece (envs/tetris.py:543-564), staged in LDS
+  // by regions (no per-byte index arithmetic): bedrock fill, playfield cells, piece cells — with row stride RS = the
+  // image width (RGB: board | queue/holder strip; DICT: the padded board itself).
+  constexpr int WP = G::WP, HP = G::HP, PC = WP * HP;
+  const int Q = p.queue_size;
+  const bool rgb = p.obs_mode == TG_OBS_RGB;
+  const int ML = 4 * (Q > 1 ? Q : 1);
+  const int RS = rgb ? WP + ML : WP;
+  const int NPX = HP * RS;
+  uint8_t* img = slab + G::LDS_SLAB;
+  uint8_t* msk = img + IDS;
+  uint32_t* lut = reinterpret_cast<uint32_t*>(msk + MSK);
+  if (lane < 9) lut[lane] = c_rgb_lut[lane];
+  for (int i = lane * 16; i < IDS; i += 1024) *reinterpret_cast<uint4*>(img + i) = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+  if (!rgb)
+    for (int i = lane * 16; i < MSK; i += 1024) *reinterpret_cast<uint4*>(msk + i) = make_uint4(0u, 0u, 0u, 0u);
+  wave_sync();
+  for (int i = lane; i < G::CELLS; i += 64) {
+    const int R = i / W, c = i - R * W;
+    img[R * RS + 4 + c] = slab[i];
+  }
+  if (rgb) {
+    // wrappers/observation.py:38-74: queue strip (rotation 0, values id + 2) on top, holder at the bottom (ones when
+    // empty, else the held matrix with its rotation and values), ones in between (already filled)
+    for (int i = lane; i < 16 * Q; i += 64) {
+      const int q = i >> 4, R = (i >> 2) & 3, c = i & 3;
+      const int t = (int)((s.queue >> (8 * q)) & 0xFF);
+      img[R * RS + WP + 4 * q + c] = ((c_shapes.mask[t < 7 ? t : 0][0] >> (4 * R + c)) & 1u) ? (uint8_t)(t + 2) : (uint8_t)0;
     }
-    wave_sync();
+    if (lane < 16 && s.hp != TG_NONE)
+      img[(HP - 4 + (lane >> 2)) * RS + WP + (lane & 3)] = ((c_shapes.mask[s.hp][s.hr] >> lane) & 1u) ? (uint8_t)s.hv : (uint8_t)0;
+  } else {
+    // active_tetromino_mask: the n x n bounding box of the native matrix (envs/tetris.py:572-576)
+    const int n = c_shapes.n[s.piece];
+    const int k = lane >> 2, c = lane & 3;
+    if (lane < 16 && k < n && c < n && s.y + k < HP && s.x + c < WP) msk[(s.y + k) * WP + s.x + c] = 1;
+  }
+  wave_sync();
+  if (!coll && lane < 16 && ((shape >> lane) & 1u)) {  // free cells only: board + matrix == matrix value
+    const int a = (s.y + (lane >> 2)) * RS + s.x + (lane & 3);
+    img[a] = (uint8_t)(img[a] + s.val);
+  }
+  wave_sync();
+  if (rgb) {
+    // four pixels → three dwords; the image leaves as one contiguous, coalesced stream
     uint32_t* dst = reinterpret_cast<uint32_t*>(p.obs + (size_t)env * (size_t)NPX * 3);
-    for (int j = lane; j < NPX * 3 / 4; j += 64) {
-      uint32_t v = 0;
+    for (int q = lane; q < NPX / 4; q += 64) {
+      const uint32_t ids = *reinterpret_cast<const uint32_t*>(img + 4 * q);
+      uint32_t c4[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int b = 4 * j + t, px = b / 3, ch = b - 3 * px;
-        v |= ((lut[ids[px]] >> (8 * ch)) & 0xFFu) << (8 * t);
+        const uint32_t id = (ids >> (8 * t)) & 0xFFu;
+        c4[t] = lut[id <= 8 ? id : 8];
       }
-      dst[j] = v;
+      dst[3 * q] = c4[0] | (c4[1] << 24);
+      dst[3 * q + 1] = (c4[1] >> 8) | (c4[2] << 16);
+      dst[3 * q + 2] = (c4[2] >> 16) | (c4[3] << 8);
     }
     return;
   }
-  if (p.obs_mode != TG_OBS_DICT) return;
-  constexpr int WP = G::WP, HP = G::HP, PC = WP * HP;
+  // DICT layout: board[B][Hp][Wp] | mask[B][Hp][Wp] | holder[B][4][4] | queue[B][4][4*Q]  (envs/tetris.py:566-615)
   const size_t B = (size_t)p.batch;
   uint8_t* o_board = p.obs + (size_t)env * PC;
   uint8_t* o_mask = p.obs + B * PC + (size_t)env * PC;
   uint8_t* o_holder = p.obs + 2 * B * PC + (size_t)env * 16;
-  const int Q = p.queue_size;
   uint8_t* o_queue = p.obs + 2 * B * PC + B * 16 + (size_t)env * 16 * Q;
-  const int n = c_shapes.n[s.piece];
-  // padded board with the projected piece, and the bounding-box mask; 4 bytes per lane per pass
-  for (int base = 0; base < PC; base += 256) {
-    const int i0 = base + lane * 4;
-    uint32_t vb = 0, vm = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = i0 + j;
-      const int R = i / WP, Cc = i - R * WP;
-      const int col = Cc - 4;
-      const bool inb = (unsigned)col < (unsigned)W && R < H;
-      uint32_t b = inb ? (uint32_t)slab[inb ? R * W + col : 0] : 1u;
-      const int k = R - s.y, c = Cc - s.x;
-      const bool inbox = (unsigned)k < 4u && (unsigned)c < 4u;
-      if (!coll && inbox && ((shape >> (4 * k + c)) & 1u)) b = (b + (uint32_t)s.val) & 0xFFu;
-      const uint32_t mk = ((unsigned)k < (unsigned)n && (unsigned)c < (unsigned)n) ? 1u : 0u;
-      vb |= b << (8 * j);
-      vm |= mk << (8 * j);
+  if constexpr (PC % 16 == 0) {
+    for (int i = lane * 16; i < PC; i += 1024) {
+      *reinterpret_cast<uint4*>(o_board + i) = *reinterpret_cast<const uint4*>(img + i);
+      *reinterpret_cast<uint4*>(o_mask + i) = *reinterpret_cast<const uint4*>(msk + i);
     }
-    if (i0 + 3 < PC) {
-      *reinterpret_cast<uint32_t*>(o_board + i0) = vb;
-      *reinterpret_cast<uint32_t*>(o_mask + i0) = vm;
-    } else {
-      for (int j = 0; j < 4; ++j)
-        if (i0 + j < PC) { o_board[i0 + j] = (uint8_t)(vb >> (8 * j)); o_mask[i0 + j] = (uint8_t)(vm >> (8 * j)); }
+  } else {
+    for (int i = lane * 4; i < PC; i += 256) {
+      *reinterpret_cast<uint32_t*>(o_board + i) = *reinterpret_cast<const uint32_t*>(img + i);
+      *reinterpret_cast<uint32_t*>(o_mask + i) = *reinterpret_cast<const uint32_t*>(msk + i);
     }
   }
   if (lane < 16) {  // holder: ones when empty, else the held matrix (keeps its rotation and values)
@@ -1100,6 +1092,48 @@ __global__ __launch_bounds__(kBlock) void observe_kernel(const ObserveParams p) 
     const int t = (int)((s.queue >> (8 * q)) & 0xFF);
     const uint32_t m = c_shapes.mask[t < 7 ? t : 0][0];
     o_queue[i] = ((m >> (4 * row + c)) & 1u) ? (uint8_t)(t + 2) : (uint8_t)0;
+  }
+}
+
+
+// One-env-per-wave kernels of 65 536 waves are bound by waves x load latency (measured: 30 µs for the 62 MB DICT
+// surface); here a wave owns kObserveEnvsPerWave consecutive envs and has all their slab / record loads in flight
+// before the first one is packed.
+template <int W, int H>
+__global__ __launch_bounds__(kBlock) void observe_kernel(const ObserveParams p) {
+  using G = Geo<W, H>;
+  constexpr int NE = kObserveEnvsPerWave;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock * ObserveGeo<W, H>::PER_WAVE];
+  const int lane = threadIdx.x & 63;
+  const int wave = rfl((int)(threadIdx.x >> 6));
+  const int env0 = (blockIdx.x * kWavesPerBlock + wave) * NE;
+  if (env0 >= p.batch) return;
+  uint8_t* slab = lds + wave * ObserveGeo<W, H>::PER_WAVE;
+  uint32_t* slab_dw = reinterpret_cast<uint32_t*>(slab);
+  uint32_t bv[NE][G::DPL];
+  uint4 ra[NE], rb[NE];
+#pragma unroll
+  for (int j = 0; j < NE; ++j) {
+    const int env = env0 + j < p.batch ? env0 + j : p.batch - 1;
+    const uint32_t* gboard = reinterpret_cast<const uint32_t*>(p.board + (size_t)env * G::CELLS);
+#pragma unroll
+    for (int k = 0; k < G::DPL; ++k) bv[j][k] = gboard[lane + 64 * k];  // (buffers carry tail padding: unmasked)
+    const uint4* r4 = reinterpret_cast<const uint4*>(p.rec + (size_t)env * 8);
+    ra[j] = r4[0];
+    rb[j] = r4[1];
+  }
+#pragma unroll
+  for (int j = 0; j < NE; ++j) {
+    if (env0 + j >= p.batch) break;
+#pragma unroll
+    for (int k = 0; k < G::DPL; ++k) slab_dw[lane + 64 * k] = bv[j][k];
+    const uint32_t d[8] = {rfl(ra[j].x), rfl(ra[j].y), rfl(ra[j].z), rfl(ra[j].w),
+                           rfl(rb[j].x), rfl(rb[j].y), rfl(rb[j].z), rfl(rb[j].w)};
+    EnvS s;
+    raw_to_env(s, d);
+    wave_sync();
+    observe_env<W, H>(p, env0 + j, lane, slab, s);
+    wave_sync();
   }
 }
 
@@ -1130,27 +1164,56 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {  // murmur3 finaliser
   return x;
 }
 
+// Legal columns of one (piece, rotation) form a range: the placement x = col + padding - n/2 is legal iff every
+// occupied matrix column c satisfies 0 <= col - n/2 + c < W  ⇔  col in [n/2 - cmin, W - 1 + n/2 - cmax].
 __global__ __launch_bounds__(256) void grouped_kernel(const GroupedParams p) {
   const int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= p.batch) return;
   const uint32_t d0 = p.rec[(size_t)env * 8];
   const int piece = d0 & 0xFF, rot = (d0 >> 8) & 3;
-  const int NA = 4 * p.width;
-  int n_legal = 0;
-  for (int a = 0; a < NA; ++a) {
-    const bool l = grouped_legal(p.shapes, piece, rot, a, p.width);
-    if (p.mask) p.mask[(size_t)env * NA + a] = l ? 1 : 0;
-    n_legal += l ? 1 : 0;
+  const int W = p.width, NA = 4 * W;
+  const int n_half = piece == 0 ? 2 : 1;
+  int lo[4], hi[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t sh = (uint32_t)(p.shapes[piece] >> (16 * ((rot + r) & 3))) & 0xFFFFu;
+    const uint32_t m = (sh | (sh >> 4) | (sh >> 8) | (sh >> 12)) & 0xFu;  // occupied matrix columns
+    const int cmin = __builtin_ctz(m), cmax = 31 - __builtin_clz(m);
+    lo[r] = n_half - cmin > 0 ? n_half - cmin : 0;
+    hi[r] = W - 1 + n_half - cmax < W - 1 ? W - 1 + n_half - cmax : W - 1;
+  }
+  if (p.mask) {
+    uint32_t* mrow = reinterpret_cast<uint32_t*>(p.mask + (size_t)env * NA);  // 4 flags of a column = one dword
+    for (int c = 0; c < W; ++c) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v |= (c >= lo[r] && c <= hi[r] ? 1u : 0u) << (8 * r);
+      mrow[c] = v;
+    }
   }
   if (p.actions) {
+    int n_legal = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) n_legal += hi[r] >= lo[r] ? hi[r] - lo[r] + 1 : 0;
     int pick = 0;
     if (n_legal > 0) {
+      // the k-th legal action in increasing action id (= column-major, rotation-minor) order
       int k = (int)(mix32(mix32(p.seed ^ (uint32_t)env * 0x9E3779B9u) + p.counter) % (uint32_t)n_legal);
-      for (int a = 0; a < NA; ++a)
-        if (grouped_legal(p.shapes, piece, rot, a, p.width)) {
-          if (k == 0) { pick = a; break; }
-          --k;
+      for (int c = 0; c < W; ++c) {
+        int nc = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nc += (c >= lo[r] && c <= hi[r]) ? 1 : 0;
+        if (k < nc) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (c >= lo[r] && c <= hi[r]) {
+              if (k == 0) pick = c * 4 + r;
+              --k;
+            }
+          break;
         }
+        k -= nc;
+      }
     }
     p.actions[env] = pick;
   }
