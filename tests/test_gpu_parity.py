@@ -301,3 +301,54 @@ def test_sharded_streams_engine_vs_oracle(ruleset, B, monkeypatch):
             np.testing.assert_array_equal(ge[k], go[k], err_msg=f"rng.{k}")
     e.dev_free(d)
     e.close()
+
+
+@pytest.mark.parametrize("fuse", [1, 2, 4, 8])
+@pytest.mark.parametrize("ruleset,W,H,Q,B,autoreset,grouped", [
+    (N.RULESET_NUMPY, 10, 20, 4, 1000, N.AUTORESET_SAME_STEP, False),
+    (N.RULESET_NUMPY, 10, 20, 4, 4096, N.AUTORESET_NEXT_STEP, False),
+    (N.RULESET_NUMPY, 10, 20, 7, 700, N.AUTORESET_SAME_STEP, False),   # queue 7: resets consume two shuffles
+    (N.RULESET_NUMPY, 20, 40, 7, 300, N.AUTORESET_SAME_STEP, True),    # grouped hard drops: a lock every transition
+    (N.RULESET_NUMPY, 6, 12, 2, 500, N.AUTORESET_NONE, False),
+    (N.RULESET_FUNCTIONAL, 10, 20, 7, 1000, N.AUTORESET_SAME_STEP, False),
+])
+def test_fused_rollout_equals_single_transitions(fuse, ruleset, W, H, Q, B, autoreset, grouped, monkeypatch):
+    """tg_step_k keeps state on chip across up to TG_FUSE transitions per launch (one barrier per transition, the
+    observation of every transition still written): final observation, outputs, state, generator and episode
+    statistics must equal K single transitions of the oracle, for K that are and are not multiples of the group."""
+    monkeypatch.setenv("TG_FUSE", str(fuse))
+    numpy_rules = ruleset == N.RULESET_NUMPY
+    obs = N.OBS_BOARD if numpy_rules else N.OBS_FN
+    po_obs = po.OBS_BOARD if numpy_rules else po.OBS_FN
+    na = 4 * W if grouped else (8 if numpy_rules else 7)
+    e = Engine(B, W, H, ruleset=ruleset, queue_size=Q, obs_mode=obs, autoreset=autoreset, grouped=grouped, episode_stats=True)
+    o = po.OracleBatch(B, W, H, ruleset, True, Q)
+    seeds = np.arange(77, 77 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(fuse * 100 + W)
+    ret = np.zeros(B); ln = np.zeros(B, np.int64)
+    for K in (1, 2, 3, 5, 8, 13, 40, 64):
+        acts = rng.integers(0, na, (K, B)).astype(np.int8)
+        d = e.dev_alloc(acts.nbytes)
+        e.dev_upload(d, acts)
+        e.step_k_device(d, K)
+        for k in range(K):
+            if grouped:
+                ro, to, lo, _ = o.grouped_step(acts[k].astype(np.int32), autoreset=autoreset)
+            else:
+                ro, to, lo = o.step(acts[k].astype(np.int32), autoreset=autoreset)
+        got = e.fetch_outputs()
+        np.testing.assert_array_equal(got[0], ro, err_msg=f"reward K={K}")
+        np.testing.assert_array_equal(got[1], to, err_msg=f"terminated K={K}")
+        np.testing.assert_array_equal(got[2], lo, err_msg=f"lines K={K}")
+        np.testing.assert_array_equal(e.observation(), o.observe(po_obs), err_msg=f"obs K={K}")
+        ge, go = _cmp_state(e, o, f"K={K}")
+        if numpy_rules:
+            for f in ("state_lo", "state_hi", "inc_lo", "inc_hi", "uinteger", "has_uint32"):
+                np.testing.assert_array_equal(ge[f], go[f], err_msg=f"rng.{f} K={K}")
+        e.dev_free(d)
+        if autoreset == N.AUTORESET_NONE:
+            _, term, _ = got
+            if term.any():
+                e.reset(mask=term); o.reset(mask=term)
+    e.close()

@@ -159,6 +159,7 @@ struct tg_handle {
   uint64_t* d_ring = nullptr;  // bits kernel: permutation rings, double-buffered by launch parity [2][B]
   uint8_t* d_hbuf = nullptr;   // bits kernel: consumed counters [2][B]
   int ring_cur = 0;            // parity the next step launch reads
+  int fuse_max = 4;            // TG_FUSE: transitions per launch in tg_step_k (1..8)
   // TG_STREAMS=n (default 1) spreads the step launches of one transition over n streams (contiguous env shards).
   // Kept as a tested knob, off by default — measured on MI355X: every launch costs ≈2.8-3.4 µs of
   // command-processor time whichever stream it is on, so n shards cost n launch floors per transition (8.3 µs →
@@ -300,6 +301,8 @@ tg::KParams step_params(tg_handle* h) {
   p.ring_cur = h->ring_cur;
   p.ring_stride = (uint32_t)h->B;
   p.cols_bytes = (uint32_t)h->L.cols_bytes;
+  p.nsteps = 1;
+  p.act_stride = (uint32_t)h->B;
   return p;
 }
 
@@ -532,6 +535,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     CRCHK(hipStreamSynchronize(h->stream));
   }
   {
+    if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > 8 ? 8 : v); }
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
     int want = 1;
     if (const char* e = getenv("TG_STREAMS")) want = atoi(e);
@@ -676,11 +680,18 @@ int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K) {
   if (!h || !actions_dev || K <= 0) return h ? fail(h, TG_EINVAL, "tg_step_k: bad arguments") : TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   if (h->B % 4 != 0) return fail(h, TG_EINVAL, "tg_step_k: batch must be a multiple of 4 (packed int8 action rows)");
-  auto enqueue = [&]() -> int {  // K transitions, one launch each (per shard)
+  // Transitions per launch: the bits kernel keeps records, masks and slabs on chip across up to TG_FUSE (default 4,
+  // max 8) consecutive transitions of a rollout — one launch floor and one slab round trip per group instead of per
+  // transition.  tg_step always launches one transition.
+  const int fuse_max = h->fuse_max;
+  const bool post_kernel = h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB;
+  const int fuse = (h->d_cols && !post_kernel) ? fuse_max : 1;
+  auto enqueue = [&]() -> int {  // K transitions, `fuse` per launch (per shard)
     tg::KParams p = step_params(h);
     p.act_i8 = 1;
-    for (int k = 0; k < K; ++k) {
+    for (int k = 0; k < K; k += fuse) {
       p.actions = actions_dev + (size_t)k * h->B;
+      p.nsteps = K - k < fuse ? K - k : fuse;
       p.ring_cur = h->ring_cur;
       int rc = launch_step_all(h, p);
       if (rc != TG_OK) return rc;

@@ -76,7 +76,7 @@ struct BitsGeo {
   static constexpr int NIT = (NCH + 63) / 64;
   static constexpr int OFF_TAB = SLABS;             // cell table, column table, cell table (logic wave's copy): 3 x 64 B
   static constexpr int OFF_POST = OFF_TAB + 192;    // uint4 [EPW]: what the stream wave has to do per env
-  static constexpr int OFF_COLS = OFF_POST + EPW * 16;  // T [EPW][CST]: [0] bedrock, [1..W] playfield columns, [W+1] bedrock
+  static constexpr int OFF_COLS = OFF_POST + 2 * EPW * 16;  // (post is double-buffered by transition parity)  // T [EPW][CST]: [0] bedrock, [1..W] playfield columns, [W+1] bedrock
   static constexpr int CST = (W + 2) | 1;           // odd stride: conflict-free for same-index accesses of the 64 lanes
   static constexpr int BYTES = OFF_COLS + EPW * CST * (int)sizeof(T);
   static_assert(W % 2 == 0, "column masks are moved as 8-byte pairs");
@@ -206,6 +206,10 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   const int slot = live ? lane : (int)nlive - 1;  // dead lanes shadow the last live env (identical, benign LDS writes)
   const uint32_t env = base_env + (uint32_t)slot;
   const bool need_slab = p.obs_mode == TG_OBS_BOARD || p.obs_mode == TG_OBS_FN;
+  // p.nsteps consecutive transitions in this launch (tg_step_k): records / masks / slabs stay in registers and LDS in
+  // between, only actions come in and observations go out per transition; one s_barrier per transition, and the
+  // stream wave packs transition k while the logic wave already decides transition k + 1
+  const int nsteps = p.nsteps > 1 ? p.nsteps : 1;
 
 #ifdef TG_PHASE_TIMING
   unsigned long long tstamp[8];  // kept in SGPRs and written at the very end: a store per stamp would itself be waited on
@@ -224,6 +228,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
     const uint32_t ee = on ? e : B - 1u;
     uint64_t ring = bp.ring[(size_t)bp.cur * bp.pstride + ee];
     const int Hn = bp.hbuf[(size_t)bp.cur * bp.pstride + ee];
+    for (int rep = 0; rep < 2; ++rep) {  // (a ring emptied by one launch is refilled completely)
     const int Tn = (int)(ring >> 56);
     const bool need = on && (int)(int8_t)(uint8_t)(Tn - Hn) < 2;
     if (__any(need)) {
@@ -248,6 +253,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
         ring &= ~((0x0FFFFFFFULL << (28 * sl)) | (0xFFULL << 56));
         ring |= ((uint64_t)sig << (28 * sl)) | ((uint64_t)((Tn + 1) & 0xFF) << 56);
       }
+    }
     }
     if (on) bp.ring[(size_t)(1 - bp.cur) * bp.pstride + e] = ring;
     return;
@@ -290,8 +296,14 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
       }
     }
     TG_BITS_STAMP(1);
+    LaneBoard<W, H, 1> bd;
+    bd.my = lds + slot * S;
+    bd.sub = 0;
+    bool dirty_any = false;  // this lane's env changed its slab in some transition of the launch
+    for (int step = 0; step < nsteps; ++step) {
+    const bool last = step == nsteps - 1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();  // the logic wave has published what happened to every env
+    __builtin_amdgcn_s_barrier();  // the logic wave has published what happened to every env in this transition
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 #ifndef TG_NO_PRIO_SWAP
     __builtin_amdgcn_s_setprio(3);  // from here on this wave is the workgroup's critical path
@@ -299,12 +311,10 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
     TG_BITS_STAMP(2);
     // post record of this lane's env: x = lock {cells | val << 16 | place << 24 | clear << 25 | reset << 26},
     // y = lock {x | y << 8}, z = observation {cells | val << 16 | show << 24}, w = observation {x | y << 8}
-    const uint4 po = post[slot];
+    const uint4 po = post[(step & 1) * EPW + slot];
     const bool place = live && ((po.x >> 24) & 1u), do_clear = live && ((po.x >> 25) & 1u), do_reset = live && ((po.x >> 26) & 1u);
     const bool dirty = place || do_reset;
-    LaneBoard<W, H, 1> bd;
-    bd.my = lds + slot * S;
-    bd.sub = 0;
+    dirty_any = dirty_any || dirty;
     if (__any(dirty)) {
       bd.stamp(po.x & 0xFFFFu, (int)(po.y & 0xFFu), (int)((po.y >> 8) & 0xFFu), (po.x >> 16) & 0xFFu,
                RULESET == TG_RULESET_FUNCTIONAL, place);
@@ -323,8 +333,10 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
         for (int i = lane; i < S / 4; i += 64) sw[i] = 0u;
       }
       wave_sync();
+    }
+    if (last && __any(dirty_any)) {
       // board write-back: every changed env's lane copies its own slab (8-byte aligned in LDS and in HBM)
-      if (dirty) {
+      if (dirty_any) {
         const u32x2* src = reinterpret_cast<const u32x2*>(bd.my);
         uint8_t* dst = p.board + (size_t)env * S;
         constexpr int NU = S / 8, UB = NU <= 32 ? NU : 20;  // batches: all reads of a batch in flight before its stores
@@ -346,8 +358,9 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
     }
     TG_BITS_STAMP(3);
     if (need_slab) {
+      const bool show = live && ((po.z >> 24) & 1u);
       bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu),
-               p.obs_mode == TG_OBS_FN ? 0xFFu : ((po.z >> 16) & 0xFFu), false, live && ((po.z >> 24) & 1u));
+               p.obs_mode == TG_OBS_FN ? 0xFFu : ((po.z >> 16) & 0xFFu), false, show);
       wave_sync();
       u32x4* odst = reinterpret_cast<u32x4*>(p.obs + (size_t)base_env * S);
       const bool fn = p.obs_mode == TG_OBS_FN;
@@ -386,6 +399,12 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
         }
       }
     }
+    if (need_slab && !last) {  // the slab in LDS is the board again: the drawn piece only ever covers free cells
+      wave_sync();
+      bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu), 0u, false, live && ((po.z >> 24) & 1u));
+      wave_sync();
+    }
+    }  // transitions
     TG_BITS_STAMP(4);
 #ifdef TG_PHASE_TIMING
     if (p.dbg && lane == 0)
@@ -403,8 +422,21 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   if (lane < 7) { tab_cells = c_cells.cells[lane]; tab_cols = c_colmasks.cols[lane]; }
   const uint4* rec4 = reinterpret_cast<const uint4*>(p.rec) + (size_t)env * 2;
   const uint4 ra = rec4[0], rb = rec4[1];
-  const int action_in = p.act_i8 ? (int)reinterpret_cast<const int8_t*>(p.actions)[env]
-                                 : reinterpret_cast<const int32_t*>(p.actions)[env];
+  // the actions of all transitions of this launch, requested up front (int8 rows: one byte per transition and env)
+  uint64_t apack = 0;
+  int action0 = 0;
+  if (p.act_i8) {
+    uint8_t ab[8];  // unconditional loads (row index clamped): all in flight together, no wait between them
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      ab[k] = reinterpret_cast<const uint8_t*>(p.actions)[(size_t)(k < nsteps ? k : nsteps - 1) * p.act_stride + env];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) apack |= (uint64_t)ab[k] << (8 * k);
+  } else {
+    action0 = reinterpret_cast<const int32_t*>(p.actions)[env];
+  }
+  tg_episode_rec ep{};
+  if (p.episode) ep = p.episode[env];
   uint64_t ring = 0;
   int Hc = 0;
   if (RULESET == TG_RULESET_NUMPY) {
@@ -439,20 +471,25 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   lane_unpack(s, ra, rb);
   const int Q = p.queue_size;
   const int grav = p.gravity;
-  float reward = 0.0f;
-  int lines = 0;
-  bool final_coll = false;
-  // consumer side of the permutation ring (NUMPY).  g = the generator state the reference would hold after the
-  // shuffles consumed so far in this step (loaded lazily: from the ring slot's state on a consumption, from tg_rng_rec
-  // for the rare in-line shuffle)
+  // consumer side of the permutation ring (NUMPY).  Consuming an entry is pure register work (no loads inside the
+  // transition loop: vmcnt is in issue order and a load there would be waited on every transition).  The generator
+  // state the reference would hold afterwards is the state stored with the LAST consumed entry; it is fetched once,
+  // after the loop.  g holds that state only after an in-line shuffle (ring exhausted: rare).
   const int ringT = (int)(ring >> 56);
-  bool consumed = false;
+  bool consumed = false, last_ring = false, g_valid = false, inc_loaded = false;
   BitsRng g;
   g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
   g.uinteger = g.has32 = 0;
   g.loaded = false;
-  bool inc_loaded = false;
   const uint4* rng4 = reinterpret_cast<const uint4*>(p.rng + env);
+  auto load_entry_state = [&](const bool on) {  // state after the last consumed ring entry (index Hc - 1)
+    if (on) {
+      const uint4* a4 = bp.ahead + (size_t)env * 4 + 2 * ((Hc - 1) & 1);
+      const uint4 f0 = a4[0], f1 = a4[1];
+      g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
+      g.uinteger = f1.x; g.has32 = f1.y;
+    }
+  };
   // BagRandomizer reshuffle (components/tetromino_randomizer.py:42-46, 84) / reset shuffle (:87-91) for the lanes in `need`
   auto consume_perm = [&](const bool need, const bool from_identity) {
     if (!__any(need)) return;
@@ -460,12 +497,12 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
     const bool from_ring = need && av > 0;
     const bool fb = need && av <= 0;
     uint32_t sig = (uint32_t)(ring >> (28 * (Hc & 1))) & 0x0FFFFFFFu;
-    if (__any(fb)) {  // rare: ring exhausted (three shuffles within two steps) → shuffle in-line
-      if (fb && !g.loaded) {
+    if (__any(fb)) {  // rare: ring exhausted → shuffle in-line, from the state the generator holds right now
+      load_entry_state(fb && !g_valid && consumed && last_ring);
+      if (fb && !g_valid && !(consumed && last_ring)) {
         const uint4 f0 = rng4[0], f1 = rng4[2];
         g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
         g.uinteger = f1.x; g.has32 = f1.y;
-        g.loaded = true;
       }
       if (fb && !inc_loaded) {
         const uint4 gi = rng4[1];
@@ -473,16 +510,17 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
         inc_loaded = true;
       }
       bits_shuffle_perm(g, sig, fb);
-    }
-    if (from_ring) {  // the slot's state becomes the generator state (stored in D; nothing waits for this load before)
-      const uint4* a4 = bp.ahead + (size_t)env * 4 + 2 * (Hc & 1);
-      const uint4 f0 = a4[0], f1 = a4[1];
-      g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
-      g.uinteger = f1.x; g.has32 = f1.y;
-      g.loaded = true;
+      if (fb) g_valid = true;
     }
     const uint64_t nb = bits_apply_perm(sig, from_identity ? 0x06050403020100ULL : s.bag);
-    if (need) { s.bag = nb; s.bidx = 0; Hc = (Hc + 1) & 0xFF; consumed = true; }
+    if (need) {
+      s.bag = nb; s.bidx = 0; Hc = (Hc + 1) & 0xFF; consumed = true;
+      last_ring = from_ring;
+      if (from_ring) g_valid = false;
+    }
+    // a single-transition launch fetches the entry's state right away (it is only needed after the barrier); inside
+    // a transition loop the fetch is deferred to the end of the launch
+    if (nsteps == 1) load_entry_state(from_ring);
   };
   // BagRandomizer.get_next_tetromino (:65-85): eager reshuffle when the 7th piece is drawn
   auto randomizer_next = [&](const bool on) -> int {
@@ -505,6 +543,12 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   r.loaded = false;
   r.dirty = false;
 
+  bool cols_dirty_any = false;
+  for (int step = 0; step < nsteps; ++step) {
+  const int action_in = p.act_i8 ? (int)(int8_t)(apack >> (8 * step)) : action0;
+  float reward = 0.0f;
+  int lines = 0;
+  bool final_coll = false;
   const bool pending = p.autoreset == TG_AUTORESET_NEXT_STEP && (s.flags & TG_F_PENDING_RESET);
   bool frozen = RULESET == TG_RULESET_FUNCTIONAL && (s.flags & TG_F_GAME_OVER);
   auto colmask = [&](int piece, int rot) -> uint32_t { return (uint32_t)(col_tab[piece] >> (16 * rot)) & 0xFFFFu; };
@@ -809,41 +853,41 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
       final_coll = false;
     }
   }
-  const bool cols_dirty = live && (place || do_reset);
+  cols_dirty_any = cols_dirty_any || (live && (place || do_reset));
   // publish the payload work of this lane's env to the stream wave
   {
     const bool show = live && (RULESET == TG_RULESET_NUMPY ? !final_coll : !(s.flags & TG_F_GAME_OVER));
     const uint32_t ocells = lane_cells(cell_tab_l, s.piece, s.rot);
-    if (live) post[slot] = make_uint4(lock_cells | ((uint32_t)(lock_val & 0xFF) << 16) | ((place ? 1u : 0u) << 24) |
+    if (live) post[(step & 1) * EPW + slot] = make_uint4(lock_cells | ((uint32_t)(lock_val & 0xFF) << 16) | ((place ? 1u : 0u) << 24) |
                                 ((do_clear ? 1u : 0u) << 25) | ((do_reset ? 1u : 0u) << 26),
                             (uint32_t)(lock_x & 0xFF) | ((uint32_t)(lock_y & 0xFF) << 8),
                             ocells | ((uint32_t)(s.val & 0xFF) << 16) | ((show ? 1u : 0u) << 24),
                             (uint32_t)(s.x & 0xFF) | ((uint32_t)(s.y & 0xFF) << 8));
   }
   TG_BITS_STAMP(5);
+  if (pending) {  // the NEXT_STEP reset step belongs to no episode (gymnasium RecordEpisodeStatistics)
+    ep.ret = 0.0f; ep.len = 0;
+  } else {
+    ep.ret += reward;
+    ep.len += 1;
+    if (terminated) { ep.last_ret = ep.ret; ep.last_len = ep.len; ep.ret = 0.0f; ep.len = 0; }
+  }
+  if (step == nsteps - 1 && live)  // the outputs of the LAST transition remain in the buffers
+    st_stream(reinterpret_cast<u32x2*>(p.out + env), u32x2{__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8)});
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
+  }  // transitions
 #ifndef TG_NO_PRIO_SWAP
   __builtin_amdgcn_s_setprio(0);
 #endif
-  // ---- D: per-env stores: outputs, first record half, column masks ----
+  // ---- D: per-env stores: first record half, episode statistics, column masks ----
+  const bool cols_dirty = cols_dirty_any;
   uint4 oa, ob;
   lane_pack(s, oa, ob);
   uint4* rec_out = reinterpret_cast<uint4*>(p.rec) + (size_t)env * 2;
   if (live) {
     TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out), (u32x4{oa.x, oa.y, oa.z, oa.w}));
-    st_stream(reinterpret_cast<u32x2*>(p.out + env), u32x2{__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8)});
-    if (p.episode) {
-      tg_episode_rec ep = p.episode[env];
-      if (pending) {  // the NEXT_STEP reset step belongs to no episode (gymnasium RecordEpisodeStatistics)
-        ep.ret = 0.0f; ep.len = 0;
-      } else {
-        ep.ret += reward;
-        ep.len += 1;
-        if (terminated) { ep.last_ret = ep.ret; ep.last_len = ep.len; ep.ret = 0.0f; ep.len = 0; }
-      }
-      p.episode[env] = ep;
-    }
+    if (p.episode) p.episode[env] = ep;
   }
   if (__any(cols_dirty)) {
     T nv[W];
@@ -865,6 +909,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   // ---- E: generator bookkeeping: the consumed shuffles' end state is what the reference's generator now holds ----
   if (RULESET == TG_RULESET_NUMPY) {
     if (live) bp.hbuf[(size_t)(1 - bp.cur) * bp.pstride + env] = (uint8_t)Hc;
+    if (nsteps > 1) load_entry_state(live && consumed && last_ring);
     if (live && consumed) {
       uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
       rng_out[0] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));

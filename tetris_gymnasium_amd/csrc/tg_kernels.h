@@ -54,6 +54,8 @@ struct KParams {
   int ring_cur;             // bits kernel only: launch parity
   uint32_t ring_stride;     // bits kernel only: elements between the parities of ring / hbuf
   uint32_t cols_bytes;      // bits kernel only: bytes per env of `cols` (host-side shard offsets)
+  int nsteps;               // bits kernel only: transitions per launch (tg_step_k), int8 action rows act_stride apart
+  uint32_t act_stride;
 };
 
 struct ResetParams {

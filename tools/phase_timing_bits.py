@@ -16,7 +16,8 @@ e = Engine(B, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP)
 e.reset(np.arange(1, B + 1, dtype=np.uint64))
 acts = np.random.default_rng(0).integers(0, 8, (80, B)).astype(np.int8)
 d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts)
-e.step_k_device(d, 79); e.sync(); e.step_k_device(d + 79 * B, 1); e.sync()
+KL = int(os.environ.get('TG_LAST_K', '1'))
+e.step_k_device(d, 80 - KL); e.sync(); e.step_k_device(d + (80 - KL) * B, KL); e.sync()
 nb = B // 64
 buf = np.zeros((B // 16, 16), np.uint64)
 e.lib.tg_debug_phase_times.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
