@@ -128,6 +128,10 @@ def main():
     ap.add_argument("--obs", choices=["board", "dict", "fn", "none", "rgb"], default="board")
     ap.add_argument("--ruleset", choices=["numpy", "functional"], default="numpy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse", type=int, default=1,
+                    help="transitions per launch of the timed rollout (TG_FUSE). Default 1: `value` is the "
+                         "one-launch-per-transition number; the fused rollout is reported beside it")
+    ap.add_argument("--no-fused-rollout", action="store_true")
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE config 5: 20x40 board, queue_size 7, grouped hard-drop action set, legal actions sampled on device")
     args = ap.parse_args()
@@ -144,6 +148,7 @@ def main():
     obs_mode = {"board": N.OBS_BOARD, "dict": N.OBS_DICT, "fn": N.OBS_FN, "none": N.OBS_NONE, "rgb": N.OBS_RGB}[args.obs]
     n_act = 8 if ruleset == N.RULESET_NUMPY else 7
     lo, hi, seeds = D.shard(B)
+    os.environ["TG_FUSE"] = str(args.fuse)  # read by tg_create
     e = Engine(B, W, H, ruleset=ruleset, queue_size=(Q if ruleset == N.RULESET_NUMPY else 7), obs_mode=obs_mode,
                autoreset=N.AUTORESET_SAME_STEP, device=local, env_offset=lo, grouped=args.config5)
     e.reset(seeds)
@@ -181,6 +186,36 @@ def main():
     barrier()
     elapsed, gpu_ms = D.max(t1 - t0, gpu_ms)
 
+    # The same rollout with the engine's default grouping (8 transitions per launch, state resident on chip in
+    # between): reported beside `value`, never instead of it.
+    fused = None
+    if not args.config5 and not args.no_fused_rollout and args.fuse == 1 and args.obs in ("board", "fn", "none"):
+        G = 8
+        os.environ["TG_FUSE"] = str(G)
+        e2 = Engine(B, W, H, ruleset=ruleset, queue_size=(Q if ruleset == N.RULESET_NUMPY else 7), obs_mode=obs_mode,
+                    autoreset=N.AUTORESET_SAME_STEP, device=local, env_offset=lo)
+        e2.reset(seeds)
+        d2 = e2.dev_alloc(acts.nbytes)
+        e2.dev_upload(d2, acts)
+        ksteps = max(G, (min(args.steps, T) // G) * G)
+        e2.step_k_device(d2, min(T, 64)); e2.sync()
+        barrier(); e2.sync()
+        f0 = time.perf_counter(); e2.timer_start()
+        e2.step_k_device(d2, ksteps)
+        f_gpu_ms = e2.timer_stop(); e2.sync()
+        f1 = time.perf_counter()
+        barrier()
+        f_elapsed, f_gpu_ms = D.max(f1 - f0, f_gpu_ms)
+        fb = H * W + 1 + (2 * H * W + 64 + 8) / G  # obs write + action; board read/write-back, record, outputs once per launch
+        fused = {"transitions_per_launch": G, "steps": ksteps, "value": throughput(world, B, ksteps, f_elapsed),
+                 "unit": "env steps/s", "ms_per_step": f_elapsed / ksteps * 1e3, "launch_ms": f_gpu_ms / (ksteps // G),
+                 "alg_bytes_per_env_step": fb, "achieved_gbps": fb * B / (f_gpu_ms / ksteps * 1e-3) / 1e9,
+                 "frac_of_hbm_peak": fb * B / (f_gpu_ms / ksteps * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                 "note": "tg_step_k with TG_FUSE=8: records, column masks and uint8 slabs stay in registers/LDS across the "
+                         "8 transitions of a launch; the observation of every transition is still written"}
+        e2.dev_free(d2)
+        e2.close()
+
     if rank == 0:
         bytes_alg = alg_bytes_per_step(W, H, args.obs)
         launch_ms = gpu_ms / args.steps
@@ -209,12 +244,15 @@ def main():
                                     f"→ teleport + hard drop), legal actions sampled on device, obs={args.obs}, same-step "
                                     f"autoreset") if args.config5 else
                                    f"Batch {B} envs/GPU, {W}x{H} board, {args.ruleset} rule-set, uniform random "
-                                   f"actions (int8, resident in HBM), obs={args.obs}, same-step autoreset",
+                                   f"actions (int8, resident in HBM), obs={args.obs}, same-step autoreset, "
+                                   f"{args.fuse} transition(s) per launch",
                        "envs_per_gpu": B, "total_envs": world * B, "parallelism": f"env-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "step_kernel", "kernel_ms": launch_ms, "alg_bytes_per_env_step": bytes_alg},
         }
+        if fused is not None:
+            out["fused_rollout"] = fused
         try:
             out["hbm_copy_gbps"] = e.stream_copy_gbps(1 << 30, 10)
         except Exception as ex:  # pragma: no cover

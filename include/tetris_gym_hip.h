@@ -182,9 +182,11 @@ int tg_reset(tg_handle* h, const uint64_t* seeds, const uint8_t* mask);
  * Asynchronous on the handle's stream; results land in TG_BUF_STEP_OUT / TG_BUF_OBS. */
 int tg_step(tg_handle* h, const int32_t* actions, int kind);
 
-/* K consecutive transitions with pre-generated actions i8 [K][B] resident in DEVICE memory
- * (rollout / benchmark helper: one kernel launch per transition, no host round trip; the outputs of
- *  the last step remain in the buffers, per-episode sums go to TG_BUF_EPISODE when enabled). */
+/* K consecutive transitions with pre-generated actions i8 [K][B] resident in DEVICE memory (rollout helper, no host
+ * round trip; the outputs of the last transition remain in the buffers, per-episode sums go to TG_BUF_EPISODE when
+ * enabled).  The default kernel runs up to TG_FUSE (environment variable, default and maximum 8) transitions per
+ * launch with the per-env state resident on chip in between; the observation is written after every transition.
+ * Results are identical to K calls of tg_step. */
 int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K);
 
 /* Device pointer and size of an engine-owned buffer. */

@@ -159,7 +159,7 @@ struct tg_handle {
   uint64_t* d_ring = nullptr;  // bits kernel: permutation rings, double-buffered by launch parity [2][B]
   uint8_t* d_hbuf = nullptr;   // bits kernel: consumed counters [2][B]
   int ring_cur = 0;            // parity the next step launch reads
-  int fuse_max = 4;            // TG_FUSE: transitions per launch in tg_step_k (1..8)
+  int fuse_max = 8;            // TG_FUSE: transitions per launch in tg_step_k (1..8)
   // TG_STREAMS=n (default 1) spreads the step launches of one transition over n streams (contiguous env shards).
   // Kept as a tested knob, off by default — measured on MI355X: every launch costs ≈2.8-3.4 µs of
   // command-processor time whichever stream it is on, so n shards cost n launch floors per transition (8.3 µs →
@@ -360,8 +360,8 @@ int launch_step_all(tg_handle* h, const tg::KParams& p) {
     q.out = p.out + o;
     if (p.episode) q.episode = p.episode + o;
     if (p.cols) q.cols = (uint8_t*)p.cols + o * p.cols_bytes;
-    if (p.ahead) q.ahead = p.ahead + o * 4;
-    if (p.ring) q.ring = p.ring + o;
+    if (p.ahead) q.ahead = p.ahead + o * 2 * tg::kRing;
+    if (p.ring) q.ring = p.ring + o * 2;
     if (p.hbuf) q.hbuf = p.hbuf + o;
     h->L.step(q, h->sh_stream[i]);
   }
@@ -515,10 +515,10 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   if (g_kernel_lanes == 16 && !want_final) {
     CRCHK(hipMalloc(&h->d_cols, B * L.cols_bytes + kTailPad));
     CRCHK(hipMemsetAsync(h->d_cols, 0, B * L.cols_bytes + kTailPad, h->stream));
-    CRCHK(hipMalloc((void**)&h->d_ahead, B * 64 + kTailPad));
-    CRCHK(hipMemsetAsync(h->d_ahead, 0, B * 64 + kTailPad, h->stream));
-    CRCHK(hipMalloc((void**)&h->d_ring, 2 * B * 8 + kTailPad));
-    CRCHK(hipMemsetAsync(h->d_ring, 0, 2 * B * 8 + kTailPad, h->stream));
+    CRCHK(hipMalloc((void**)&h->d_ahead, B * 32 * tg::kRing + kTailPad));
+    CRCHK(hipMemsetAsync(h->d_ahead, 0, B * 32 * tg::kRing + kTailPad, h->stream));
+    CRCHK(hipMalloc((void**)&h->d_ring, 2 * B * 16 + kTailPad));
+    CRCHK(hipMemsetAsync(h->d_ring, 0, 2 * B * 16 + kTailPad, h->stream));
     CRCHK(hipMalloc((void**)&h->d_hbuf, 2 * B + kTailPad));
     CRCHK(hipMemsetAsync(h->d_hbuf, 0, 2 * B + kTailPad, h->stream));
   }
@@ -680,7 +680,7 @@ int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K) {
   if (!h || !actions_dev || K <= 0) return h ? fail(h, TG_EINVAL, "tg_step_k: bad arguments") : TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   if (h->B % 4 != 0) return fail(h, TG_EINVAL, "tg_step_k: batch must be a multiple of 4 (packed int8 action rows)");
-  // Transitions per launch: the bits kernel keeps records, masks and slabs on chip across up to TG_FUSE (default 4,
+  // Transitions per launch: the bits kernel keeps records, masks and slabs on chip across up to TG_FUSE (default and
   // max 8) consecutive transitions of a rollout — one launch floor and one slab round trip per group instead of per
   // transition.  tg_step always launches one transition.
   const int fuse_max = h->fuse_max;

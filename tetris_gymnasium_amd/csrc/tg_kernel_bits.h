@@ -144,15 +144,16 @@ __device__ __forceinline__ uint64_t bits_apply_perm(const uint32_t sig, const ui
 }
 
 // The bag permutations of an env are produced ahead of their use by separate RNG workgroups of the same launch
-// (role split by blockIdx) and consumed by the logic wave: a two-entry ring per env with monotonic 8-bit counters,
+// (role split by blockIdx) and consumed by the logic wave: a four-entry ring per env with monotonic 8-bit counters,
 // T = permutations produced (owned by the RNG role), H = permutations consumed (owned by the logic wave).  Entry i
-// lives in slot i & 1.  Everything one role reads from the other is double-buffered by launch parity (`cur`), so
+// lives in slot i & 3.  Everything one role reads from the other is double-buffered by launch parity (`cur`), so
 // both roles work on the snapshot of the previous launch boundary and never on each other's stores of this launch
 // (L2 is per XCD; cross-workgroup visibility inside a launch is not guaranteed).
 struct BitsParams {
   void* cols;      // ColT [B][W]
-  uint4* ahead;    // [B][2 slots][2]: generator state AFTER the slot's shuffle {state_lo, state_hi} {uinteger, has32, 0, 0}
-  uint64_t* ring;  // [2 parities][B]: bits 0..27 permutation of slot 0, 28..55 slot 1 (7 nibbles each), 56..63 T
+  uint4* ahead;    // [B][4 slots][2]: generator state AFTER the slot's shuffle {state_lo, state_hi} {uinteger, has32, 0, 0}
+  uint64_t* ring;  // [2 parities][B][2]: word 0 = permutations of slots 0 | 1 << 28 (7 nibbles each) | T << 56,
+                   //                      word 1 = slots 2 | 3 << 28
   uint8_t* hbuf;   // [2 parities][B]: H
   int cur;         // parity this launch reads; it writes 1 - cur
   int nrb;         // number of leading RNG workgroups (128 envs each)
@@ -161,6 +162,13 @@ struct BitsParams {
 
 // native 16-byte vector for the slab stream: HIP's uint4 is a struct whose copies become memcpy intrinsics, which
 // kept the staging array in scratch memory (and made the kernel wait for every slab load right after issuing it)
+constexpr int kRing = 4;  // entries per permutation ring
+
+__device__ __forceinline__ uint32_t ring_get(const uint64_t w0, const uint64_t w1, const int slot) {
+  const uint64_t w = (slot & 2) ? w1 : w0;
+  return (uint32_t)(w >> (28 * (slot & 1))) & 0x0FFFFFFFu;
+}
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x4 __attribute__((aligned(8))) u32x4_a8;  // 16-byte access at 8-byte alignment (env slabs: S % 8 == 0)
@@ -226,36 +234,42 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
     const uint32_t e = blockIdx.x * 128u + threadIdx.x;
     const bool on = e < B;
     const uint32_t ee = on ? e : B - 1u;
-    uint64_t ring = bp.ring[(size_t)bp.cur * bp.pstride + ee];
+    const uint4 rw = reinterpret_cast<const uint4*>(bp.ring)[(size_t)bp.cur * bp.pstride + ee];
+    uint64_t w0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32), w1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
     const int Hn = bp.hbuf[(size_t)bp.cur * bp.pstride + ee];
-    for (int rep = 0; rep < 2; ++rep) {  // (a ring emptied by one launch is refilled completely)
-    const int Tn = (int)(ring >> 56);
-    const bool need = on && (int)(int8_t)(uint8_t)(Tn - Hn) < 2;
-    if (__any(need)) {
-      BitsRng g;
-      g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
-      g.uinteger = g.has32 = 0;
-      g.loaded = false;
-      uint4* a4 = bp.ahead + (size_t)ee * 4;
-      if (need) {  // frontier = state after entry T - 1
-        const uint4 f0 = a4[2 * ((Tn - 1) & 1)], f1 = a4[2 * ((Tn - 1) & 1) + 1];
+    BitsRng g;
+    g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
+    g.uinteger = g.has32 = 0;
+    g.loaded = false;
+    uint4* a4 = bp.ahead + (size_t)ee * (2 * kRing);
+    for (int rep = 0; rep < kRing; ++rep) {  // (a ring emptied by one launch is refilled completely)
+      const int Tn = (int)(w0 >> 56);
+      const bool need = on && (int)(int8_t)(uint8_t)(Tn - Hn) < kRing;
+      if (!__any(need)) break;
+      if (need && !g.loaded) {  // frontier = state after entry T - 1; later entries continue from the registers
+        const int fs = (Tn - 1) & (kRing - 1);
+        const uint4 f0 = a4[2 * fs], f1 = a4[2 * fs + 1];
         const uint4 gi = reinterpret_cast<const uint4*>(p.rng + ee)[1];
         g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
         g.i_lo = (uint64_t)gi.x | ((uint64_t)gi.y << 32); g.i_hi = (uint64_t)gi.z | ((uint64_t)gi.w << 32);
         g.uinteger = f1.x; g.has32 = f1.y;
+        g.loaded = true;
       }
       uint32_t sig = 0;
       bits_shuffle_perm(g, sig, need);
       if (need) {
-        const int sl = Tn & 1;
+        const int sl = Tn & (kRing - 1);
         a4[2 * sl] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
         a4[2 * sl + 1] = make_uint4(g.uinteger, g.has32, 0u, 0u);
-        ring &= ~((0x0FFFFFFFULL << (28 * sl)) | (0xFFULL << 56));
-        ring |= ((uint64_t)sig << (28 * sl)) | ((uint64_t)((Tn + 1) & 0xFF) << 56);
+        const uint64_t m = 0x0FFFFFFFULL << (28 * (sl & 1)), v = (uint64_t)sig << (28 * (sl & 1));
+        if (sl & 2) w1 = (w1 & ~m) | v;
+        else w0 = (w0 & ~m) | v;
+        w0 = (w0 & ~(0xFFULL << 56)) | ((uint64_t)((Tn + 1) & 0xFF) << 56);
       }
     }
-    }
-    if (on) bp.ring[(size_t)(1 - bp.cur) * bp.pstride + e] = ring;
+    if (on)
+      reinterpret_cast<uint4*>(bp.ring)[(size_t)(1 - bp.cur) * bp.pstride + e] =
+          make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
     return;
   }
   TG_BITS_STAMP(0);
@@ -437,10 +451,12 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   }
   tg_episode_rec ep{};
   if (p.episode) ep = p.episode[env];
-  uint64_t ring = 0;
+  uint64_t ring0 = 0, ring1 = 0;
   int Hc = 0;
   if (RULESET == TG_RULESET_NUMPY) {
-    ring = bp.ring[(size_t)bp.cur * bp.pstride + env];
+    const uint4 rw = reinterpret_cast<const uint4*>(bp.ring)[(size_t)bp.cur * bp.pstride + env];
+    ring0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32);
+    ring1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
     Hc = bp.hbuf[(size_t)bp.cur * bp.pstride + env];
   }
   T cv[W];
@@ -475,7 +491,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   // transition loop: vmcnt is in issue order and a load there would be waited on every transition).  The generator
   // state the reference would hold afterwards is the state stored with the LAST consumed entry; it is fetched once,
   // after the loop.  g holds that state only after an in-line shuffle (ring exhausted: rare).
-  const int ringT = (int)(ring >> 56);
+  const int ringT = (int)(ring0 >> 56);
   bool consumed = false, last_ring = false, g_valid = false, inc_loaded = false;
   BitsRng g;
   g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
@@ -484,7 +500,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   const uint4* rng4 = reinterpret_cast<const uint4*>(p.rng + env);
   auto load_entry_state = [&](const bool on) {  // state after the last consumed ring entry (index Hc - 1)
     if (on) {
-      const uint4* a4 = bp.ahead + (size_t)env * 4 + 2 * ((Hc - 1) & 1);
+      const uint4* a4 = bp.ahead + (size_t)env * (2 * kRing) + 2 * ((Hc - 1) & (kRing - 1));
       const uint4 f0 = a4[0], f1 = a4[1];
       g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
       g.uinteger = f1.x; g.has32 = f1.y;
@@ -496,7 +512,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
     const int av = (int)(int8_t)(uint8_t)(ringT - Hc);  // entries left for this lane
     const bool from_ring = need && av > 0;
     const bool fb = need && av <= 0;
-    uint32_t sig = (uint32_t)(ring >> (28 * (Hc & 1))) & 0x0FFFFFFFu;
+    uint32_t sig = ring_get(ring0, ring1, Hc & (kRing - 1));
     if (__any(fb)) {  // rare: ring exhausted → shuffle in-line, from the state the generator holds right now
       load_entry_state(fb && !g_valid && consumed && last_ring);
       if (fb && !g_valid && !(consumed && last_ring)) {
@@ -963,8 +979,9 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
   if (p.ruleset != TG_RULESET_NUMPY) return;
   const size_t B = (size_t)p.batch;
   const bool moved = p.force || (p.mask ? p.mask[env] != 0 : true);
+  uint4* ring4 = reinterpret_cast<uint4*>(p.ring);
   if (!moved) {  // ring untouched: make both parities agree with the one the next launch reads
-    p.ring[(size_t)(1 - p.cur) * B + env] = p.ring[(size_t)p.cur * B + env];
+    ring4[(size_t)(1 - p.cur) * B + env] = ring4[(size_t)p.cur * B + env];
     p.hbuf[(size_t)(1 - p.cur) * B + env] = p.hbuf[(size_t)p.cur * B + env];
     return;
   }
@@ -985,18 +1002,19 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
     rng_store(r, p.rng + env, 0);
   }
   rec[7] = 0;
-  uint64_t ring = 2ULL << 56;  // T = 2, H = 0: entries 0 and 1
-  uint4* a4 = p.ahead + (size_t)env * 4;
-  for (int sl = 0; sl < 2; ++sl) {
+  uint64_t w[2] = {(uint64_t)kRing << 56, 0};  // T = kRing, H = 0: entries 0 .. kRing - 1
+  uint4* a4 = p.ahead + (size_t)env * (2 * kRing);
+  for (int sl = 0; sl < kRing; ++sl) {
     const uint64_t perm = pcg_shuffle7(r, 0x06050403020100ULL);
     uint64_t sig = 0;
     for (int k = 0; k < 7; ++k) sig |= ((perm >> (8 * k)) & 0xF) << (4 * k);
-    ring |= sig << (28 * sl);
+    w[sl >> 1] |= sig << (28 * (sl & 1));
     a4[2 * sl] = make_uint4((uint32_t)r.s_lo, (uint32_t)(r.s_lo >> 32), (uint32_t)r.s_hi, (uint32_t)(r.s_hi >> 32));
     a4[2 * sl + 1] = make_uint4(r.uinteger, r.has32, 0u, 0u);
   }
-  p.ring[env] = ring;
-  p.ring[B + env] = ring;
+  const uint4 rw = make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
+  ring4[env] = rw;
+  ring4[B + env] = rw;
   p.hbuf[env] = 0;
   p.hbuf[B + env] = 0;
 }
