@@ -58,7 +58,9 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     using BG = tg::BitsGeo<W, H>;
     const int nrb = RS == TG_RULESET_NUMPY ? (p.batch + 127) / 128 : 0;  // leading RNG workgroups (tg_kernel_bits.h)
     const tg::BitsParams bp{p.cols, p.ahead, p.ring, p.hbuf, p.ring_cur, nrb, p.ring_stride};
-    hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS>), dim3(nrb + (p.batch + BG::EPW - 1) / BG::EPW), dim3(128), BG::BYTES, s, p, bp);
+    const dim3 grid(nrb + (p.batch + BG::EPW - 1) / BG::EPW);
+    if (p.nsteps > 1) hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, true>), grid, dim3(128), BG::BYTES, s, p, bp);
+    else hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, false>), grid, dim3(128), BG::BYTES, s, p, bp);
     return;
   }
   if (g_kernel_lanes == 8 && !p.final_obs) {  // "block": two-phase kernel with workgroup-level slow-path compaction

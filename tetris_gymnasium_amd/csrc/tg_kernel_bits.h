@@ -191,7 +191,9 @@ __device__ __forceinline__ void st_stream(V* dst, const V v) {
 #define TG_ST_STATE(ptr, val) (*(ptr) = (val))
 #endif
 
-template <int W, int H, int RULESET>
+// MULTI = false: one transition per launch (tg_step; the loop below collapses).  MULTI = true: p.nsteps transitions
+// per launch (tg_step_k).  Two instantiations so that profiles list the two kinds of launches separately.
+template <int W, int H, int RULESET, bool MULTI>
 __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, const BitsParams bp) {
   using BG = BitsGeo<W, H>;
   using T = ColT<H>;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   // p.nsteps consecutive transitions in this launch (tg_step_k): records / masks / slabs stay in registers and LDS in
   // between, only actions come in and observations go out per transition; one s_barrier per transition, and the
   // stream wave packs transition k while the logic wave already decides transition k + 1
-  const int nsteps = p.nsteps > 1 ? p.nsteps : 1;
+  const int nsteps = MULTI ? (p.nsteps > 1 ? p.nsteps : 1) : 1;
 
 #ifdef TG_PHASE_TIMING
   unsigned long long tstamp[8];  // kept in SGPRs and written at the very end: a store per stamp would itself be waited on

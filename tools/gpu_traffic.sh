@@ -2,9 +2,9 @@
 # Runs ON THE GPU BOX: HBM traffic counters (separate --pmc passes, as the MI355X guide prescribes) for the step
 # kernel, calibrated on the stream-copy kernel of the same run (known bytes).  Output: gpurun_out/<tag>/traffic.json
 TAG=${1:-traffic}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE -d $OUT/f -o f -- python3 bench.py --steps 32 --warmup 8 --no-cpu-baseline > $OUT/f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/w -o w -- python3 bench.py --steps 32 --warmup 8 --no-cpu-baseline > $OUT/w.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/h -o h -- python3 bench.py --steps 32 --warmup 8 --no-cpu-baseline > $OUT/h.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/f -o f -- python3 bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-fused-rollout > $OUT/f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/w -o w -- python3 bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-fused-rollout > $OUT/w.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/h -o h -- python3 bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-fused-rollout > $OUT/h.log 2>&1
 python3 - <<PY
 import sqlite3, json
 def mean(db, kern, ctr):
