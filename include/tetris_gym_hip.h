@@ -189,6 +189,12 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind);
  * Results are identical to K calls of tg_step. */
 int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K);
 
+/* tg_step_k that also keeps the trajectory: the observation of transition k goes to obs_traj_dev + k * B * obs_bytes
+ * (layout of the handle's obs_mode; TG_BUF_OBS still receives the last one) and its outputs to out_traj_dev[k][B].
+ * Both are caller-owned DEVICE buffers; either may be NULL.  What a random-policy data collector or a search that
+ * rolls out action sequences needs from `for k: obs, r, d, _, info = env.step(a[k])` (envs/tetris.py:203-272). */
+int tg_rollout(tg_handle* h, const int8_t* actions_dev, int K, uint8_t* obs_traj_dev, tg_step_out* out_traj_dev);
+
 /* Device pointer and size of an engine-owned buffer. */
 int tg_device_ptr(tg_handle* h, int which, void** ptr, size_t* bytes);
 

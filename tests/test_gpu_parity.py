@@ -352,3 +352,32 @@ def test_fused_rollout_equals_single_transitions(fuse, ruleset, W, H, Q, B, auto
             if term.any():
                 e.reset(mask=term); o.reset(mask=term)
     e.close()
+
+
+@pytest.mark.parametrize("fuse", [1, 8])
+@pytest.mark.parametrize("ruleset,obs,B", [(N.RULESET_NUMPY, N.OBS_BOARD, 1500), (N.RULESET_FUNCTIONAL, N.OBS_FN, 640),
+                                           (N.RULESET_NUMPY, N.OBS_RGB, 200)])
+def test_rollout_trajectory_equals_stepwise(fuse, ruleset, obs, B, monkeypatch):
+    """tg_rollout keeps the whole trajectory (observation + reward / terminated / lines of every transition): must
+    equal stepping the oracle one transition at a time — written by the fused kernel itself (BOARD / FN) or by the
+    copy fallback (RGB)."""
+    monkeypatch.setenv("TG_FUSE", str(fuse))
+    numpy_rules = ruleset == N.RULESET_NUMPY
+    po_obs = {N.OBS_BOARD: po.OBS_BOARD, N.OBS_FN: po.OBS_FN, N.OBS_RGB: po.OBS_RGB}[obs]
+    e = Engine(B, 10, 20, ruleset=ruleset, obs_mode=obs, autoreset=N.AUTORESET_SAME_STEP)
+    o = po.OracleBatch(B, 10, 20, ruleset)
+    seeds = np.arange(9, 9 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(fuse + B)
+    for K in (3, 21, 16):
+        acts = rng.integers(0, 8 if numpy_rules else 7, (K, B)).astype(np.int8)
+        tobs, trew, tterm, tlines = e.rollout(acts)
+        for k in range(K):
+            ro, to, lo = o.step(acts[k].astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+            np.testing.assert_array_equal(trew[k], ro, err_msg=f"reward k={k}")
+            np.testing.assert_array_equal(tterm[k], to, err_msg=f"terminated k={k}")
+            np.testing.assert_array_equal(tlines[k], lo, err_msg=f"lines k={k}")
+            np.testing.assert_array_equal(tobs[k], o.observe(po_obs), err_msg=f"obs k={k} (K={K})")
+        np.testing.assert_array_equal(e.observation(), o.observe(po_obs))  # the engine's buffer holds the last one
+        _cmp_state(e, o, f"K={K}")
+    e.close()

@@ -359,6 +359,8 @@ int launch_step_all(tg_handle* h, const tg::KParams& p) {
     q.rng = p.rng + o;
     q.actions = p.act_i8 ? (const void*)((const int8_t*)p.actions + o) : (const void*)((const int32_t*)p.actions + o);
     if (p.obs) q.obs = p.obs + o * obs_bytes_per_env(&h->cfg);
+    if (p.obs_traj) q.obs_traj = p.obs_traj + o * obs_bytes_per_env(&h->cfg);
+    if (p.out_traj) q.out_traj = p.out_traj + o;
     q.out = p.out + o;
     if (p.episode) q.episode = p.episode + o;
     if (p.cols) q.cols = (uint8_t*)p.cols + o * p.cols_bytes;
@@ -678,16 +680,23 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind) {
   return TG_OK;
 }
 
-int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K) {
-  if (!h || !actions_dev || K <= 0) return h ? fail(h, TG_EINVAL, "tg_step_k: bad arguments") : TG_EINVAL;
+int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K) { return tg_rollout(h, actions_dev, K, nullptr, nullptr); }
+
+int tg_rollout(tg_handle* h, const int8_t* actions_dev, int K, uint8_t* obs_traj_dev, tg_step_out* out_traj_dev) {
+  if (!h || !actions_dev || K <= 0) return h ? fail(h, TG_EINVAL, "tg_rollout: bad arguments") : TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
-  if (h->B % 4 != 0) return fail(h, TG_EINVAL, "tg_step_k: batch must be a multiple of 4 (packed int8 action rows)");
+  if (h->B % 4 != 0) return fail(h, TG_EINVAL, "tg_rollout: batch must be a multiple of 4 (packed int8 action rows)");
   // Transitions per launch: the bits kernel keeps records, masks and slabs on chip across up to TG_FUSE (default and
   // max 8) consecutive transitions of a rollout — one launch floor and one slab round trip per group instead of per
   // transition.  tg_step always launches one transition.
   const int fuse_max = h->fuse_max;
   const bool post_kernel = h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB;
   const int fuse = (h->d_cols && !post_kernel) ? fuse_max : 1;
+  const size_t obs_stride = (size_t)h->B * obs_bytes_per_env(&h->cfg);
+  if (obs_traj_dev && h->cfg.obs_mode == TG_OBS_NONE) return fail(h, TG_EINVAL, "tg_rollout: the handle has no observation (TG_OBS_NONE)");
+  // trajectories are written by the step kernel itself when it packs the observation (bits kernel, BOARD / FN);
+  // otherwise every transition is one launch followed by device-to-device copies of the engine's buffers
+  const bool in_kernel = h->d_cols && !post_kernel;
   auto enqueue = [&]() -> int {  // K transitions, `fuse` per launch (per shard)
     tg::KParams p = step_params(h);
     p.act_i8 = 1;
@@ -695,12 +704,25 @@ int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K) {
       p.actions = actions_dev + (size_t)k * h->B;
       p.nsteps = K - k < fuse ? K - k : fuse;
       p.ring_cur = h->ring_cur;
+      if (in_kernel) {
+        p.obs_traj = obs_traj_dev ? obs_traj_dev + (size_t)k * obs_stride : nullptr;
+        p.out_traj = out_traj_dev ? (uint2*)out_traj_dev + (size_t)k * h->B : nullptr;
+        p.obs_traj_stride = obs_stride;
+      }
       int rc = launch_step_all(h, p);
       if (rc != TG_OK) return rc;
       h->ring_cur ^= 1;
       if (h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) {  // packed by its own kernel after every transition
         rc = launch_observe_dict(h);
         if (rc != TG_OK) return rc;
+      }
+      if (!in_kernel && (obs_traj_dev || out_traj_dev)) {
+        rc = join_shards(h);
+        if (rc != TG_OK) return rc;
+        if (obs_traj_dev)
+          HIPCHK(h, hipMemcpyAsync(obs_traj_dev + (size_t)k * obs_stride, h->buf[TG_BUF_OBS], obs_stride, hipMemcpyDeviceToDevice, h->stream));
+        if (out_traj_dev)
+          HIPCHK(h, hipMemcpyAsync(out_traj_dev + (size_t)k * h->B, h->buf[TG_BUF_STEP_OUT], (size_t)h->B * sizeof(tg_step_out), hipMemcpyDeviceToDevice, h->stream));
       }
     }
     return TG_OK;

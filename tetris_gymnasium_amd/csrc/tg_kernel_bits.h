@@ -132,15 +132,14 @@ __device__ __forceinline__ void bits_shuffle_perm(BitsRng& g, uint32_t& sig, con
   }
 }
 
-// shuffled[k] = src[P[k]]  on 7-byte arrays packed in a 64-bit word
+// shuffled[k] = src[P[k]]  on 7-byte arrays packed in a 64-bit word: the nibbles of P become the byte selectors of
+// two v_perm_b32 over the pool {src.hi : src.lo} (selector 0..3 = low dword bytes, 4..7 = high dword bytes, 0x0C = 0)
 __device__ __forceinline__ uint64_t bits_apply_perm(const uint32_t sig, const uint64_t src) {
-  uint64_t out = 0;
-#pragma unroll
-  for (int k = 0; k < 7; ++k) {
-    const uint32_t pk = (sig >> (4 * k)) & 7u;
-    out |= ((src >> (8 * pk)) & 0xFFULL) << (8 * k);
-  }
-  return out;
+  const uint32_t sel_lo = (sig & 0xFu) | ((sig & 0xF0u) << 4) | ((sig & 0xF00u) << 8) | ((sig & 0xF000u) << 12);
+  const uint32_t s2 = sig >> 16;
+  const uint32_t sel_hi = (s2 & 0xFu) | ((s2 & 0xF0u) << 4) | ((s2 & 0xF00u) << 8) | 0x0C000000u;
+  const uint32_t lo = (uint32_t)src, hi = (uint32_t)(src >> 32);
+  return (uint64_t)__builtin_amdgcn_perm(hi, lo, sel_lo) | ((uint64_t)__builtin_amdgcn_perm(hi, lo, sel_hi) << 32);
 }
 
 // The bag permutations of an env are produced ahead of their use by separate RNG workgroups of the same launch
@@ -378,7 +377,11 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
       bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu),
                p.obs_mode == TG_OBS_FN ? 0xFFu : ((po.z >> 16) & 0xFFu), false, show);
       wave_sync();
-      u32x4* odst = reinterpret_cast<u32x4*>(p.obs + (size_t)base_env * S);
+      // trajectory output (tg_rollout): every transition has its own slot; the engine's buffer gets the last one
+      const bool to_traj = p.obs_traj != nullptr && !last;
+      uint8_t* obase = to_traj ? p.obs_traj + (size_t)step * p.obs_traj_stride : p.obs;
+      u32x4* odst = reinterpret_cast<u32x4*>(obase + (size_t)base_env * S);
+      u32x4* odst2 = reinterpret_cast<u32x4*>((p.obs_traj ? p.obs_traj + (size_t)step * p.obs_traj_stride : p.obs) + (size_t)base_env * S);
       const bool fn = p.obs_mode == TG_OBS_FN;
       auto bin1 = [](uint32_t x) -> uint32_t {  // bytes: 0xFF (active) stays -1, other non-zero → 1  (tetris_fn.py:137-158)
         const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
@@ -399,7 +402,10 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
           const int c = lane + 64 * k;
-          if (c < NCH) st_stream(&odst[c], o[k]);
+          if (c < NCH) {
+            st_stream(&odst[c], o[k]);
+            if (last && p.obs_traj) st_stream(&odst2[c], o[k]);
+          }
         }
       } else {
         for (uint32_t c = lane; c < nchunks; c += 64) {
@@ -407,10 +413,14 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
           if (fn) vv = u32x4{bin1(vv.x), bin1(vv.y), bin1(vv.z), bin1(vv.w)};
           if (c * 16u + 16u <= nbytes) {
             odst[c] = vv;
+            if (last && p.obs_traj) odst2[c] = vv;
           } else {  // ragged tail of a partial wave
             const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
-            for (uint32_t i = 0; c * 16u + i < nbytes; ++i)
-              p.obs[(size_t)base_env * S + c * 16u + i] = (uint8_t)(w4[i >> 2] >> (8 * (i & 3)));
+            for (uint32_t i = 0; c * 16u + i < nbytes; ++i) {
+              const uint8_t bv = (uint8_t)(w4[i >> 2] >> (8 * (i & 3)));
+              reinterpret_cast<uint8_t*>(odst)[c * 16u + i] = bv;
+              if (last && p.obs_traj) reinterpret_cast<uint8_t*>(odst2)[c * 16u + i] = bv;
+            }
           }
         }
       }
@@ -892,6 +902,9 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   }
   if (step == nsteps - 1 && live)  // the outputs of the LAST transition remain in the buffers
     st_stream(reinterpret_cast<u32x2*>(p.out + env), u32x2{__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8)});
+  if (p.out_traj && live)
+    st_stream(reinterpret_cast<u32x2*>(p.out_traj + (size_t)step * p.act_stride + env),
+              u32x2{__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8)});
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   }  // transitions

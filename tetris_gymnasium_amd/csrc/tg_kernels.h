@@ -56,6 +56,9 @@ struct KParams {
   uint32_t cols_bytes;      // bits kernel only: bytes per env of `cols` (host-side shard offsets)
   int nsteps;               // bits kernel only: transitions per launch (tg_step_k), int8 action rows act_stride apart
   uint32_t act_stride;
+  uint8_t* obs_traj;        // optional (tg_rollout): observation of transition k of this launch at obs_traj + k * obs_traj_stride
+  uint2* out_traj;          // optional: outputs of transition k at out_traj + k * act_stride
+  size_t obs_traj_stride;   // bytes between transitions (the handle's batch * observation bytes per env)
 };
 
 struct ResetParams {

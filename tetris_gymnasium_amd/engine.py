@@ -86,6 +86,44 @@ class Engine:
     def step_k_device(self, actions_dev_ptr, k):
         self._chk(self.lib.tg_step_k(self.h, C.c_void_p(actions_dev_ptr), int(k)), "tg_step_k")
 
+    def rollout(self, actions):
+        """K transitions with the given actions int8[K][B] in one call (tg_rollout: the default kernel runs up to 8 per
+        launch with the state resident on chip).  Returns (obs[K][B]..., reward f32[K][B], terminated u8[K][B],
+        lines u8[K][B]) — what K calls of step() + observation() would have returned."""
+        a = np.ascontiguousarray(actions, dtype=np.int8)
+        if a.ndim != 2 or a.shape[1] != self.B:
+            raise ValueError("actions must have shape (K, batch)")
+        K = a.shape[0]
+        per_env = self.lib.tg_obs_bytes_per_env(C.byref(self.cfg))
+        d_a = self.dev_alloc(a.nbytes)
+        d_o = self.dev_alloc(K * self.B * per_env) if per_env else None
+        d_r = self.dev_alloc(K * self.B * N.STEP_OUT.itemsize)
+        try:
+            self.dev_upload(d_a, a)
+            self._chk(self.lib.tg_rollout(self.h, C.c_void_p(d_a), K, C.c_void_p(d_o) if d_o else None, C.c_void_p(d_r)),
+                      "tg_rollout")
+            out = np.empty((K, self.B), N.STEP_OUT)
+            self._chk(self.lib.tg_dev_download(self.h, N.ptr(out), C.c_void_p(d_r), out.nbytes), "tg_dev_download")
+            obs = None
+            if d_o:
+                raw = np.empty(K * self.B * per_env, np.uint8)
+                self._chk(self.lib.tg_dev_download(self.h, N.ptr(raw), C.c_void_p(d_o), raw.nbytes), "tg_dev_download")
+                if self.obs_mode == N.OBS_BOARD:
+                    obs = raw.reshape(K, self.B, self.H, self.W)
+                elif self.obs_mode == N.OBS_FN:
+                    obs = raw.view(np.int8).reshape(K, self.B, self.H, self.W)
+                elif self.obs_mode == N.OBS_RGB:
+                    obs = raw.reshape(K, self.B, self.Hp, self.Wp + self.P * max(1, self.Q), 3)
+                else:
+                    obs = raw.reshape(K, self.B * per_env)  # DICT: the engine's flat layout per transition
+        finally:
+            self.dev_free(d_a)
+            if d_o:
+                self.dev_free(d_o)
+            self.dev_free(d_r)
+        return (obs, np.ascontiguousarray(out["reward"]), np.ascontiguousarray(out["terminated"]),
+                np.ascontiguousarray(out["lines"]))
+
     def step(self, actions):
         """One transition; returns (reward f32[B], terminated u8[B], lines u8[B])."""
         self.step_async(actions)

@@ -161,6 +161,17 @@ class TetrisVectorEnv(VectorEnvBase):
             infos["board"] = self._cur_feats  # wrappers/grouped.py:261-264 info["board"]
         return obs, rewards, terminations, truncations, infos
 
+    def rollout(self, actions):
+        """K transitions for pre-generated actions [K][num_envs] in one call per device (tg_rollout: up to 8 transitions
+        per launch, state resident on chip).  Returns (obs[K][num_envs]..., rewards, terminations, lines) — the
+        trajectory a `for k: envs.step(actions[k])` loop would have produced (autoreset as configured)."""
+        actions = np.asarray(actions, np.int8)
+        parts = [e.rollout(actions[:, lo:hi]) for e, (lo, hi) in zip(self.engines, self.ranges)]
+        obs = None if parts[0][0] is None else np.concatenate([p[0] for p in parts], axis=1)
+        return (obs, np.concatenate([p[1] for p in parts], axis=1).astype(np.float64),
+                np.concatenate([p[2] for p in parts], axis=1).astype(bool),
+                np.concatenate([p[3] for p in parts], axis=1).astype(np.int32))
+
     def close(self, **kwargs):
         for e in self.engines:
             e.close()
