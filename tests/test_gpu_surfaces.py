@@ -1,6 +1,7 @@
 """GPU tests of the three Python surfaces: the reference's own tests restated against the drop-in
 `Tetris` class and the functional `reset/step/batched_*`, plus the VectorEnv adapter against the oracle."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -365,4 +366,73 @@ def test_vector_env_rgb_and_placement_boards():
         a = np.array([rng.choice(np.flatnonzero(m)) for m in om])
         obs, rew, term, trunc, info = env.step(a)
         o.grouped_step(a, autoreset=po.AUTORESET_SAME_STEP)
+    env.close()
+
+
+def test_wrapper_classes_rgb_and_features():
+    """The reference's wrapper classes over the drop-in Tetris env (tests/test_wrappers/*: RGB shape (24, 34, 3); feature
+    values on the mock board: heights, max 11, holes 3, bumpiness 14, tests/helpers/mock.py:35-39)."""
+    from tests import replay
+    from tetris_gymnasium_amd.wrappers import FeatureVectorObservation, RgbObservation
+    env = RgbObservation(Tetris())
+    o = po.OracleBatch(1)
+    obs, info = env.reset(seed=42)
+    o.reset(np.array([42], np.uint64))
+    assert obs.shape == (24, 34, 3) and obs.dtype == np.uint8 and env.observation_space.shape == (24, 34, 3)
+    np.testing.assert_array_equal(obs, o.observe(po.OBS_RGB)[0])
+    rng = np.random.default_rng(4)
+    for t in range(60):
+        a = int(rng.integers(0, 8))
+        obs, r, d, tr, info = env.step(a)
+        ro, to, lo = o.step(np.array([a]))
+        assert r == ro[0] and d == bool(to[0])
+        np.testing.assert_array_equal(obs, o.observe(po.OBS_RGB)[0], err_msg=f"t={t}")
+        if d:
+            obs, _ = env.reset(); o.reset()
+            np.testing.assert_array_equal(obs, o.observe(po.OBS_RGB)[0])
+    env.close()
+
+    fx = replay.load(os.path.join(os.path.dirname(__file__), "golden"), "ref_tests_grouped")
+    env = FeatureVectorObservation(Tetris())
+    env.reset(seed=42)
+    env.unwrapped.board = fx["mock_board"].copy()  # poked like the reference's tests do
+    env.unwrapped.y = 0
+    f = env.observation(None)
+    # the active piece at y = 0 lies in the wiped rows 0-1, so the mock board's known answers apply
+    assert list(f[:10]) == list(fx["heights"]) and f[10] == int(fx["max_height"]) and f[11] == int(fx["holes"]) \
+        and f[12] == int(fx["bumpiness"])
+    sub = FeatureVectorObservation(env.env, report_height=False, report_holes=False)
+    assert sub.observation_space.shape == (2,) and list(sub.observation(None)) == [f[10], f[12]]
+    env.close()
+
+
+@pytest.mark.parametrize("with_features", [False, True])
+def test_wrapper_class_grouped(with_features):
+    """GroupedActionsObservations(env[, observation_wrappers=[FeatureVectorObservation(env)]]) as used by
+    examples/train_lin_grouped.py: obs (40, 24, 18) or (40, 13), info["action_mask"], info["board"], -0.1 on illegal."""
+    from tetris_gymnasium_amd.wrappers import FeatureVectorObservation, GroupedActionsObservations
+    base = Tetris()
+    env = GroupedActionsObservations(base, observation_wrappers=[FeatureVectorObservation(base)] if with_features else None)
+    o = po.OracleBatch(1)
+    obs, info = env.reset(seed=7)
+    o.reset(np.array([7], np.uint64))
+    assert env.action_space.n == 40 and obs.shape == ((40, 13) if with_features else (40, 24, 18))
+    rng = np.random.default_rng(11)
+    for t in range(80):
+        om, ob = o.grouped_enumerate(boards=True)
+        np.testing.assert_array_equal(info["action_mask"], om[0])
+        if with_features:
+            np.testing.assert_array_equal(obs, o.grouped_features()[0])
+            np.testing.assert_array_equal(info["board"], o.features()[0])
+        else:
+            np.testing.assert_array_equal(obs, ob[0])
+        legal = np.flatnonzero(om[0])
+        a = int(rng.choice(legal)) if rng.random() < 0.9 else int(rng.integers(0, 40))
+        obs, r, d, tr, info = env.step(a)
+        ro, to, lo, ill = o.grouped_step(np.array([a]))
+        assert d == bool(to[0]) and (r == -0.1 if ill[0] else r == ro[0]), (t, a, r, ro, ill)
+        if d:
+            if ill[0]:
+                assert np.all(obs == env.observation_space.high)
+            obs, info = env.reset(); o.reset()
     env.close()

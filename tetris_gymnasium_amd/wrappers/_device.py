@@ -1,0 +1,43 @@
+"""Shared plumbing of the wrapper classes: a one-env auxiliary engine that mirrors the wrapped env's state on demand
+and runs the wrapper's kernel (RGB pack, feature vectors, placement enumeration, grouped step) on it."""
+from __future__ import annotations
+
+from .. import _native as N
+from ..engine import Engine
+
+
+class WrapperBase:
+    """Minimal gymnasium.Wrapper look-alike (works with and without gymnasium installed): forwards unknown
+    attributes to the wrapped env, exposes `.env` and `.unwrapped`."""
+
+    def __init__(self, env):
+        self.env = env
+
+    @property
+    def unwrapped(self):
+        return getattr(self.env, "unwrapped", self.env)
+
+    def __getattr__(self, name):
+        if name.startswith("_") or name == "env":
+            raise AttributeError(name)
+        return getattr(self.env, name)
+
+    def close(self):
+        for a in ("_aux",):
+            e = self.__dict__.get(a)
+            if e is not None:
+                e.close()
+                self.__dict__[a] = None
+        self.env.close()
+
+
+def aux_engine(env, **kw) -> Engine:
+    u = env.unwrapped
+    return Engine(1, u.width, u.height, ruleset=N.RULESET_NUMPY, gravity=u.gravity_enabled, queue_size=u.queue.size,
+                  device=u._engine.cfg.device, **kw)
+
+
+def mirror(env, aux: Engine) -> None:
+    """Copy the wrapped env's full state (board, record, generator) into the auxiliary engine."""
+    st = env.unwrapped.get_state()
+    aux.set_state(board=st.board, rec=st.rec, rng=st.rng)

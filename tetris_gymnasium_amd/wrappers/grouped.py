@@ -1,0 +1,81 @@
+"""`GroupedActionsObservations`: reference tetris_gymnasium/wrappers/grouped.py:17-294."""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _native as N
+from .._gym_compat import spaces
+from ..envs.tetris import TetrisState
+from ._device import WrapperBase, aux_engine, mirror
+from .observation import FeatureVectorObservation
+
+
+class GroupedActionsObservations(WrapperBase):
+    """action = column * 4 + rotations → teleport + hard drop; observation = one entry per action (the board each
+    placement would produce, or its feature vector when `observation_wrappers=[FeatureVectorObservation(env)]`);
+    `info["action_mask"]` marks placements that collide with the frame.  Enumeration, mask, features and the grouped
+    transition all run on the device."""
+
+    def __init__(self, env, observation_wrappers=None, terminate_on_illegal_action: bool = True):
+        super().__init__(env)
+        u = env.unwrapped
+        if observation_wrappers and not (len(observation_wrappers) == 1 and
+                                         isinstance(observation_wrappers[0], FeatureVectorObservation)):
+            raise NotImplementedError("observation_wrappers: only [FeatureVectorObservation(env)] has a device kernel")
+        self.observation_wrappers = observation_wrappers
+        self.terminate_on_illegal_action = terminate_on_illegal_action
+        self.action_space = spaces.Discrete(u.width * 4)
+        single = observation_wrappers[-1].observation_space.shape if observation_wrappers else \
+            (u.height_padded, u.width_padded)
+        self.observation_space = spaces.Box(low=0, high=u.height * u.width, shape=(u.width * 4,) + tuple(single),
+                                            dtype=np.float32)
+        self.legal_actions_mask = np.ones(self.action_space.n)
+        self._aux = aux_engine(env, obs_mode=N.OBS_NONE, grouped=True, features=bool(observation_wrappers),
+                               terminate_on_illegal=terminate_on_illegal_action)
+
+    def encode_action(self, x, r):
+        return x * 4 + r
+
+    def decode_action(self, action):
+        return action // 4, action % 4
+
+    # -- observation of the env's CURRENT state (the aux engine must already mirror it) ---------------
+    def _observe(self):
+        if self.observation_wrappers:
+            placement, current = self._aux.features()
+            self.legal_actions_mask = self._aux.legal_mask()[0].astype(np.float64)
+            fv = self.observation_wrappers[0]
+            return fv.select(placement[0]), fv.select(current[0])
+        mask, boards = self._aux.placement_boards()
+        self.legal_actions_mask = mask[0].astype(np.float64)
+        return boards[0], None
+
+    def observation(self, observation=None):
+        mirror(self.env, self._aux)
+        return self._observe()[0]
+
+    def reset(self, *, seed=None, options=None):
+        obs, info = self.env.reset(seed=seed, options=options)
+        mirror(self.env, self._aux)
+        grouped, current = self._observe()
+        info["board"] = current if self.observation_wrappers else obs
+        info["action_mask"] = self.legal_actions_mask
+        return grouped, info
+
+    def step(self, action):
+        u = self.env.unwrapped
+        mirror(self.env, self._aux)
+        if self.legal_actions_mask[action] == 0 and self.terminate_on_illegal_action:
+            observation = np.ones(self.observation_space.shape) * self.observation_space.high
+            return observation, u.rewards.invalid_action, True, False, \
+                {"action_mask": self.legal_actions_mask, "lines_cleared": 0}
+        rew, term, lines = self._aux.step(np.array([int(action)], np.int32))  # grouped transition on the device
+        b, r, g = self._aux.get_state()
+        u.set_state(TetrisState(b, r, g))
+        illegal = float(rew[0]) < 0
+        reward = u.rewards.invalid_action if illegal else int(rew[0])
+        grouped, current = self._observe()
+        info = {"lines_cleared": int(lines[0]), "action_mask": self.legal_actions_mask}
+        if not illegal:
+            info["board"] = current if self.observation_wrappers else u._obs()
+        return grouped, reward, bool(term[0]), False, info
