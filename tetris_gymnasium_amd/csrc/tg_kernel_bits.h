@@ -1,4 +1,5 @@
-// tg_kernel_bits.h — fifth formulation of the step kernel: rule logic on per-env COLUMN BITMASKS, one env per lane.
+// tg_kernel_bits.h — fifth formulation of the step kernel (the default): rule logic on per-env COLUMN BITMASKS, one
+// env per lane, in a workgroup of two specialised waves, with the bag shuffles produced ahead by other workgroups.
 //
 // Why (measured, profiles/r01/block1_*): at batch 65 536 every workgroup of a launch is resident at once, so the
 // launch time is the critical path of ONE workgroup, not a throughput; 78 % of the wave cycles of the byte-probing
@@ -7,18 +8,20 @@
 //   * besides the uint8 playfield (the state the reference defines, envs/tetris.py:632-641) every env carries an
 //     acceleration structure: one bitmask per playfield column (bit r = cell (r, c) is filled), W words per env in
 //     HBM (40 B at 10x20), kept consistent by this kernel and rebuilt by bits_prepare_kernel after reset/set_state;
-//   * ONE LDS round trip fetches the six columns around the piece; every collision test of the step (tentative
-//     here/below, current here/below), the hard drop (the reference's step-wise loop == first set bit of the
-//     "piece at row r collides" mask below y) and the lock are register ALU on those six words;
-//   * full rows = AND over the W columns (the reference's whole-board scan, envs/tetris.py:493-494), the spawn
-//     collision reads the same registers; line-clear compaction of the masks is bit arithmetic (rare path);
-//   * the uint8 slab is only the payload: it streams HBM → LDS → HBM while the logic runs, receives the locked
-//     cells / cleared rows / resets afterwards and leaves as the observation (coalesced 16-byte accesses);
-//   * numpy's Generator.shuffle draws do not depend on the array being shuffled (Fisher-Yates positions only), so
-//     the NEXT bag permutation is computed one shuffle ahead and kept in the env record (7 nibbles): using it is a
-//     nibble gather; the PCG64 loop that refreshes it runs at the END of the step, after all stores were issued.
-//     The generator state the reference would hold (tg_get_state) stays in tg_rng_rec; the state after the
-//     look-ahead shuffle lives in a device-private buffer and is promoted when the permutation is consumed.
+//   * LOGIC WAVE: ONE LDS round trip fetches the six columns around the piece; every collision test of the step
+//     (tentative here/below, current here/below), the hard drop (the reference's step-wise loop == first set bit of
+//     the "piece at row r collides" mask below y) and the lock are register ALU on those six words; full rows = AND
+//     over the W columns (the reference's whole-board scan, envs/tetris.py:493-494), the spawn collision reads the
+//     same registers; line-clear compaction of the masks is bit arithmetic (rare path);
+//   * STREAM WAVE: the uint8 slab is only the payload: it streams HBM → LDS while the logic wave decides, receives
+//     the locked cells / cleared rows / resets after one s_barrier, goes back to the board where it changed and
+//     leaves as the observation (coalesced 16-byte accesses, nontemporal);
+//   * RNG ROLE (leading workgroups of the same launch): numpy's Generator.shuffle draws do not depend on the array
+//     being shuffled (Fisher-Yates positions only), so every env owns a ring of four future bag permutations
+//     (7 nibbles each) produced ahead of their use; consuming one is a byte permute (v_perm_b32).  The generator
+//     state the reference would hold (tg_get_state) stays in tg_rng_rec: it is promoted from the ring entry's
+//     stored state when a permutation is consumed;
+//   * tg_step_k / tg_rollout run up to 8 transitions per launch with all of the above resident on chip in between.
 // Bit-identical to the other four step kernels and to the oracle (tests/test_gpu_*.py run against all of them).
 #pragma once
 #include <type_traits>
@@ -75,18 +78,18 @@ struct BitsGeo {
   static constexpr int NCH = SLABS / 16;
   static constexpr int NIT = (NCH + 63) / 64;
   static constexpr int OFF_TAB = SLABS;             // cell table, column table, cell table (logic wave's copy): 3 x 64 B
-  static constexpr int OFF_POST = OFF_TAB + 192;    // uint4 [EPW]: what the stream wave has to do per env
-  static constexpr int OFF_COLS = OFF_POST + 2 * EPW * 16;  // (post is double-buffered by transition parity)  // T [EPW][CST]: [0] bedrock, [1..W] playfield columns, [W+1] bedrock
+  static constexpr int OFF_POST = OFF_TAB + 192;    // uint4 [2][EPW]: what the stream wave has to do per env (double-buffered by transition parity)
+  static constexpr int OFF_COLS = OFF_POST + 2 * EPW * 16;  // T [EPW][CST]: [0] bedrock, [1..W] playfield columns, [W+1] bedrock
   static constexpr int CST = (W + 2) | 1;           // odd stride: conflict-free for same-index accesses of the 64 lanes
   static constexpr int BYTES = OFF_COLS + EPW * CST * (int)sizeof(T);
   static_assert(W % 2 == 0, "column masks are moved as 8-byte pairs");
 };
 
-// look-ahead generator context of one lane (NUMPY rule-set)
+// numpy PCG64 generator of one lane (NUMPY rule-set): 128-bit state, stream increment, buffered 32-bit half
 struct BitsRng {
-  uint64_t s_lo, s_hi, i_lo, i_hi;  // frontier state (after the last COMPUTED shuffle) and the stream increment
+  uint64_t s_lo, s_hi, i_lo, i_hi;
   uint32_t uinteger, has32;
-  bool loaded;                      // per lane: only lanes that shuffle fetch their generator
+  bool loaded;  // RNG role: the frontier state has been fetched (later entries of a launch continue from registers)
 };
 
 // Fisher-Yates positions of Generator.shuffle on a 7-array (numpy/random/_generator.pyx shuffle → random_interval,
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
 #endif
   if ((int)blockIdx.x < bp.nrb) {
     // =====================================================================================================
-    // RNG ROLE (leading workgroups, 128 envs each): append one permutation to every ring that holds fewer than two.
+    // RNG ROLE (leading workgroups, 128 envs each): refill every ring that holds fewer than kRing permutations.
     // Generator.shuffle on the 7-bag = numpy PCG64 + masked rejection (components/tetromino_randomizer.py:42-46, 84).
     // =====================================================================================================
     if (RULESET != TG_RULESET_NUMPY) return;
