@@ -148,6 +148,9 @@ def main():
     obs_mode = {"board": N.OBS_BOARD, "dict": N.OBS_DICT, "fn": N.OBS_FN, "none": N.OBS_NONE, "rgb": N.OBS_RGB}[args.obs]
     n_act = 8 if ruleset == N.RULESET_NUMPY else 7
     lo, hi, seeds = D.shard(B)
+    ndev = N.load().tg_device_count()
+    if ndev > 0:
+        local = local % ndev  # (more ranks than devices only happens when testing the N > 1 path on a 1-GPU box)
     os.environ["TG_FUSE"] = str(args.fuse)  # read by tg_create
     e = Engine(B, W, H, ruleset=ruleset, queue_size=(Q if ruleset == N.RULESET_NUMPY else 7), obs_mode=obs_mode,
                autoreset=N.AUTORESET_SAME_STEP, device=local, env_offset=lo, grouped=args.config5)

@@ -1022,7 +1022,8 @@ __device__ __forceinline__ void observe_env(const ObserveParams& p, const int en
   uint8_t* msk = img + IDS;
   uint32_t* lut = reinterpret_cast<uint32_t*>(msk + MSK);
   if (lane < 9) lut[lane] = c_rgb_lut[lane];
-  for (int i = lane * 16; i < IDS; i += 1024) *reinterpret_cast<uint4*>(img + i) = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+  const int fill = rgb ? IDS : MSK;  // bytes of the image area in use (rounded up to 16)
+  for (int i = lane * 16; i < fill; i += 1024) *reinterpret_cast<uint4*>(img + i) = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
   if (!rgb)
     for (int i = lane * 16; i < MSK; i += 1024) *reinterpret_cast<uint4*>(msk + i) = make_uint4(0u, 0u, 0u, 0u);
   wave_sync();
@@ -1091,12 +1092,11 @@ __device__ __forceinline__ void observe_env(const ObserveParams& p, const int en
     if (s.hp != TG_NONE) v = ((c_shapes.mask[s.hp][s.hr] >> lane) & 1u) ? (uint8_t)s.hv : (uint8_t)0;
     o_holder[lane] = v;
   }
-  for (int i = lane; i < 16 * Q; i += 64) {  // queue strip [4][4*Q]: rotation 0, values id+2
-    const int row = i / (4 * Q), cc = i - row * 4 * Q;
-    const int q = cc >> 2, c = cc & 3;
+  for (int i = lane; i < 16 * Q; i += 64) {  // queue strip [4][4*Q]: rotation 0, values id+2 (i = piece, row, column)
+    const int q = i >> 4, row = (i >> 2) & 3, c = i & 3;
     const int t = (int)((s.queue >> (8 * q)) & 0xFF);
     const uint32_t m = c_shapes.mask[t < 7 ? t : 0][0];
-    o_queue[i] = ((m >> (4 * row + c)) & 1u) ? (uint8_t)(t + 2) : (uint8_t)0;
+    o_queue[row * 4 * Q + 4 * q + c] = ((m >> (4 * row + c)) & 1u) ? (uint8_t)(t + 2) : (uint8_t)0;
   }
 }
 
