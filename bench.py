@@ -164,10 +164,8 @@ def main():
     e.dev_upload(d_acts, acts)
 
     def run(k0, k):
-        if args.config5:  # one pass = sample a legal placement per env on the device + the grouped step
-            for i in range(k):
-                e.sample_legal_actions(seed=rank + 1, counter=k0 + i, fetch=False)
-                e.step_sampled()
+        if args.config5:  # legal placements drawn on the device inside the step kernel (tg_grouped_rollout)
+            e.grouped_rollout(k, seed=rank + 1, counter0=k0, fetch=False)
             return
         done = 0
         while done < k:  # cycle through the resident action rows

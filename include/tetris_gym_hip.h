@@ -220,6 +220,14 @@ int tg_grouped_enumerate(tg_handle* h, uint8_t* boards_dev);
  * (seed, counter, env). Step afterwards with tg_step(h, <TG_BUF_ACTIONS pointer>, TG_MEM_DEVICE). */
 int tg_grouped_sample(tg_handle* h, uint32_t seed, uint32_t counter);
 
+/* K transitions of the uniform-random-LEGAL policy of the grouped action set, drawn on the device: transition k uses
+ * exactly the action tg_grouped_sample(h, seed, counter0 + k) would draw for the state at that point (so the result
+ * equals K x {tg_grouped_sample; tg_step}).  Optional caller-owned DEVICE outputs: the drawn actions i8 [K][B], the
+ * observation and output trajectories as in tg_rollout.  The default kernel draws inside the step kernel and runs up
+ * to TG_FUSE transitions per launch (BASELINE config 5: 20x40, queue 7, random legal placements). */
+int tg_grouped_rollout(tg_handle* h, uint32_t seed, uint32_t counter0, int K, int8_t* actions_out_dev,
+                       uint8_t* obs_traj_dev, tg_step_out* out_traj_dev);
+
 /* Feature observations of the current state (NUMPY rule-set), written to TG_BUF_PLACEMENT_FEATS / TG_BUF_FEATS:
  *  - per placement (column*4 + rotations): heights[W], max height, holes, bumpiness of the board that placement
  *    produces, i.e. GroupedActionsObservations(env, observation_wrappers=[FeatureVectorObservation(env)])

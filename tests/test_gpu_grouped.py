@@ -187,3 +187,41 @@ def test_placement_boards_engine_vs_oracle_random_states(W, H, Q):
         np.testing.assert_array_equal(boards, ob, err_msg=f"boards t={t}")
         a = e.sample_legal_actions(seed=9, counter=t)
         e.step_sampled(); o.grouped_step(a, autoreset=po.AUTORESET_SAME_STEP)
+
+
+@pytest.mark.parametrize("kernel_fuse", [1, 8])
+@pytest.mark.parametrize("W,H,Q,B", [(20, 40, 7, 1000), (10, 20, 4, 2500)])
+def test_grouped_rollout_equals_sample_then_step(W, H, Q, B, kernel_fuse, monkeypatch):
+    """tg_grouped_rollout draws the random legal placement inside the step kernel (up to 8 transitions per launch):
+    actions, outputs and final state must equal K x {tg_grouped_sample; tg_step} on a second engine, and the oracle
+    stepped with the drawn actions."""
+    monkeypatch.setenv("TG_FUSE", str(kernel_fuse))
+    kw = dict(queue_size=Q, obs_mode=N.OBS_BOARD, grouped=True, autoreset=N.AUTORESET_SAME_STEP)
+    a_eng, b_eng = Engine(B, W, H, **kw), Engine(B, W, H, **kw)
+    o = po.OracleBatch(B, W, H, queue_size=Q)
+    seeds = np.arange(31, 31 + B, dtype=np.uint64)
+    a_eng.reset(seeds); b_eng.reset(seeds); o.reset(seeds)
+    counter = 0
+    for K in (1, 5, 19, 32):
+        acts, rew, term, lines = a_eng.grouped_rollout(K, seed=77, counter0=counter)
+        for k in range(K):
+            mask = b_eng.legal_mask()
+            a = b_eng.sample_legal_actions(seed=77, counter=counter + k)
+            np.testing.assert_array_equal(acts[k], a, err_msg=f"drawn action k={k} (K={K})")
+            assert mask[np.arange(B), a].all()
+            b_eng.step_sampled()
+            rb, tb, lb = b_eng.fetch_outputs()
+            ro, to, lo, ill = o.grouped_step(a.astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+            for got, ref, ora, nm in ((rew[k], rb, ro, "reward"), (term[k], tb, to, "terminated"), (lines[k], lb, lo, "lines")):
+                np.testing.assert_array_equal(got, ref, err_msg=f"{nm} k={k}")
+                np.testing.assert_array_equal(got, ora, err_msg=f"{nm} vs oracle k={k}")
+            assert not ill.any()
+        counter += K
+        np.testing.assert_array_equal(a_eng.observation(), o.observe(po.OBS_BOARD))
+        ba, ra, ga = a_eng.get_state(); bo, ro2, go = o.get_state()
+        np.testing.assert_array_equal(ba, bo)
+        for f in ra.dtype.names:
+            if f != "reserved":
+                np.testing.assert_array_equal(ra[f], ro2[f], err_msg=f)
+        np.testing.assert_array_equal(ga["state_lo"], go["state_lo"])
+    a_eng.close(); b_eng.close()

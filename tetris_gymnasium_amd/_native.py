@@ -64,6 +64,7 @@ SYMBOLS = {
     "tg_step": (_i, [_vp, _vp, _i]),
     "tg_step_k": (_i, [_vp, _vp, _i]),
     "tg_rollout": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "tg_grouped_rollout": (_i, [_vp, C.c_uint32, C.c_uint32, _i, _vp, _vp, _vp]),
     "tg_device_ptr": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_sz)]),
     "tg_fetch": (_i, [_vp, _i, _vp, _sz]),
     "tg_get_state": (_i, [_vp, _vp, _vp, _vp]),

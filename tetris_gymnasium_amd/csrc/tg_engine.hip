@@ -361,6 +361,8 @@ int launch_step_all(tg_handle* h, const tg::KParams& p) {
     if (p.obs) q.obs = p.obs + o * obs_bytes_per_env(&h->cfg);
     if (p.obs_traj) q.obs_traj = p.obs_traj + o * obs_bytes_per_env(&h->cfg);
     if (p.out_traj) q.out_traj = p.out_traj + o;
+    if (p.act_traj) q.act_traj = p.act_traj + o;
+    q.env_index_base = (uint32_t)o;
     q.out = p.out + o;
     if (p.episode) q.episode = p.episode + o;
     if (p.cols) q.cols = (uint8_t*)p.cols + o * p.cols_bytes;
@@ -680,10 +682,34 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind) {
   return TG_OK;
 }
 
+__global__ void narrow_actions_kernel(const int32_t* src, int8_t* dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (int8_t)src[i];
+}
+
+static int run_grouped(tg_handle* h, bool mask, bool sample, uint32_t seed, uint32_t counter);
+
+// the common body of tg_step_k / tg_rollout (actions given) and tg_grouped_rollout (actions drawn on the device)
+static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, uint32_t seed, uint32_t counter0, int K,
+                        int8_t* act_traj_dev, uint8_t* obs_traj_dev, tg_step_out* out_traj_dev);
+
 int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K) { return tg_rollout(h, actions_dev, K, nullptr, nullptr); }
 
 int tg_rollout(tg_handle* h, const int8_t* actions_dev, int K, uint8_t* obs_traj_dev, tg_step_out* out_traj_dev) {
   if (!h || !actions_dev || K <= 0) return h ? fail(h, TG_EINVAL, "tg_rollout: bad arguments") : TG_EINVAL;
+  return rollout_impl(h, actions_dev, false, 0, 0, K, nullptr, obs_traj_dev, out_traj_dev);
+}
+
+int tg_grouped_rollout(tg_handle* h, uint32_t seed, uint32_t counter0, int K, int8_t* actions_out_dev,
+                       uint8_t* obs_traj_dev, tg_step_out* out_traj_dev) {
+  if (!h || K <= 0) return h ? fail(h, TG_EINVAL, "tg_grouped_rollout: bad arguments") : TG_EINVAL;
+  if (h->cfg.action_set != TG_ACTIONS_GROUPED)
+    return fail(h, TG_EINVAL, "tg_grouped_rollout: handle was not created with TG_ACTIONS_GROUPED");
+  return rollout_impl(h, nullptr, true, seed, counter0, K, actions_out_dev, obs_traj_dev, out_traj_dev);
+}
+
+static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, uint32_t seed, uint32_t counter0, int K,
+                        int8_t* act_traj_dev, uint8_t* obs_traj_dev, tg_step_out* out_traj_dev) {
   HIPCHK(h, hipSetDevice(h->cfg.device));
   if (h->B % 4 != 0) return fail(h, TG_EINVAL, "tg_rollout: batch must be a multiple of 4 (packed int8 action rows)");
   // Transitions per launch: the bits kernel keeps records, masks and slabs on chip across up to TG_FUSE (default and
@@ -691,17 +717,35 @@ int tg_rollout(tg_handle* h, const int8_t* actions_dev, int K, uint8_t* obs_traj
   // transition.  tg_step always launches one transition.
   const int fuse_max = h->fuse_max;
   const bool post_kernel = h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB;
-  const int fuse = (h->d_cols && !post_kernel) ? fuse_max : 1;
+  const int fuse = (h->d_cols && !post_kernel) ? fuse_max : 1;  // (sampled rollouts outside the bits kernel: one per launch, below)
   const size_t obs_stride = (size_t)h->B * obs_bytes_per_env(&h->cfg);
   if (obs_traj_dev && h->cfg.obs_mode == TG_OBS_NONE) return fail(h, TG_EINVAL, "tg_rollout: the handle has no observation (TG_OBS_NONE)");
   // trajectories are written by the step kernel itself when it packs the observation (bits kernel, BOARD / FN);
   // otherwise every transition is one launch followed by device-to-device copies of the engine's buffers
   const bool in_kernel = h->d_cols && !post_kernel;
+  const bool sample_in_kernel = sampled && in_kernel;
   auto enqueue = [&]() -> int {  // K transitions, `fuse` per launch (per shard)
     tg::KParams p = step_params(h);
     p.act_i8 = 1;
     for (int k = 0; k < K; k += fuse) {
-      p.actions = actions_dev + (size_t)k * h->B;
+      if (sample_in_kernel) {
+        p.actions = nullptr;
+        p.sample_mode = 1;
+        p.sample_seed = seed;
+        p.sample_counter = counter0 + (uint32_t)k;
+        p.act_traj = act_traj_dev ? act_traj_dev + (size_t)k * h->B : nullptr;
+      } else if (sampled) {  // other kernels / surfaces: the sampling kernel, then one transition from its int32 actions
+        int rcs = join_shards(h);
+        if (rcs == TG_OK) rcs = run_grouped(h, false, true, seed, counter0 + (uint32_t)k);
+        if (rcs != TG_OK) return rcs;
+        if (act_traj_dev)
+          hipLaunchKernelGGL(narrow_actions_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream,
+                             (const int32_t*)h->buf[TG_BUF_ACTIONS], act_traj_dev + (size_t)k * h->B, h->B);
+        p.actions = h->buf[TG_BUF_ACTIONS];
+        p.act_i8 = 0;
+      } else {
+        p.actions = actions_dev + (size_t)k * h->B;
+      }
       p.nsteps = K - k < fuse ? K - k : fuse;
       p.ring_cur = h->ring_cur;
       if (in_kernel) {

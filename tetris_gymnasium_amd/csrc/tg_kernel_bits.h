@@ -454,7 +454,9 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   // the actions of all transitions of this launch, requested up front (int8 rows: one byte per transition and env)
   uint64_t apack = 0;
   int action0 = 0;
-  if (p.act_i8) {
+  if (p.sample_mode) {
+    // (actions are drawn per transition below)
+  } else if (p.act_i8) {
     uint8_t ab[8];  // unconditional loads (row index clamped): all in flight together, no wait between them
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -576,7 +578,53 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
 
   bool cols_dirty_any = false;
   for (int step = 0; step < nsteps; ++step) {
-  const int action_in = p.act_i8 ? (int)(int8_t)(apack >> (8 * step)) : action0;
+  int action_in = p.act_i8 ? (int)(int8_t)(apack >> (8 * step)) : action0;
+  if (RULESET == TG_RULESET_NUMPY && p.sample_mode) {
+    // uniform over the legal placements of the CURRENT piece (wrappers/grouped.py:104-122: legal = inside the frame).
+    // Legal columns of a rotation form a range [lo_r, hi_r]; actions are ordered column-major, rotation-minor; the
+    // k-th legal one is found by bisection on the number of legal actions in columns < c.  Same draw as grouped_kernel.
+    const int n_half = s.piece == 0 ? 2 : 1;
+    int lo[4], cnt[4], n_legal = 0;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const uint32_t cm = (uint32_t)(col_tab[s.piece] >> (16 * ((s.rot + rr) & 3))) & 0xFFFFu;
+      const uint32_t occ = ((cm & 0xFu) ? 1u : 0u) | ((cm & 0xF0u) ? 2u : 0u) | ((cm & 0xF00u) ? 4u : 0u) | ((cm & 0xF000u) ? 8u : 0u);
+      const int cmin = (int)__builtin_ctz(occ), cmax = 31 - (int)__builtin_clz(occ);
+      const int l = n_half - cmin > 0 ? n_half - cmin : 0;
+      const int h = W - 1 + n_half - cmax < W - 1 ? W - 1 + n_half - cmax : W - 1;
+      lo[rr] = l;
+      cnt[rr] = h >= l ? h - l + 1 : 0;
+      n_legal += cnt[rr];
+    }
+    int pick = 0;
+    if (n_legal > 0) {
+      const uint32_t gidx = p.env_index_base + env;
+      int k = (int)(mix32(mix32(p.sample_seed ^ gidx * 0x9E3779B9u) + p.sample_counter + (uint32_t)step) % (uint32_t)n_legal);
+      auto below = [&](const int c) -> int {  // legal actions in columns < c
+        int f = 0;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { const int d = c - lo[rr]; f += d < 0 ? 0 : (d > cnt[rr] ? cnt[rr] : d); }
+        return f;
+      };
+      int a = 0, b = W - 1;  // the column holding the k-th legal action: largest c with below(c) <= k
+#pragma unroll 1
+      while (a < b) {
+        const int m = (a + b + 1) >> 1;
+        if (below(m) <= k) a = m; else b = m - 1;
+      }
+      k -= below(a);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const bool legal_here = a >= lo[rr] && a < lo[rr] + cnt[rr];
+        if (legal_here) {
+          if (k == 0) pick = a * 4 + rr;
+          --k;
+        }
+      }
+    }
+    action_in = pick;
+    if (p.act_traj && live) p.act_traj[(size_t)step * p.act_stride + env] = (int8_t)pick;
+  }
   float reward = 0.0f;
   int lines = 0;
   bool final_coll = false;

@@ -59,6 +59,12 @@ struct KParams {
   uint8_t* obs_traj;        // optional (tg_rollout): observation of transition k of this launch at obs_traj + k * obs_traj_stride
   uint2* out_traj;          // optional: outputs of transition k at out_traj + k * act_stride
   size_t obs_traj_stride;   // bytes between transitions (the handle's batch * observation bytes per env)
+  // bits kernel only, grouped action set: draw the action of every transition on the device, uniformly from the env's
+  // legal placements (the rule of grouped_kernel / tg_grouped_sample: same hash, same order) instead of reading it
+  int sample_mode;
+  uint32_t sample_seed, sample_counter;  // transition k of the launch uses counter + k
+  uint32_t env_index_base;  // handle-local index of this launch's env 0 (stream shards)
+  int8_t* act_traj;         // optional: the drawn actions, rows act_stride apart
 };
 
 struct ResetParams {

@@ -188,6 +188,28 @@ class Engine:
         if fetch:
             return self._fetch(N.BUF_ACTIONS, np.empty(self.B, np.int32))
 
+    def grouped_rollout(self, K, seed=0, counter0=0, fetch=True):
+        """K transitions of the uniform-random-legal policy drawn on the device (tg_grouped_rollout).  With fetch=True
+        returns (actions i8[K][B], reward f32[K][B], terminated u8[K][B], lines u8[K][B]); fetch=False only enqueues."""
+        if not fetch:
+            self._chk(self.lib.tg_grouped_rollout(self.h, int(seed) & 0xFFFFFFFF, int(counter0) & 0xFFFFFFFF, int(K),
+                                                  None, None, None), "tg_grouped_rollout")
+            return None
+        d_a = self.dev_alloc(K * self.B)
+        d_r = self.dev_alloc(K * self.B * N.STEP_OUT.itemsize)
+        try:
+            self._chk(self.lib.tg_grouped_rollout(self.h, int(seed) & 0xFFFFFFFF, int(counter0) & 0xFFFFFFFF, int(K),
+                                                  C.c_void_p(d_a), None, C.c_void_p(d_r)), "tg_grouped_rollout")
+            acts = np.empty((K, self.B), np.int8)
+            out = np.empty((K, self.B), N.STEP_OUT)
+            self._chk(self.lib.tg_dev_download(self.h, N.ptr(acts), C.c_void_p(d_a), acts.nbytes), "tg_dev_download")
+            self._chk(self.lib.tg_dev_download(self.h, N.ptr(out), C.c_void_p(d_r), out.nbytes), "tg_dev_download")
+        finally:
+            self.dev_free(d_a)
+            self.dev_free(d_r)
+        return (acts, np.ascontiguousarray(out["reward"]), np.ascontiguousarray(out["terminated"]),
+                np.ascontiguousarray(out["lines"]))
+
     def step_sampled(self):
         """Step with the actions left in the device actions buffer by sample_legal_actions()."""
         ptr, _ = self.device_ptr(N.BUF_ACTIONS)
