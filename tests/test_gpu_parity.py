@@ -381,3 +381,30 @@ def test_rollout_trajectory_equals_stepwise(fuse, ruleset, obs, B, monkeypatch):
         np.testing.assert_array_equal(e.observation(), o.observe(po_obs))  # the engine's buffer holds the last one
         _cmp_state(e, o, f"K={K}")
     e.close()
+
+
+@pytest.mark.parametrize("B,T", [(4096, 256), (65536, 192), (524288, 96)])
+def test_baseline_batch_sizes_against_oracle(B, T):
+    """BASELINE.json's batch sizes (configs 2-4: 4 096, 65 536, 8 x 65 536 envs, 10x20, uniform random actions, env i
+    seeded 1 + i, same-step autoreset) on one device, whole trajectories of reward / terminated / lines against the
+    oracle plus the final observation and the full state incl. every env's generator."""
+    e = Engine(B, 10, 20, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP, episode_stats=True)
+    o = po.OracleBatch(B, 10, 20, nthreads=8)
+    seeds = np.arange(1, B + 1, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(0)
+    n_done = 0
+    for t0 in range(0, T, 48):
+        K = min(48, T - t0)
+        acts = rng.integers(0, 8, (K, B)).astype(np.int8)
+        _, rew, term, lines = e.rollout(acts, want_obs=False)
+        for k in range(K):
+            ro, to, lo = o.step(acts[k].astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+            assert np.array_equal(rew[k], ro) and np.array_equal(term[k], to) and np.array_equal(lines[k], lo), f"t={t0 + k}"
+        n_done += int(term.sum())
+    np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_BOARD))
+    ge, go = _cmp_state(e, o, "final")
+    for f in ("state_lo", "state_hi", "inc_lo", "inc_hi", "uinteger", "has_uint32"):
+        np.testing.assert_array_equal(ge[f], go[f], err_msg=f"rng.{f}")
+    assert n_done > B // 4  # episodes ended and restarted inside the run (mean episode: 63 transitions)
+    e.close()

@@ -86,7 +86,7 @@ class Engine:
     def step_k_device(self, actions_dev_ptr, k):
         self._chk(self.lib.tg_step_k(self.h, C.c_void_p(actions_dev_ptr), int(k)), "tg_step_k")
 
-    def rollout(self, actions):
+    def rollout(self, actions, want_obs=True):
         """K transitions with the given actions int8[K][B] in one call (tg_rollout: the default kernel runs up to 8 per
         launch with the state resident on chip).  Returns (obs[K][B]..., reward f32[K][B], terminated u8[K][B],
         lines u8[K][B]) — what K calls of step() + observation() would have returned."""
@@ -96,7 +96,7 @@ class Engine:
         K = a.shape[0]
         per_env = self.lib.tg_obs_bytes_per_env(C.byref(self.cfg))
         d_a = self.dev_alloc(a.nbytes)
-        d_o = self.dev_alloc(K * self.B * per_env) if per_env else None
+        d_o = self.dev_alloc(K * self.B * per_env) if (per_env and want_obs) else None
         d_r = self.dev_alloc(K * self.B * N.STEP_OUT.itemsize)
         try:
             self.dev_upload(d_a, a)
