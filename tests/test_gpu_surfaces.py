@@ -436,3 +436,38 @@ def test_wrapper_class_grouped(with_features):
                 assert np.all(obs == env.observation_space.high)
             obs, info = env.reset(); o.reset()
     env.close()
+
+
+@pytest.mark.parametrize("W,H,Q,B", [(10, 20, 4, 1000), (20, 40, 7, 200), (10, 24, 1, 300), (6, 12, 2, 132), (12, 24, 4, 64)])
+def test_dict_observation_engine_vs_oracle(W, H, Q, B, monkeypatch):
+    """TG_OBS_DICT = Tetris._get_obs (envs/tetris.py:566-615).  On the default kernel the four arrays are packed by the
+    step kernel's two waves (board by the stream wave, mask / holder / queue by the logic wave) for board sizes whose
+    padded area is a multiple of 16 bytes, by the observe kernel otherwise (10x24); also after fused rollouts."""
+    monkeypatch.setenv("TG_FUSE", "8")
+    e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_DICT, autoreset=N.AUTORESET_SAME_STEP)
+    o = po.OracleBatch(B, W, H, queue_size=Q)
+    seeds = np.arange(3, 3 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(W + H)
+
+    def same(msg):
+        got, ref = e.observation(), o.observe(po.OBS_DICT)
+        for k in ("board", "active_tetromino_mask", "holder", "queue"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{k} {msg}")
+
+    same("reset")
+    for t in range(60):
+        a = rng.choice(8, B, p=[.12, .12, .12, .12, .12, .1, .2, .1])  # many hold swaps
+        re_, te, le = e.step(a)
+        ro, to, lo = o.step(a, autoreset=po.AUTORESET_SAME_STEP)
+        np.testing.assert_array_equal(te, to)
+        same(f"t={t}")
+    for K in (5, 16, 27):
+        acts = rng.integers(0, 8, (K, B)).astype(np.int8)
+        d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts)
+        e.step_k_device(d, K)
+        for k in range(K):
+            o.step(acts[k].astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+        same(f"after fused K={K}")
+        e.dev_free(d)
+    e.close()

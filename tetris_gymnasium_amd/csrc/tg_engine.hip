@@ -59,8 +59,9 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     const int nrb = RS == TG_RULESET_NUMPY ? (p.batch + 127) / 128 : 0;  // leading RNG workgroups (tg_kernel_bits.h)
     const tg::BitsParams bp{p.cols, p.ahead, p.ring, p.hbuf, p.ring_cur, nrb, p.ring_stride};
     const dim3 grid(nrb + (p.batch + BG::EPW - 1) / BG::EPW);
-    if (p.nsteps > 1) hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, true>), grid, dim3(128), BG::BYTES, s, p, bp);
-    else hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, false>), grid, dim3(128), BG::BYTES, s, p, bp);
+    const size_t lds = (p.obs_mode == TG_OBS_DICT && p.dict_in_kernel && BG::DICT_OK) ? BG::BYTES_DICT : BG::BYTES;
+    if (p.nsteps > 1) hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, true>), grid, dim3(128), lds, s, p, bp);
+    else hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, false>), grid, dim3(128), lds, s, p, bp);
     return;
   }
   if (g_kernel_lanes == 8 && !p.final_obs) {  // "block": two-phase kernel with workgroup-level slow-path compaction
@@ -162,6 +163,7 @@ struct tg_handle {
   uint8_t* d_hbuf = nullptr;   // bits kernel: consumed counters [2][B]
   int ring_cur = 0;            // parity the next step launch reads
   int fuse_max = 8;            // TG_FUSE: transitions per launch in tg_step_k (1..8)
+  bool dict_in_kernel = false; // TG_OBS_DICT packed by the bits step kernel itself (no observe launch after a transition)
   // TG_STREAMS=n (default 1) spreads the step launches of one transition over n streams (contiguous env shards).
   // Kept as a tested knob, off by default — measured on MI355X: every launch costs ≈2.8-3.4 µs of
   // command-processor time whichever stream it is on, so n shards cost n launch floors per transition (8.3 µs →
@@ -305,6 +307,7 @@ tg::KParams step_params(tg_handle* h) {
   p.cols_bytes = (uint32_t)h->L.cols_bytes;
   p.nsteps = 1;
   p.act_stride = (uint32_t)h->B;
+  p.dict_in_kernel = h->dict_in_kernel ? 1 : 0;
   return p;
 }
 
@@ -541,6 +544,8 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     CRCHK(hipStreamSynchronize(h->stream));
   }
   {
+    h->dict_in_kernel = h->d_cols && cfg->obs_mode == TG_OBS_DICT && ((cfg->width + 8) * (cfg->height + 4)) % 16 == 0 &&
+                        !(getenv("TG_DICT_KERNEL") && atoi(getenv("TG_DICT_KERNEL")) == 0);
     if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > 8 ? 8 : v); }
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
     int want = 1;
@@ -678,7 +683,7 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind) {
   }
   h->ring_cur ^= 1;
   HIPCHK(h, hipGetLastError());
-  if (h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) return launch_observe_dict(h);
+  if ((h->cfg.obs_mode == TG_OBS_DICT && !h->dict_in_kernel) || h->cfg.obs_mode == TG_OBS_RGB) return launch_observe_dict(h);
   return TG_OK;
 }
 
@@ -716,7 +721,7 @@ static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, u
   // max 8) consecutive transitions of a rollout — one launch floor and one slab round trip per group instead of per
   // transition.  tg_step always launches one transition.
   const int fuse_max = h->fuse_max;
-  const bool post_kernel = h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB;
+  const bool post_kernel = (h->cfg.obs_mode == TG_OBS_DICT && !h->dict_in_kernel) || h->cfg.obs_mode == TG_OBS_RGB;
   const int fuse = (h->d_cols && !post_kernel) ? fuse_max : 1;  // (sampled rollouts outside the bits kernel: one per launch, below)
   const size_t obs_stride = (size_t)h->B * obs_bytes_per_env(&h->cfg);
   if (obs_traj_dev && h->cfg.obs_mode == TG_OBS_NONE) return fail(h, TG_EINVAL, "tg_rollout: the handle has no observation (TG_OBS_NONE)");
@@ -756,7 +761,7 @@ static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, u
       int rc = launch_step_all(h, p);
       if (rc != TG_OK) return rc;
       h->ring_cur ^= 1;
-      if (h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) {  // packed by its own kernel after every transition
+      if (post_kernel) {  // packed by its own kernel after every transition
         rc = launch_observe_dict(h);
         if (rc != TG_OK) return rc;
       }

@@ -81,7 +81,13 @@ struct BitsGeo {
   static constexpr int OFF_POST = OFF_TAB + 192;    // uint4 [2][EPW]: what the stream wave has to do per env (double-buffered by transition parity)
   static constexpr int OFF_COLS = OFF_POST + 2 * EPW * 16;  // T [EPW][CST]: [0] bedrock, [1..W] playfield columns, [W+1] bedrock
   static constexpr int CST = (W + 2) | 1;           // odd stride: conflict-free for same-index accesses of the 64 lanes
-  static constexpr int BYTES = OFF_COLS + EPW * CST * (int)sizeof(T);
+  static constexpr int BYTES = ((OFF_COLS + EPW * CST * (int)sizeof(T) + 15) / 16) * 16;
+  // TG_OBS_DICT packed in the kernel: two staging buffers of 8 padded boards behind BYTES (stream wave: board, logic
+  // wave: active_tetromino_mask)
+  static constexpr int PC = (W + 8) * (H + 4);
+  static constexpr int OFF_DICT = BYTES;
+  static constexpr int BYTES_DICT = BYTES + 2 * 8 * PC;
+  static constexpr bool DICT_OK = PC % 16 == 0 && EPW % 8 == 0;
   static_assert(W % 2 == 0, "column masks are moved as 8-byte pairs");
 };
 
@@ -218,6 +224,8 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   const int slot = live ? lane : (int)nlive - 1;  // dead lanes shadow the last live env (identical, benign LDS writes)
   const uint32_t env = base_env + (uint32_t)slot;
   const bool need_slab = p.obs_mode == TG_OBS_BOARD || p.obs_mode == TG_OBS_FN;
+  const bool dict = BG::DICT_OK && p.obs_mode == TG_OBS_DICT && p.dict_in_kernel;
+  constexpr int WP = W + 8, HP = H + 4, PC = BG::PC;
   // p.nsteps consecutive transitions in this launch (tg_step_k): records / masks / slabs stay in registers and LDS in
   // between, only actions come in and observations go out per transition; one s_barrier per transition, and the
   // stream wave packs transition k while the logic wave already decides transition k + 1
@@ -428,7 +436,38 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
         }
       }
     }
-    if (need_slab && !last) {  // the slab in LDS is the board again: the drawn piece only ever covers free cells
+    if (dict) {
+      // obs["board"] (envs/tetris.py:566-571): the padded board with the projected piece.  Eight envs at a time: a lane
+      // builds padded rows (bedrock | playfield row | bedrock) in the staging buffer, then the group leaves as one
+      // contiguous coalesced block of 8 * Hp * Wp bytes.
+      bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu), (po.z >> 16) & 0xFFu, false,
+               live && ((po.z >> 24) & 1u));
+      wave_sync();
+      uint8_t* grp = lds + BG::OFF_DICT;
+      uint8_t* dst0 = p.obs_traj ? p.obs_traj + (size_t)step * p.obs_traj_stride : p.obs;
+      uint8_t* dst1 = (last && p.obs_traj) ? p.obs : nullptr;
+      for (int g0 = 0; g0 < EPW; g0 += 8) {
+        for (int t = lane; t < 8 * HP; t += 64) {
+          const int el = t / HP, R = t - el * HP;
+          uint16_t* drow = reinterpret_cast<uint16_t*>(grp + el * PC + R * WP);
+          drow[0] = 0x0101; drow[1] = 0x0101; drow[(W + 4) / 2] = 0x0101; drow[(W + 6) / 2] = 0x0101;
+          const uint16_t* srow = reinterpret_cast<const uint16_t*>(lds + (g0 + el) * S + (R < H ? R : 0) * W);
+#pragma unroll
+          for (int c2 = 0; c2 < W / 2; ++c2) drow[2 + c2] = R < H ? srow[c2] : (uint16_t)0x0101;
+        }
+        wave_sync();
+        for (int c = lane; c < 8 * PC / 16; c += 64) {
+          const uint32_t e = (uint32_t)g0 + (uint32_t)c / (PC / 16);
+          if (e < nlive) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(grp + 16 * c);
+            st_stream(reinterpret_cast<u32x4*>(dst0 + ((size_t)base_env + g0) * PC + 16 * (size_t)c), v);
+            if (dst1) st_stream(reinterpret_cast<u32x4*>(dst1 + ((size_t)base_env + g0) * PC + 16 * (size_t)c), v);
+          }
+        }
+        wave_sync();
+      }
+    }
+    if ((need_slab || dict) && !last) {  // the slab in LDS is the board again: the drawn piece only ever covers free cells
       wave_sync();
       bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu), 0u, false, live && ((po.z >> 24) & 1u));
       wave_sync();
@@ -941,7 +980,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
                                 ((do_clear ? 1u : 0u) << 25) | ((do_reset ? 1u : 0u) << 26),
                             (uint32_t)(lock_x & 0xFF) | ((uint32_t)(lock_y & 0xFF) << 8),
                             ocells | ((uint32_t)(s.val & 0xFF) << 16) | ((show ? 1u : 0u) << 24),
-                            (uint32_t)(s.x & 0xFF) | ((uint32_t)(s.y & 0xFF) << 8));
+                            (uint32_t)(s.x & 0xFF) | ((uint32_t)(s.y & 0xFF) << 8) | ((uint32_t)(s.piece & 0xFF) << 16));
   }
   TG_BITS_STAMP(5);
   if (pending) {  // the NEXT_STEP reset step belongs to no episode (gymnasium RecordEpisodeStatistics)
@@ -958,6 +997,62 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
               u32x2{__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8)});
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
+  if (dict) {
+    // the other three arrays of the dict observation (envs/tetris.py:572-615), while the stream wave packs the board:
+    // active_tetromino_mask = bounding box of the native matrix, holder = ones when empty else the held matrix,
+    // queue strip = next pieces at rotation 0.  Layout: board[B][Hp][Wp] | mask[B][Hp][Wp] | holder[B][4][4] | queue[B][4][4Q]
+    const size_t Bt = p.act_stride;  // the handle's batch
+    uint8_t* dsts[2] = {p.obs_traj ? p.obs_traj + (size_t)step * p.obs_traj_stride : p.obs,
+                        (step == nsteps - 1 && p.obs_traj) ? p.obs : nullptr};
+    uint8_t* grpm = lds + BG::OFF_DICT + 8 * BG::PC;
+    for (int g0 = 0; g0 < EPW; g0 += 8) {
+      for (int i = lane * 16; i < 8 * BG::PC; i += 1024) *reinterpret_cast<uint4*>(grpm + i) = make_uint4(0u, 0u, 0u, 0u);
+      wave_sync();
+      for (int t = lane; t < 128; t += 64) {
+        const int el = t >> 4, k = (t >> 2) & 3, c = t & 3;
+        const uint4 po = post[(step & 1) * EPW + g0 + el];
+        const int x = (int)(po.w & 0xFFu), y = (int)((po.w >> 8) & 0xFFu), pc = (int)((po.w >> 16) & 0xFFu);
+        const int n = pc == 0 ? 4 : (pc == 1 ? 2 : 3);
+        if ((uint32_t)(g0 + el) < nlive && k < n && c < n && y + k < HP && x + c < WP) grpm[el * BG::PC + (y + k) * WP + x + c] = 1;
+      }
+      wave_sync();
+      for (int c = lane; c < 8 * BG::PC / 16; c += 64) {
+        const uint32_t e = (uint32_t)g0 + (uint32_t)c / (BG::PC / 16);
+        if (e < nlive) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(grpm + 16 * c);
+#pragma unroll
+          for (int d = 0; d < 2; ++d)
+            if (dsts[d]) st_stream(reinterpret_cast<u32x4*>(dsts[d] + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC + 16 * (size_t)c), v);
+        }
+      }
+      wave_sync();
+    }
+    if (live) {
+      auto spread = [](const uint32_t nib, const uint32_t val) -> uint32_t {  // 4 cells of a matrix row → 4 bytes
+        return ((nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21)) * val;
+      };
+      u32x4 hv4 = u32x4{0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
+      if (s.hp != TG_NONE) {
+        const uint32_t hm = (uint32_t)c_shapes.mask[s.hp][s.hr];
+        hv4 = u32x4{spread(hm & 0xFu, (uint32_t)s.hv), spread((hm >> 4) & 0xFu, (uint32_t)s.hv),
+                    spread((hm >> 8) & 0xFu, (uint32_t)s.hv), spread((hm >> 12) & 0xFu, (uint32_t)s.hv)};
+      }
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        if (!dsts[d]) continue;
+        uint8_t* o_holder = dsts[d] + 2 * Bt * BG::PC + (size_t)env * 16;
+        uint8_t* o_queue = dsts[d] + 2 * Bt * BG::PC + Bt * 16 + (size_t)env * 16 * Q;
+        *reinterpret_cast<u32x4*>(o_holder) = hv4;
+        for (int q = 0; q < Q; ++q) {
+          const int t = (int)((s.queue >> (8 * q)) & 0xFF);
+          const uint32_t m = (uint32_t)c_shapes.mask[t < 7 ? t : 0][0];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            *reinterpret_cast<uint32_t*>(o_queue + rr * 4 * Q + 4 * q) = spread((m >> (4 * rr)) & 0xFu, (uint32_t)(t + 2));
+        }
+      }
+    }
+  }
   }  // transitions
 #ifndef TG_NO_PRIO_SWAP
   __builtin_amdgcn_s_setprio(0);
