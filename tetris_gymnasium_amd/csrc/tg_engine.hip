@@ -59,9 +59,23 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     const int nrb = RS == TG_RULESET_NUMPY ? (p.batch + 127) / 128 : 0;  // leading RNG workgroups (tg_kernel_bits.h)
     const tg::BitsParams bp{p.cols, p.ahead, p.ring, p.hbuf, p.ring_cur, nrb, p.ring_stride};
     const dim3 grid(nrb + (p.batch + BG::EPW - 1) / BG::EPW);
-    const size_t lds = (p.obs_mode == TG_OBS_DICT && p.dict_in_kernel && BG::DICT_OK) ? BG::BYTES_DICT : BG::BYTES;
-    if (p.nsteps > 1) hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, true>), grid, dim3(128), lds, s, p, bp);
-    else hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, false>), grid, dim3(128), lds, s, p, bp);
+    const bool dict = p.obs_mode == TG_OBS_DICT && p.dict_in_kernel && BG::DICT_OK;
+    const bool traj = p.obs_traj || p.out_traj || p.act_traj;
+    const size_t lds = dict ? BG::BYTES_DICT : BG::BYTES;
+    constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample;
+#define TG_LAUNCH_BITS(F) hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (F)>), grid, dim3(128), lds, s, p, bp)
+    if constexpr (RS == TG_RULESET_NUMPY) {
+      if (p.sample_mode) { TG_LAUNCH_BITS(M | T | S); return; }
+      if (dict) {
+        if (p.nsteps > 1 || traj) TG_LAUNCH_BITS(M | T | D);
+        else TG_LAUNCH_BITS(D);
+        return;
+      }
+    }
+    if (traj) TG_LAUNCH_BITS(M | T);
+    else if (p.nsteps > 1) TG_LAUNCH_BITS(M);
+    else TG_LAUNCH_BITS(0);
+#undef TG_LAUNCH_BITS
     return;
   }
   if (g_kernel_lanes == 8 && !p.final_obs) {  // "block": two-phase kernel with workgroup-level slow-path compaction

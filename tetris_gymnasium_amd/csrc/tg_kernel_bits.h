@@ -199,10 +199,19 @@ __device__ __forceinline__ void st_stream(V* dst, const V v) {
 #define TG_ST_STATE(ptr, val) (*(ptr) = (val))
 #endif
 
-// MULTI = false: one transition per launch (tg_step; the loop below collapses).  MULTI = true: p.nsteps transitions
-// per launch (tg_step_k).  Two instantiations so that profiles list the two kinds of launches separately.
-template <int W, int H, int RULESET, bool MULTI>
-__global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, const BitsParams bp) {
+// FEAT selects what an instantiation carries (the optional features cost registers and instructions in the hot loops
+// even when switched off at run time: measured +4 % on the one-transition launch, +18 % on fused rollouts):
+//   kFeatMulti  p.nsteps transitions per launch (tg_step_k / tg_rollout); without it the loop collapses (tg_step)
+//   kFeatTraj   trajectory outputs (obs_traj / out_traj / act_traj)
+//   kFeatDict   TG_OBS_DICT packed by the two waves
+//   kFeatSample actions drawn on the device (grouped action set)
+// Profiles list the kinds of launches separately.
+constexpr int kFeatMulti = 1, kFeatTraj = 2, kFeatDict = 4, kFeatSample = 8;
+
+template <int W, int H, int RULESET, int FEAT>
+__global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, const BitsParams bp) {
+  constexpr bool MULTI = (FEAT & kFeatMulti) != 0, TRAJ = (FEAT & kFeatTraj) != 0, DICTK = (FEAT & kFeatDict) != 0,
+                 SAMPLE = (FEAT & kFeatSample) != 0;
   using BG = BitsGeo<W, H>;
   using T = ColT<H>;
   constexpr int S = BG::S, EPW = BG::EPW, NCH = BG::NCH, NIT = BG::NIT, CST = BG::CST;
@@ -224,12 +233,16 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   const int slot = live ? lane : (int)nlive - 1;  // dead lanes shadow the last live env (identical, benign LDS writes)
   const uint32_t env = base_env + (uint32_t)slot;
   const bool need_slab = p.obs_mode == TG_OBS_BOARD || p.obs_mode == TG_OBS_FN;
-  const bool dict = BG::DICT_OK && p.obs_mode == TG_OBS_DICT && p.dict_in_kernel;
+  const bool dict = DICTK && BG::DICT_OK && p.obs_mode == TG_OBS_DICT && p.dict_in_kernel;
   constexpr int WP = W + 8, HP = H + 4, PC = BG::PC;
   // p.nsteps consecutive transitions in this launch (tg_step_k): records / masks / slabs stay in registers and LDS in
   // between, only actions come in and observations go out per transition; one s_barrier per transition, and the
   // stream wave packs transition k while the logic wave already decides transition k + 1
   const int nsteps = MULTI ? (p.nsteps > 1 ? p.nsteps : 1) : 1;
+  uint8_t* const obs_traj = TRAJ ? p.obs_traj : nullptr;
+  uint2* const out_traj = TRAJ ? p.out_traj : nullptr;
+  int8_t* const act_traj = TRAJ ? p.act_traj : nullptr;
+  const bool sample_mode = SAMPLE && p.sample_mode;
 
 #ifdef TG_PHASE_TIMING
   unsigned long long tstamp[8];  // kept in SGPRs and written at the very end: a store per stamp would itself be waited on
@@ -389,10 +402,10 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
                p.obs_mode == TG_OBS_FN ? 0xFFu : ((po.z >> 16) & 0xFFu), false, show);
       wave_sync();
       // trajectory output (tg_rollout): every transition has its own slot; the engine's buffer gets the last one
-      const bool to_traj = p.obs_traj != nullptr && !last;
-      uint8_t* obase = to_traj ? p.obs_traj + (size_t)step * p.obs_traj_stride : p.obs;
+      const bool to_traj = obs_traj != nullptr && !last;
+      uint8_t* obase = to_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs;
       u32x4* odst = reinterpret_cast<u32x4*>(obase + (size_t)base_env * S);
-      u32x4* odst2 = reinterpret_cast<u32x4*>((p.obs_traj ? p.obs_traj + (size_t)step * p.obs_traj_stride : p.obs) + (size_t)base_env * S);
+      u32x4* odst2 = reinterpret_cast<u32x4*>((obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs) + (size_t)base_env * S);
       const bool fn = p.obs_mode == TG_OBS_FN;
       auto bin1 = [](uint32_t x) -> uint32_t {  // bytes: 0xFF (active) stays -1, other non-zero → 1  (tetris_fn.py:137-158)
         const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
@@ -415,7 +428,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
           const int c = lane + 64 * k;
           if (c < NCH) {
             st_stream(&odst[c], o[k]);
-            if (last && p.obs_traj) st_stream(&odst2[c], o[k]);
+            if (last && obs_traj) st_stream(&odst2[c], o[k]);
           }
         }
       } else {
@@ -424,13 +437,13 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
           if (fn) vv = u32x4{bin1(vv.x), bin1(vv.y), bin1(vv.z), bin1(vv.w)};
           if (c * 16u + 16u <= nbytes) {
             odst[c] = vv;
-            if (last && p.obs_traj) odst2[c] = vv;
+            if (last && obs_traj) odst2[c] = vv;
           } else {  // ragged tail of a partial wave
             const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
             for (uint32_t i = 0; c * 16u + i < nbytes; ++i) {
               const uint8_t bv = (uint8_t)(w4[i >> 2] >> (8 * (i & 3)));
               reinterpret_cast<uint8_t*>(odst)[c * 16u + i] = bv;
-              if (last && p.obs_traj) reinterpret_cast<uint8_t*>(odst2)[c * 16u + i] = bv;
+              if (last && obs_traj) reinterpret_cast<uint8_t*>(odst2)[c * 16u + i] = bv;
             }
           }
         }
@@ -444,8 +457,8 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
                live && ((po.z >> 24) & 1u));
       wave_sync();
       uint8_t* grp = lds + BG::OFF_DICT;
-      uint8_t* dst0 = p.obs_traj ? p.obs_traj + (size_t)step * p.obs_traj_stride : p.obs;
-      uint8_t* dst1 = (last && p.obs_traj) ? p.obs : nullptr;
+      uint8_t* dst0 = obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs;
+      uint8_t* dst1 = (last && obs_traj) ? p.obs : nullptr;
       for (int g0 = 0; g0 < EPW; g0 += 8) {
         for (int t = lane; t < 8 * HP; t += 64) {
           const int el = t / HP, R = t - el * HP;
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   // the actions of all transitions of this launch, requested up front (int8 rows: one byte per transition and env)
   uint64_t apack = 0;
   int action0 = 0;
-  if (p.sample_mode) {
+  if (sample_mode) {
     // (actions are drawn per transition below)
   } else if (p.act_i8) {
     uint8_t ab[8];  // unconditional loads (row index clamped): all in flight together, no wait between them
@@ -618,7 +631,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   bool cols_dirty_any = false;
   for (int step = 0; step < nsteps; ++step) {
   int action_in = p.act_i8 ? (int)(int8_t)(apack >> (8 * step)) : action0;
-  if (RULESET == TG_RULESET_NUMPY && p.sample_mode) {
+  if (RULESET == TG_RULESET_NUMPY && sample_mode) {
     // uniform over the legal placements of the CURRENT piece (wrappers/grouped.py:104-122: legal = inside the frame).
     // Legal columns of a rotation form a range [lo_r, hi_r]; actions are ordered column-major, rotation-minor; the
     // k-th legal one is found by bisection on the number of legal actions in columns < c.  Same draw as grouped_kernel.
@@ -662,7 +675,7 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
       }
     }
     action_in = pick;
-    if (p.act_traj && live) p.act_traj[(size_t)step * p.act_stride + env] = (int8_t)pick;
+    if (act_traj && live) act_traj[(size_t)step * p.act_stride + env] = (int8_t)pick;
   }
   float reward = 0.0f;
   int lines = 0;
@@ -992,8 +1005,8 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
   }
   if (step == nsteps - 1 && live)  // the outputs of the LAST transition remain in the buffers
     st_stream(reinterpret_cast<u32x2*>(p.out + env), u32x2{__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8)});
-  if (p.out_traj && live)
-    st_stream(reinterpret_cast<u32x2*>(p.out_traj + (size_t)step * p.act_stride + env),
+  if (out_traj && live)
+    st_stream(reinterpret_cast<u32x2*>(out_traj + (size_t)step * p.act_stride + env),
               u32x2{__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8)});
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
@@ -1002,8 +1015,8 @@ __global__ __launch_bounds__(128, 1) void step_kernel_bits(const KParams p, cons
     // active_tetromino_mask = bounding box of the native matrix, holder = ones when empty else the held matrix,
     // queue strip = next pieces at rotation 0.  Layout: board[B][Hp][Wp] | mask[B][Hp][Wp] | holder[B][4][4] | queue[B][4][4Q]
     const size_t Bt = p.act_stride;  // the handle's batch
-    uint8_t* dsts[2] = {p.obs_traj ? p.obs_traj + (size_t)step * p.obs_traj_stride : p.obs,
-                        (step == nsteps - 1 && p.obs_traj) ? p.obs : nullptr};
+    uint8_t* dsts[2] = {obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs,
+                        (step == nsteps - 1 && obs_traj) ? p.obs : nullptr};
     uint8_t* grpm = lds + BG::OFF_DICT + 8 * BG::PC;
     for (int g0 = 0; g0 < EPW; g0 += 8) {
       for (int i = lane * 16; i < 8 * BG::PC; i += 1024) *reinterpret_cast<uint4*>(grpm + i) = make_uint4(0u, 0u, 0u, 0u);

@@ -9,9 +9,10 @@ sys.path.insert(0, ROOT)
 args = sys.argv[1:]
 fa, fb = (args[:args.index("--")], args[args.index("--") + 1:]) if "--" in args else (args, [])
 os.environ.setdefault("TG_FUSE", "1")
-src = os.path.join(ROOT, "tetris_gymnasium_amd", "csrc", "tg_engine.hip")
 procs = []
 for tag, flags in (("A", fa), ("B", fb)):
+    root = os.environ.get("AB_SRC_" + tag, ROOT)  # (another source tree for this side, e.g. an older commit's csrc)
+    src = os.path.join(root, "tetris_gymnasium_amd", "csrc", "tg_engine.hip")
     procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                                    "-DTG_FOR_EACH_SIZE(X)=X(10,20)", *flags, "-shared", "-o", f"/tmp/libtg_{tag}.so", src]))
 assert all(p.wait() == 0 for p in procs)
@@ -19,6 +20,12 @@ from tetris_gymnasium_amd import _native as N
 from tetris_gymnasium_amd import Engine
 B, K = int(os.environ.get("AB_BATCH", "65536")), 512
 acts = np.random.default_rng(0).integers(0, 8, (K, B)).astype(np.int8)
+import ctypes
+for tag in "AB":  # older builds may lack entry points added later: bind only what both export
+    lib = ctypes.CDLL(f"/tmp/libtg_{tag}.so")
+    for name in list(N.SYMBOLS):
+        if not hasattr(lib, name):
+            del N.SYMBOLS[name]
 eng = {}
 for tag in ("A", "B", "A2", "B2"):  # two engines per build: buffer placement varies too
     N._lib = None
