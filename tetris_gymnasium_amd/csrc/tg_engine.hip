@@ -49,8 +49,9 @@ int g_step_blocks = 0;  // persistent grid size (blocks); set once per process f
 int g_kernel_lanes = 16;
 int g_block_waves = 4;  // TG_BLOCK_WAVES: waves per workgroup of the block kernel (4 → 64 envs, 8 → 128 envs)
 int g_stagger = 0;  // TG_STAGGER: odd waves of the lane kernels start this many x64 cycles late
-size_t g_lds_pad = 0;
-int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = experimental pipelined pair of groups per wave (measured slower: the prefetched inputs spill), 1 = off  // TG_LDS_PAD: extra dynamic LDS per wave = occupancy limiter (staggers the waves of a SIMD)
+size_t g_lds_pad = 0;       // TG_LDS_PAD: extra dynamic LDS per wave of the lane kernels = occupancy limiter
+int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = lane kernels' pipelined pair of groups per wave (measured slower:
+                            // the prefetched inputs spill), 1 = off
 
 template <int W, int H, int RS>
 void launch_step(const tg::KParams& p, hipStream_t s) {
@@ -510,7 +511,12 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     if (const char* e4 = getenv("TG_STAGGER")) g_stagger = atoi(e4);
     if (const char* e3 = getenv("TG_GROUPS_PER_WAVE")) g_groups_per_wave = atoi(e3) > 0 ? atoi(e3) : 1;
     if (const char* k = getenv("TG_KERNEL"))
-      g_kernel_lanes = strcmp(k, "wave") == 0 ? 0 : (strcmp(k, "lanes") == 0 ? 1 : (strcmp(k, "pair") == 0 ? 2 : (strcmp(k, "quad") == 0 ? 4 : (strcmp(k, "block") == 0 ? 8 : 16))));
+      g_kernel_lanes = strcmp(k, "wave") == 0    ? 0
+                       : strcmp(k, "lanes") == 0 ? 1
+                       : strcmp(k, "pair") == 0  ? 2
+                       : strcmp(k, "quad") == 0  ? 4
+                       : strcmp(k, "block") == 0 ? 8
+                                                 : 16;
     if (const char* bw = getenv("TG_BLOCK_WAVES")) g_block_waves = atoi(bw) == 8 ? 8 : 4;
     g_step_blocks = per_cu > 0 ? prop.multiProcessorCount * per_cu : -1;
   }
@@ -839,9 +845,9 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
     for (size_t i = 0; i < B; ++i) {
       const tg_env_rec& r = rec[i];
       if (r.piece > 6 || r.rot > 3 || (r.holder_piece != TG_NONE && (r.holder_piece > 6 || r.holder_rot > 3)) ||
-          r.bag_index > 7)
-        return fail(h, TG_EINVAL, "tg_set_state: record %zu out of range (piece %d rot %d holder %d bag_index %d)", i,
-                    r.piece, r.rot, r.holder_piece, r.bag_index);
+          r.bag_index > 7 || r.x > h->W + 4 || r.y > h->H + 3)
+        return fail(h, TG_EINVAL, "tg_set_state: record %zu out of range (piece %d rot %d holder %d bag_index %d x %d y %d)", i,
+                    r.piece, r.rot, r.holder_piece, r.bag_index, r.x, r.y);
       for (int k = 0; k < 7; ++k)
         if (r.bag[k] > 6 || (k < h->Q && h->cfg.ruleset == TG_RULESET_NUMPY && r.queue[k] > 6))
           return fail(h, TG_EINVAL, "tg_set_state: record %zu holds a tetromino index > 6", i);

@@ -227,7 +227,10 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   const int wave = rfl((int)(threadIdx.x >> 6));
 
   const uint32_t B = (uint32_t)p.batch;
-  const uint32_t base_env = (blockIdx.x - (uint32_t)bp.nrb) * (uint32_t)EPW;  // (meaningless in the RNG role)
+  // role split by blockIdx: the RNG workgroups lead (placing them last measured the same)
+  const bool rng_role = (int)blockIdx.x < bp.nrb;
+  const uint32_t step_block = blockIdx.x - (uint32_t)bp.nrb, rng_block = blockIdx.x;
+  const uint32_t base_env = step_block * (uint32_t)EPW;  // (meaningless in the RNG role)
   const uint32_t nlive = B - base_env < (uint32_t)EPW ? B - base_env : (uint32_t)EPW;
   const bool live = (uint32_t)lane < nlive;
   const int slot = live ? lane : (int)nlive - 1;  // dead lanes shadow the last live env (identical, benign LDS writes)
@@ -250,13 +253,13 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
 #else
 #define TG_BITS_STAMP(i) do {} while (0)
 #endif
-  if ((int)blockIdx.x < bp.nrb) {
+  if (rng_role) {
     // =====================================================================================================
     // RNG ROLE (leading workgroups, 128 envs each): refill every ring that holds fewer than kRing permutations.
     // Generator.shuffle on the 7-bag = numpy PCG64 + masked rejection (components/tetromino_randomizer.py:42-46, 84).
     // =====================================================================================================
     if (RULESET != TG_RULESET_NUMPY) return;
-    const uint32_t e = blockIdx.x * 128u + threadIdx.x;
+    const uint32_t e = rng_block * 128u + threadIdx.x;
     const bool on = e < B;
     const uint32_t ee = on ? e : B - 1u;
     const uint4 rw = reinterpret_cast<const uint4*>(bp.ring)[(size_t)bp.cur * bp.pstride + ee];
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     TG_BITS_STAMP(4);
 #ifdef TG_PHASE_TIMING
     if (p.dbg && lane == 0)
-      for (int i = 0; i < 5; ++i) p.dbg[(size_t)(blockIdx.x - bp.nrb) * 16 + 8 + i] = tstamp[i];
+      for (int i = 0; i < 5; ++i) p.dbg[(size_t)step_block * 16 + 8 + i] = tstamp[i];
 #endif
     return;
   }
@@ -1112,7 +1115,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   TG_BITS_STAMP(7);
 #ifdef TG_PHASE_TIMING
   if (p.dbg && lane == 0)
-    for (int i = 0; i < 8; ++i) p.dbg[(size_t)(blockIdx.x - bp.nrb) * 16 + i] = tstamp[i];
+    for (int i = 0; i < 8; ++i) p.dbg[(size_t)step_block * 16 + i] = tstamp[i];
 #endif
   if (live && (ob.x != rb.x || ob.y != rb.y || ob.z != rb.z || ob.w != rb.w))
     TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out + 1), (u32x4{ob.x, ob.y, ob.z, ob.w}));
