@@ -259,6 +259,9 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     // Generator.shuffle on the 7-bag = numpy PCG64 + masked rejection (components/tetromino_randomizer.py:42-46, 84).
     // =====================================================================================================
     if (RULESET != TG_RULESET_NUMPY) return;
+#ifdef TG_PHASE_TIMING
+    const unsigned long long rng_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const uint32_t e = rng_block * 128u + threadIdx.x;
     const bool on = e < B;
     const uint32_t ee = on ? e : B - 1u;
@@ -298,6 +301,13 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     if (on)
       reinterpret_cast<uint4*>(bp.ring)[(size_t)(1 - bp.cur) * bp.pstride + e] =
           make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+#ifdef TG_PHASE_TIMING
+    if (p.dbg && (threadIdx.x & 63) == 0) {  // lifetime of the RNG waves, behind the step workgroups' stamps
+      const size_t slot = (size_t)(gridDim.x - bp.nrb) * 16 + (size_t)rng_block * 4 + (threadIdx.x >> 6) * 2;
+      p.dbg[slot] = rng_t0;
+      p.dbg[slot + 1] = __builtin_amdgcn_s_memtime();
+    }
+#endif
     return;
   }
   TG_BITS_STAMP(0);

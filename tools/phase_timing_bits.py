@@ -28,6 +28,9 @@ def show(t, names):
     dd = np.diff(t, axis=1)
     for i, nm in enumerate(names):
         print(f"  {nm:44s} mean {dd[:, i].mean():8.1f}   p50 {np.median(dd[:, i]):8.1f}   max {dd[:, i].max():8.1f}")
+rb = buf.reshape(-1)[nb * 16: nb * 16 + (B // 128) * 4].reshape(-1, 2).astype(np.int64)
+rl = rb[:, 1] - rb[:, 0]
+print(f"RNG waves ({len(rl)}): lifetime mean {rl.mean():.0f} p50 {np.median(rl):.0f} max {rl.max()}")
 print("logic wave:")
 show(tl, ["A small loads + cols->LDS", "B0 unpack/swap + window read", "B1 tests/decide", "B2 lock path",
           "B3 reset path + publish", "barrier + D rec/out/cols stores", "E refresh (PCG)"])
