@@ -471,3 +471,24 @@ def test_dict_observation_engine_vs_oracle(W, H, Q, B, monkeypatch):
         same(f"after fused K={K}")
         e.dev_free(d)
     e.close()
+
+
+def test_rollout_entry_points_reject_bad_arguments():
+    """Error behaviour of the rollout entry points: negative TG_E* codes + message, never a crash or a silent fallback."""
+    import ctypes as C
+    from tetris_gymnasium_amd.engine import EngineError
+    e = Engine(130, obs_mode=N.OBS_BOARD)  # 130 % 4 != 0: int8 action rows cannot be packed
+    e.reset(np.arange(1, 131, dtype=np.uint64))
+    with pytest.raises(EngineError, match="multiple of 4"):
+        e.rollout(np.zeros((3, 130), np.int8))
+    with pytest.raises(EngineError, match="TG_ACTIONS_GROUPED"):
+        e.grouped_rollout(4)
+    assert e.lib.tg_rollout(e.h, None, 4, None, None) < 0 and e.lib.tg_rollout(e.h, C.c_void_p(1), 0, None, None) < 0
+    e.close()
+    e = Engine(128, obs_mode=N.OBS_NONE)
+    e.reset(np.arange(1, 129, dtype=np.uint64))
+    d = e.dev_alloc(128 * 4)
+    assert e.lib.tg_rollout(e.h, C.c_void_p(d), 4, C.c_void_p(d), None) < 0  # no observation surface to record
+    assert b"TG_OBS_NONE" in e.lib.tg_last_error(e.h)
+    e.dev_free(d)
+    e.close()
