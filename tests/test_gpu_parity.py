@@ -303,7 +303,7 @@ def test_sharded_streams_engine_vs_oracle(ruleset, B, monkeypatch):
     e.close()
 
 
-@pytest.mark.parametrize("fuse", [1, 2, 4, 8])
+@pytest.mark.parametrize("fuse,ring_fill", [(1, 4), (2, 4), (4, 4), (8, 4), (8, 1), (3, 0)])
 @pytest.mark.parametrize("ruleset,W,H,Q,B,autoreset,grouped", [
     (N.RULESET_NUMPY, 10, 20, 4, 1000, N.AUTORESET_SAME_STEP, False),
     (N.RULESET_NUMPY, 10, 20, 4, 4096, N.AUTORESET_NEXT_STEP, False),
@@ -312,11 +312,14 @@ def test_sharded_streams_engine_vs_oracle(ruleset, B, monkeypatch):
     (N.RULESET_NUMPY, 6, 12, 2, 500, N.AUTORESET_NONE, False),
     (N.RULESET_FUNCTIONAL, 10, 20, 7, 1000, N.AUTORESET_SAME_STEP, False),
 ])
-def test_fused_rollout_equals_single_transitions(fuse, ruleset, W, H, Q, B, autoreset, grouped, monkeypatch):
+def test_fused_rollout_equals_single_transitions(fuse, ring_fill, ruleset, W, H, Q, B, autoreset, grouped, monkeypatch):
     """tg_step_k keeps state on chip across up to TG_FUSE transitions per launch (one barrier per transition, the
     observation of every transition still written): final observation, outputs, state, generator and episode
     statistics must equal K single transitions of the oracle, for K that are and are not multiples of the group."""
     monkeypatch.setenv("TG_FUSE", str(fuse))
+    # ring_fill < 4: the RNG workgroups keep fewer look-ahead permutations, so the logic wave's in-line shuffle (ring run
+    # dry: practically unreachable with the full ring) is exercised all the time; 0 = it does every shuffle itself
+    monkeypatch.setenv("TG_RING_FILL", str(ring_fill))
     numpy_rules = ruleset == N.RULESET_NUMPY
     obs = N.OBS_BOARD if numpy_rules else N.OBS_FN
     po_obs = po.OBS_BOARD if numpy_rules else po.OBS_FN

@@ -58,7 +58,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
   if (p.cols && !p.final_obs) {  // "bits": the handle carries the column masks / look-ahead permutations
     using BG = tg::BitsGeo<W, H>;
     const int nrb = RS == TG_RULESET_NUMPY ? (p.batch + 127) / 128 : 0;  // leading RNG workgroups (tg_kernel_bits.h)
-    const tg::BitsParams bp{p.cols, p.ahead, p.ring, p.hbuf, p.ring_cur, nrb, p.ring_stride};
+    const tg::BitsParams bp{p.cols, p.ahead, p.ring, p.hbuf, p.ring_cur, nrb, p.ring_stride, p.ring_fill};
     const dim3 grid(nrb + (p.batch + BG::EPW - 1) / BG::EPW);
     const bool dict = p.obs_mode == TG_OBS_DICT && p.dict_in_kernel && BG::DICT_OK;
     const bool traj = p.obs_traj || p.out_traj || p.act_traj;
@@ -178,6 +178,7 @@ struct tg_handle {
   uint8_t* d_hbuf = nullptr;   // bits kernel: consumed counters [2][B]
   int ring_cur = 0;            // parity the next step launch reads
   int fuse_max = 8;            // TG_FUSE: transitions per launch in tg_step_k (1..8)
+  int ring_fill = tg::kRing;   // TG_RING_FILL (tests): fewer look-ahead permutations → the consumer's in-line shuffle runs
   bool dict_in_kernel = false; // TG_OBS_DICT packed by the bits step kernel itself (no observe launch after a transition)
   // TG_STREAMS=n (default 1) spreads the step launches of one transition over n streams (contiguous env shards).
   // Kept as a tested knob, off by default — measured on MI355X: every launch costs ≈2.8-3.4 µs of
@@ -323,6 +324,7 @@ tg::KParams step_params(tg_handle* h) {
   p.nsteps = 1;
   p.act_stride = (uint32_t)h->B;
   p.dict_in_kernel = h->dict_in_kernel ? 1 : 0;
+  p.ring_fill = h->ring_fill;
   return p;
 }
 
@@ -566,6 +568,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   {
     h->dict_in_kernel = h->d_cols && cfg->obs_mode == TG_OBS_DICT && ((cfg->width + 8) * (cfg->height + 4)) % 16 == 0 &&
                         !(getenv("TG_DICT_KERNEL") && atoi(getenv("TG_DICT_KERNEL")) == 0);
+    if (const char* e = getenv("TG_RING_FILL")) { const int v = atoi(e); h->ring_fill = v < 0 ? 0 : (v > tg::kRing ? tg::kRing : v); }
     if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > 8 ? 8 : v); }
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
     int want = 1;

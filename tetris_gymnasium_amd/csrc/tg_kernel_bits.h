@@ -166,6 +166,7 @@ struct BitsParams {
   int cur;         // parity this launch reads; it writes 1 - cur
   int nrb;         // number of leading RNG workgroups (128 envs each)
   uint32_t pstride;  // elements between the two parities of ring / hbuf (the handle's whole batch)
+  int fill;          // entries the RNG role keeps in a ring (kRing; tests lower it to exercise the consumer's in-line shuffle)
 };
 
 // native 16-byte vector for the slab stream: HIP's uint4 is a struct whose copies become memcpy intrinsics, which
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     uint4* a4 = bp.ahead + (size_t)ee * (2 * kRing);
     for (int rep = 0; rep < kRing; ++rep) {  // (a ring emptied by one launch is refilled completely)
       const int Tn = (int)(w0 >> 56);
-      const bool need = on && (int)(int8_t)(uint8_t)(Tn - Hn) < kRing;
+      const bool need = on && (int)(int8_t)(uint8_t)(Tn - Hn) < bp.fill;
       if (!__any(need)) break;
       if (need && !g.loaded) {  // frontier = state after entry T - 1; later entries continue from the registers
         const int fs = (Tn - 1) & (kRing - 1);

@@ -65,6 +65,7 @@ struct KParams {
   uint32_t sample_seed, sample_counter;  // transition k of the launch uses counter + k
   uint32_t env_index_base;  // handle-local index of this launch's env 0 (stream shards)
   int8_t* act_traj;         // optional: the drawn actions, rows act_stride apart
+  int ring_fill;            // bits kernel only: ring entries the RNG role maintains (TG_RING_FILL, default all)
   int dict_in_kernel;       // bits kernel only: TG_OBS_DICT is packed by the step kernel's two waves (sizes with (H+4)(W+8) % 16 == 0)
 };
 
