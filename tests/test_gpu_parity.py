@@ -411,3 +411,47 @@ def test_baseline_batch_sizes_against_oracle(B, T):
         np.testing.assert_array_equal(ge[f], go[f], err_msg=f"rng.{f}")
     assert n_done > B // 4  # episodes ended and restarted inside the run (mean episode: 63 transitions)
     e.close()
+
+
+@pytest.mark.parametrize("ruleset", [N.RULESET_NUMPY, N.RULESET_FUNCTIONAL])
+@pytest.mark.parametrize("fuse", [1, 8])
+def test_fused_rollout_with_frequent_line_clears(ruleset, fuse, monkeypatch):
+    """Dense stacks (full rows except a narrow gap) + hard-drop-heavy actions: line clears (mask compaction in the logic
+    wave, cooperative uint8 row compaction in the stream wave, the functional rule-set's row-0 quirk) happen all the time
+    inside fused groups; outputs of every transition and the final state against the oracle."""
+    monkeypatch.setenv("TG_FUSE", str(fuse))
+    B, W, H = 768, 10, 20
+    numpy_rules = ruleset == N.RULESET_NUMPY
+    obs, po_obs = (N.OBS_BOARD, po.OBS_BOARD) if numpy_rules else (N.OBS_FN, po.OBS_FN)
+    e = Engine(B, W, H, ruleset=ruleset, obs_mode=obs, autoreset=N.AUTORESET_SAME_STEP)
+    o = po.OracleBatch(B, W, H, ruleset)
+    seeds = np.arange(100, 100 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(fuse + ruleset)
+    hard = 5 if numpy_rules else 6
+    total_lines = 0
+    for rnd in range(6):
+        b = np.zeros((B, H, W), np.uint8)
+        for i in range(B):
+            top = rng.integers(8, 15)
+            b[i, top:] = rng.integers(2, 9, (H - top, W))
+            g = rng.integers(0, W - 2)
+            b[i, top:, g:g + rng.integers(1, 3)] = 0
+            if rng.random() < 0.2:
+                b[i, 0, :] = 3 if rng.random() < 0.5 else 0  # occupied top row: the functional clear copies row 0 down
+                b[i, 0, rng.integers(0, W)] = 0
+        e.set_state(board=b); o.set_state(board=b)
+        K = 40
+        acts = rng.choice(8 if numpy_rules else 7, (K, B), p=None).astype(np.int8)
+        acts[rng.random((K, B)) < 0.35] = hard
+        _, rew, term, lines = e.rollout(acts, want_obs=False)
+        for k in range(K):
+            ro, to, lo = o.step(acts[k].astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+            np.testing.assert_array_equal(lines[k], lo, err_msg=f"lines round {rnd} k={k}")
+            np.testing.assert_array_equal(rew[k], ro, err_msg=f"reward round {rnd} k={k}")
+            np.testing.assert_array_equal(term[k], to, err_msg=f"terminated round {rnd} k={k}")
+        total_lines += int(lines.sum())
+        np.testing.assert_array_equal(e.observation(), o.observe(po_obs), err_msg=f"obs round {rnd}")
+        _cmp_state(e, o, f"round {rnd}")
+    assert total_lines > B // 4  # hundreds of clears inside the fused groups
+    e.close()
