@@ -1000,7 +1000,8 @@ struct ObserveGeo {
   using G = Geo<W, H>;
   static constexpr int IDS = ((G::HP * (G::WP + 28) + 15) / 16) * 16;  // image ids: padded board (+ RGB: queue/holder strip)
   static constexpr int MSK = ((G::HP * G::WP + 15) / 16) * 16;         // DICT: active_tetromino_mask
-  static constexpr int PER_WAVE = G::LDS_SLAB + IDS + MSK + 64;
+  static constexpr int RGBB = 3 * IDS;                                 // RGB: the packed image, staged for 16-byte stores
+  static constexpr int PER_WAVE = G::LDS_SLAB + IDS + MSK + 64 + RGBB;
 };
 
 // one env's observation from its slab (already staged in LDS) and record
@@ -1063,7 +1064,10 @@ __device__ __forceinline__ void observe_env(const ObserveParams& p, const int en
   wave_sync();
   if (rgb) {
     // four pixels → three dwords; the image leaves as one contiguous, coalesced stream
-    uint32_t* dst = reinterpret_cast<uint32_t*>(p.obs + (size_t)env * (size_t)NPX * 3);
+    uint32_t* stg = reinterpret_cast<uint32_t*>(msk + MSK + 64);  // staged, then streamed out 16 bytes per lane
+    uint8_t* gdst = p.obs + (size_t)env * (size_t)NPX * 3;
+    const bool wide = (NPX * 3) % 16 == 0;
+    uint32_t* dst = wide ? stg : reinterpret_cast<uint32_t*>(gdst);
     for (int q = lane; q < NPX / 4; q += 64) {
       const uint32_t ids = *reinterpret_cast<const uint32_t*>(img + 4 * q);
       uint32_t c4[4];
@@ -1075,6 +1079,11 @@ __device__ __forceinline__ void observe_env(const ObserveParams& p, const int en
       dst[3 * q] = c4[0] | (c4[1] << 24);
       dst[3 * q + 1] = (c4[1] >> 8) | (c4[2] << 16);
       dst[3 * q + 2] = (c4[2] >> 16) | (c4[3] << 8);
+    }
+    if (wide) {
+      wave_sync();
+      for (int i = lane * 16; i < NPX * 3; i += 1024)
+        *reinterpret_cast<uint4*>(gdst + i) = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(stg) + i);
     }
     return;
   }
