@@ -19,7 +19,7 @@ assert all(p.wait() == 0 for p in procs)
 from tetris_gymnasium_amd import _native as N
 from tetris_gymnasium_amd import Engine
 B, K = int(os.environ.get("AB_BATCH", "65536")), 512
-acts = np.random.default_rng(0).integers(0, 8, (K, B)).astype(np.int8)
+acts = np.random.default_rng(0).integers(0, 7 if os.environ.get('AB_RULESET') == 'functional' else 8, (K, B)).astype(np.int8)
 import ctypes
 for tag in "AB":  # older builds may lack entry points added later: bind only what both export
     lib = ctypes.CDLL(f"/tmp/libtg_{tag}.so")
@@ -30,7 +30,9 @@ eng = {}
 for tag in ("A", "B", "A2", "B2"):  # two engines per build: buffer placement varies too
     N._lib = None
     N.LIB_PATH = f"/tmp/libtg_{tag[0]}.so"
-    e = Engine(B, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP)
+    fnrules = os.environ.get("AB_RULESET", "numpy") == "functional"
+    e = Engine(B, ruleset=(N.RULESET_FUNCTIONAL if fnrules else N.RULESET_NUMPY), obs_mode=(N.OBS_FN if fnrules else N.OBS_BOARD),
+               autoreset=N.AUTORESET_SAME_STEP)
     e.reset(np.arange(1, B + 1, dtype=np.uint64))
     d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts)
     e.step_k_device(d, 64); e.sync()
