@@ -1,78 +1,99 @@
 #!/usr/bin/env python3
 """bench.py — env steps/sec of the batched Tetris step on MI355X (BASELINE.json's metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                       (self-launching: N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path (one step kernel) over one batch of 65 536 envs per GPU (10x20 board,
-NumPy rule-set, uniform random actions resident in HBM, autoreset so the batch never drains).  One
-process per GPU; envs are sharded by contiguous ranges with NO data-path collective (weak scaling);
-torch.distributed (gloo) is used only for the barrier and the max-over-ranks of the timing.
-Rank 0 prints ONE JSON line.
+A "step" = one pass of the hot path (ONE launch of the step kernel) over one batch of 65 536 envs per GPU (10x20
+board, NumPy rule-set, uniform random int8 actions resident in HBM, same-step autoreset so the batch never drains).
+One process per GPU; envs are sharded by contiguous ranges (global env i = rank * 65536 + local i, seed 1 + i) with
+NO data-path collective (weak scaling).  torch.distributed (gloo) carries only the barrier, the max-over-ranks of the
+timing and the per-rank timing list.
+
+`--gpus N` without a torchrun environment makes THIS process a launcher: it spawns N fresh rank processes
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and waits for them.  The launcher never loads the HIP
+library and makes no HIP call — a process that has touched the GPU must not fork/exec ranks.  With more ranks than
+devices (`--gpus 2` on a 1-GPU box) ranks share devices round-robin: that exercises the N > 1 path, it is not a
+scaling number.
+
+Rank 0 prints ONE JSON line.  At N = 1 the line also carries one block per further BASELINE config (`blocks`:
+config 2 = 4 096 envs, config 5 = 20x40 / queue 7 / grouped action set, the reference's dict observation, the fused
+rollout), each with its own `roofline` and `cpu_baseline`.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-
-from tetris_gymnasium_amd import Engine, _native as N  # noqa: E402
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PROFILED = os.path.join(ROOT, "profiles", "latest.json")  # rocprofv3 figures of the committed profiles, per block
 
 
-def alg_bytes_per_step(W, H, obs):
-    """board read + observation write + board write-back (p_lock fixed at 1.0) + 76 B of
-    packed scalar state / action / outputs.  Dict surface: padded board + mask + holder + queue written."""
-    if obs == "dict":
-        return H * W + H * W + (2 * (H + 4) * (W + 8) + 16 + 64) + 76
-    return 3 * H * W + 76
+# ------------------------------------------------------------------------------------------------------------------
+# launcher (parent process: no HIP, no engine import)
+# ------------------------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
-def cpu_baseline(W, H, Q, budget_s=12.0):
-    """The oracle's C restatement (kind "port") on this host's cores, bounded sample of the same workload."""
-    from oracle import pyoracle as po
-
-    try:
-        avail = len(os.sched_getaffinity(0))  # cores this process may actually use (cgroup/affinity), not the box total
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    try:  # cgroup v2 CPU quota of the container (e.g. "1600000 100000" = 16 cores on a 256-CPU host)
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            avail = min(avail, max(1, int(q) // int(per)))
-    except Exception:
-        pass
-    cores = max(1, min(avail, 64))  # OpenMP over envs
-    B = 16384
-    o = po.OracleBatch(B, W, H, po.RULESET_NUMPY, True, Q, nthreads=cores)
-    o.reset(np.arange(1, B + 1, dtype=np.uint64))
-    rng = np.random.default_rng(0)
-    acts = rng.integers(0, 8, (64, B)).astype(np.int32)
-    for t in range(8):
-        o.step(acts[t], autoreset=po.AUTORESET_SAME_STEP)
-    n = 0
-    t0 = time.perf_counter()
-    while True:
-        o.step(acts[n % 64], autoreset=po.AUTORESET_SAME_STEP)
-        o.observe(po.OBS_BOARD)
-        n += 1
-        if time.perf_counter() - t0 > budget_s:
+def launch_ranks(n: int, argv, script: str | None = None, timeout_s: float = 3600.0) -> int:
+    """Spawn `n` fresh rank processes of `script` (default: this file) with the torchrun environment contract and wait.
+    Returns the first non-zero exit code (the other ranks are then terminated by PID), else 0.  Makes no HIP call."""
+    script = script or os.path.abspath(__file__)
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TG_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script, *argv], env=env))
+    deadline = time.monotonic() + timeout_s
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+        if rc != 0 or time.monotonic() > deadline:
+            for p in live:  # exactly the processes started above
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            if rc == 0:
+                rc = 124
             break
-    dt = time.perf_counter() - t0
-    return {"value": B * n / dt, "unit": "env steps/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"{B} envs x {n} steps of the same workload (C oracle, OpenMP over envs, incl. observation pack)"}
+        time.sleep(0.02)
+    return rc
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------------------------
 class Dist:
-    """torch.distributed plumbing for N > 1 (one process per GPU): rendezvous, barrier, max-over-ranks.
+    """torch.distributed plumbing for N > 1 (one process per GPU): rendezvous, barrier, max-over-ranks, timing gather.
     No data-path collective exists — envs are independent shards."""
 
     def __init__(self, backend="gloo"):
@@ -101,6 +122,17 @@ class Dist:
         self.pg.all_reduce(t, op=self.pg.ReduceOp.MAX)
         return tuple(float(v) for v in t)
 
+    def gather(self, value: float):
+        """The value of every rank, in rank order (timing metadata only)."""
+        if self.pg is None:
+            return [float(value)]
+        import torch
+
+        mine = torch.tensor([value], dtype=torch.float64)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.pg.all_gather(parts, mine)
+        return [float(p[0]) for p in parts]
+
     def shard(self, envs_per_rank):
         """Weak scaling: rank r owns global envs [r*B, (r+1)*B), seeds 1 + global index."""
         lo = self.rank * envs_per_rank
@@ -117,7 +149,195 @@ def throughput(world, envs_per_rank, steps, max_elapsed_s):
     return world * envs_per_rank * steps / max_elapsed_s
 
 
-def main():
+def alg_bytes_per_step(W, H, obs, Q=4):
+    """board read + observation write + board write-back (p_lock fixed at 1.0) + 76 B of packed scalar
+    state / action / outputs.  Dict surface: padded board + mask + holder + queue strips written instead of H*W."""
+    if obs == "dict":
+        return H * W + H * W + (2 * (H + 4) * (W + 8) + 16 + 16 * Q) + 76
+    return 3 * H * W + 76
+
+
+def host_threads() -> int:
+    """Cores this process may actually use: affinity mask and cgroup v2 quota, not the box total."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            avail = min(avail, max(1, int(q) // int(per)))
+    except Exception:
+        pass
+    return max(1, min(avail, 64))
+
+
+def cpu_baseline(W, H, Q, B, *, grouped=False, obs="board", budget_s=6.0, action_seed=0):
+    """SURVEY §8d(i) / BASELINE.md §3: the oracle's C restatement (kind "port") on this host, the SAME workload as the GPU
+    block (same B, seeds 1 + i, actions of the same generator, same-step autoreset, observation packed every step),
+    timed at 1 thread and at all usable cores on a bounded number of steps (`budget_s` seconds per thread count).
+    `value` is the all-cores rate."""
+    from oracle import pyoracle as po
+
+    mode = {"board": po.OBS_BOARD, "dict": po.OBS_DICT}[obs]
+    full_B = B
+    if grouped:  # the wrapper's step re-derives the legal mask from all 4W placements (wrappers/grouped.py:124-207,
+        B = min(B, 8192)  # as the reference does): ~40 us per env-step on one core — sample the first 8 192 envs
+    seeds = np.arange(1, B + 1, dtype=np.uint64)
+    rng = np.random.default_rng(action_seed)
+    T = 64
+    acts = rng.integers(0, 8, (T, B)).astype(np.int32)
+    res = {}
+    cores = host_threads()
+    for nt in ([1] if cores == 1 else [1, cores]):
+        o = po.OracleBatch(B, W, H, po.RULESET_NUMPY, True, Q, nthreads=nt)
+        o.reset(seeds)
+
+        def one(t):
+            if grouped:  # uniform over the legal placements (drawn outside the timed sections)
+                mask = o.grouped_enumerate()
+                u = rng.random(B)
+                cnt = mask.sum(1)
+                k = np.minimum((u * cnt).astype(np.int64), cnt - 1)
+                a = (np.cumsum(mask, 1) > k[:, None]).argmax(1).astype(np.int32)
+                t0 = time.perf_counter()
+                o.grouped_step(a, True, po.AUTORESET_SAME_STEP)
+            else:
+                t0 = time.perf_counter()
+                o.step(acts[t % T], autoreset=po.AUTORESET_SAME_STEP)
+            o.observe(mode)
+            return time.perf_counter() - t0
+
+        for t in range(4):
+            one(t)
+        n, spent, wall0 = 0, 0.0, time.perf_counter()
+        while spent < budget_s and time.perf_counter() - wall0 < 3 * budget_s:
+            spent += one(n)
+            n += 1
+        res[nt] = (B * n / spent, n)
+    all_rate, all_n = res[cores]
+    one_rate, one_n = res[1]
+    return {"value": all_rate, "unit": "env steps/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
+            "single_thread": {"value": one_rate, "cores": 1, "steps": one_n},
+            "sample": f"{'first ' if B != full_B else ''}{B} envs x {all_n} steps at {cores} threads, x {one_n} steps at 1 thread: the same workload as the "
+                      f"GPU block (C oracle, OpenMP over envs, step + observation pack"
+                      f"{'; legal-action draw not timed' if grouped else ''})",
+            "reference_python_single_env": "~3.4k steps/s on one 2.6 GHz Xeon core, measured in the survey container, "
+                                           "not on this host (BASELINE.md §2)"}
+
+
+def profiled(block: str) -> dict:
+    """rocprofv3 figures of the committed profiles for this block (profiles/latest.json), or {}."""
+    try:
+        return json.load(open(PROFILED)).get(block, {})
+    except Exception:
+        return {}
+
+
+def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, warmup, reps, fuse=1, local=0,
+              want_cpu=True, cpu_budget=6.0, copy_first=False):
+    """One benchmark block on every rank: W warm-up launches, EXACTLY `steps` timed launches bracketed by barrier + device
+    sync on both sides (wall clock → value), then `reps` further repetitions of the same region timed with HIP events on
+    the engine's stream (median → roofline)."""
+    from tetris_gymnasium_amd import Engine, _native as N
+
+    rs = N.RULESET_NUMPY if ruleset == "numpy" else N.RULESET_FUNCTIONAL
+    obs_mode = {"board": N.OBS_BOARD, "dict": N.OBS_DICT, "fn": N.OBS_FN, "none": N.OBS_NONE, "rgb": N.OBS_RGB}[obs]
+    n_act = 8 if rs == N.RULESET_NUMPY else 7
+    lo, hi, seeds = D.shard(B)
+    os.environ["TG_FUSE"] = str(fuse)  # read by tg_create
+    e = Engine(B, W, H, ruleset=rs, queue_size=(Q if rs == N.RULESET_NUMPY else 7), obs_mode=obs_mode,
+               autoreset=N.AUTORESET_SAME_STEP, device=local, env_offset=lo, grouped=grouped)
+    e.reset(seeds)
+    copy_gbps = None
+    if copy_first:  # the practical ceiling, measured before the timed region (it also brings the clocks up)
+        try:
+            copy_gbps = e.stream_copy_gbps(1 << 30, 20)
+        except Exception:  # pragma: no cover
+            copy_gbps = None
+    # pre-generated uniform random actions, uploaded once: [T][B] int8 resident in HBM
+    T = min(max(warmup + steps, fuse), 512)
+    T = (T + fuse - 1) // fuse * fuse
+    acts = np.random.default_rng(D.rank).integers(0, n_act, (T, B)).astype(np.int8)
+    d_acts = e.dev_alloc(acts.nbytes)
+    e.dev_upload(d_acts, acts)
+
+    def run(k0, k):
+        if grouped:  # legal placements drawn on the device inside the step kernel (tg_grouped_rollout)
+            e.grouped_rollout(k, seed=D.rank + 1, counter0=k0, fetch=False)
+            return
+        done = 0
+        while done < k:  # cycle through the resident action rows
+            row = (k0 + done) % T
+            n = min(k - done, T - row)
+            e.step_k_device(d_acts + row * B, n)
+            done += n
+
+    run(0, warmup)
+    e.sync()
+    D.barrier()
+    e.sync()
+    t0 = time.perf_counter()
+    e.timer_start()
+    run(warmup, steps)
+    ev_ms = e.timer_stop()  # HIP events on the engine's own stream; synchronises
+    e.sync()
+    t1 = time.perf_counter()
+    D.barrier()
+    (elapsed,) = D.max(t1 - t0)
+    per_rank_ms = D.gather((t1 - t0) / steps * 1e3)
+    # repetitions of the same timed region, HIP events only: the median is what the roofline figure uses
+    rep_us = [ev_ms / steps * 1e3]
+    k0 = warmup + steps
+    for _ in range(max(0, reps - 1)):
+        e.timer_start()
+        run(k0, steps)
+        rep_us.append(e.timer_stop() / steps * 1e3)
+        k0 += steps
+    kernel_us = statistics.median(rep_us)
+    (kernel_us,) = D.max(kernel_us)
+    launches_per_step = 1.0 / fuse
+    out = None
+    if D.rank == 0:
+        if fuse == 1:
+            bytes_alg = alg_bytes_per_step(W, H, obs, Q)
+        else:  # obs write + action per transition; board read / write-back, record, outputs once per launch
+            bytes_alg = H * W + 1 + (2 * H * W + 64 + 8) / fuse
+        achieved = bytes_alg * B / (kernel_us * 1e-6) / 1e9
+        prof = profiled(name)
+        sym = e.step_kernel_name(fuse, grouped)
+        out = {
+            "value": throughput(D.world, B, steps, elapsed), "unit": "env steps/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "per_rank_ms_per_step": per_rank_ms,
+            "config": {"workload": (f"Batch {B} envs/GPU, {W}x{H} board, queue_size {Q}, "
+                                    + ("grouped action set (column*4+rotation -> teleport + hard drop), legal actions drawn "
+                                       "on device inside the step kernel, " if grouped else
+                                       f"{ruleset} rule-set, uniform random actions (int8, resident in HBM), ")
+                                    + f"obs={obs}, same-step autoreset, {fuse} transition(s) per launch"),
+                       "envs_per_gpu": B, "total_envs": D.world * B,
+                       "parallelism": f"env-sharded x{D.world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": prof.get("hbm_bytes_per_launch"), "traffic_source": prof.get("traffic_source"),
+                         "kernel": sym, "kernel_ms": kernel_us * 1e-3 / launches_per_step if fuse > 1 else kernel_us * 1e-3,
+                         "kernel_us_per_step_reps": [round(x, 3) for x in rep_us],
+                         "kernel_us_rocprof": prof.get("kernel_us"), "rocprof_source": prof.get("kernel_source"),
+                         "alg_bytes_per_env_step": bytes_alg,
+                         "resident": "Infinity Cache" if bytes_alg * B < 200e6 else "HBM",
+                         "note": "achieved = algorithmic bytes x envs / median HIP-event launch time over "
+                                 f"{len(rep_us)} repetitions of the timed region; at this batch the working set fits the "
+                                 "256 MB Infinity Cache, so the HBM-peak fraction is nominal (launch floor + latency bound)"},
+        }
+        if copy_gbps is not None:
+            out["hbm_copy_gbps"] = copy_gbps
+        if want_cpu and D.world == 1 and ruleset == "numpy" and obs in ("board", "dict"):
+            out["cpu_baseline"] = cpu_baseline(W, H, Q, B, grouped=grouped, obs=obs, budget_s=cpu_budget)
+    e.dev_free(d_acts)
+    e.close()
+    return out
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)
@@ -127,148 +347,88 @@ def main():
     ap.add_argument("--height", type=int, default=20)
     ap.add_argument("--obs", choices=["board", "dict", "fn", "none", "rgb"], default="board")
     ap.add_argument("--ruleset", choices=["numpy", "functional"], default="numpy")
+    ap.add_argument("--reps", type=int, default=7, help="repetitions of the timed region for the roofline median (>= 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse", type=int, default=1,
                     help="transitions per launch of the timed rollout (TG_FUSE). Default 1: `value` is the "
-                         "one-launch-per-transition number; the fused rollout is reported beside it")
-    ap.add_argument("--no-fused-rollout", action="store_true")
+                         "one-launch-per-transition number; the fused rollout is reported in blocks")
+    ap.add_argument("--no-blocks", action="store_true", help="only the headline block (profiling runs)")
     ap.add_argument("--config5", action="store_true",
-                    help="BASELINE config 5: 20x40 board, queue_size 7, grouped hard-drop action set, legal actions sampled on device")
-    args = ap.parse_args()
+                    help="make BASELINE config 5 the headline block: 20x40 board, queue_size 7, grouped hard-drop action "
+                         "set, legal actions sampled on device")
+    return ap.parse_args(argv)
 
+
+def rank_main(args) -> int:
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:  # checked before the rendezvous (a mismatched job would hang in it)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: launch with `python bench.py --gpus N` (self-"
+              f"launching) or torchrun --nproc-per-node N with the same N", file=sys.stderr)
+        return 2
     D = Dist()
-    rank, world, local = D.rank, D.world, D.local
-    barrier = D.barrier
+    from tetris_gymnasium_amd import _native as N
 
-    W, H, B = args.width, args.height, args.batch
-    Q = 4
+    ndev = N.load().tg_device_count()  # (first HIP call of this process: the launcher has long since forked)
+    if ndev <= 0:
+        print("bench.py: no HIP device visible (this engine has no CPU fallback)", file=sys.stderr)
+        return 3
+    local = D.local % ndev  # more ranks than devices only when exercising the N > 1 path on a smaller box
+    W, H, B, Q = args.width, args.height, args.batch, 4
+    grouped = False
     if args.config5:
-        W, H, Q = 20, 40, 7
-    ruleset = N.RULESET_NUMPY if args.ruleset == "numpy" else N.RULESET_FUNCTIONAL
-    obs_mode = {"board": N.OBS_BOARD, "dict": N.OBS_DICT, "fn": N.OBS_FN, "none": N.OBS_NONE, "rgb": N.OBS_RGB}[args.obs]
-    n_act = 8 if ruleset == N.RULESET_NUMPY else 7
-    lo, hi, seeds = D.shard(B)
-    ndev = N.load().tg_device_count()
-    if ndev > 0:
-        local = local % ndev  # (more ranks than devices only happens when testing the N > 1 path on a 1-GPU box)
-    os.environ["TG_FUSE"] = str(args.fuse)  # read by tg_create
-    e = Engine(B, W, H, ruleset=ruleset, queue_size=(Q if ruleset == N.RULESET_NUMPY else 7), obs_mode=obs_mode,
-               autoreset=N.AUTORESET_SAME_STEP, device=local, env_offset=lo, grouped=args.config5)
-    e.reset(seeds)
-
-    # pre-generated uniform random actions, uploaded once: [T][B] int8 resident in HBM
-    T = min(args.warmup + args.steps, 512)
-    rng = np.random.default_rng(rank)
-    acts = rng.integers(0, n_act, (T, B)).astype(np.int8)
-    d_acts = e.dev_alloc(acts.nbytes)
-    e.dev_upload(d_acts, acts)
-
-    def run(k0, k):
-        if args.config5:  # legal placements drawn on the device inside the step kernel (tg_grouped_rollout)
-            e.grouped_rollout(k, seed=rank + 1, counter0=k0, fetch=False)
-            return
-        done = 0
-        while done < k:  # cycle through the resident action rows
-            row = (k0 + done) % T
-            n = min(k - done, T - row)
-            e.step_k_device(d_acts + row * B, n)
-            done += n
-
-    run(0, args.warmup)
-    e.sync()
-    barrier()
-    e.sync()
-    t0 = time.perf_counter()
-    e.timer_start()
-    run(args.warmup, args.steps)
-    gpu_ms = e.timer_stop()  # HIP events on the engine's own stream
-    e.sync()
-    t1 = time.perf_counter()
-    barrier()
-    elapsed, gpu_ms = D.max(t1 - t0, gpu_ms)
-
-    # The same rollout with the engine's default grouping (8 transitions per launch, state resident on chip in
-    # between): reported beside `value`, never instead of it.
-    fused = None
-    if not args.config5 and not args.no_fused_rollout and args.fuse == 1 and args.obs in ("board", "fn", "none"):
-        G = 8
-        os.environ["TG_FUSE"] = str(G)
-        e2 = Engine(B, W, H, ruleset=ruleset, queue_size=(Q if ruleset == N.RULESET_NUMPY else 7), obs_mode=obs_mode,
-                    autoreset=N.AUTORESET_SAME_STEP, device=local, env_offset=lo)
-        e2.reset(seeds)
-        d2 = e2.dev_alloc(acts.nbytes)
-        e2.dev_upload(d2, acts)
-        ksteps = max(G, (min(args.steps, T) // G) * G)
-        e2.step_k_device(d2, min(T, 64)); e2.sync()
-        barrier(); e2.sync()
-        f0 = time.perf_counter(); e2.timer_start()
-        e2.step_k_device(d2, ksteps)
-        f_gpu_ms = e2.timer_stop(); e2.sync()
-        f1 = time.perf_counter()
-        barrier()
-        f_elapsed, f_gpu_ms = D.max(f1 - f0, f_gpu_ms)
-        fb = H * W + 1 + (2 * H * W + 64 + 8) / G  # obs write + action; board read/write-back, record, outputs once per launch
-        fused = {"transitions_per_launch": G, "steps": ksteps, "value": throughput(world, B, ksteps, f_elapsed),
-                 "unit": "env steps/s", "ms_per_step": f_elapsed / ksteps * 1e3, "launch_ms": f_gpu_ms / (ksteps // G),
-                 "alg_bytes_per_env_step": fb, "achieved_gbps": fb * B / (f_gpu_ms / ksteps * 1e-3) / 1e9,
-                 "frac_of_hbm_peak": fb * B / (f_gpu_ms / ksteps * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                 "note": "tg_step_k with TG_FUSE=8: records, column masks and uint8 slabs stay in registers/LDS across the "
-                         "8 transitions of a launch; the observation of every transition is still written"}
-        e2.dev_free(d2)
-        e2.close()
-
-    if rank == 0:
-        bytes_alg = alg_bytes_per_step(W, H, args.obs)
-        launch_ms = gpu_ms / args.steps
-        achieved = bytes_alg * B / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "env steps/sec (whole node), 10x20 board, batch=65536 per GPU",
-            "value": throughput(world, B, args.steps, elapsed),
-            "unit": "env steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": (f"Batch {B} envs/GPU, {W}x{H} board, queue_size 7, grouped action set (column*4+rotation "
-                                    f"→ teleport + hard drop), legal actions sampled on device, obs={args.obs}, same-step "
-                                    f"autoreset") if args.config5 else
-                                   f"Batch {B} envs/GPU, {W}x{H} board, {args.ruleset} rule-set, uniform random "
-                                   f"actions (int8, resident in HBM), obs={args.obs}, same-step autoreset, "
-                                   f"{args.fuse} transition(s) per launch",
-                       "envs_per_gpu": B, "total_envs": world * B, "parallelism": f"env-sharded x{world}, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "step_kernel", "kernel_ms": launch_ms, "alg_bytes_per_env_step": bytes_alg},
-        }
-        if fused is not None:
-            out["fused_rollout"] = fused
-        try:
-            out["hbm_copy_gbps"] = e.stream_copy_gbps(1 << 30, 10)
-        except Exception as ex:  # pragma: no cover
-            out["hbm_copy_gbps"] = None
-            out["hbm_copy_error"] = str(ex)
-        if world == 1 and not args.no_cpu_baseline:
-            if not args.config5:
-                out["cpu_baseline"] = cpu_baseline(W, H, Q)
-                out["cpu_baseline"]["reference_python_single_env"] = \
-                    "~3.4k steps/s on one 2.6 GHz Xeon core, measured in the survey container, not on this host"
+        W, H, Q, grouped = 20, 40, 7, True
+    reps = max(5, args.reps)
+    want_cpu = not args.no_cpu_baseline
+    head = run_block(D, "config5" if args.config5 else ("dict" if args.obs == "dict" else "config3"), W=W, H=H, Q=Q, B=B,
+                     obs=args.obs, ruleset=args.ruleset, grouped=grouped, steps=args.steps, warmup=args.warmup,
+                     reps=reps, fuse=args.fuse, local=local, want_cpu=want_cpu, copy_first=True)
+    blocks = {}
+    std_head = not args.config5 and args.obs == "board" and args.ruleset == "numpy" and args.fuse == 1 \
+        and (W, H, B) == (10, 20, 65536)
+    if D.world == 1 and not args.no_blocks and std_head:
+        ks, kw = max(args.steps, 256), max(args.warmup, 64)
+        common = dict(ruleset="numpy", steps=ks, warmup=kw, reps=reps, local=local, want_cpu=want_cpu, cpu_budget=3.0)
+        blocks["config2"] = run_block(D, "config2", W=10, H=20, Q=4, B=4096, obs="board", grouped=False, **common)
+        blocks["config5"] = run_block(D, "config5", W=20, H=40, Q=7, B=65536, obs="board", grouped=True, **common)
+        blocks["dict"] = run_block(D, "dict", W=10, H=20, Q=4, B=65536, obs="dict", grouped=False, **common)
+        blocks["fused_rollout"] = run_block(D, "fused8", W=10, H=20, Q=4, B=65536, obs="board", grouped=False, fuse=8,
+                                            ruleset="numpy", steps=(ks + 7) // 8 * 8, warmup=64, reps=reps, local=local,
+                                            want_cpu=False)
+        if blocks["fused_rollout"]:
+            blocks["fused_rollout"]["note"] = ("tg_step_k with TG_FUSE=8: records, column masks and uint8 slabs stay in "
+                                               "registers/LDS across the 8 transitions of a launch; the observation of "
+                                               "every transition is still written; reported beside `value`, never as it")
+    elif D.world > 1 and not args.no_blocks and std_head:
+        pass  # the further configs are single-GPU cases (BASELINE.json configs[1], [4]); config 4 IS this run at N = 8
+    if D.rank == 0:
+        out = {"metric": "env steps/sec (whole node), 10x20 board, batch=65536 per GPU",
+               "value": head["value"], "unit": "env steps/s", "n_gpus": D.world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "u8", "data": "synthetic", "config": head["config"],
+               "per_rank_ms_per_step": head["per_rank_ms_per_step"], "roofline": head["roofline"]}
+        if "hbm_copy_gbps" in head:
+            out["hbm_copy_gbps"] = head["hbm_copy_gbps"]
+        if "cpu_baseline" in head:
+            out["cpu_baseline"] = head["cpu_baseline"]
+        if args.ruleset == "functional":
+            out["parity_note"] = "functional rule-set: piece sequence (jax threefry) is parity-unpinned (DESIGN §5)"
+        if blocks:
+            out["blocks"] = blocks
         print(json.dumps(out), flush=True)
-    e.dev_free(d_acts)
-    e.close()
     D.close()
+    return 0
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, argv)  # this process stays HIP-free
+    return rank_main(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -241,6 +241,10 @@ int tg_sync(tg_handle* h);
 int tg_timer_start(tg_handle* h);
 int tg_timer_stop(tg_handle* h, float* elapsed_ms); /* records stop, synchronises, returns ms */
 
+/* Symbol of the step-kernel instantiation a tg_step / tg_step_k / tg_rollout / tg_grouped_rollout call on this handle
+ * launches (the name rocprofv3's kernel trace lists), e.g. "tg::step_kernel_bits<10, 20, 0, 0>".  bench.py reports it. */
+int tg_step_kernel_name(tg_handle* h, int transitions_per_launch, int trajectory, int sampled, char* buf, size_t n);
+
 /* Host utility: numpy SeedSequence(seed) → PCG64 initial state, as tg_rng_rec (pinned by tests). */
 int tg_seed_pcg64(uint64_t seed, tg_rng_rec* out);
 

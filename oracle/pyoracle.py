@@ -82,6 +82,8 @@ def lib() -> C.CDLL:
         L.tgo_set_threefry_partitionable.argtypes = [i32]
         L.tgo_fn_score.restype = i32
         L.tgo_fn_score.argtypes = [i32]
+        L.tgo_fn_clear_rows.restype = i32
+        L.tgo_fn_clear_rows.argtypes = [vp, i32, i32]
         L.tgo_np_score.restype = i32
         L.tgo_np_score.argtypes = [i32, i32]
         L.tgo_np_matrix.restype = i32

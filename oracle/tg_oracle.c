@@ -572,6 +572,20 @@ static int fn_clear_filled_rows(env_t* e) {
   return n;
 }
 
+/* test hook: fn_clear_filled_rows on a bare H x W playfield (values as stored: 0 empty, >0 filled), in place */
+int tgo_fn_clear_rows(uint8_t* playfield, int W, int H) {
+  env_t* e = (env_t*)calloc(1, sizeof(env_t));
+  e->W = W; e->H = H; e->P = 4; e->Wp = W + 8; e->Hp = H + 4;
+  create_board(e);
+  for (int r = 0; r < H; ++r)
+    for (int c = 0; c < W; ++c) e->board[r * e->Wp + e->P + c] = playfield[r * W + c];
+  int n = fn_clear_filled_rows(e);
+  for (int r = 0; r < H; ++r)
+    for (int c = 0; c < W; ++c) playfield[r * W + c] = e->board[r * e->Wp + e->P + c];
+  free(e);
+  return n;
+}
+
 /* functional/queue.py:38-67 bag_queue_get_next_element (returned key is discarded by the caller,
  * envs/tetris_fn.py:388-390) */
 static int fn_queue_next(env_t* e) {

@@ -66,6 +66,7 @@ void tgo_set_threefry_partitionable(int on); /* default 1 (jax >= 0.5.0 default)
 
 /* single-function probes used by the restated reference unit tests */
 int tgo_fn_score(int rows_cleared);                                 /* functional/core.py:124-146 */
+int tgo_fn_clear_rows(uint8_t* playfield, int width, int height);   /* functional/core.py:185-227 on a bare H x W field, in place */
 int tgo_np_score(int rows_cleared, int width);                      /* envs/tetris.py:621-630 */
 /* tetromino matrices: NUMPY native n×n (values piece+2) rotated r times by np.rot90(k=1);
  * returns n, writes n*n bytes. FUNCTIONAL: 4×4 binary LUT (functional/tetrominoes.py:124-148). */

@@ -17,8 +17,16 @@ from oracle import pyoracle as po  # noqa: E402
 
 
 def main():
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--expect-world", type=int, default=2)
+    ap.add_argument("--fail-rank", type=int, default=-1)
+    args = ap.parse_args()
+    if args.fail_rank == int(os.environ.get("RANK", "0")):
+        sys.exit(7)  # a rank that dies before the rendezvous: the launcher must end the job, not hang
     D = bench.Dist(backend="gloo")
-    assert D.world == 2
+    assert D.world == args.expect_world == 2
     B, T = 64, 40
     lo, hi, seeds = D.shard(B)
     assert (lo, hi) == (D.rank * B, (D.rank + 1) * B) and seeds[0] == 1 + lo
@@ -31,6 +39,7 @@ def main():
     elapsed = 0.5 + D.rank  # rank 1 is "slower": the max over ranks must win
     (mx,) = D.max(elapsed)
     assert mx == 1.5
+    assert D.gather(elapsed) == [0.5, 1.5]
     assert bench.throughput(D.world, B, T, mx) == 2 * B * T / 1.5
     mine = torch.from_numpy(o.get_state()[0].copy())
     parts = [torch.empty_like(mine) for _ in range(2)]

@@ -225,3 +225,39 @@ def test_grouped_rollout_equals_sample_then_step(W, H, Q, B, kernel_fuse, monkey
                 np.testing.assert_array_equal(ra[f], ro2[f], err_msg=f)
         np.testing.assert_array_equal(ga["state_lo"], go["state_lo"])
     a_eng.close(); b_eng.close()
+
+
+def test_config5_full_size_against_oracle():
+    """BASELINE.json config 5 at its full size: 65 536 envs, 20x40 board, queue_size 7, grouped hard-drop action set
+    (wrappers/grouped.py:209-269), uniform random legal placements drawn inside the step kernel (tg_grouped_rollout,
+    8 transitions per launch), env i seeded 1 + i, same-step autoreset.  Whole trajectory of drawn actions (legal under
+    the oracle's mask) / reward / terminated / lines against OracleBatch.grouped_step, then the final observation, boards,
+    records and every env's generator."""
+    B, W, H, Q, T = 65536, 20, 40, 7, 40
+    e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_BOARD, grouped=True, autoreset=N.AUTORESET_SAME_STEP)
+    o = po.OracleBatch(B, W, H, queue_size=Q, nthreads=8)
+    seeds = np.arange(1, B + 1, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    n_done = n_lock = 0
+    for t0 in range(0, T, 20):
+        K = min(20, T - t0)
+        acts, rew, term, lines = e.grouped_rollout(K, seed=5, counter0=t0)
+        for k in range(K):
+            if k % 10 == 0:
+                om = o.grouped_enumerate()
+                assert om[np.arange(B), acts[k]].all(), f"illegal draw at t={t0 + k}"
+            ro, to, lo, ill = o.grouped_step(acts[k].astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+            assert not ill.any()
+            assert np.array_equal(rew[k], ro) and np.array_equal(term[k], to) and np.array_equal(lines[k], lo), f"t={t0 + k}"
+            n_lock += int((ro > 0).sum())
+        n_done += int(term.sum())
+    np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_BOARD))
+    be, re_, ge = e.get_state(); bo, ro2, go = o.get_state()
+    np.testing.assert_array_equal(be, bo)
+    for f in re_.dtype.names:
+        if f != "reserved":
+            np.testing.assert_array_equal(re_[f], ro2[f], err_msg=f)
+    for f in ("state_lo", "state_hi", "inc_lo", "inc_hi", "uinteger", "has_uint32"):
+        np.testing.assert_array_equal(ge[f], go[f], err_msg=f"rng.{f}")
+    assert n_lock > B * T // 2  # every grouped step is a hard drop + lock
+    e.close()

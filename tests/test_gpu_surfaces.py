@@ -431,6 +431,12 @@ def test_wrapper_class_grouped(with_features):
         obs, r, d, tr, info = env.step(a)
         ro, to, lo, ill = o.grouped_step(np.array([a]))
         assert d == bool(to[0]) and (r == -0.1 if ill[0] else r == ro[0]), (t, a, r, ro, ill)
+        if not with_features and not ill[0]:
+            # info["board"] = the base env's observation dict AFTER the transition (wrappers/grouped.py:261-264), not
+            # the reset-time buffer: the base engine never steps here, its state is uploaded (set_state → tg_observe)
+            ref = o.observe(po.OBS_DICT)
+            for kk in ("board", "active_tetromino_mask", "holder", "queue"):
+                np.testing.assert_array_equal(info["board"][kk], ref[kk][0], err_msg=f"info['board'][{kk}] t={t}")
         if d:
             if ill[0]:
                 assert np.all(obs == env.observation_space.high)

@@ -76,6 +76,7 @@ SYMBOLS = {
     "tg_sync": (_i, [_vp]),
     "tg_timer_start": (_i, [_vp]),
     "tg_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "tg_step_kernel_name": (_i, [_vp, _i, _i, _i, C.c_char_p, _sz]),
     "tg_seed_pcg64": (_i, [C.c_uint64, _vp]),
     "tg_obs_bytes_per_env": (_i, [C.POINTER(TgConfig)]),
     "tg_num_actions": (_i, [C.POINTER(TgConfig)]),

@@ -32,6 +32,7 @@ thread_local std::string g_create_err;
 struct Launchers {
   void (*features)(const tg::FeatureParams&, hipStream_t);
   void (*step)(const tg::KParams&, hipStream_t);
+  void (*step_name)(const tg::KParams&, char*, size_t);
   void (*reset)(const tg::ResetParams&, hipStream_t);
   void (*observe)(const tg::ObserveParams&, hipStream_t);
   void (*prepare)(const tg::PrepareParams&, hipStream_t);
@@ -53,6 +54,27 @@ size_t g_lds_pad = 0;       // TG_LDS_PAD: extra dynamic LDS per wave of the lan
 int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = lane kernels' pipelined pair of groups per wave (measured slower:
                             // the prefetched inputs spill), 1 = off
 
+// which instantiation of the bits kernel a launch with these parameters uses (FEAT flags, tg_kernel_bits.h)
+template <int W, int H, int RS>
+int bits_feat(const tg::KParams& p) {
+  using BG = tg::BitsGeo<W, H>;
+  constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample;
+  const bool dict = p.obs_mode == TG_OBS_DICT && p.dict_in_kernel && BG::DICT_OK;
+  const bool traj = p.obs_traj || p.out_traj || p.act_traj;
+  if (RS == TG_RULESET_NUMPY) {
+    if (p.sample_mode) return M | T | S;
+    if (dict) return (p.nsteps > 1 || traj) ? (M | T | D) : D;
+  }
+  if (traj) return M | T;
+  return p.nsteps > 1 ? M : 0;
+}
+
+template <int W, int H, int RS>
+void step_name(const tg::KParams& p, char* buf, size_t n) {
+  if (p.cols && !p.final_obs) snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat<W, H, RS>(p));
+  else snprintf(buf, n, "tg::step_kernel%s<%d, %d, %d>", g_kernel_lanes == 8 ? "_block" : (g_kernel_lanes ? "_lanes" : ""), W, H, RS);
+}
+
 template <int W, int H, int RS>
 void launch_step(const tg::KParams& p, hipStream_t s) {
   if (p.cols && !p.final_obs) {  // "bits": the handle carries the column masks / look-ahead permutations
@@ -60,21 +82,17 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     const int nrb = RS == TG_RULESET_NUMPY ? (p.batch + 127) / 128 : 0;  // leading RNG workgroups (tg_kernel_bits.h)
     const tg::BitsParams bp{p.cols, p.ahead, p.ring, p.hbuf, p.ring_cur, nrb, p.ring_stride, p.ring_fill};
     const dim3 grid(nrb + (p.batch + BG::EPW - 1) / BG::EPW);
-    const bool dict = p.obs_mode == TG_OBS_DICT && p.dict_in_kernel && BG::DICT_OK;
-    const bool traj = p.obs_traj || p.out_traj || p.act_traj;
-    const size_t lds = dict ? BG::BYTES_DICT : BG::BYTES;
     constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample;
+    const int feat = bits_feat<W, H, RS>(p);
+    const size_t lds = (feat & D) ? BG::BYTES_DICT : BG::BYTES;
 #define TG_LAUNCH_BITS(F) hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (F)>), grid, dim3(128), lds, s, p, bp)
     if constexpr (RS == TG_RULESET_NUMPY) {
-      if (p.sample_mode) { TG_LAUNCH_BITS(M | T | S); return; }
-      if (dict) {
-        if (p.nsteps > 1 || traj) TG_LAUNCH_BITS(M | T | D);
-        else TG_LAUNCH_BITS(D);
-        return;
-      }
+      if (feat == (M | T | S)) { TG_LAUNCH_BITS(M | T | S); return; }
+      if (feat == (M | T | D)) { TG_LAUNCH_BITS(M | T | D); return; }
+      if (feat == D) { TG_LAUNCH_BITS(D); return; }
     }
-    if (traj) TG_LAUNCH_BITS(M | T);
-    else if (p.nsteps > 1) TG_LAUNCH_BITS(M);
+    if (feat == (M | T)) TG_LAUNCH_BITS(M | T);
+    else if (feat == M) TG_LAUNCH_BITS(M);
     else TG_LAUNCH_BITS(0);
 #undef TG_LAUNCH_BITS
     return;
@@ -137,10 +155,10 @@ bool find_launchers(int W, int H, int ruleset, Launchers* out) {
 #define X(w, h)                                                                                     \
   if (W == w && H == h) {                                                                           \
     if (ruleset == TG_RULESET_NUMPY)                                                                \
-      *out = {launch_features<w, h>, launch_step<w, h, TG_RULESET_NUMPY>, launch_reset<w, h, TG_RULESET_NUMPY>, launch_observe<w, h>, \
+      *out = {launch_features<w, h>, launch_step<w, h, TG_RULESET_NUMPY>, step_name<w, h, TG_RULESET_NUMPY>, launch_reset<w, h, TG_RULESET_NUMPY>, launch_observe<w, h>, \
               launch_prepare<w, h>, launch_placements<w, h>, tg::bits_cols_bytes<w, h>()};          \
     else                                                                                            \
-      *out = {launch_features<w, h>, launch_step<w, h, TG_RULESET_FUNCTIONAL>, launch_reset<w, h, TG_RULESET_FUNCTIONAL>,  \
+      *out = {launch_features<w, h>, launch_step<w, h, TG_RULESET_FUNCTIONAL>, step_name<w, h, TG_RULESET_FUNCTIONAL>, launch_reset<w, h, TG_RULESET_FUNCTIONAL>,  \
               launch_observe<w, h>, launch_prepare<w, h>, launch_placements<w, h>, tg::bits_cols_bytes<w, h>()}; \
     return true;                                                                                    \
   }
@@ -959,7 +977,24 @@ int tg_sync(tg_handle* h) {
   if (!h) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
+  // short waits are polled (a blocking hipStreamSynchronize costs tens of microseconds of wake-up latency, which is
+  // several step launches); after ~200 us of polling fall back to the blocking wait
+  for (int i = 0; i < 4000; ++i) {
+    const hipError_t q = hipStreamQuery(h->stream);
+    if (q == hipSuccess) return TG_OK;
+    if (q != hipErrorNotReady) return fail(h, TG_EHIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  return TG_OK;
+}
+
+int tg_step_kernel_name(tg_handle* h, int transitions_per_launch, int trajectory, int sampled, char* buf, size_t n) {
+  if (!h || !buf || n == 0) return TG_EINVAL;
+  tg::KParams p = step_params(h);
+  p.nsteps = transitions_per_launch > 1 ? transitions_per_launch : 1;
+  p.sample_mode = sampled ? 1 : 0;
+  if (trajectory) p.out_traj = (uint2*)h->buf[TG_BUF_STEP_OUT];  // (only its non-nullness selects the instantiation)
+  h->L.step_name(p, buf, n);
   return TG_OK;
 }
 
@@ -1025,18 +1060,30 @@ int tg_stream_copy_gbps(tg_handle* h, size_t bytes, int iters, float* gbps) {
   if (hipMalloc(&b, bytes) != hipSuccess) { (void)hipFree(a); return fail(h, TG_ENOMEM, "tg_stream_copy_gbps: hipMalloc failed"); }
   (void)hipMemsetAsync(a, 1, bytes, h->stream);
   const size_t n = bytes / 16;
-  hipLaunchKernelGGL(tg::stream_copy_kernel, dim3(2048), dim3(256), 0, h->stream, (const float4*)a, (float4*)b, n);
-  (void)hipEventRecord(h->ev0, h->stream);
-  for (int i = 0; i < iters; ++i)
-    hipLaunchKernelGGL(tg::stream_copy_kernel, dim3(2048), dim3(256), 0, h->stream, (const float4*)a, (float4*)b, n);
-  (void)hipEventRecord(h->ev1, h->stream);
-  hipError_t e = hipEventSynchronize(h->ev1);
-  float ms = 0.f;
-  if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->ev0, h->ev1);
+  // the ceiling is the best of a few launch shapes (which one wins depends on the size: tools/ubench/copy_ceiling.hip)
+  float best = 0.f;
+  hipError_t e = hipSuccess;
+  auto timed = [&](auto kern, int grid) {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, h->stream, (const tg::copy_vec*)a, (tg::copy_vec*)b, n);
+    (void)hipEventRecord(h->ev0, h->stream);
+    for (int i = 0; i < iters; ++i)
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, h->stream, (const tg::copy_vec*)a, (tg::copy_vec*)b, n);
+    (void)hipEventRecord(h->ev1, h->stream);
+    hipError_t er = hipEventSynchronize(h->ev1);
+    float ms = 0.f;
+    if (er == hipSuccess) er = hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    if (er != hipSuccess) { e = er; return; }
+    const float g = (float)(2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9);
+    if (g > best) best = g;
+  };
+  timed(tg::stream_copy_kernel<4, false>, 2048);
+  timed(tg::stream_copy_kernel<4, true>, 2048);
+  timed(tg::stream_copy_kernel<8, true>, 2048);
+  timed(tg::stream_copy_kernel<4, true>, 8192);
   (void)hipFree(a);
   (void)hipFree(b);
   if (e != hipSuccess) return fail(h, TG_EHIP, "tg_stream_copy_gbps: %s", hipGetErrorString(e));
-  *gbps = (float)(2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9);
+  *gbps = best;
   return TG_OK;
 }
 

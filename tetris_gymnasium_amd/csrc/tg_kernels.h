@@ -1241,11 +1241,29 @@ __global__ __launch_bounds__(256) void grouped_kernel(const GroupedParams p) {
   }
 }
 
-// float4 grid-stride stream copy: the practical HBM ceiling reported beside the roofline
-__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+// stream copy: the practical HBM ceiling reported beside the roofline.  U 16-byte vectors in flight per lane, all loads
+// of a tile issued before its stores; NT = nontemporal stores (tools/ubench/copy_ceiling.hip sweeps the variants)
+typedef uint32_t copy_vec __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void stream_copy_kernel(const copy_vec* __restrict__ src, copy_vec* __restrict__ dst,
                                                           size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    dst[i] = src[i];
+  const size_t tile = (size_t)256 * U;
+  for (size_t base = (size_t)blockIdx.x * tile; base < n; base += (size_t)gridDim.x * tile) {
+    copy_vec v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const size_t i = base + (size_t)k * 256 + threadIdx.x;
+      v[k] = src[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const size_t i = base + (size_t)k * 256 + threadIdx.x;
+      if (i < n) {
+        if (NT) __builtin_nontemporal_store(v[k], dst + i);
+        else dst[i] = v[k];
+      }
+    }
+  }
 }
 
 }  // namespace tg

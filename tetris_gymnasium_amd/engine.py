@@ -90,9 +90,14 @@ class Engine:
         """K transitions with the given actions int8[K][B] in one call (tg_rollout: the default kernel runs up to 8 per
         launch with the state resident on chip).  Returns (obs[K][B]..., reward f32[K][B], terminated u8[K][B],
         lines u8[K][B]) — what K calls of step() + observation() would have returned."""
-        a = np.ascontiguousarray(actions, dtype=np.int8)
+        a = np.asarray(actions)
         if a.ndim != 2 or a.shape[1] != self.B:
             raise ValueError("actions must have shape (K, batch)")
+        if self.ruleset == N.RULESET_NUMPY and ((a < 0) | (a >= self.n_actions)).any():
+            # envs/tetris.py:215-217 asserts action_space.contains(action); device-resident actions (tg_step_k / tg_rollout
+            # with device pointers) are NOT range-checked: the kernel takes `action & 7` of the base action set
+            raise ValueError(f"action outside Discrete({self.n_actions})")
+        a = np.ascontiguousarray(a, dtype=np.int8)
         K = a.shape[0]
         per_env = self.lib.tg_obs_bytes_per_env(C.byref(self.cfg))
         d_a = self.dev_alloc(a.nbytes)
@@ -245,6 +250,10 @@ class Engine:
         g = None if rng is None else np.ascontiguousarray(rng, dtype=N.RNG_REC)
         if b is not None and b.shape != (self.B, self.H, self.W):
             raise ValueError(f"board must have shape {(self.B, self.H, self.W)}")
+        if r is not None and r.shape != (self.B,):
+            raise ValueError(f"rec must have shape ({self.B},) of tg_env_rec (got {r.shape})")
+        if g is not None and g.shape != (self.B,):
+            raise ValueError(f"rng must have shape ({self.B},) of tg_rng_rec (got {g.shape})")
         self._chk(self.lib.tg_set_state(self.h, N.ptr(b), N.ptr(r), N.ptr(g)), "tg_set_state")
 
     def episode_stats(self):
@@ -282,6 +291,13 @@ class Engine:
         ms = C.c_float()
         self._chk(self.lib.tg_timer_stop(self.h, C.byref(ms)), "tg_timer_stop")
         return ms.value
+
+    def step_kernel_name(self, transitions_per_launch=1, sampled=False, trajectory=False) -> str:
+        """Symbol of the step-kernel instantiation the corresponding entry point launches (as rocprofv3 lists it)."""
+        buf = C.create_string_buffer(128)
+        self._chk(self.lib.tg_step_kernel_name(self.h, int(transitions_per_launch), int(bool(trajectory)),
+                                               int(bool(sampled)), buf, 128), "tg_step_kernel_name")
+        return buf.value.decode()
 
     def stream_copy_gbps(self, nbytes=1 << 30, iters=10) -> float:
         g = C.c_float()

@@ -10,6 +10,8 @@ collective: envs are independent.  Consumes/produces what the reference's traine
 """
 from __future__ import annotations
 
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 from . import _native as N
@@ -103,60 +105,96 @@ class TetrisVectorEnv(VectorEnvBase):
             self.action_space = spaces.MultiDiscrete([n_act] * self.num_envs)
             self.observation_space = None
         self._prev_len = np.zeros(self.num_envs, np.uint32)
+        # one host thread per engine (= per device): launches, fetches and the NumPy unpacking of a shard run beside the
+        # other shards' (ctypes releases the GIL inside the C ABI; calls on ONE handle stay serialised on its thread)
+        self._pool = ThreadPoolExecutor(len(self.engines), thread_name_prefix="tg-shard") if len(self.engines) > 1 else None
 
     # ---- helpers --------------------------------------------------------------------------------
-    def _gather_obs(self):
+    def _each(self, fn):
+        """fn(engine, lo, hi) for every shard, each on its own thread; results in shard order."""
+        jobs = [(e, lo, hi) for e, (lo, hi) in zip(self.engines, self.ranges)]
+        if self._pool is None:
+            return [fn(*j) for j in jobs]
+        return list(self._pool.map(lambda j: fn(*j), jobs))
+
+    def _shard_obs(self, e):
+        """(observation of one shard, its current feature vectors or None)"""
         if self.obs_kind == "placement_features":
-            parts = [e.features() for e in self.engines]
-            self._cur_feats = np.concatenate([p[1] for p in parts])
-            return np.concatenate([p[0] for p in parts])
+            pf, cf = e.features()
+            return pf, cf
         if self.obs_kind == "placement_boards":
-            return np.concatenate([e.placement_boards()[1] for e in self.engines])
-        parts = [e.observation() for e in self.engines]
-        if isinstance(parts[0], dict):
-            return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
-        return np.concatenate(parts)
+            return e.placement_boards()[1], None
+        return e.observation(), None
+
+    def _join_obs(self, parts):
+        if self.obs_kind == "placement_features":
+            self._cur_feats = np.concatenate([p[1] for p in parts])
+        obs = [p[0] for p in parts]
+        if isinstance(obs[0], dict):
+            return {k: np.concatenate([o[k] for o in obs]) for k in obs[0]}
+        return np.concatenate(obs)
 
     # ---- gymnasium.vector API ---------------------------------------------------------------------
     def reset(self, *, seed=None, options=None):
         mask = None if not options else options.get("reset_mask")
-        for e, (lo, hi) in zip(self.engines, self.ranges):
+        self._reset_count = getattr(self, "_reset_count", 0) + 1
+
+        def one(e, lo, hi):
             if isinstance(seed, (list, tuple, np.ndarray)):
                 seeds = np.asarray(seed, np.uint64)[lo:hi]
             elif seed is None and self.ruleset == N.RULESET_NUMPY:
                 seeds = None  # keep running generators (never-seeded envs get 1 + global index)
+            elif seed is None:
+                # functional rule-set: the key of a reset is an explicit input (envs/tetris_fn.py:318-324); an unseeded
+                # reset must not replay the previous episodes, so every unseeded reset derives fresh per-env keys
+                seeds = default_seeds(lo, hi, 1 + (self._reset_count - 1) * self.num_envs)
             else:
                 seeds = default_seeds(lo, hi, seed)
             e.reset(seeds, None if mask is None else np.asarray(mask, np.uint8)[lo:hi])
+            return (e.legal_mask() if self.grouped else None), self._shard_obs(e)
+
+        parts = self._each(one)
         self._prev_len[:] = 0
         info = {"lines_cleared": np.zeros(self.num_envs, np.int32)}
         if self.grouped:
-            info["action_mask"] = np.concatenate([e.legal_mask() for e in self.engines])
-        obs = self._gather_obs()
+            info["action_mask"] = np.concatenate([p[0] for p in parts])
+        obs = self._join_obs([p[1] for p in parts])
         if self.obs_kind == "placement_features":
             info["board"] = self._cur_feats
         return obs, info
 
     def step(self, actions):
         actions = np.asarray(actions, np.int32).reshape(self.num_envs)
-        for e, (lo, hi) in zip(self.engines, self.ranges):  # launch on every device first ...
+
+        def one(e, lo, hi):  # launch, then collect everything this shard returns, on the shard's own thread
             e.step_async(actions[lo:hi])
-        outs = [e.fetch_outputs() for e in self.engines]   # ... then collect
+            out = e.fetch_outputs()
+            ep = e.episode_stats() if (self.episode_stats and out[1].any()) else None
+            lm = e.legal_mask() if self.grouped else None
+            return out, ep, lm, self._shard_obs(e)
+
+        parts = self._each(one)
+        outs = [p[0] for p in parts]
         rewards = np.concatenate([o[0] for o in outs]).astype(np.float64)
         terminations = np.concatenate([o[1] for o in outs]).astype(bool)
         lines = np.concatenate([o[2] for o in outs]).astype(np.int32)
         infos = {"lines_cleared": lines, "_lines_cleared": np.ones(self.num_envs, bool)}
         if self.episode_stats and terminations.any():
-            ep = np.concatenate([e.episode_stats() for e in self.engines])
-            infos["episode"] = {"r": np.where(terminations, ep["last_ret"], 0.0).astype(np.float64),
-                                "l": np.where(terminations, ep["last_len"], 0).astype(np.int32)}
+            r = np.zeros(self.num_envs, np.float64)
+            ln = np.zeros(self.num_envs, np.int32)
+            for (lo, hi), p in zip(self.ranges, parts):
+                if p[1] is not None:
+                    t = terminations[lo:hi]
+                    r[lo:hi] = np.where(t, p[1]["last_ret"], 0.0)
+                    ln[lo:hi] = np.where(t, p[1]["last_len"], 0)
+            infos["episode"] = {"r": r, "l": ln}
             infos["_episode"] = terminations.copy()
         if self.grouped:  # the mask the NEXT action must be drawn from (wrappers/grouped.py:266-267)
-            infos["action_mask"] = np.concatenate([e.legal_mask() for e in self.engines])
+            infos["action_mask"] = np.concatenate([p[2] for p in parts])
             illegal = np.concatenate([o[0] for o in outs]) < 0
             rewards[illegal] = -0.1  # rewards.invalid_action as a Python float, not float32(-0.1)
         truncations = np.zeros(self.num_envs, bool)
-        obs = self._gather_obs()
+        obs = self._join_obs([p[3] for p in parts])
         if self.obs_kind == "placement_features":
             infos["board"] = self._cur_feats  # wrappers/grouped.py:261-264 info["board"]
         return obs, rewards, terminations, truncations, infos
@@ -165,14 +203,23 @@ class TetrisVectorEnv(VectorEnvBase):
         """K transitions for pre-generated actions [K][num_envs] in one call per device (tg_rollout: up to 8 transitions
         per launch, state resident on chip).  Returns (obs[K][num_envs]..., rewards, terminations, lines) — the
         trajectory a `for k: envs.step(actions[k])` loop would have produced (autoreset as configured)."""
-        actions = np.asarray(actions, np.int8)
-        parts = [e.rollout(actions[:, lo:hi]) for e, (lo, hi) in zip(self.engines, self.ranges)]
+        actions = np.asarray(actions)
+        n_act = self.single_action_space.n
+        if actions.ndim != 2 or actions.shape[1] != self.num_envs:
+            raise ValueError("actions must have shape (K, num_envs)")
+        if self.ruleset == N.RULESET_NUMPY and ((actions < 0) | (actions >= n_act)).any():
+            raise ValueError(f"action outside Discrete({n_act})")  # envs/tetris.py:215-217 asserts action_space.contains
+        actions = actions.astype(np.int8)
+        parts = self._each(lambda e, lo, hi: e.rollout(actions[:, lo:hi]))
         obs = None if parts[0][0] is None else np.concatenate([p[0] for p in parts], axis=1)
         return (obs, np.concatenate([p[1] for p in parts], axis=1).astype(np.float64),
                 np.concatenate([p[2] for p in parts], axis=1).astype(bool),
                 np.concatenate([p[3] for p in parts], axis=1).astype(np.int32))
 
     def close(self, **kwargs):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         for e in self.engines:
             e.close()
         self.engines = []
