@@ -498,3 +498,55 @@ def test_rollout_entry_points_reject_bad_arguments():
     assert b"TG_OBS_NONE" in e.lib.tg_last_error(e.h)
     e.dev_free(d)
     e.close()
+
+
+@pytest.mark.parametrize("mode", ["numpy", "functional", "grouped", "numpy_20x40"])
+@pytest.mark.parametrize("fuse", [1, 8])
+def test_final_observation_same_step_autoreset(mode, fuse, monkeypatch):
+    """TG_FLAG_FINAL_OBS (what gymnasium's same-step autoreset reports as infos["final_observation"], consumed by
+    examples/train_cnn.py:312-316): when an env ends its episode and resets inside the same transition, TG_BUF_OBS holds
+    the observation of the NEW episode and TG_BUF_FINAL_OBS the observation of the terminal state — written by the default
+    step kernel's stream wave before the reset zeroes the slab.  Oracle: step without autoreset, observe, reset the
+    terminated envs (running generators)."""
+    monkeypatch.setenv("TG_FUSE", str(fuse))
+    W, H, Q = (20, 40, 7) if mode == "numpy_20x40" else (10, 20, 4)
+    B = 1536
+    fn = mode == "functional"
+    grouped = mode == "grouped"
+    ruleset, obs, po_obs = (N.RULESET_FUNCTIONAL, N.OBS_FN, po.OBS_FN) if fn else (N.RULESET_NUMPY, N.OBS_BOARD, po.OBS_BOARD)
+    e = Engine(B, W, H, ruleset=ruleset, queue_size=(7 if fn else Q), obs_mode=obs, autoreset=N.AUTORESET_SAME_STEP,
+               final_obs=True, grouped=grouped)
+    o = po.OracleBatch(B, W, H, ruleset, queue_size=(7 if fn else Q))
+    seeds = np.arange(21, 21 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(fuse)
+    n_act = 4 * W if grouped else (7 if fn else 8)
+    expect = np.zeros((B, H, W), np.int8 if fn else np.uint8)
+    ever = np.zeros(B, bool)
+    K = 8 if fuse > 1 else 1
+    for it in range(320 // K if mode != "numpy_20x40" else 480 // K):
+        acts = rng.integers(0, n_act, (K, B))
+        if not grouped:
+            acts[rng.random((K, B)) < 0.3] = 6 if fn else 5  # hard drops: episodes end quickly
+        if K == 1:
+            rew, term, lines = e.step(acts[0])
+            rews, terms = rew[None], term[None]
+        else:
+            _, rews, terms, _ = e.rollout(acts.astype(np.int8), want_obs=False)
+        for k in range(K):
+            if grouped:
+                ro, to, lo, ill = o.grouped_step(acts[k].astype(np.int32))
+            else:
+                ro, to, lo = o.step(acts[k].astype(np.int32))
+            np.testing.assert_array_equal(terms[k], to, err_msg=f"terminated it={it} k={k}")
+            np.testing.assert_array_equal(rews[k], ro, err_msg=f"reward it={it} k={k}")
+            t = to.astype(bool)
+            if t.any():
+                expect[t] = o.observe(po_obs)[t]
+                ever |= t
+                o.reset(None, t.astype(np.uint8))
+        np.testing.assert_array_equal(e.observation(), o.observe(po_obs), err_msg=f"obs it={it}")
+        got = e.final_observation()
+        np.testing.assert_array_equal(got[ever], expect[ever], err_msg=f"final obs it={it}")
+    assert ever.sum() > B // 2
+    e.close()

@@ -58,9 +58,10 @@ int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = lane kernels' pipelined p
 template <int W, int H, int RS>
 int bits_feat(const tg::KParams& p) {
   using BG = tg::BitsGeo<W, H>;
-  constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample;
+  constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal;
   const bool dict = p.obs_mode == TG_OBS_DICT && p.dict_in_kernel && BG::DICT_OK;
   const bool traj = p.obs_traj || p.out_traj || p.act_traj;
+  if (p.final_obs) return (p.nsteps > 1 || traj) ? (M | T | F) : F;  // (TG_OBS_BOARD / TG_OBS_FN handles only)
   if (RS == TG_RULESET_NUMPY) {
     if (p.sample_mode) return M | T | S;
     if (dict) return (p.nsteps > 1 || traj) ? (M | T | D) : D;
@@ -71,21 +72,23 @@ int bits_feat(const tg::KParams& p) {
 
 template <int W, int H, int RS>
 void step_name(const tg::KParams& p, char* buf, size_t n) {
-  if (p.cols && !p.final_obs) snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat<W, H, RS>(p));
+  if (p.cols) snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat<W, H, RS>(p));
   else snprintf(buf, n, "tg::step_kernel%s<%d, %d, %d>", g_kernel_lanes == 8 ? "_block" : (g_kernel_lanes ? "_lanes" : ""), W, H, RS);
 }
 
 template <int W, int H, int RS>
 void launch_step(const tg::KParams& p, hipStream_t s) {
-  if (p.cols && !p.final_obs) {  // "bits": the handle carries the column masks / look-ahead permutations
+  if (p.cols) {  // "bits": the handle carries the column masks / look-ahead permutations
     using BG = tg::BitsGeo<W, H>;
     const int nrb = RS == TG_RULESET_NUMPY ? (p.batch + 127) / 128 : 0;  // leading RNG workgroups (tg_kernel_bits.h)
     const tg::BitsParams bp{p.cols, p.ahead, p.ring, p.hbuf, p.ring_cur, nrb, p.ring_stride, p.ring_fill};
     const dim3 grid(nrb + (p.batch + BG::EPW - 1) / BG::EPW);
-    constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample;
+    constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal;
     const int feat = bits_feat<W, H, RS>(p);
-    const size_t lds = (feat & D) ? BG::BYTES_DICT : BG::BYTES;
-#define TG_LAUNCH_BITS(F) hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (F)>), grid, dim3(128), lds, s, p, bp)
+    const size_t lds = (feat & D) ? BG::BYTES_DICT : ((feat & F) ? BG::BYTES_FIN : BG::BYTES);
+#define TG_LAUNCH_BITS(FT) hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(128), lds, s, p, bp)
+    if (feat == F) { TG_LAUNCH_BITS(F); return; }
+    if (feat == (M | T | F)) { TG_LAUNCH_BITS(M | T | F); return; }
     if constexpr (RS == TG_RULESET_NUMPY) {
       if (feat == (M | T | S)) { TG_LAUNCH_BITS(M | T | S); return; }
       if (feat == (M | T | D)) { TG_LAUNCH_BITS(M | T | D); return; }
@@ -196,7 +199,7 @@ struct tg_handle {
   uint8_t* d_hbuf = nullptr;   // bits kernel: consumed counters [2][B]
   int ring_cur = 0;            // parity the next step launch reads
   int fuse_max = 8;            // TG_FUSE: transitions per launch in tg_step_k (1..8)
-  int ring_fill = tg::kRing;   // TG_RING_FILL (tests): fewer look-ahead permutations → the consumer's in-line shuffle runs
+  int ring_fill = tg::kRing - 1;  // TG_RING_FILL (tests): fewer look-ahead permutations → the consumer's in-line shuffle runs
   bool dict_in_kernel = false; // TG_OBS_DICT packed by the bits step kernel itself (no observe launch after a transition)
   // TG_STREAMS=n (default 1) spreads the step launches of one transition over n streams (contiguous env shards).
   // Kept as a tested knob, off by default — measured on MI355X: every launch costs ≈2.8-3.4 µs of
@@ -433,6 +436,20 @@ int launch_prepare_bits(tg_handle* h, const uint8_t* d_mask, int force) {
   return TG_OK;
 }
 
+// bits kernel, NUMPY rules: bring TG_BUF_RNG up to date with the generators the reference would hold now (a transition
+// leaves the state in the permutation ring's `ahead` slots, tg_kernel_bits.h)
+int launch_materialize_rng(tg_handle* h) {
+  if (!h->d_cols || h->cfg.ruleset != TG_RULESET_NUMPY) return TG_OK;
+  tg::MaterializeParams q{};
+  q.rng = (tg_rng_rec*)h->buf[TG_BUF_RNG];
+  q.ahead = h->d_ahead;
+  q.hbuf = h->d_hbuf + (size_t)h->ring_cur * (size_t)h->B;
+  q.batch = h->B;
+  hipLaunchKernelGGL(tg::bits_materialize_rng_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, q);
+  HIPCHK(h, hipGetLastError());
+  return TG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -561,7 +578,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   CRCHK(hipMalloc((void**)&h->d_new_rng, B * sizeof(tg_rng_rec)));
   CRCHK(hipMalloc((void**)&h->d_reseed, B));
   CRCHK(hipMalloc((void**)&h->d_mask, B));
-  if (g_kernel_lanes == 16 && !want_final) {
+  if (g_kernel_lanes == 16) {
     CRCHK(hipMalloc(&h->d_cols, B * L.cols_bytes + kTailPad));
     CRCHK(hipMemsetAsync(h->d_cols, 0, B * L.cols_bytes + kTailPad, h->stream));
     CRCHK(hipMalloc((void**)&h->d_ahead, B * 32 * tg::kRing + kTailPad));
@@ -586,7 +603,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   {
     h->dict_in_kernel = h->d_cols && cfg->obs_mode == TG_OBS_DICT && ((cfg->width + 8) * (cfg->height + 4)) % 16 == 0 &&
                         !(getenv("TG_DICT_KERNEL") && atoi(getenv("TG_DICT_KERNEL")) == 0);
-    if (const char* e = getenv("TG_RING_FILL")) { const int v = atoi(e); h->ring_fill = v < 0 ? 0 : (v > tg::kRing ? tg::kRing : v); }
+    if (const char* e = getenv("TG_RING_FILL")) { const int v = atoi(e); h->ring_fill = v < 0 ? 0 : (v > tg::kRing - 1 ? tg::kRing - 1 : v); }
     if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > 8 ? 8 : v); }
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
     int want = 1;
@@ -643,6 +660,7 @@ int tg_reset(tg_handle* h, const uint64_t* seeds, const uint8_t* mask) {
   if (!h) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
+  { int rcm = launch_materialize_rng(h); if (rcm != TG_OK) return rcm; }  // an unseeded reset continues the running generator
   const size_t B = (size_t)h->B;
   bool any_reseed = false;
   h->h_new_rng.resize(B);
@@ -763,13 +781,13 @@ static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, u
   // transition.  tg_step always launches one transition.
   const int fuse_max = h->fuse_max;
   const bool post_kernel = (h->cfg.obs_mode == TG_OBS_DICT && !h->dict_in_kernel) || h->cfg.obs_mode == TG_OBS_RGB;
-  const int fuse = (h->d_cols && !post_kernel) ? fuse_max : 1;  // (sampled rollouts outside the bits kernel: one per launch, below)
   const size_t obs_stride = (size_t)h->B * obs_bytes_per_env(&h->cfg);
   if (obs_traj_dev && h->cfg.obs_mode == TG_OBS_NONE) return fail(h, TG_EINVAL, "tg_rollout: the handle has no observation (TG_OBS_NONE)");
   // trajectories are written by the step kernel itself when it packs the observation (bits kernel, BOARD / FN);
   // otherwise every transition is one launch followed by device-to-device copies of the engine's buffers
   const bool in_kernel = h->d_cols && !post_kernel;
-  const bool sample_in_kernel = sampled && in_kernel;
+  const bool sample_in_kernel = sampled && in_kernel && !h->buf[TG_BUF_FINAL_OBS];  // (no sampling + final-observation instantiation)
+  const int fuse = (in_kernel && (!sampled || sample_in_kernel)) ? fuse_max : 1;  // (actions drawn by the sampling kernel: one transition per launch)
   auto enqueue = [&]() -> int {  // K transitions, `fuse` per launch (per shard)
     tg::KParams p = step_params(h);
     p.act_i8 = 1;
@@ -825,6 +843,12 @@ static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, u
 
 int tg_device_ptr(tg_handle* h, int which, void** ptr, size_t* bytes) {
   if (!h || which < 0 || which >= TG_BUF_COUNT) return h ? fail(h, TG_EINVAL, "tg_device_ptr: bad buffer id %d", which) : TG_EINVAL;
+  if (which == TG_BUF_RNG) {  // (enqueued on the handle's stream: tg_sync before reading the buffer from elsewhere)
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rcj = join_shards(h);
+    if (rcj == TG_OK) rcj = launch_materialize_rng(h);
+    if (rcj != TG_OK) return rcj;
+  }
   if (ptr) *ptr = h->buf[which];
   if (bytes) *bytes = h->bytes[which];
   return TG_OK;
@@ -835,6 +859,7 @@ int tg_fetch(tg_handle* h, int which, void* host_dst, size_t bytes) {
   if (bytes > h->bytes[which]) return fail(h, TG_EINVAL, "tg_fetch: %zu bytes requested, buffer %d holds %zu", bytes, which, h->bytes[which]);
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
+  if (which == TG_BUF_RNG) { int rcm = launch_materialize_rng(h); if (rcm != TG_OK) return rcm; }
   if (bytes) HIPCHK(h, hipMemcpyAsync(host_dst, h->buf[which], bytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return TG_OK;
@@ -845,6 +870,7 @@ int tg_get_state(tg_handle* h, uint8_t* board, tg_env_rec* rec, tg_rng_rec* rng)
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   const size_t B = (size_t)h->B;
+  if (rng) { int rcm = launch_materialize_rng(h); if (rcm != TG_OK) return rcm; }
   if (board) HIPCHK(h, hipMemcpyAsync(board, h->buf[TG_BUF_BOARD], B * h->cells, hipMemcpyDeviceToHost, h->stream));
   if (rec) HIPCHK(h, hipMemcpyAsync(rec, h->buf[TG_BUF_REC], B * sizeof(tg_env_rec), hipMemcpyDeviceToHost, h->stream));
   if (rng) HIPCHK(h, hipMemcpyAsync(rng, h->buf[TG_BUF_RNG], B * sizeof(tg_rng_rec), hipMemcpyDeviceToHost, h->stream));
@@ -861,6 +887,7 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
   if (!h) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
+  if (!rng) { int rcm = launch_materialize_rng(h); if (rcm != TG_OK) return rcm; }  // the rings are rebuilt from TG_BUF_RNG below
   const size_t B = (size_t)h->B;
   if (rec)
     for (size_t i = 0; i < B; ++i) {

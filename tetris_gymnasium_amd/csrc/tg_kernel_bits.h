@@ -88,8 +88,13 @@ struct BitsGeo {
   static constexpr int OFF_DICT = BYTES;
   static constexpr int BYTES_DICT = BYTES + 2 * 8 * PC;
   static constexpr bool DICT_OK = PC % 16 == 0 && EPW % 8 == 0;
+  // TG_FLAG_FINAL_OBS (observation BOARD / FN only, never together with the dict staging): uint2 [2][EPW] behind BYTES —
+  // the terminal piece of every env that ends its episode in this transition
+  static constexpr int OFF_FIN = BYTES;
+  static constexpr int BYTES_FIN = BYTES + 2 * EPW * 8;
   static_assert(W % 2 == 0, "column masks are moved as 8-byte pairs");
 };
+
 
 // numpy PCG64 generator of one lane (NUMPY rule-set): 128-bit state, stream increment, buffered 32-bit half
 struct BitsRng {
@@ -152,26 +157,37 @@ __device__ __forceinline__ uint64_t bits_apply_perm(const uint32_t sig, const ui
 }
 
 // The bag permutations of an env are produced ahead of their use by separate RNG workgroups of the same launch
-// (role split by blockIdx) and consumed by the logic wave: a four-entry ring per env with monotonic 8-bit counters,
+// (role split by blockIdx) and consumed by the logic wave: a four-slot ring per env with monotonic counters (mod 128),
 // T = permutations produced (owned by the RNG role), H = permutations consumed (owned by the logic wave).  Entry i
 // lives in slot i & 3.  Everything one role reads from the other is double-buffered by launch parity (`cur`), so
 // both roles work on the snapshot of the previous launch boundary and never on each other's stores of this launch
 // (L2 is per XCD; cross-workgroup visibility inside a launch is not guaranteed).
+//
+// The generator state the reference would hold (tg_get_state, pinned against numpy) is NOT touched by a transition:
+// `ahead` keeps the state after every ring entry, the RNG role never overwrites the slot of the last consumed entry
+// (it looks ahead kRing - 1 entries), so "the generator now" = ahead[(H - 1) & 3] — read only by
+// bits_materialize_rng_kernel (before tg_get_state / tg_reset / tg_set_state / a fetch of TG_BUF_RNG) and by the two
+// rare paths below.  No load, no wait and no store of generator state on the transition's path.
+//   ring exhausted → the logic wave shuffles in line, starting from that state; the state after an in-line shuffle goes
+//   to tg_rng_rec and bit 7 of the H byte (`inl`) says so; the RNG role then resynchronises (T := H, frontier = tg_rng_rec).
+//   `ahead` is written by the RNG role only.
 struct BitsParams {
   void* cols;      // ColT [B][W]
   uint4* ahead;    // [B][4 slots][2]: generator state AFTER the slot's shuffle {state_lo, state_hi} {uinteger, has32, 0, 0}
   uint64_t* ring;  // [2 parities][B][2]: word 0 = permutations of slots 0 | 1 << 28 (7 nibbles each) | T << 56,
                    //                      word 1 = slots 2 | 3 << 28
-  uint8_t* hbuf;   // [2 parities][B]: H
+  uint8_t* hbuf;   // [2 parities][B]: H (bits 0-6) | inl << 7 (the state after entry H - 1 is in tg_rng_rec, not in `ahead`)
   int cur;         // parity this launch reads; it writes 1 - cur
-  int nrb;         // number of leading RNG workgroups (128 envs each)
+  int nrb;         // number of leading RNG workgroups (kRngEnvs envs each)
   uint32_t pstride;  // elements between the two parities of ring / hbuf (the handle's whole batch)
-  int fill;          // entries the RNG role keeps in a ring (kRing; tests lower it to exercise the consumer's in-line shuffle)
+  int fill;          // entries the RNG role keeps ahead in a ring (kRing - 1; tests lower it to exercise the consumer's in-line shuffle)
 };
 
 // native 16-byte vector for the slab stream: HIP's uint4 is a struct whose copies become memcpy intrinsics, which
 // kept the staging array in scratch memory (and made the kernel wait for every slab load right after issuing it)
-constexpr int kRing = 4;  // entries per permutation ring
+constexpr int kRing = 4;  // slots per permutation ring: kRing - 1 entries ahead + the last consumed one
+__device__ __forceinline__ int ring_diff(const int a, const int b) { return ((a - b) << 25) >> 25; }  // counters are mod 128
+constexpr int kRngEnvs = 1024;  // envs scanned by one RNG-role workgroup (128 threads x 8)
 
 __device__ __forceinline__ uint32_t ring_get(const uint64_t w0, const uint64_t w1, const int slot) {
   const uint64_t w = (slot & 2) ? w1 : w0;
@@ -206,13 +222,47 @@ __device__ __forceinline__ void st_stream(V* dst, const V v) {
 //   kFeatTraj   trajectory outputs (obs_traj / out_traj / act_traj)
 //   kFeatDict   TG_OBS_DICT packed by the two waves
 //   kFeatSample actions drawn on the device (grouped action set)
+//   kFeatFinal  TG_FLAG_FINAL_OBS: the terminal observation of a same-step-autoreset env goes to TG_BUF_FINAL_OBS
 // Profiles list the kinds of launches separately.
-constexpr int kFeatMulti = 1, kFeatTraj = 2, kFeatDict = 4, kFeatSample = 8;
+constexpr int kFeatMulti = 1, kFeatTraj = 2, kFeatDict = 4, kFeatSample = 8, kFeatFinal = 16;
+
+// bytes: 0xFF (active) stays -1, other non-zero → 1  (the functional observation, envs/tetris_fn.py:137-158)
+__device__ __forceinline__ uint32_t bits_bin1(const uint32_t x) {
+  const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+  const uint32_t ff = ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u;
+  return (nz >> 7) | ((ff >> 7) * 0xFFu);
+}
+
+// one lane copies its env's slab LDS → HBM (8-byte aligned on both sides): batches of 8-byte LDS reads, all reads of a
+// batch in flight before its 16-byte stores.  BIN: through the functional observation's byte map.
+template <int S, bool BIN>
+__device__ __forceinline__ void bits_copy_slab(const uint8_t* src_lds, uint8_t* dst) {
+  const u32x2* src = reinterpret_cast<const u32x2*>(src_lds);
+  constexpr int NU = S / 8, UB = NU <= 32 ? NU : 20;
+  static_assert(S % 8 == 0, "slabs are copied in 8-byte units, stored in pairs");
+#pragma unroll 1
+  for (int u0 = 0; u0 < NU; u0 += UB) {
+    u32x2 t2[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) t2[u] = src[u0 + u < NU ? u0 + u : NU - 1];
+    if (BIN) {
+#pragma unroll
+      for (int u = 0; u < UB; ++u) t2[u] = u32x2{bits_bin1(t2[u].x), bits_bin1(t2[u].y)};
+    }
+#pragma unroll
+    for (int u = 0; u + 1 < UB; u += 2)  // 16-byte stores at 8-byte alignment
+      if (u0 + u + 1 < NU)
+        *reinterpret_cast<u32x4_a8*>(dst + 8 * (u0 + u)) = u32x4{t2[u].x, t2[u].y, t2[u + 1].x, t2[u + 1].y};
+      else if (u0 + u < NU)
+        *reinterpret_cast<u32x2*>(dst + 8 * (u0 + u)) = t2[u];
+    if (UB % 2 == 1 && u0 + UB - 1 < NU) *reinterpret_cast<u32x2*>(dst + 8 * (u0 + UB - 1)) = t2[UB - 1];
+  }
+}
 
 template <int W, int H, int RULESET, int FEAT>
 __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, const BitsParams bp) {
   constexpr bool MULTI = (FEAT & kFeatMulti) != 0, TRAJ = (FEAT & kFeatTraj) != 0, DICTK = (FEAT & kFeatDict) != 0,
-                 SAMPLE = (FEAT & kFeatSample) != 0;
+                 SAMPLE = (FEAT & kFeatSample) != 0, FINAL = (FEAT & kFeatFinal) != 0;
   using BG = BitsGeo<W, H>;
   using T = ColT<H>;
   constexpr int S = BG::S, EPW = BG::EPW, NCH = BG::NCH, NIT = BG::NIT, CST = BG::CST;
@@ -224,6 +274,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   uint64_t* cell_tab = reinterpret_cast<uint64_t*>(lds + BG::OFF_TAB);
   uint64_t* col_tab = cell_tab + 8;
   uint4* post = reinterpret_cast<uint4*>(lds + BG::OFF_POST);
+  u32x2* postF = reinterpret_cast<u32x2*>(lds + BG::OFF_FIN);  // (FINAL instantiations only)
   const int lane = threadIdx.x & 63;
   const int wave = rfl((int)(threadIdx.x >> 6));
 
@@ -247,10 +298,18 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   uint2* const out_traj = TRAJ ? p.out_traj : nullptr;
   int8_t* const act_traj = TRAJ ? p.act_traj : nullptr;
   const bool sample_mode = SAMPLE && p.sample_mode;
+  uint8_t* const final_obs = FINAL ? p.final_obs : nullptr;
 
 #ifdef TG_PHASE_TIMING
   unsigned long long tstamp[8];  // kept in SGPRs and written at the very end: a store per stamp would itself be waited on
-#define TG_BITS_STAMP(i) tstamp[i] = __builtin_amdgcn_s_memtime()
+  // s_memtime = shader cycles of THIS CU's counter (phases of one wave); TG_STAMP_REALTIME: the device-wide 100 MHz
+  // counter instead (absolute timeline across workgroups, tools/phase_timeline_bits.py)
+#ifdef TG_STAMP_REALTIME
+#define TG_NOW() __builtin_amdgcn_s_memrealtime()
+#else
+#define TG_NOW() __builtin_amdgcn_s_memtime()
+#endif
+#define TG_BITS_STAMP(i) tstamp[i] = TG_NOW()
 #else
 #define TG_BITS_STAMP(i) do {} while (0)
 #endif
@@ -261,42 +320,57 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     // =====================================================================================================
     if (RULESET != TG_RULESET_NUMPY) return;
 #ifdef TG_PHASE_TIMING
-    const unsigned long long rng_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long rng_t0 = TG_NOW();
 #endif
     const uint32_t e = rng_block * 128u + threadIdx.x;
     const bool on = e < B;
     const uint32_t ee = on ? e : B - 1u;
     const uint4 rw = reinterpret_cast<const uint4*>(bp.ring)[(size_t)bp.cur * bp.pstride + ee];
     uint64_t w0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32), w1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
-    const int Hn = bp.hbuf[(size_t)bp.cur * bp.pstride + ee];
-    BitsRng g;
-    g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
-    g.uinteger = g.has32 = 0;
-    g.loaded = false;
-    uint4* a4 = bp.ahead + (size_t)ee * (2 * kRing);
-    for (int rep = 0; rep < kRing; ++rep) {  // (a ring emptied by one launch is refilled completely)
-      const int Tn = (int)(w0 >> 56);
-      const bool need = on && (int)(int8_t)(uint8_t)(Tn - Hn) < bp.fill;
-      if (!__any(need)) break;
-      if (need && !g.loaded) {  // frontier = state after entry T - 1; later entries continue from the registers
-        const int fs = (Tn - 1) & (kRing - 1);
-        const uint4 f0 = a4[2 * fs], f1 = a4[2 * fs + 1];
-        const uint4 gi = reinterpret_cast<const uint4*>(p.rng + ee)[1];
-        g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
-        g.i_lo = (uint64_t)gi.x | ((uint64_t)gi.y << 32); g.i_hi = (uint64_t)gi.z | ((uint64_t)gi.w << 32);
-        g.uinteger = f1.x; g.has32 = f1.y;
-        g.loaded = true;
-      }
-      uint32_t sig = 0;
-      bits_shuffle_perm(g, sig, need);
-      if (need) {
-        const int sl = Tn & (kRing - 1);
-        a4[2 * sl] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
-        a4[2 * sl + 1] = make_uint4(g.uinteger, g.has32, 0u, 0u);
-        const uint64_t m = 0x0FFFFFFFULL << (28 * (sl & 1)), v = (uint64_t)sig << (28 * (sl & 1));
-        if (sl & 2) w1 = (w1 & ~m) | v;
-        else w0 = (w0 & ~m) | v;
-        w0 = (w0 & ~(0xFFULL << 56)) | ((uint64_t)((Tn + 1) & 0xFF) << 56);
+    const int Hraw = bp.hbuf[(size_t)bp.cur * bp.pstride + ee];
+    const int Hn = Hraw & 0x7F;
+    const bool inl = (Hraw & 0x80) != 0;
+#ifndef TG_RNG_PRIO
+#define TG_RNG_PRIO 2  // between the stream wave before its barrier (1) and the logic wave (3): A/B in profiles/r02
+#endif
+    __builtin_amdgcn_s_setprio(TG_RNG_PRIO);
+    // ONE entry per env and launch (a second one waits for the next launch: 13 % of the waves would otherwise run two
+    // shuffles back to back and become the tail of the launch — measured 7.0 us vs 5.8 us for the step workgroups)
+    {
+      int Tn = (int)(w0 >> 56) & 0x7F;
+      const int d = ring_diff(Tn, Hn);
+      const bool need = on && d < bp.fill;
+      if (__any(need)) {
+        BitsRng g;
+        g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
+        g.uinteger = g.has32 = 0;
+        g.loaded = false;
+        uint4* a4 = bp.ahead + (size_t)ee * (2 * kRing);
+        const uint4* rng4 = reinterpret_cast<const uint4*>(p.rng + ee);
+        if (need) {
+          // frontier = state after entry T - 1.  The consumer may have run past T with in-line shuffles (d <= 0): the
+          // entries below H are dead — continue from the consumer's state (ahead[(H - 1) & 3], or tg_rng_rec when `inl`)
+          const bool resync = d <= 0;
+          if (resync) Tn = Hn;
+          const int fs = (Tn - 1) & (kRing - 1);
+          const bool from_rec = resync && inl;
+          const uint4 f0 = *(from_rec ? rng4 : a4 + 2 * fs), f1 = *(from_rec ? rng4 + 2 : a4 + 2 * fs + 1);
+          const uint4 gi = rng4[1];
+          g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
+          g.i_lo = (uint64_t)gi.x | ((uint64_t)gi.y << 32); g.i_hi = (uint64_t)gi.z | ((uint64_t)gi.w << 32);
+          g.uinteger = f1.x; g.has32 = f1.y;
+        }
+        uint32_t sig = 0;
+        bits_shuffle_perm(g, sig, need);
+        if (need) {
+          const int sl = Tn & (kRing - 1);
+          a4[2 * sl] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
+          a4[2 * sl + 1] = make_uint4(g.uinteger, g.has32, 0u, 0u);
+          const uint64_t m = 0x0FFFFFFFULL << (28 * (sl & 1)), v = (uint64_t)sig << (28 * (sl & 1));
+          if (sl & 2) w1 = (w1 & ~m) | v;
+          else w0 = (w0 & ~m) | v;
+          w0 = (w0 & ~(0xFFULL << 56)) | ((uint64_t)((Tn + 1) & 0x7F) << 56);
+        }
       }
     }
     if (on)
@@ -306,7 +380,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     if (p.dbg && (threadIdx.x & 63) == 0) {  // lifetime of the RNG waves, behind the step workgroups' stamps
       const size_t slot = (size_t)(gridDim.x - bp.nrb) * 16 + (size_t)rng_block * 4 + (threadIdx.x >> 6) * 2;
       p.dbg[slot] = rng_t0;
-      p.dbg[slot + 1] = __builtin_amdgcn_s_memtime();
+      p.dbg[slot + 1] = TG_NOW();
     }
 #endif
     return;
@@ -378,6 +452,25 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
         todo &= todo - 1;
         (void)clear_rows<W, H, RULESET>(lds + l * S, lane);
       }
+      if (FINAL && final_obs) {
+        // TG_FLAG_FINAL_OBS: the slab still holds the terminal board of an env that ends its episode here — draw the
+        // terminal piece (if the reference would project it), let the env's lane copy it out, un-draw
+        const u32x2 pf = postF[(step & 1) * EPW + slot];
+        const bool fin = do_reset && ((pf.x >> 25) & 1u);
+        if (__any(fin)) {
+          const bool showf = fin && ((pf.x >> 24) & 1u);
+          const bool fnm = p.obs_mode == TG_OBS_FN;
+          bd.stamp(pf.x & 0xFFFFu, (int)(pf.y & 0xFFu), (int)((pf.y >> 8) & 0xFFu), fnm ? 0xFFu : ((pf.x >> 16) & 0xFFu), false, showf);
+          wave_sync();
+          if (fin) {
+            if (fnm) bits_copy_slab<S, true>(bd.my, final_obs + (size_t)env * S);
+            else bits_copy_slab<S, false>(bd.my, final_obs + (size_t)env * S);
+          }
+          wave_sync();
+          bd.stamp(pf.x & 0xFFFFu, (int)(pf.y & 0xFFu), (int)((pf.y >> 8) & 0xFFu), 0u, false, showf);
+          wave_sync();
+        }
+      }
       todo = __ballot(do_reset);
       while (todo) {  // cooperative zero of a reset env's slab
         const int l = (int)__builtin_ctzll(todo);
@@ -389,25 +482,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     }
     if (last && __any(dirty_any)) {
       // board write-back: every changed env's lane copies its own slab (8-byte aligned in LDS and in HBM)
-      if (dirty_any) {
-        const u32x2* src = reinterpret_cast<const u32x2*>(bd.my);
-        uint8_t* dst = p.board + (size_t)env * S;
-        constexpr int NU = S / 8, UB = NU <= 32 ? NU : 20;  // batches: all reads of a batch in flight before its stores
-        static_assert(S % 8 == 0, "slabs are copied in 8-byte units, stored in pairs");
-#pragma unroll 1
-        for (int u0 = 0; u0 < NU; u0 += UB) {
-          u32x2 t2[UB];
-#pragma unroll
-          for (int u = 0; u < UB; ++u) t2[u] = src[u0 + u < NU ? u0 + u : NU - 1];
-#pragma unroll
-          for (int u = 0; u + 1 < UB; u += 2)  // 16-byte stores at 8-byte alignment
-            if (u0 + u + 1 < NU)
-              *reinterpret_cast<u32x4_a8*>(dst + 8 * (u0 + u)) = u32x4{t2[u].x, t2[u].y, t2[u + 1].x, t2[u + 1].y};
-            else if (u0 + u < NU)
-              *reinterpret_cast<u32x2*>(dst + 8 * (u0 + u)) = t2[u];
-          if (UB % 2 == 1 && u0 + UB - 1 < NU) *reinterpret_cast<u32x2*>(dst + 8 * (u0 + UB - 1)) = t2[UB - 1];
-        }
-      }
+      if (dirty_any) bits_copy_slab<S, false>(bd.my, p.board + (size_t)env * S);
     }
     TG_BITS_STAMP(3);
     if (need_slab) {
@@ -421,11 +496,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
       u32x4* odst = reinterpret_cast<u32x4*>(obase + (size_t)base_env * S);
       u32x4* odst2 = reinterpret_cast<u32x4*>((obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs) + (size_t)base_env * S);
       const bool fn = p.obs_mode == TG_OBS_FN;
-      auto bin1 = [](uint32_t x) -> uint32_t {  // bytes: 0xFF (active) stays -1, other non-zero → 1  (tetris_fn.py:137-158)
-        const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
-        const uint32_t ff = ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u;
-        return (nz >> 7) | ((ff >> 7) * 0xFFu);
-      };
+      auto bin1 = [](uint32_t x) -> uint32_t { return bits_bin1(x); };
       if (full_wave) {
         u32x4 o[NIT];
 #pragma unroll
@@ -540,7 +611,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     const uint4 rw = reinterpret_cast<const uint4*>(bp.ring)[(size_t)bp.cur * bp.pstride + env];
     ring0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32);
     ring1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
-    Hc = bp.hbuf[(size_t)bp.cur * bp.pstride + env];
+    Hc = bp.hbuf[(size_t)bp.cur * bp.pstride + env];  // H | inl << 7, split below
   }
   T cv[W];
   {
@@ -570,36 +641,29 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   lane_unpack(s, ra, rb);
   const int Q = p.queue_size;
   const int grav = p.gravity;
-  // consumer side of the permutation ring (NUMPY).  Consuming an entry is pure register work (no loads inside the
-  // transition loop: vmcnt is in issue order and a load there would be waited on every transition).  The generator
-  // state the reference would hold afterwards is the state stored with the LAST consumed entry; it is fetched once,
-  // after the loop.  g holds that state only after an in-line shuffle (ring exhausted: rare).
-  const int ringT = (int)(ring0 >> 56);
-  bool consumed = false, last_ring = false, g_valid = false, inc_loaded = false;
+  // consumer side of the permutation ring (NUMPY).  Consuming an entry is pure register work: a nibble gather from the
+  // ring word loaded at launch start; the generator state is not touched (see the protocol above).  g holds the state
+  // only after an in-line shuffle (ring exhausted: rare).
+  const int ringT = (int)(ring0 >> 56) & 0x7F;
+  bool inl = (Hc & 0x80) != 0;  // the state after entry H - 1 is in tg_rng_rec (an in-line shuffle produced it)
+  Hc &= 0x7F;
+  bool g_valid = false, inc_loaded = false;
   BitsRng g;
   g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
   g.uinteger = g.has32 = 0;
   g.loaded = false;
   const uint4* rng4 = reinterpret_cast<const uint4*>(p.rng + env);
-  auto load_entry_state = [&](const bool on) {  // state after the last consumed ring entry (index Hc - 1)
-    if (on) {
-      const uint4* a4 = bp.ahead + (size_t)env * (2 * kRing) + 2 * ((Hc - 1) & (kRing - 1));
-      const uint4 f0 = a4[0], f1 = a4[1];
-      g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
-      g.uinteger = f1.x; g.has32 = f1.y;
-    }
-  };
   // BagRandomizer reshuffle (components/tetromino_randomizer.py:42-46, 84) / reset shuffle (:87-91) for the lanes in `need`
   auto consume_perm = [&](const bool need, const bool from_identity) {
     if (!__any(need)) return;
-    const int av = (int)(int8_t)(uint8_t)(ringT - Hc);  // entries left for this lane
+    const int av = ring_diff(ringT, Hc);  // entries left for this lane
     const bool from_ring = need && av > 0;
     const bool fb = need && av <= 0;
     uint32_t sig = ring_get(ring0, ring1, Hc & (kRing - 1));
     if (__any(fb)) {  // rare: ring exhausted → shuffle in-line, from the state the generator holds right now
-      load_entry_state(fb && !g_valid && consumed && last_ring);
-      if (fb && !g_valid && !(consumed && last_ring)) {
-        const uint4 f0 = rng4[0], f1 = rng4[2];
+      if (fb && !g_valid) {
+        const uint4* a4 = bp.ahead + (size_t)env * (2 * kRing) + 2 * ((Hc - 1) & (kRing - 1));
+        const uint4 f0 = *(inl ? rng4 : a4), f1 = *(inl ? rng4 + 2 : a4 + 1);
         g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
         g.uinteger = f1.x; g.has32 = f1.y;
       }
@@ -609,17 +673,13 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
         inc_loaded = true;
       }
       bits_shuffle_perm(g, sig, fb);
-      if (fb) g_valid = true;
+      if (fb) { g_valid = true; inl = true; }
     }
     const uint64_t nb = bits_apply_perm(sig, from_identity ? 0x06050403020100ULL : s.bag);
     if (need) {
-      s.bag = nb; s.bidx = 0; Hc = (Hc + 1) & 0xFF; consumed = true;
-      last_ring = from_ring;
-      if (from_ring) g_valid = false;
+      s.bag = nb; s.bidx = 0; Hc = (Hc + 1) & 0x7F;
+      if (from_ring) { g_valid = false; inl = false; }
     }
-    // a single-transition launch fetches the entry's state right away (it is only needed after the barrier); inside
-    // a transition loop the fetch is deferred to the end of the launch
-    if (nsteps == 1) load_entry_state(from_ring);
   };
   // BagRandomizer.get_next_tetromino (:65-85): eager reshuffle when the 7th piece is drawn
   auto randomizer_next = [&](const bool on) -> int {
@@ -732,11 +792,18 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   const bool hard = stepped && (e & 0x40u) != 0;
   // swap (envs/tetris.py:242-252, components/tetromino_holder.py:31-49)
   const bool swap_eff = RULESET == TG_RULESET_NUMPY && stepped && (e & 0x80u) && !(s.flags & TG_F_HAS_SWAPPED);
+  // NUMPY: the visible queue is consumed lazily.  A transition takes at most two pieces from the env's stream (a hold
+  // with an empty holder, then a lock's spawn); WHICH pieces is known without touching the randomizer: the head of the
+  // queue, then its second entry (queue_size 1: the bag entry the first pop draws).  The pops themselves — queue shift,
+  // bag draw, reshuffle from the permutation ring — are owed (`npop`) and applied after the publish, beside the stream
+  // wave's tail instead of in front of it.
+  int npop = 0;
+  const int up0 = (int)(s.queue & 0xFF);
+  const int up1 = Q >= 2 ? (int)((s.queue >> 8) & 0xFF) : (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
   if (RULESET == TG_RULESET_NUMPY && __any(swap_eff)) {
     const bool empty = swap_eff && s.hp == TG_NONE;
-    const int popped = queue_pop(empty);  // spawn_tetromino; its collision result is ignored
     if (swap_eff) {
-      if (empty) { tp = popped; tr = 0; tv = popped + 2; }
+      if (empty) { tp = up0; tr = 0; tv = up0 + 2; npop = 1; }  // spawn_tetromino; its collision result is ignored
       else { tp = s.hp; tr = s.hr; tv = s.hv; }
       s.hp = s.piece; s.hr = s.rot; s.hv = s.val;
       s.flags |= TG_F_HAS_SWAPPED;
@@ -890,9 +957,10 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     if (place) s.flags &= ~TG_F_FULLROW;
     // spawn the next piece
     if (RULESET == TG_RULESET_NUMPY) {
-      const int np_ = queue_pop(place);  // envs/tetris.py:393-401
+      const int np_ = npop ? up1 : up0;  // envs/tetris.py:393-401 (TetrominoQueue.get_next_tetromino: the pop is owed)
       if (place) {
         s.piece = np_; s.rot = 0; s.val = np_ + 2; s.x = np_spawn_x<W>(np_); s.y = 0;
+        npop += 1;
       }
     } else {  // envs/tetris_fn.py:370-413 place_active_tetromino
       lane_rng_ensure(r);
@@ -953,31 +1021,35 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   const int terminated = (!pending && ((s.flags & TG_F_GAME_OVER) || (g_illegal && p.grouped_term))) ? 1 : 0;
   const bool do_reset = live && (pending || (terminated && p.autoreset == TG_AUTORESET_SAME_STEP));
   if (terminated && p.autoreset == TG_AUTORESET_NEXT_STEP && !pending) s.flags |= TG_F_PENDING_RESET;
+  if (FINAL && final_obs && live) {  // the terminal piece, before the reset replaces it (TG_FLAG_FINAL_OBS)
+    const bool fin = do_reset && terminated;
+    const bool showf = fin && (RULESET == TG_RULESET_NUMPY ? !final_coll : false);
+    postF[(step & 1) * EPW + slot] =
+        u32x2{lane_cells(cell_tab_l, s.piece, s.rot) | ((uint32_t)(s.val & 0xFF) << 16) | ((showf ? 1u : 0u) << 24) | ((fin ? 1u : 0u) << 25),
+              (uint32_t)(s.x & 0xFF) | ((uint32_t)(s.y & 0xFF) << 8)};
+  }
+  // The first piece of a new episode, for the publish.  NUMPY (envs/tetris.py:274-307, tetromino_randomizer.py:87-91): the
+  // reset shuffles a fresh identity bag and draws its element 0 = nibble 0 of the permutation the reset will consume —
+  // the ring entry behind those this transition's owed pops consume (a pop wraps the bag at most once).  Everything else
+  // of the reset (queue, bag, holder, flags) is bookkeeping after the publish.  Ring too short for that (rare): the
+  // bookkeeping runs first (`early_book`, wave-uniform) and the publish reads its result.
+  bool early_book = false;
   if (__any(do_reset)) {
-    if (do_reset) {
-#pragma unroll
-      for (int c = 0; c < W; ++c) colsL[1 + c] = FLOOR;
-    }
-    if (RULESET == TG_RULESET_NUMPY) {  // envs/tetris.py:274-307, tetromino_queue.py:23-33, tetromino_randomizer.py:87-91
-      consume_perm(do_reset, true);
-      if (Q <= 5) {
-        // Q draws fill the queue, the pop takes its head and draws one more: Q + 1 <= 6 draws never wrap the fresh bag
-        if (do_reset) {
-          s.piece = (int)(s.bag & 0xFF);
-          s.queue = (s.bag >> 8) & ((1ULL << (8 * Q)) - 1ULL);
-          s.bidx = Q + 1;
-          s.x = np_spawn_x<W>(s.piece);
-        }
-      } else {
-        if (do_reset) s.queue = 0;
-        for (int i = 0; i < Q; ++i) {
-          const int t = randomizer_next(do_reset);
-          if (do_reset) s.queue |= (uint64_t)t << (8 * i);
-        }
-        const int first = queue_pop(do_reset);
-        if (do_reset) { s.piece = first; s.x = np_spawn_x<W>(first); }
+    if (RULESET == TG_RULESET_NUMPY) {
+      const int Hr = Hc + ((s.bidx + npop >= 7) ? 1 : 0);
+      const bool have = ring_diff(ringT, Hr) > 0;
+      early_book = __any(do_reset && !have);
+      if (do_reset) {
+        s.piece = (int)(ring_get(ring0, ring1, Hr & (kRing - 1)) & 0xFu);
+        s.x = np_spawn_x<W>(s.piece);
+        s.rot = 0; s.y = 0; s.val = s.piece + 2;
+        final_coll = false;
       }
     } else {  // envs/tetris_fn.py:318-367
+      if (do_reset) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) colsL[1 + c] = FLOOR;
+      }
       lane_rng_ensure(r);
       uint32_t a0, a1, b0, b1;
       threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);
@@ -988,28 +1060,73 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
         r.k0 = b0; r.k1 = b1;
         r.dirty = true;
         s.x = (W + 8) / 2 - 2;
+        s.rot = 0; s.y = 0; s.val = s.piece + 2;
+        s.hp = TG_NONE; s.hr = 0; s.hv = 0;
+        s.flags = 0;
+        s.score = 0.0f;
+        final_coll = false;
       }
-    }
-    if (do_reset) {
-      s.rot = 0; s.y = 0; s.val = s.piece + 2;
-      s.hp = TG_NONE; s.hr = 0; s.hv = 0;
-      s.flags = 0;
-      s.score = 0.0f;
-      final_coll = false;
     }
   }
   cols_dirty_any = cols_dirty_any || (live && (place || do_reset));
-  // publish the payload work of this lane's env to the stream wave
-  {
-    const bool show = live && (RULESET == TG_RULESET_NUMPY ? !final_coll : !(s.flags & TG_F_GAME_OVER));
-    const uint32_t ocells = lane_cells(cell_tab_l, s.piece, s.rot);
-    if (live) post[(step & 1) * EPW + slot] = make_uint4(lock_cells | ((uint32_t)(lock_val & 0xFF) << 16) | ((place ? 1u : 0u) << 24) |
-                                ((do_clear ? 1u : 0u) << 25) | ((do_reset ? 1u : 0u) << 26),
-                            (uint32_t)(lock_x & 0xFF) | ((uint32_t)(lock_y & 0xFF) << 8),
-                            ocells | ((uint32_t)(s.val & 0xFF) << 16) | ((show ? 1u : 0u) << 24),
-                            (uint32_t)(s.x & 0xFF) | ((uint32_t)(s.y & 0xFF) << 8) | ((uint32_t)(s.piece & 0xFF) << 16));
+  // Two passes so that the bookkeeping exists once in the code: pass 0 publishes (after the bookkeeping when early_book),
+  // pass 1 does the bookkeeping in the normal case — behind the barrier, while the stream wave already works.
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    if (RULESET == TG_RULESET_NUMPY && (pass == 0) == early_book) {
+      // ---- bookkeeping: the owed pops in order (TetrominoQueue.get_next_tetromino, components/tetromino_queue.py:35-42),
+      // then the reset's randomizer / queue / holder state ----
+#pragma unroll 1
+      for (int k = 0; k < 2; ++k) {
+        const bool on = k < npop;
+        if (!__any(on)) break;
+        (void)queue_pop(on);
+      }
+      if (__any(do_reset)) {
+        if (do_reset) {
+#pragma unroll
+          for (int c = 0; c < W; ++c) colsL[1 + c] = FLOOR;
+        }
+        consume_perm(do_reset, true);  // tetromino_queue.py:23-33, tetromino_randomizer.py:87-91
+        if (Q <= 5) {
+          // Q draws fill the queue, the pop takes its head and draws one more: Q + 1 <= 6 draws never wrap the fresh bag
+          if (do_reset) {
+            s.piece = (int)(s.bag & 0xFF);
+            s.queue = (s.bag >> 8) & ((1ULL << (8 * Q)) - 1ULL);
+            s.bidx = Q + 1;
+          }
+        } else {
+          if (do_reset) s.queue = 0;
+          for (int i = 0; i < Q; ++i) {
+            const int t = randomizer_next(do_reset);
+            if (do_reset) s.queue |= (uint64_t)t << (8 * i);
+          }
+          const int first = queue_pop(do_reset);
+          if (do_reset) s.piece = first;
+        }
+        if (do_reset) {
+          s.x = np_spawn_x<W>(s.piece);
+          s.rot = 0; s.y = 0; s.val = s.piece + 2;
+          s.hp = TG_NONE; s.hr = 0; s.hv = 0;
+          s.flags = 0;
+          s.score = 0.0f;
+        }
+      }
+    }
+    if (pass == 0) {
+      // publish the payload work of this lane's env to the stream wave
+      const bool show = live && (RULESET == TG_RULESET_NUMPY ? !final_coll : !(s.flags & TG_F_GAME_OVER));
+      const uint32_t ocells = lane_cells(cell_tab_l, s.piece, s.rot);
+      if (live) post[(step & 1) * EPW + slot] = make_uint4(lock_cells | ((uint32_t)(lock_val & 0xFF) << 16) | ((place ? 1u : 0u) << 24) |
+                                  ((do_clear ? 1u : 0u) << 25) | ((do_reset ? 1u : 0u) << 26),
+                              (uint32_t)(lock_x & 0xFF) | ((uint32_t)(lock_y & 0xFF) << 8),
+                              ocells | ((uint32_t)(s.val & 0xFF) << 16) | ((show ? 1u : 0u) << 24),
+                              (uint32_t)(s.x & 0xFF) | ((uint32_t)(s.y & 0xFF) << 8) | ((uint32_t)(s.piece & 0xFF) << 16));
+      TG_BITS_STAMP(5);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      __builtin_amdgcn_s_barrier();
+    }
   }
-  TG_BITS_STAMP(5);
   if (pending) {  // the NEXT_STEP reset step belongs to no episode (gymnasium RecordEpisodeStatistics)
     ep.ret = 0.0f; ep.len = 0;
   } else {
@@ -1022,8 +1139,6 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   if (out_traj && live)
     st_stream(reinterpret_cast<u32x2*>(out_traj + (size_t)step * p.act_stride + env),
               u32x2{__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8)});
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
   if (dict) {
     // the other three arrays of the dict observation (envs/tetris.py:572-615), while the stream wave packs the board:
     // active_tetromino_mask = bounding box of the native matrix, holder = ones when empty else the held matrix,
@@ -1110,11 +1225,10 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   }
 
   TG_BITS_STAMP(6);
-  // ---- E: generator bookkeeping: the consumed shuffles' end state is what the reference's generator now holds ----
+  // ---- E: consumed counter; the generator state only after an in-line shuffle (otherwise `ahead` holds it) ----
   if (RULESET == TG_RULESET_NUMPY) {
-    if (live) bp.hbuf[(size_t)(1 - bp.cur) * bp.pstride + env] = (uint8_t)Hc;
-    if (nsteps > 1) load_entry_state(live && consumed && last_ring);
-    if (live && consumed) {
+    if (live) bp.hbuf[(size_t)(1 - bp.cur) * bp.pstride + env] = (uint8_t)(Hc | (inl ? 0x80 : 0));
+    if (live && g_valid) {
       uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
       rng_out[0] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
       *reinterpret_cast<uint2*>(rng_out + 2) = make_uint2(g.uinteger, g.has32);
@@ -1190,9 +1304,11 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
     rng_store(r, p.rng + env, 0);
   }
   rec[7] = 0;
-  uint64_t w[2] = {(uint64_t)kRing << 56, 0};  // T = kRing, H = 0: entries 0 .. kRing - 1
+  // T = kRing - 1, H = 0: entries 0 .. kRing - 2 ahead; "the state after entry -1" = the generator as it stands in
+  // tg_rng_rec (inl = 1), which this kernel leaves where the reference's generator is
+  uint64_t w[2] = {(uint64_t)(kRing - 1) << 56, 0};
   uint4* a4 = p.ahead + (size_t)env * (2 * kRing);
-  for (int sl = 0; sl < kRing; ++sl) {
+  for (int sl = 0; sl < kRing - 1; ++sl) {
     const uint64_t perm = pcg_shuffle7(r, 0x06050403020100ULL);
     uint64_t sig = 0;
     for (int k = 0; k < 7; ++k) sig |= ((perm >> (8 * k)) & 0xF) << (4 * k);
@@ -1203,8 +1319,33 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
   const uint4 rw = make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
   ring4[env] = rw;
   ring4[B + env] = rw;
-  p.hbuf[env] = 0;
-  p.hbuf[B + env] = 0;
+  p.hbuf[env] = 0x80;
+  p.hbuf[B + env] = 0x80;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bits_materialize_rng_kernel: write "the generator the reference holds now" into tg_rng_rec.  A transition never
+// touches tg_rng_rec (see the ring protocol); the state after the last consumed shuffle sits in ahead[(H - 1) & 3]
+// unless an in-line shuffle already put it into the record (inl).  Runs before anything reads TG_BUF_RNG: tg_get_state,
+// tg_reset (a reset without a seed continues the running generator), tg_set_state, tg_fetch / tg_device_ptr of the buffer.
+// ------------------------------------------------------------------------------------------------
+struct MaterializeParams {
+  tg_rng_rec* rng;
+  const uint4* ahead;
+  const uint8_t* hbuf;  // the parity the next launch reads
+  int batch;
+};
+
+__global__ __launch_bounds__(256) void bits_materialize_rng_kernel(const MaterializeParams p) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= p.batch) return;
+  const int Hraw = p.hbuf[env];
+  if (Hraw & 0x80) return;
+  const uint4* a4 = p.ahead + (size_t)env * (2 * kRing) + 2 * (((Hraw & 0x7F) - 1) & (kRing - 1));
+  const uint4 f0 = a4[0], f1 = a4[1];
+  uint4* out = reinterpret_cast<uint4*>(p.rng + env);
+  out[0] = f0;
+  *reinterpret_cast<uint2*>(out + 2) = make_uint2(f1.x, f1.y);
 }
 
 }  // namespace tg
