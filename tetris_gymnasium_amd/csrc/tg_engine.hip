@@ -187,6 +187,9 @@ struct tg_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Launchers L{};
+  void* arena = nullptr;  // the one device allocation behind every buffer below
+  size_t arena_size = 0, arena_off = 0, arena_skew = 0;
+  int arena_count = 0;
   void* buf[TG_BUF_COUNT] = {};
   size_t bytes[TG_BUF_COUNT] = {};
   tg_rng_rec* d_new_rng = nullptr;
@@ -303,11 +306,24 @@ void seed_pcg64_host(uint64_t seed, tg_rng_rec* out) {
 // unmasked (lanes past the end of the last env's slab read padding instead of faulting).
 constexpr size_t kTailPad = 4096;
 
+// All device state of a handle comes from ONE allocation (`arena`), carved in 4 KiB-aligned pieces in a fixed order:
+// where the buffers sit relative to each other is then the same for every handle (separate hipMalloc calls gave
+// launch times that differed by up to 0.5 us between two handles of the same process: profiles/r02 placement runs).
+// TG_ALLOC_SKEW=n (bytes, default below) adds n x (piece index) to the offsets so that streams read and written at the
+// same relative position (board / observation slabs) do not start on the same channel.
+hipError_t arena_take(tg_handle* h, void** out, size_t n) {
+  const size_t off = ((h->arena_off + 4095) / 4096) * 4096 + h->arena_skew * (size_t)h->arena_count;
+  if (off + n > h->arena_size) return hipErrorOutOfMemory;
+  *out = (uint8_t*)h->arena + off;
+  h->arena_off = off + n;
+  h->arena_count += 1;
+  return hipSuccess;
+}
+
 int alloc_buf(tg_handle* h, int which, size_t n) {
   h->bytes[which] = n;
   if (n == 0) return TG_OK;
-  HIPCHK(h, hipMalloc(&h->buf[which], n + kTailPad));
-  HIPCHK(h, hipMemsetAsync(h->buf[which], 0, n + kTailPad, h->stream));
+  HIPCHK(h, arena_take(h, &h->buf[which], n + kTailPad));
   return TG_OK;
 }
 
@@ -571,22 +587,30 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
       /*EPISODE*/ (cfg->flags & TG_FLAG_EPISODE_STATS) ? B * sizeof(tg_episode_rec) : 0,
       /*PLACEMENT_FEATS*/ (cfg->flags & TG_FLAG_FEATURES) ? B * 4 * (size_t)cfg->width * (size_t)(cfg->width + 3) : 0,
       /*FEATS*/ (cfg->flags & TG_FLAG_FEATURES) ? B * (size_t)(cfg->width + 3) : 0};
+  {
+    h->arena_skew = 0;
+    if (const char* e = getenv("TG_ALLOC_SKEW")) h->arena_skew = (size_t)(atol(e) > 0 ? atol(e) : 0);
+    const int n_pieces = TG_BUF_COUNT + 8;
+    size_t total = 0;
+    for (int i = 0; i < TG_BUF_COUNT; ++i) total += sizes[i] + kTailPad + 4096;
+    total += B * sizeof(tg_rng_rec) + 2 * B + B * L.cols_bytes + B * 32 * tg::kRing + 2 * B * 16 + 2 * B + 8 * (kTailPad + 4096);
+    total += h->arena_skew * (size_t)n_pieces * (size_t)n_pieces;
+    CRCHK(hipMalloc(&h->arena, total));
+    h->arena_size = total;
+    CRCHK(hipMemsetAsync(h->arena, 0, total, h->stream));
+  }
   for (int i = 0; i < TG_BUF_COUNT; ++i) {
     int rc = alloc_buf(h, i, sizes[i]);
     if (rc != TG_OK) return bail(rc);
   }
-  CRCHK(hipMalloc((void**)&h->d_new_rng, B * sizeof(tg_rng_rec)));
-  CRCHK(hipMalloc((void**)&h->d_reseed, B));
-  CRCHK(hipMalloc((void**)&h->d_mask, B));
+  CRCHK(arena_take(h, (void**)&h->d_new_rng, B * sizeof(tg_rng_rec)));
+  CRCHK(arena_take(h, (void**)&h->d_reseed, B));
+  CRCHK(arena_take(h, (void**)&h->d_mask, B));
   if (g_kernel_lanes == 16) {
-    CRCHK(hipMalloc(&h->d_cols, B * L.cols_bytes + kTailPad));
-    CRCHK(hipMemsetAsync(h->d_cols, 0, B * L.cols_bytes + kTailPad, h->stream));
-    CRCHK(hipMalloc((void**)&h->d_ahead, B * 32 * tg::kRing + kTailPad));
-    CRCHK(hipMemsetAsync(h->d_ahead, 0, B * 32 * tg::kRing + kTailPad, h->stream));
-    CRCHK(hipMalloc((void**)&h->d_ring, 2 * B * 16 + kTailPad));
-    CRCHK(hipMemsetAsync(h->d_ring, 0, 2 * B * 16 + kTailPad, h->stream));
-    CRCHK(hipMalloc((void**)&h->d_hbuf, 2 * B + kTailPad));
-    CRCHK(hipMemsetAsync(h->d_hbuf, 0, 2 * B + kTailPad, h->stream));
+    CRCHK(arena_take(h, &h->d_cols, B * L.cols_bytes + kTailPad));
+    CRCHK(arena_take(h, (void**)&h->d_ahead, B * 32 * tg::kRing + kTailPad));
+    CRCHK(arena_take(h, (void**)&h->d_ring, 2 * B * 16 + kTailPad));
+    CRCHK(arena_take(h, (void**)&h->d_hbuf, 2 * B + kTailPad));
   }
 #ifdef TG_PHASE_TIMING
   CRCHK(hipMalloc(&h->dbg, ((B + 15) / 16) * 16 * 8));
@@ -641,15 +665,7 @@ void tg_destroy(tg_handle* h) {
     if (ev) (void)hipEventDestroy(ev);
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (int i = 0; i < TG_BUF_COUNT; ++i)
-    if (h->buf[i]) (void)hipFree(h->buf[i]);
-  if (h->d_new_rng) (void)hipFree(h->d_new_rng);
-  if (h->d_reseed) (void)hipFree(h->d_reseed);
-  if (h->d_mask) (void)hipFree(h->d_mask);
-  if (h->d_cols) (void)hipFree(h->d_cols);
-  if (h->d_ahead) (void)hipFree(h->d_ahead);
-  if (h->d_ring) (void)hipFree(h->d_ring);
-  if (h->d_hbuf) (void)hipFree(h->d_hbuf);
+  if (h->arena) (void)hipFree(h->arena);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -209,10 +209,33 @@ __device__ __forceinline__ void st_stream(V* dst, const V v) {
 #endif
 }
 
-// state that the NEXT launch reads again (board, records): TG_NT_STATE also streams it
-#ifdef TG_NT_STATE
-#define TG_ST_STATE(ptr, val) st_stream(ptr, val)
+// state that the NEXT launch reads again (board, records, rings).  TG_STATE_ST: 0 = plain stores (dirty in the XCD's L2
+// until the end-of-kernel write-back), 1 = nontemporal (default: measured -0.45 us per launch with the chunk-major
+// write-back, profiles/r02 — the dirty lines leave while the kernel still runs, the boundary to the next launch gets
+// shorter), 2 = write-through (sc1; measured +0.3 us).  The column masks stay plain 8-byte stores (nontemporal: no gain).
+#ifndef TG_STATE_ST
+#define TG_STATE_ST 1
+#endif
+template <typename V>
+__device__ __forceinline__ void st_state(V* dst, const V v) {
+  static_assert(sizeof(V) == 16 || sizeof(V) == 8, "state stores are 8 or 16 bytes");
+  if constexpr (TG_STATE_ST == 1) {
+    __builtin_nontemporal_store(v, dst);
+  } else if constexpr (TG_STATE_ST == 2) {
+    if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+  } else {
+    *dst = v;
+  }
+}
+#define TG_ST_STATE(ptr, val) st_state(ptr, val)
+#ifdef TG_COLS_NT
+#define TG_ST_COLS(ptr, val) st_state(ptr, val)
 #else
+#define TG_ST_COLS(ptr, val) (*(ptr) = (val))
+#endif
+#ifdef TG_REC_PLAIN
+#undef TG_ST_STATE
 #define TG_ST_STATE(ptr, val) (*(ptr) = (val))
 #endif
 
@@ -373,9 +396,15 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
         }
       }
     }
-    if (on)
-      reinterpret_cast<uint4*>(bp.ring)[(size_t)(1 - bp.cur) * bp.pstride + e] =
-          make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+    if (on) {
+      u32x4* rdst = reinterpret_cast<u32x4*>(bp.ring) + (size_t)(1 - bp.cur) * bp.pstride + e;
+      const u32x4 rv = u32x4{(uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32)};
+#ifdef TG_RING_PLAIN
+      *rdst = rv;
+#else
+      st_state(rdst, rv);
+#endif
+    }
 #ifdef TG_PHASE_TIMING
     if (p.dbg && (threadIdx.x & 63) == 0) {  // lifetime of the RNG waves, behind the step workgroups' stamps
       const size_t slot = (size_t)(gridDim.x - bp.nrb) * 16 + (size_t)rng_block * 4 + (threadIdx.x >> 6) * 2;
@@ -385,6 +414,12 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
 #endif
     return;
   }
+#ifdef TG_WG_STAGGER
+  // experiment: half of the step workgroups start late (k x 512 cycles) so that their load / store bursts fall into the
+  // other half's compute phase
+  if ((step_block >> 3) & 1u)
+    for (int i = 0; i < TG_WG_STAGGER; ++i) __builtin_amdgcn_s_sleep(8);
+#endif
   TG_BITS_STAMP(0);
 
   if (wave == 1) {
@@ -481,8 +516,44 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
       wave_sync();
     }
     if (last && __any(dirty_any)) {
+#ifdef TG_WB_PER_LANE
       // board write-back: every changed env's lane copies its own slab (8-byte aligned in LDS and in HBM)
       if (dirty_any) bits_copy_slab<S, false>(bd.my, p.board + (size_t)env * S);
+#else
+      // board write-back, chunk-major: lane l of pass k owns the 16-byte chunk l + 64 k of the workgroup's slab block and
+      // stores it when it holds bytes of a changed env.  Neighbouring lanes write neighbouring chunks, so a changed
+      // slab costs ~4 full cache-line writes instead of 13 partial ones from its own lane (the launch's store burst is
+      // bound by line operations, not bytes).  A chunk shared with an unchanged neighbour rewrites that env's bytes as
+      // they are.
+      const uint64_t dm = __ballot(dirty_any);
+      u32x4* bdst = reinterpret_cast<u32x4*>(p.board + (size_t)base_env * S);
+      u32x4 wv[NIT];
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int c = lane + 64 * k;
+        wv[k] = lds4[c < NCH ? c : NCH - 1];
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const uint32_t c = (uint32_t)lane + 64u * k;
+        const uint32_t e0 = (16u * c) / (uint32_t)S, e1r = (16u * c + 15u) / (uint32_t)S;
+        const uint32_t e1 = e1r < (uint32_t)EPW ? e1r : (uint32_t)EPW - 1u;
+        const bool hit = c < nchunks && (((dm >> e0) | (dm >> e1)) & 1ull) != 0;
+        if (hit) {
+          if (c * 16u + 16u <= nbytes) {
+#ifdef TG_WB_PLAIN
+            bdst[c] = wv[k];
+#else
+            st_state(&bdst[c], wv[k]);
+#endif
+          } else {  // ragged tail of a partial wave
+            const uint32_t w4[4] = {wv[k].x, wv[k].y, wv[k].z, wv[k].w};
+            for (uint32_t i = 0; c * 16u + i < nbytes; ++i)
+              reinterpret_cast<uint8_t*>(bdst)[c * 16u + i] = (uint8_t)(w4[i >> 2] >> (8 * (i & 3)));
+          }
+        }
+      }
+#endif
     }
     TG_BITS_STAMP(3);
     if (need_slab) {
@@ -603,8 +674,9 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   } else {
     action0 = reinterpret_cast<const int32_t*>(p.actions)[env];
   }
-  tg_episode_rec ep{};
-  if (p.episode) ep = p.episode[env];
+  // (unconditional load, from the record when there is no statistics buffer: a branch here makes the compiler wait for
+  // the load before it issues the ones below — two memory round trips instead of one)
+  tg_episode_rec ep = *(p.episode ? p.episode + env : reinterpret_cast<const tg_episode_rec*>(rec4));
   uint64_t ring0 = 0, ring1 = 0;
   int Hc = 0;
   if (RULESET == TG_RULESET_NUMPY) {
@@ -1216,10 +1288,10 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
       uint2* gc = reinterpret_cast<uint2*>(reinterpret_cast<T*>(bp.cols) + (size_t)env * W);
       if constexpr (sizeof(T) == 4) {
 #pragma unroll
-        for (int k = 0; k < W / 2; ++k) gc[k] = make_uint2((uint32_t)nv[2 * k], (uint32_t)nv[2 * k + 1]);
+        for (int k = 0; k < W / 2; ++k) TG_ST_COLS(reinterpret_cast<u32x2*>(gc + k), (u32x2{(uint32_t)nv[2 * k], (uint32_t)nv[2 * k + 1]}));
       } else {
 #pragma unroll
-        for (int c = 0; c < W; ++c) gc[c] = make_uint2((uint32_t)nv[c], (uint32_t)((uint64_t)nv[c] >> 32));
+        for (int c = 0; c < W; ++c) TG_ST_COLS(reinterpret_cast<u32x2*>(gc + c), (u32x2{(uint32_t)nv[c], (uint32_t)((uint64_t)nv[c] >> 32)}));
       }
     }
   }

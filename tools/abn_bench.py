@@ -3,7 +3,9 @@
 box-to-box spread on this pool exceeds most kernel changes).  Every variant is a source tree (a copy of csrc under _ab/<tag>/
 or the working tree) plus optional -D flags:
 
-    tools/abn_bench.py tag[=srcdir][:-Dflag[:-Dflag...]] ...        env: AB_BATCH, AB_RULESET, AB_OBS, AB_STEPS
+    tools/abn_bench.py tag[=srcdir][:-Dflag[:-Dflag...]][@ENV=value...] ...        env: AB_BATCH, AB_RULESET, AB_OBS, AB_STEPS
+
+@ENV=value pairs are set while the variant's engines are created (knobs tg_create reads, e.g. TG_ALLOC_SKEW).
 
 srcdir is a directory holding tg_engine.hip (default: tetris_gymnasium_amd/csrc).  Prints median / min us per step and a
 checksum of the final state per variant (variants of the same rules must agree)."""
@@ -13,11 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("TG_FUSE", "1")
 variants = []
+envs = {}
 for a in sys.argv[1:]:
+    a, *kv = a.split("@")
     head, *flags = a.split(":")
     tag, _, src = head.partition("=")
     src = os.path.join(ROOT, src) if src else os.path.join(ROOT, "tetris_gymnasium_amd", "csrc")
     variants.append((tag, src, flags))
+    envs[tag] = dict(x.split("=", 1) for x in kv)
 procs = []
 for tag, src, flags in variants:
     procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -41,10 +46,13 @@ for tag, _, _ in variants:
     for rep in ("", "'"):  # two engines per build: buffer placement varies too
         N._lib = None
         N.LIB_PATH = f"/tmp/libtg_{tag}.so"
+        os.environ.update(envs[tag])
         e = Engine(B, ruleset=(N.RULESET_FUNCTIONAL if fn else N.RULESET_NUMPY), obs_mode=obs, autoreset=N.AUTORESET_SAME_STEP)
         e.reset(np.arange(1, B + 1, dtype=np.uint64))
         d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts)
         e.step_k_device(d, 64); e.sync()
+        for k in envs[tag]:
+            os.environ.pop(k, None)
         eng[tag + rep] = (e, d)
 res = {t: [] for t in eng}
 for rep in range(7):
