@@ -949,6 +949,12 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
     int rc = launch_prepare_bits(h, nullptr, 1);
     if (rc != TG_OK) return rc;
   }
+  // TG_BUF_OBS of the DICT / RGB surfaces is kept up to date incrementally by the transitions (holder / queue strips are
+  // stored only when they change): re-pack it from the uploaded state
+  if (h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) {
+    int rc = launch_observe_dict(h);
+    if (rc != TG_OK) return rc;
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return TG_OK;
 }

@@ -77,17 +77,18 @@ struct BitsGeo {
   static constexpr int SLABS = ((EPW * S + 15) / 16) * 16;
   static constexpr int NCH = SLABS / 16;
   static constexpr int NIT = (NCH + 63) / 64;
-  static constexpr int OFF_TAB = SLABS;             // cell table, column table, cell table (logic wave's copy): 3 x 64 B
-  static constexpr int OFF_POST = OFF_TAB + 192;    // uint4 [2][EPW]: what the stream wave has to do per env (double-buffered by transition parity)
+  static constexpr int OFF_TAB = SLABS;             // cell table, column table, cell table (logic wave's copy), row-mask table: 4 x 64 B
+  static constexpr int OFF_POST = OFF_TAB + 256;    // uint4 [2][EPW]: what the stream wave has to do per env (double-buffered by transition parity)
   static constexpr int OFF_COLS = OFF_POST + 2 * EPW * 16;  // T [EPW][CST]: [0] bedrock, [1..W] playfield columns, [W+1] bedrock
   static constexpr int CST = (W + 2) | 1;           // odd stride: conflict-free for same-index accesses of the 64 lanes
   static constexpr int BYTES = ((OFF_COLS + EPW * CST * (int)sizeof(T) + 15) / 16) * 16;
-  // TG_OBS_DICT packed in the kernel: two staging buffers of 8 padded boards behind BYTES (stream wave: board, logic
+  // TG_OBS_DICT packed in the kernel: two staging buffers of GD padded boards behind BYTES (stream wave: board, logic
   // wave: active_tetromino_mask)
   static constexpr int PC = (W + 8) * (H + 4);
+  static constexpr int GD = 16;
   static constexpr int OFF_DICT = BYTES;
-  static constexpr int BYTES_DICT = BYTES + 2 * 8 * PC;
-  static constexpr bool DICT_OK = PC % 16 == 0 && EPW % 8 == 0;
+  static constexpr int BYTES_DICT = BYTES + 2 * GD * PC;
+  static constexpr bool DICT_OK = PC % 16 == 0 && EPW % GD == 0 && H % 2 == 0;
   // TG_FLAG_FINAL_OBS (observation BOARD / FN only, never together with the dict staging): uint2 [2][EPW] behind BYTES —
   // the terminal piece of every env that ends its episode in this transition
   static constexpr int OFF_FIN = BYTES;
@@ -256,6 +257,72 @@ __device__ __forceinline__ uint32_t bits_bin1(const uint32_t x) {
   return (nz >> 7) | ((ff >> 7) * 0xFFu);
 }
 
+// Two playfield rows (2 W bytes = 2 W / 4 dwords, row pairs start dword-aligned because W is even) → the same two rows of
+// the padded board (bedrock | row | bedrock, W + 8 bytes each; envs/tetris.py:632-641).  Both rows map source byte → output
+// byte with a shift that is a multiple of 4 (4 and 12), so every output dword is a constant, a source dword, or half of each.
+template <int W>
+__device__ __forceinline__ void dict_pair(const uint32_t (&src)[2 * W / 4], uint32_t (&out)[(2 * W + 16) / 4]) {
+  constexpr int WP = W + 8;
+#pragma unroll
+  for (int j = 0; j < 2 * WP / 4; ++j) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int pos = 4 * j + b;
+      const int srcb = (pos >= 4 && pos < 4 + W) ? pos - 4 : ((pos >= WP + 4 && pos < WP + 4 + W) ? pos - 12 : -1);
+      if (srcb >= 0) v |= src[srcb / 4] & (0xFFu << (8 * b));
+      else v |= 0x01u << (8 * b);
+    }
+    out[j] = v;
+  }
+}
+
+// obs["active_tetromino_mask"] (envs/tetris.py:572-576: the bounding box of the native matrix) of GD envs: stamp the boxes
+// into an all-zero staging buffer, let the group leave as one contiguous block, un-stamp.  `pw` = the .w words of the
+// envs' post records {x | y << 8 | piece << 16}.
+template <int W, int H, int GD>
+__device__ __forceinline__ void dict_mask_group(uint8_t* buf, const uint4* post_g, const uint32_t nlive_g, const int lane,
+                                                uint8_t* dst0, uint8_t* dst1) {
+  constexpr int WP = W + 8, HP = H + 4, PC = WP * HP, NCHG = GD * PC / 16, CT = (NCHG + 63) / 64, ST = GD * 16 / 64;
+  int addr[ST];
+  uint32_t pws[ST];
+#pragma unroll
+  for (int i = 0; i < ST; ++i) pws[i] = post_g[(lane + 64 * i) >> 4].w;
+#pragma unroll
+  for (int i = 0; i < ST; ++i) {
+    const int t = lane + 64 * i;
+    const int el = t >> 4, k = (t >> 2) & 3, c = t & 3;
+    const uint32_t pw = pws[i];
+    const int x = (int)(pw & 0xFFu), y = (int)((pw >> 8) & 0xFFu), pc = (int)((pw >> 16) & 0xFFu);
+    const int n = pc == 0 ? 4 : (pc == 1 ? 2 : 3);
+    const bool ok = (uint32_t)el < nlive_g && k < n && c < n && y + k < HP && x + c < WP;
+    addr[i] = ok ? el * PC + (y + k) * WP + x + c : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < ST; ++i)
+    if (addr[i] >= 0) buf[addr[i]] = 1;
+  wave_sync();
+  u32x4 v[CT];
+#pragma unroll
+  for (int i = 0; i < CT; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = reinterpret_cast<const u32x4*>(buf)[c < NCHG ? c : NCHG - 1];
+  }
+#pragma unroll
+  for (int i = 0; i < CT; ++i) {
+    const int c = lane + 64 * i;
+    if (c < NCHG && (uint32_t)c / (PC / 16) < nlive_g) {
+      st_stream(reinterpret_cast<u32x4*>(dst0 + 16 * (size_t)c), v[i]);
+      if (dst1) st_stream(reinterpret_cast<u32x4*>(dst1 + 16 * (size_t)c), v[i]);
+    }
+  }
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < ST; ++i)
+    if (addr[i] >= 0) buf[addr[i]] = 0;
+  wave_sync();
+}
+
 // one lane copies its env's slab LDS → HBM (8-byte aligned on both sides): batches of 8-byte LDS reads, all reads of a
 // batch in flight before its 16-byte stores.  BIN: through the functional observation's byte map.
 template <int S, bool BIN>
@@ -357,43 +424,46 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
 #define TG_RNG_PRIO 2  // between the stream wave before its barrier (1) and the logic wave (3): A/B in profiles/r02
 #endif
     __builtin_amdgcn_s_setprio(TG_RNG_PRIO);
-    // ONE entry per env and launch (a second one waits for the next launch: 13 % of the waves would otherwise run two
-    // shuffles back to back and become the tail of the launch — measured 7.0 us vs 5.8 us for the step workgroups)
-    {
+    // One-transition launches: ONE entry per env and launch (a second one waits for the next launch: 13 % of the waves
+    // would otherwise run two shuffles back to back and become the tail of the launch — measured 7.0 us vs 5.8 us for the
+    // step workgroups).  Launches of several transitions consume more per env and are long anyway: refill completely.
+    const int max_reps = nsteps > 1 ? kRing - 1 : 1;
+    BitsRng g;
+    g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
+    g.uinteger = g.has32 = 0;
+    g.loaded = false;
+    uint4* a4 = bp.ahead + (size_t)ee * (2 * kRing);
+    const uint4* rng4 = reinterpret_cast<const uint4*>(p.rng + ee);
+    for (int rep = 0; rep < max_reps; ++rep) {
       int Tn = (int)(w0 >> 56) & 0x7F;
       const int d = ring_diff(Tn, Hn);
       const bool need = on && d < bp.fill;
-      if (__any(need)) {
-        BitsRng g;
-        g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
-        g.uinteger = g.has32 = 0;
-        g.loaded = false;
-        uint4* a4 = bp.ahead + (size_t)ee * (2 * kRing);
-        const uint4* rng4 = reinterpret_cast<const uint4*>(p.rng + ee);
-        if (need) {
-          // frontier = state after entry T - 1.  The consumer may have run past T with in-line shuffles (d <= 0): the
-          // entries below H are dead — continue from the consumer's state (ahead[(H - 1) & 3], or tg_rng_rec when `inl`)
-          const bool resync = d <= 0;
-          if (resync) Tn = Hn;
-          const int fs = (Tn - 1) & (kRing - 1);
-          const bool from_rec = resync && inl;
-          const uint4 f0 = *(from_rec ? rng4 : a4 + 2 * fs), f1 = *(from_rec ? rng4 + 2 : a4 + 2 * fs + 1);
-          const uint4 gi = rng4[1];
-          g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
-          g.i_lo = (uint64_t)gi.x | ((uint64_t)gi.y << 32); g.i_hi = (uint64_t)gi.z | ((uint64_t)gi.w << 32);
-          g.uinteger = f1.x; g.has32 = f1.y;
-        }
-        uint32_t sig = 0;
-        bits_shuffle_perm(g, sig, need);
-        if (need) {
-          const int sl = Tn & (kRing - 1);
-          a4[2 * sl] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
-          a4[2 * sl + 1] = make_uint4(g.uinteger, g.has32, 0u, 0u);
-          const uint64_t m = 0x0FFFFFFFULL << (28 * (sl & 1)), v = (uint64_t)sig << (28 * (sl & 1));
-          if (sl & 2) w1 = (w1 & ~m) | v;
-          else w0 = (w0 & ~m) | v;
-          w0 = (w0 & ~(0xFFULL << 56)) | ((uint64_t)((Tn + 1) & 0x7F) << 56);
-        }
+      if (!__any(need)) break;
+      if (need && !g.loaded) {
+        // frontier = state after entry T - 1 (later entries of this visit continue from the registers).  The consumer may
+        // have run past T with in-line shuffles (d <= 0): the entries below H are dead — continue from the consumer's
+        // state (ahead[(H - 1) & 3], or tg_rng_rec when `inl`)
+        const bool resync = d <= 0;
+        if (resync) Tn = Hn;
+        const int fs = (Tn - 1) & (kRing - 1);
+        const bool from_rec = resync && inl;
+        const uint4 f0 = *(from_rec ? rng4 : a4 + 2 * fs), f1 = *(from_rec ? rng4 + 2 : a4 + 2 * fs + 1);
+        const uint4 gi = rng4[1];
+        g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
+        g.i_lo = (uint64_t)gi.x | ((uint64_t)gi.y << 32); g.i_hi = (uint64_t)gi.z | ((uint64_t)gi.w << 32);
+        g.uinteger = f1.x; g.has32 = f1.y;
+        g.loaded = true;
+      }
+      uint32_t sig = 0;
+      bits_shuffle_perm(g, sig, need);
+      if (need) {
+        const int sl = Tn & (kRing - 1);
+        a4[2 * sl] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
+        a4[2 * sl + 1] = make_uint4(g.uinteger, g.has32, 0u, 0u);
+        const uint64_t m = 0x0FFFFFFFULL << (28 * (sl & 1)), v = (uint64_t)sig << (28 * (sl & 1));
+        if (sl & 2) w1 = (w1 & ~m) | v;
+        else w0 = (w0 & ~m) | v;
+        w0 = (w0 & ~(0xFFULL << 56)) | ((uint64_t)((Tn + 1) & 0x7F) << 56);
       }
     }
     if (on) {
@@ -527,29 +597,39 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
       // they are.
       const uint64_t dm = __ballot(dirty_any);
       u32x4* bdst = reinterpret_cast<u32x4*>(p.board + (size_t)base_env * S);
-      u32x4 wv[NIT];
-#pragma unroll
-      for (int k = 0; k < NIT; ++k) {
-        const int c = lane + 64 * k;
-        wv[k] = lds4[c < NCH ? c : NCH - 1];
-      }
-#pragma unroll
-      for (int k = 0; k < NIT; ++k) {
-        const uint32_t c = (uint32_t)lane + 64u * k;
-        const uint32_t e0 = (16u * c) / (uint32_t)S, e1r = (16u * c + 15u) / (uint32_t)S;
-        const uint32_t e1 = e1r < (uint32_t)EPW ? e1r : (uint32_t)EPW - 1u;
-        const bool hit = c < nchunks && (((dm >> e0) | (dm >> e1)) & 1ull) != 0;
-        if (hit) {
-          if (c * 16u + 16u <= nbytes) {
-#ifdef TG_WB_PLAIN
-            bdst[c] = wv[k];
+      // chunks in flight per lane: all of them in the one-transition kernel; in the transition loop of the fused kernels
+      // that would cost 52 registers beside the observation pass's 52 (the kernel spilled)
+#ifdef TG_WBB
+      constexpr int WBB = TG_WBB;
 #else
-            st_state(&bdst[c], wv[k]);
+      constexpr int WBB = MULTI ? 4 : NIT;
 #endif
-          } else {  // ragged tail of a partial wave
-            const uint32_t w4[4] = {wv[k].x, wv[k].y, wv[k].z, wv[k].w};
-            for (uint32_t i = 0; c * 16u + i < nbytes; ++i)
-              reinterpret_cast<uint8_t*>(bdst)[c * 16u + i] = (uint8_t)(w4[i >> 2] >> (8 * (i & 3)));
+#pragma unroll 1
+      for (int k0 = 0; k0 < NIT; k0 += WBB) {
+        u32x4 wv[WBB];
+#pragma unroll
+        for (int kk = 0; kk < WBB; ++kk) {
+          const int c = lane + 64 * (k0 + kk);
+          wv[kk] = lds4[c < NCH ? c : NCH - 1];
+        }
+#pragma unroll
+        for (int kk = 0; kk < WBB; ++kk) {
+          const uint32_t c = (uint32_t)lane + 64u * (uint32_t)(k0 + kk);
+          const uint32_t e0 = (16u * c) / (uint32_t)S, e1r = (16u * c + 15u) / (uint32_t)S;
+          const uint32_t e1 = e1r < (uint32_t)EPW ? e1r : (uint32_t)EPW - 1u;
+          const bool hit = k0 + kk < NIT && c < nchunks && (((dm >> e0) | (dm >> e1)) & 1ull) != 0;
+          if (hit) {
+            if (c * 16u + 16u <= nbytes) {
+#ifdef TG_WB_PLAIN
+              bdst[c] = wv[kk];
+#else
+              st_state(&bdst[c], wv[kk]);
+#endif
+            } else {  // ragged tail of a partial wave
+              const uint32_t w4[4] = {wv[kk].x, wv[kk].y, wv[kk].z, wv[kk].w};
+              for (uint32_t i = 0; c * 16u + i < nbytes; ++i)
+                reinterpret_cast<uint8_t*>(bdst)[c * 16u + i] = (uint8_t)(w4[i >> 2] >> (8 * (i & 3)));
+            }
           }
         }
       }
@@ -606,31 +686,56 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
       }
     }
     if (dict) {
-      // obs["board"] (envs/tetris.py:566-571): the padded board with the projected piece.  Eight envs at a time: a lane
-      // builds padded rows (bedrock | playfield row | bedrock) in the staging buffer, then the group leaves as one
-      // contiguous coalesced block of 8 * Hp * Wp bytes.
+      // obs["board"] (envs/tetris.py:566-571): the padded board with the projected piece.  GD envs at a time: a lane
+      // turns playfield row pairs into padded row pairs (dword reads, dword writes) in the staging buffer, then the
+      // group leaves as one contiguous coalesced block of GD * Hp * Wp bytes.
       bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu), (po.z >> 16) & 0xFFu, false,
                live && ((po.z >> 24) & 1u));
       wave_sync();
       uint8_t* grp = lds + BG::OFF_DICT;
       uint8_t* dst0 = obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs;
       uint8_t* dst1 = (last && obs_traj) ? p.obs : nullptr;
-      for (int g0 = 0; g0 < EPW; g0 += 8) {
-        for (int t = lane; t < 8 * HP; t += 64) {
-          const int el = t / HP, R = t - el * HP;
-          uint16_t* drow = reinterpret_cast<uint16_t*>(grp + el * PC + R * WP);
-          drow[0] = 0x0101; drow[1] = 0x0101; drow[(W + 4) / 2] = 0x0101; drow[(W + 6) / 2] = 0x0101;
-          const uint16_t* srow = reinterpret_cast<const uint16_t*>(lds + (g0 + el) * S + (R < H ? R : 0) * W);
+      constexpr int GD = BG::GD, NPAIR = HP / 2, NS = 2 * W / 4, ND = 2 * WP / 4;
+      constexpr int BT = (GD * NPAIR + 63) / 64, NCHG = GD * PC / 16, CT = (NCHG + 63) / 64;
+      for (int g0 = 0; g0 < EPW; g0 += GD) {
+        // (all source reads of the lane's row pairs first, then all writes, then all staging reads + row ranges, then
+        // the stores: the compiler cannot reorder LDS reads over LDS writes it cannot tell apart, and every dependent
+        // round trip costs ~100 cycles of an otherwise idle wave)
+        uint32_t src[BT][NS];
 #pragma unroll
-          for (int c2 = 0; c2 < W / 2; ++c2) drow[2 + c2] = R < H ? srow[c2] : (uint16_t)0x0101;
+        for (int i = 0; i < BT; ++i) {
+          const int t = lane + 64 * i;
+          const int tt = t < GD * NPAIR ? t : GD * NPAIR - 1;
+          const int el = tt / NPAIR, k = tt - el * NPAIR;
+          const uint32_t* sp = reinterpret_cast<const uint32_t*>(lds + (g0 + el) * S + (k < H / 2 ? k : 0) * 2 * W);
+#pragma unroll
+          for (int j = 0; j < NS; ++j) src[i][j] = sp[j];
+        }
+#pragma unroll
+        for (int i = 0; i < BT; ++i) {
+          const int t = lane + 64 * i;
+          const int el = t / NPAIR, k = t - el * NPAIR;
+          if (t < GD * NPAIR) {
+            uint32_t out[ND];
+            dict_pair<W>(src[i], out);
+            uint32_t* dp = reinterpret_cast<uint32_t*>(grp + el * PC + k * 2 * WP);
+#pragma unroll
+            for (int j = 0; j < ND; ++j) dp[j] = k < H / 2 ? out[j] : 0x01010101u;  // (rows below the playfield: bedrock)
+          }
         }
         wave_sync();
-        for (int c = lane; c < 8 * PC / 16; c += 64) {
-          const uint32_t e = (uint32_t)g0 + (uint32_t)c / (PC / 16);
-          if (e < nlive) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(grp + 16 * c);
-            st_stream(reinterpret_cast<u32x4*>(dst0 + ((size_t)base_env + g0) * PC + 16 * (size_t)c), v);
-            if (dst1) st_stream(reinterpret_cast<u32x4*>(dst1 + ((size_t)base_env + g0) * PC + 16 * (size_t)c), v);
+        u32x4 v[CT];
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+          const int c = lane + 64 * i;
+          v[i] = reinterpret_cast<const u32x4*>(grp)[c < NCHG ? c : NCHG - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+          const int c = lane + 64 * i;
+          if (c < NCHG && (uint32_t)g0 + (uint32_t)c / (PC / 16) < nlive) {
+            st_stream(reinterpret_cast<u32x4*>(dst0 + ((size_t)base_env + g0) * PC + 16 * (size_t)c), v[i]);
+            if (dst1) st_stream(reinterpret_cast<u32x4*>(dst1 + ((size_t)base_env + g0) * PC + 16 * (size_t)c), v[i]);
           }
         }
         wave_sync();
@@ -655,8 +760,14 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   // =======================================================================================================
   __builtin_amdgcn_s_setprio(3);  // the decision logic is the critical path of the workgroup: it wins VALU arbitration
   T* colsL = reinterpret_cast<T*>(lds + BG::OFF_COLS) + slot * CST;
-  uint64_t tab_cells = 0, tab_cols = 0;
+  uint64_t tab_cells = 0, tab_cols = 0, tab_rows = 0;
   if (lane < 7) { tab_cells = c_cells.cells[lane]; tab_cols = c_colmasks.cols[lane]; }
+  if (DICTK && lane < 7)
+    tab_rows = (uint64_t)c_shapes.mask[lane][0] | ((uint64_t)c_shapes.mask[lane][1] << 16) |
+               ((uint64_t)c_shapes.mask[lane][2] << 32) | ((uint64_t)c_shapes.mask[lane][3] << 48);
+  if (dict)  // the mask staging buffer starts all zero (the groups un-stamp what they stamp)
+    for (int i = lane * 16; i < BG::GD * BG::PC; i += 1024)
+      *reinterpret_cast<uint4*>(lds + BG::OFF_DICT + BG::GD * BG::PC + i) = make_uint4(0u, 0u, 0u, 0u);
   const uint4* rec4 = reinterpret_cast<const uint4*>(p.rec) + (size_t)env * 2;
   const uint4 ra = rec4[0], rb = rec4[1];
   // the actions of all transitions of this launch, requested up front (int8 rows: one byte per transition and env)
@@ -701,6 +812,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   // private copies of the two piece tables for this wave (the stream wave fills cell_tab for itself after its loads)
   uint64_t* cell_tab_l = col_tab + 8;
   if (lane < 7) { cell_tab_l[lane] = tab_cells; col_tab[lane] = tab_cols; }
+  if (DICTK && lane < 7) col_tab[16 + lane] = tab_rows;
   colsL[0] = ONES;
   colsL[W + 1] = ONES;
 #pragma unroll
@@ -1218,51 +1330,56 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     const size_t Bt = p.act_stride;  // the handle's batch
     uint8_t* dsts[2] = {obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs,
                         (step == nsteps - 1 && obs_traj) ? p.obs : nullptr};
-    uint8_t* grpm = lds + BG::OFF_DICT + 8 * BG::PC;
-    for (int g0 = 0; g0 < EPW; g0 += 8) {
-      for (int i = lane * 16; i < 8 * BG::PC; i += 1024) *reinterpret_cast<uint4*>(grpm + i) = make_uint4(0u, 0u, 0u, 0u);
-      wave_sync();
-      for (int t = lane; t < 128; t += 64) {
-        const int el = t >> 4, k = (t >> 2) & 3, c = t & 3;
-        const uint4 po = post[(step & 1) * EPW + g0 + el];
-        const int x = (int)(po.w & 0xFFu), y = (int)((po.w >> 8) & 0xFFu), pc = (int)((po.w >> 16) & 0xFFu);
-        const int n = pc == 0 ? 4 : (pc == 1 ? 2 : 3);
-        if ((uint32_t)(g0 + el) < nlive && k < n && c < n && y + k < HP && x + c < WP) grpm[el * BG::PC + (y + k) * WP + x + c] = 1;
-      }
-      wave_sync();
-      for (int c = lane; c < 8 * BG::PC / 16; c += 64) {
-        const uint32_t e = (uint32_t)g0 + (uint32_t)c / (BG::PC / 16);
-        if (e < nlive) {
-          const u32x4 v = *reinterpret_cast<const u32x4*>(grpm + 16 * c);
-#pragma unroll
-          for (int d = 0; d < 2; ++d)
-            if (dsts[d]) st_stream(reinterpret_cast<u32x4*>(dsts[d] + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC + 16 * (size_t)c), v);
-        }
-      }
-      wave_sync();
-    }
-    if (live) {
+    constexpr int GD = BG::GD;
+    uint8_t* grpm = lds + BG::OFF_DICT + GD * BG::PC;  // all zero between groups (zeroed at launch start, un-stamped by every group)
+    for (int g0 = 0; g0 < EPW; g0 += GD)
+      dict_mask_group<W, H, GD>(grpm, post + (step & 1) * EPW + g0, nlive > (uint32_t)g0 ? nlive - (uint32_t)g0 : 0u, lane,
+                                dsts[0] + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC,
+                                dsts[1] ? dsts[1] + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC : nullptr);
+    // holder and queue strips change only with a hold, a spawn or a reset: TG_BUF_OBS keeps the strips of the previous
+    // transition (tg_reset / tg_observe / tg_set_state re-pack it completely), so only those envs store them; a
+    // trajectory slot is fresh memory and gets every env's strips
+    const bool hq = live && (obs_traj != nullptr || npop > 0 || swap_eff || do_reset);
+    if (__any(hq)) {
       auto spread = [](const uint32_t nib, const uint32_t val) -> uint32_t {  // 4 cells of a matrix row → 4 bytes
         return ((nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21)) * val;
       };
+      const uint64_t* row_tab = col_tab + 16;  // per piece: 4 rotations x 16-bit row-major masks
+      uint32_t hm = 0, qm[7];
+      if (s.hp != TG_NONE) hm = (uint32_t)(row_tab[s.hp] >> (16 * s.hr)) & 0xFFFFu;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const int t = (int)((s.queue >> (8 * q)) & 0xFF);
+        qm[q] = q < Q ? (uint32_t)row_tab[t < 7 ? t : 0] & 0xFFFFu : 0u;
+      }
       u32x4 hv4 = u32x4{0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
-      if (s.hp != TG_NONE) {
-        const uint32_t hm = (uint32_t)c_shapes.mask[s.hp][s.hr];
+      if (s.hp != TG_NONE)
         hv4 = u32x4{spread(hm & 0xFu, (uint32_t)s.hv), spread((hm >> 4) & 0xFu, (uint32_t)s.hv),
                     spread((hm >> 8) & 0xFu, (uint32_t)s.hv), spread((hm >> 12) & 0xFu, (uint32_t)s.hv)};
-      }
+      if (hq) {
 #pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        if (!dsts[d]) continue;
-        uint8_t* o_holder = dsts[d] + 2 * Bt * BG::PC + (size_t)env * 16;
-        uint8_t* o_queue = dsts[d] + 2 * Bt * BG::PC + Bt * 16 + (size_t)env * 16 * Q;
-        *reinterpret_cast<u32x4*>(o_holder) = hv4;
-        for (int q = 0; q < Q; ++q) {
-          const int t = (int)((s.queue >> (8 * q)) & 0xFF);
-          const uint32_t m = (uint32_t)c_shapes.mask[t < 7 ? t : 0][0];
+        for (int d = 0; d < 2; ++d) {
+          if (!dsts[d]) continue;
+          uint8_t* o_holder = dsts[d] + 2 * Bt * BG::PC + (size_t)env * 16;
+          uint8_t* o_queue = dsts[d] + 2 * Bt * BG::PC + Bt * 16 + (size_t)env * 16 * Q;
+          st_stream(reinterpret_cast<u32x4*>(o_holder), hv4);
+          if (Q == 4) {  // one 16-byte store per strip row
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr)
-            *reinterpret_cast<uint32_t*>(o_queue + rr * 4 * Q + 4 * q) = spread((m >> (4 * rr)) & 0xFu, (uint32_t)(t + 2));
+            for (int rr = 0; rr < 4; ++rr) {
+              const uint32_t t0 = (uint32_t)(s.queue & 0xFF), t1 = (uint32_t)((s.queue >> 8) & 0xFF),
+                             t2 = (uint32_t)((s.queue >> 16) & 0xFF), t3 = (uint32_t)((s.queue >> 24) & 0xFF);
+              st_stream(reinterpret_cast<u32x4*>(o_queue + rr * 16),
+                        u32x4{spread((qm[0] >> (4 * rr)) & 0xFu, t0 + 2u), spread((qm[1] >> (4 * rr)) & 0xFu, t1 + 2u),
+                              spread((qm[2] >> (4 * rr)) & 0xFu, t2 + 2u), spread((qm[3] >> (4 * rr)) & 0xFu, t3 + 2u)});
+            }
+          } else {
+            for (int q = 0; q < Q; ++q) {
+              const uint32_t t = (uint32_t)((s.queue >> (8 * q)) & 0xFF);
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr)
+                *reinterpret_cast<uint32_t*>(o_queue + rr * 4 * Q + 4 * q) = spread((qm[q] >> (4 * rr)) & 0xFu, t + 2u);
+            }
+          }
         }
       }
     }
