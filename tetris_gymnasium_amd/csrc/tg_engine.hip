@@ -38,6 +38,7 @@ struct Launchers {
   void (*prepare)(const tg::PrepareParams&, hipStream_t);
   void (*placements)(const tg::PlacementParams&, hipStream_t);
   size_t cols_bytes;  // per env: column masks of the bits kernel
+  bool dict_ok, rgb_ok;  // the bits kernel packs TG_OBS_DICT / TG_OBS_RGB itself for this board size
 };
 
 inline int grid_for(int batch) { return (batch + tg::kWavesPerBlock - 1) / tg::kWavesPerBlock; }
@@ -58,11 +59,13 @@ int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = lane kernels' pipelined p
 template <int W, int H, int RS>
 int bits_feat(const tg::KParams& p) {
   using BG = tg::BitsGeo<W, H>;
-  constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal;
+  constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
   const bool dict = p.obs_mode == TG_OBS_DICT && p.dict_in_kernel && BG::DICT_OK;
+  const bool rgb = p.obs_mode == TG_OBS_RGB && p.dict_in_kernel && BG::RGB_OK;
   const bool traj = p.obs_traj || p.out_traj || p.act_traj;
   if (p.final_obs) return (p.nsteps > 1 || traj) ? (M | T | F) : F;  // (TG_OBS_BOARD / TG_OBS_FN handles only)
   if (RS == TG_RULESET_NUMPY) {
+    if (rgb) return (p.nsteps > 1 || traj || p.sample_mode) ? (M | T | S | R) : R;
     if (p.sample_mode) return M | T | S;
     if (dict) return (p.nsteps > 1 || traj) ? (M | T | D) : D;
   }
@@ -83,13 +86,15 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     const int nrb = RS == TG_RULESET_NUMPY ? (p.batch + 127) / 128 : 0;  // leading RNG workgroups (tg_kernel_bits.h)
     const tg::BitsParams bp{p.cols, p.ahead, p.ring, p.hbuf, p.ring_cur, nrb, p.ring_stride, p.ring_fill};
     const dim3 grid(nrb + (p.batch + BG::EPW - 1) / BG::EPW);
-    constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal;
+    constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
     const int feat = bits_feat<W, H, RS>(p);
-    const size_t lds = (feat & D) ? BG::BYTES_DICT : ((feat & F) ? BG::BYTES_FIN : BG::BYTES);
+    const size_t lds = (feat & D) ? BG::BYTES_DICT : ((feat & R) ? BG::BYTES_RGB : ((feat & F) ? BG::BYTES_FIN : BG::BYTES));
 #define TG_LAUNCH_BITS(FT) hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(128), lds, s, p, bp)
     if (feat == F) { TG_LAUNCH_BITS(F); return; }
     if (feat == (M | T | F)) { TG_LAUNCH_BITS(M | T | F); return; }
     if constexpr (RS == TG_RULESET_NUMPY) {
+      if (feat == R) { TG_LAUNCH_BITS(R); return; }
+      if (feat == (M | T | S | R)) { TG_LAUNCH_BITS(M | T | S | R); return; }
       if (feat == (M | T | S)) { TG_LAUNCH_BITS(M | T | S); return; }
       if (feat == (M | T | D)) { TG_LAUNCH_BITS(M | T | D); return; }
       if (feat == D) { TG_LAUNCH_BITS(D); return; }
@@ -159,10 +164,10 @@ bool find_launchers(int W, int H, int ruleset, Launchers* out) {
   if (W == w && H == h) {                                                                           \
     if (ruleset == TG_RULESET_NUMPY)                                                                \
       *out = {launch_features<w, h>, launch_step<w, h, TG_RULESET_NUMPY>, step_name<w, h, TG_RULESET_NUMPY>, launch_reset<w, h, TG_RULESET_NUMPY>, launch_observe<w, h>, \
-              launch_prepare<w, h>, launch_placements<w, h>, tg::bits_cols_bytes<w, h>()};          \
+              launch_prepare<w, h>, launch_placements<w, h>, tg::bits_cols_bytes<w, h>(), tg::BitsGeo<w, h>::DICT_OK, tg::BitsGeo<w, h>::RGB_OK};          \
     else                                                                                            \
       *out = {launch_features<w, h>, launch_step<w, h, TG_RULESET_FUNCTIONAL>, step_name<w, h, TG_RULESET_FUNCTIONAL>, launch_reset<w, h, TG_RULESET_FUNCTIONAL>,  \
-              launch_observe<w, h>, launch_prepare<w, h>, launch_placements<w, h>, tg::bits_cols_bytes<w, h>()}; \
+              launch_observe<w, h>, launch_prepare<w, h>, launch_placements<w, h>, tg::bits_cols_bytes<w, h>(), tg::BitsGeo<w, h>::DICT_OK, tg::BitsGeo<w, h>::RGB_OK}; \
     return true;                                                                                    \
   }
   TG_FOR_EACH_SIZE(X)
@@ -625,8 +630,9 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     CRCHK(hipStreamSynchronize(h->stream));
   }
   {
-    h->dict_in_kernel = h->d_cols && cfg->obs_mode == TG_OBS_DICT && ((cfg->width + 8) * (cfg->height + 4)) % 16 == 0 &&
-                        !(getenv("TG_DICT_KERNEL") && atoi(getenv("TG_DICT_KERNEL")) == 0);
+    h->dict_in_kernel = h->d_cols && !(getenv("TG_DICT_KERNEL") && atoi(getenv("TG_DICT_KERNEL")) == 0) &&
+                        ((cfg->obs_mode == TG_OBS_DICT && L.dict_ok) ||
+                         (cfg->obs_mode == TG_OBS_RGB && L.rgb_ok && cfg->queue_size == 4));  // (the in-kernel RGB image is laid out for four queue pieces)
     if (const char* e = getenv("TG_RING_FILL")) { const int v = atoi(e); h->ring_fill = v < 0 ? 0 : (v > tg::kRing - 1 ? tg::kRing - 1 : v); }
     if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > 8 ? 8 : v); }
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
@@ -758,7 +764,7 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind) {
   }
   h->ring_cur ^= 1;
   HIPCHK(h, hipGetLastError());
-  if ((h->cfg.obs_mode == TG_OBS_DICT && !h->dict_in_kernel) || h->cfg.obs_mode == TG_OBS_RGB) return launch_observe_dict(h);
+  if ((h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) && !h->dict_in_kernel) return launch_observe_dict(h);
   return TG_OK;
 }
 
@@ -796,7 +802,7 @@ static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, u
   // max 8) consecutive transitions of a rollout — one launch floor and one slab round trip per group instead of per
   // transition.  tg_step always launches one transition.
   const int fuse_max = h->fuse_max;
-  const bool post_kernel = (h->cfg.obs_mode == TG_OBS_DICT && !h->dict_in_kernel) || h->cfg.obs_mode == TG_OBS_RGB;
+  const bool post_kernel = (h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) && !h->dict_in_kernel;
   const size_t obs_stride = (size_t)h->B * obs_bytes_per_env(&h->cfg);
   if (obs_traj_dev && h->cfg.obs_mode == TG_OBS_NONE) return fail(h, TG_EINVAL, "tg_rollout: the handle has no observation (TG_OBS_NONE)");
   // trajectories are written by the step kernel itself when it packs the observation (bits kernel, BOARD / FN);

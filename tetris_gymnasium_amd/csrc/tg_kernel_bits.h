@@ -77,8 +77,8 @@ struct BitsGeo {
   static constexpr int SLABS = ((EPW * S + 15) / 16) * 16;
   static constexpr int NCH = SLABS / 16;
   static constexpr int NIT = (NCH + 63) / 64;
-  static constexpr int OFF_TAB = SLABS;             // cell table, column table, cell table (logic wave's copy), row-mask table: 4 x 64 B
-  static constexpr int OFF_POST = OFF_TAB + 256;    // uint4 [2][EPW]: what the stream wave has to do per env (double-buffered by transition parity)
+  static constexpr int OFF_TAB = SLABS;             // cell table, column table, cell table (logic wave's copy), row-mask table, colour table: 5 x 64 B
+  static constexpr int OFF_POST = OFF_TAB + 320;    // uint4 [2][EPW]: what the stream wave has to do per env (double-buffered by transition parity)
   static constexpr int OFF_COLS = OFF_POST + 2 * EPW * 16;  // T [EPW][CST]: [0] bedrock, [1..W] playfield columns, [W+1] bedrock
   static constexpr int CST = (W + 2) | 1;           // odd stride: conflict-free for same-index accesses of the 64 lanes
   static constexpr int BYTES = ((OFF_COLS + EPW * CST * (int)sizeof(T) + 15) / 16) * 16;
@@ -89,6 +89,15 @@ struct BitsGeo {
   static constexpr int OFF_DICT = BYTES;
   static constexpr int BYTES_DICT = BYTES + 2 * GD * PC;
   static constexpr bool DICT_OK = PC % 16 == 0 && EPW % GD == 0 && H % 2 == 0;
+  // TG_OBS_RGB packed in the kernel (queue_size 4): uint4 post2[EPW] {queue bytes | holder} published by the logic wave,
+  // then one id-image staging buffer of GR envs per wave.  Image row = padded board row | 4 queue pieces x 4 columns.
+  static constexpr int RS = W + 8 + 16;
+  static constexpr int NPX = (H + 4) * RS;
+  static constexpr int IDB = ((NPX + 15) / 16) * 16;
+  static constexpr int GR = 4;
+  static constexpr int OFF_RGB = BYTES;
+  static constexpr int BYTES_RGB = BYTES + EPW * 16 + 2 * GR * IDB;
+  static constexpr bool RGB_OK = NPX % 4 == 0 && H % 2 == 0 && (EPW / 2) % GR == 0;
   // TG_FLAG_FINAL_OBS (observation BOARD / FN only, never together with the dict staging): uint2 [2][EPW] behind BYTES —
   // the terminal piece of every env that ends its episode in this transition
   static constexpr int OFF_FIN = BYTES;
@@ -210,6 +219,16 @@ __device__ __forceinline__ void st_stream(V* dst, const V v) {
 #endif
 }
 
+// the two padded arrays of the dict observation (62 MB per transition at 65 536 envs)
+template <typename V>
+__device__ __forceinline__ void st_dict(V* dst, const V v) {
+#ifdef TG_DICT_PLAIN  // (measured: nontemporal 17.9 us, plain 19.2 us per transition; the 160 MB RGB stream is the other way round)
+  *dst = v;
+#else
+  __builtin_nontemporal_store(v, dst);
+#endif
+}
+
 // state that the NEXT launch reads again (board, records, rings).  TG_STATE_ST: 0 = plain stores (dirty in the XCD's L2
 // until the end-of-kernel write-back), 1 = nontemporal (default: measured -0.45 us per launch with the chunk-major
 // write-back, profiles/r02 — the dirty lines leave while the kernel still runs, the boundary to the next launch gets
@@ -247,8 +266,9 @@ __device__ __forceinline__ void st_state(V* dst, const V v) {
 //   kFeatDict   TG_OBS_DICT packed by the two waves
 //   kFeatSample actions drawn on the device (grouped action set)
 //   kFeatFinal  TG_FLAG_FINAL_OBS: the terminal observation of a same-step-autoreset env goes to TG_BUF_FINAL_OBS
+//   kFeatRgb    TG_OBS_RGB (RgbObservation, wrappers/observation.py:38-74) packed by the two waves
 // Profiles list the kinds of launches separately.
-constexpr int kFeatMulti = 1, kFeatTraj = 2, kFeatDict = 4, kFeatSample = 8, kFeatFinal = 16;
+constexpr int kFeatMulti = 1, kFeatTraj = 2, kFeatDict = 4, kFeatSample = 8, kFeatFinal = 16, kFeatRgb = 32;
 
 // bytes: 0xFF (active) stays -1, other non-zero → 1  (the functional observation, envs/tetris_fn.py:137-158)
 __device__ __forceinline__ uint32_t bits_bin1(const uint32_t x) {
@@ -274,6 +294,134 @@ __device__ __forceinline__ void dict_pair(const uint32_t (&src)[2 * W / 4], uint
       else v |= 0x01u << (8 * b);
     }
     out[j] = v;
+  }
+}
+
+// 4 cells of a matrix row (bits) → 4 bytes of value `val`
+__device__ __forceinline__ uint32_t bits_spread(const uint32_t nib, const uint32_t val) {
+  return ((nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21)) * val;
+}
+
+// Two rows of the RgbObservation id image (wrappers/observation.py:38-74): padded board row | strip row (16 bytes: the
+// queue pieces on the top four rows, the holder on the bottom four, ones in between), from two playfield rows and the
+// two strip rows.  Byte-wise at compile time; the compiler folds it into dword moves, masks and byte permutes.
+template <int W>
+__device__ __forceinline__ void rgb_pair(const uint32_t (&src)[2 * W / 4], const uint32_t (&st0)[4], const uint32_t (&st1)[4],
+                                         uint32_t (&out)[2 * (W + 24) / 4]) {
+  constexpr int WP = W + 8, RS = WP + 16;
+#pragma unroll
+  for (int j = 0; j < 2 * RS / 4; ++j) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int pos = 4 * j + b;
+      const int row = pos >= RS ? 1 : 0, q = pos - row * RS;
+      uint32_t byte;
+      if (q < 4 || (q >= 4 + W && q < WP)) {
+        byte = 1u;
+      } else if (q < 4 + W) {
+        const int sb = q - 4 + row * W;
+        byte = (src[sb / 4] >> (8 * (sb % 4))) & 0xFFu;
+      } else {
+        const int k = q - WP;
+        byte = ((row ? st1[k / 4] : st0[k / 4]) >> (8 * (k % 4))) & 0xFFu;
+      }
+      v |= byte << (8 * b);
+    }
+    out[j] = v;
+  }
+}
+
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 __attribute__((aligned(4))) u32x3_a4;
+
+// RgbObservation of the envs [e_begin, e_end) of the workgroup (slots), GR at a time: id image built in `ids` (this wave's
+// staging buffer) from the slabs (locked cells applied, active piece drawn) and the published queue / holder, then every
+// four pixels become three dwords through the colour table and leave as 12-byte stores (a wave writes 768 contiguous
+// bytes per instruction).  post2[slot] = {queue bytes 0-3, queue bytes 4-6 | holder piece << 24, holder rot | val << 8, -}.
+template <int W, int H, int GR>
+__device__ __forceinline__ void rgb_pack(const uint8_t* slabs, const uint4* post2, const uint64_t* row_tab, const uint32_t* lut,
+                                         uint8_t* ids, const int e_begin, const int e_end, const uint32_t nlive,
+                                         const int lane, uint8_t* dst0, uint8_t* dst1) {
+  constexpr int S = W * H, WP = W + 8, HP = H + 4, RS = WP + 16, NPX = HP * RS, IDB = ((NPX + 15) / 16) * 16;
+  constexpr int NPAIR = HP / 2, NS = 2 * W / 4, ND = 2 * RS / 4;
+  constexpr int BT = (GR * NPAIR + 63) / 64, NQ = GR * NPX / 4, QT = (NQ + 63) / 64;
+  for (int e0 = e_begin; e0 < e_end; e0 += GR) {
+#pragma unroll
+    for (int i = 0; i < BT; ++i) {
+      const int t = lane + 64 * i;
+      const int tt = t < GR * NPAIR ? t : GR * NPAIR - 1;
+      const int el = tt / NPAIR, k = tt - el * NPAIR;
+      const uint32_t* sp = reinterpret_cast<const uint32_t*>(slabs + (e0 + el) * S + (k < H / 2 ? k : 0) * 2 * W);
+      uint32_t src[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) src[j] = sp[j];
+      const uint4 p2 = post2[e0 + el];
+      const uint64_t qb = (uint64_t)p2.x | ((uint64_t)(p2.y & 0x00FFFFFFu) << 32);
+      const uint32_t hp = p2.y >> 24, hr = p2.z & 0xFFu, hv = (p2.z >> 8) & 0xFFu;
+      uint32_t st[2][4];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) st[r][c] = 0x01010101u;
+      if (k < 2) {  // rows 0..3: the next four pieces at rotation 0, values id + 2
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t tq = (uint32_t)((qb >> (8 * q)) & 0xFF);
+          const uint32_t m = (uint32_t)row_tab[tq < 7 ? tq : 0] & 0xFFFFu;
+          st[0][q] = bits_spread((m >> (8 * k)) & 0xFu, tq + 2u);
+          st[1][q] = bits_spread((m >> (8 * k + 4)) & 0xFu, tq + 2u);
+        }
+      } else if (k >= NPAIR - 2 && hp != TG_NONE) {  // rows Hp-4..Hp-1: the held matrix (keeps its rotation and values)
+        const uint32_t m = (uint32_t)(row_tab[hp < 7 ? hp : 0] >> (16 * (hr & 3u))) & 0xFFFFu;
+        const int kk = k - (NPAIR - 2);
+        st[0][0] = bits_spread((m >> (8 * kk)) & 0xFu, hv);
+        st[1][0] = bits_spread((m >> (8 * kk + 4)) & 0xFu, hv);
+      }
+      if (k >= H / 2) {  // bedrock rows below the playfield
+#pragma unroll
+        for (int j = 0; j < NS; ++j) src[j] = 0x01010101u;
+      }
+      uint32_t out[ND];
+      rgb_pair<W>(src, st[0], st[1], out);
+      if (t < GR * NPAIR) {
+        uint32_t* dp = reinterpret_cast<uint32_t*>(ids + el * IDB + k * 2 * RS);
+#pragma unroll
+        for (int j = 0; j < ND; ++j) dp[j] = out[j];
+      }
+    }
+    wave_sync();
+    uint32_t idw[QT];
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+      const int q = lane + 64 * i;
+      const int ql = q < NQ ? q : NQ - 1;
+      const int el = ql / (NPX / 4), qq = ql - el * (NPX / 4);
+      idw[i] = reinterpret_cast<const uint32_t*>(ids + el * IDB)[qq];
+    }
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+      const int q = lane + 64 * i;
+      const int el = q / (NPX / 4), qq = q - el * (NPX / 4);
+      uint32_t c4[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t id = (idw[i] >> (8 * t)) & 0xFFu;
+        c4[t] = lut[id <= 8u ? id : 8u];
+      }
+      if (q < NQ && (uint32_t)(e0 + el) < nlive) {
+        const u32x3 px = u32x3{c4[0] | (c4[1] << 24), (c4[1] >> 8) | (c4[2] << 16), (c4[2] >> 16) | (c4[3] << 8)};
+        const size_t off = (size_t)(e0 + el) * (size_t)(NPX * 3) + 12u * (size_t)qq;
+#ifdef TG_RGB_NT  // (plain stores measured faster than nontemporal ones for this 160 MB write stream: tools/ubench/write_ceiling.hip)
+        __builtin_nontemporal_store(px, reinterpret_cast<u32x3_a4*>(dst0 + off));
+        if (dst1) __builtin_nontemporal_store(px, reinterpret_cast<u32x3_a4*>(dst1 + off));
+#else
+        *reinterpret_cast<u32x3_a4*>(dst0 + off) = px;
+        if (dst1) *reinterpret_cast<u32x3_a4*>(dst1 + off) = px;
+#endif
+      }
+    }
+    wave_sync();
   }
 }
 
@@ -312,8 +460,8 @@ __device__ __forceinline__ void dict_mask_group(uint8_t* buf, const uint4* post_
   for (int i = 0; i < CT; ++i) {
     const int c = lane + 64 * i;
     if (c < NCHG && (uint32_t)c / (PC / 16) < nlive_g) {
-      st_stream(reinterpret_cast<u32x4*>(dst0 + 16 * (size_t)c), v[i]);
-      if (dst1) st_stream(reinterpret_cast<u32x4*>(dst1 + 16 * (size_t)c), v[i]);
+      st_dict(reinterpret_cast<u32x4*>(dst0 + 16 * (size_t)c), v[i]);
+      if (dst1) st_dict(reinterpret_cast<u32x4*>(dst1 + 16 * (size_t)c), v[i]);
     }
   }
   wave_sync();
@@ -352,7 +500,7 @@ __device__ __forceinline__ void bits_copy_slab(const uint8_t* src_lds, uint8_t* 
 template <int W, int H, int RULESET, int FEAT>
 __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, const BitsParams bp) {
   constexpr bool MULTI = (FEAT & kFeatMulti) != 0, TRAJ = (FEAT & kFeatTraj) != 0, DICTK = (FEAT & kFeatDict) != 0,
-                 SAMPLE = (FEAT & kFeatSample) != 0, FINAL = (FEAT & kFeatFinal) != 0;
+                 SAMPLE = (FEAT & kFeatSample) != 0, FINAL = (FEAT & kFeatFinal) != 0, RGBK = (FEAT & kFeatRgb) != 0;
   using BG = BitsGeo<W, H>;
   using T = ColT<H>;
   constexpr int S = BG::S, EPW = BG::EPW, NCH = BG::NCH, NIT = BG::NIT, CST = BG::CST;
@@ -379,6 +527,10 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   const uint32_t env = base_env + (uint32_t)slot;
   const bool need_slab = p.obs_mode == TG_OBS_BOARD || p.obs_mode == TG_OBS_FN;
   const bool dict = DICTK && BG::DICT_OK && p.obs_mode == TG_OBS_DICT && p.dict_in_kernel;
+  const bool rgb = RGBK && BG::RGB_OK && p.obs_mode == TG_OBS_RGB && p.dict_in_kernel;
+  uint4* post2 = reinterpret_cast<uint4*>(lds + BG::OFF_RGB);                      // (RGB instantiations only)
+  const uint32_t* lut_l = reinterpret_cast<const uint32_t*>(lds + BG::OFF_TAB + 256);  // colour table (RGB)
+  constexpr int ELOG = EPW / 2;  // RGB: the logic wave packs the envs below, the stream wave those from ELOG on
   constexpr int WP = W + 8, HP = H + 4, PC = BG::PC;
   // p.nsteps consecutive transitions in this launch (tg_step_k): records / masks / slabs stay in registers and LDS in
   // between, only actions come in and observations go out per transition; one s_barrier per transition, and the
@@ -734,14 +886,31 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
         for (int i = 0; i < CT; ++i) {
           const int c = lane + 64 * i;
           if (c < NCHG && (uint32_t)g0 + (uint32_t)c / (PC / 16) < nlive) {
-            st_stream(reinterpret_cast<u32x4*>(dst0 + ((size_t)base_env + g0) * PC + 16 * (size_t)c), v[i]);
-            if (dst1) st_stream(reinterpret_cast<u32x4*>(dst1 + ((size_t)base_env + g0) * PC + 16 * (size_t)c), v[i]);
+            st_dict(reinterpret_cast<u32x4*>(dst0 + ((size_t)base_env + g0) * PC + 16 * (size_t)c), v[i]);
+            if (dst1) st_dict(reinterpret_cast<u32x4*>(dst1 + ((size_t)base_env + g0) * PC + 16 * (size_t)c), v[i]);
           }
         }
         wave_sync();
       }
     }
-    if ((need_slab || dict) && !last) {  // the slab in LDS is the board again: the drawn piece only ever covers free cells
+    if (rgb) {
+      // RgbObservation: draw the piece, let the logic wave know the slabs are final (second barrier), pack the upper half
+      bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu), (po.z >> 16) & 0xFFu, false,
+               live && ((po.z >> 24) & 1u));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      constexpr size_t IMG = (size_t)BG::NPX * 3;
+      uint8_t* dst0 = (obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs) + (size_t)base_env * IMG;
+      uint8_t* dst1 = (last && obs_traj) ? p.obs + (size_t)base_env * IMG : nullptr;
+      rgb_pack<W, H, BG::GR>(lds, post2, cell_tab + 24, lut_l, lds + BG::OFF_RGB + EPW * 16 + BG::GR * BG::IDB, ELOG, EPW, nlive, lane, dst0, dst1);
+      if (!last) {  // both waves are done with the slabs: un-draw below
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      }
+    }
+    if ((need_slab || dict || rgb) && !last) {  // the slab in LDS is the board again: the drawn piece only ever covers free cells
       wave_sync();
       bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu), 0u, false, live && ((po.z >> 24) & 1u));
       wave_sync();
@@ -762,7 +931,9 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   T* colsL = reinterpret_cast<T*>(lds + BG::OFF_COLS) + slot * CST;
   uint64_t tab_cells = 0, tab_cols = 0, tab_rows = 0;
   if (lane < 7) { tab_cells = c_cells.cells[lane]; tab_cols = c_colmasks.cols[lane]; }
-  if (DICTK && lane < 7)
+  uint32_t tab_lut = 0;
+  if (RGBK && lane < 9) tab_lut = c_rgb_lut[lane];
+  if ((DICTK || RGBK) && lane < 7)
     tab_rows = (uint64_t)c_shapes.mask[lane][0] | ((uint64_t)c_shapes.mask[lane][1] << 16) |
                ((uint64_t)c_shapes.mask[lane][2] << 32) | ((uint64_t)c_shapes.mask[lane][3] << 48);
   if (dict)  // the mask staging buffer starts all zero (the groups un-stamp what they stamp)
@@ -812,7 +983,8 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   // private copies of the two piece tables for this wave (the stream wave fills cell_tab for itself after its loads)
   uint64_t* cell_tab_l = col_tab + 8;
   if (lane < 7) { cell_tab_l[lane] = tab_cells; col_tab[lane] = tab_cols; }
-  if (DICTK && lane < 7) col_tab[16 + lane] = tab_rows;
+  if ((DICTK || RGBK) && lane < 7) col_tab[16 + lane] = tab_rows;
+  if (RGBK && lane < 9) reinterpret_cast<uint32_t*>(lds + BG::OFF_TAB + 256)[lane] = tab_lut;
   colsL[0] = ONES;
   colsL[W + 1] = ONES;
 #pragma unroll
@@ -1253,6 +1425,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     }
   }
   cols_dirty_any = cols_dirty_any || (live && (place || do_reset));
+  if (rgb) early_book = true;  // the image shows the queue and the holder as they are AFTER the transition: bookkeeping first
   // Two passes so that the bookkeeping exists once in the code: pass 0 publishes (after the bookkeeping when early_book),
   // pass 1 does the bookkeeping in the normal case — behind the barrier, while the stream wave already works.
 #pragma unroll 1
@@ -1298,6 +1471,9 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
       }
     }
     if (pass == 0) {
+      if (rgb && live)
+        post2[slot] = make_uint4((uint32_t)s.queue, (uint32_t)((s.queue >> 32) & 0x00FFFFFFu) | ((uint32_t)(s.hp & 0xFF) << 24),
+                                 (uint32_t)(s.hr & 0xFF) | ((uint32_t)(s.hv & 0xFF) << 8), 0u);
       // publish the payload work of this lane's env to the stream wave
       const bool show = live && (RULESET == TG_RULESET_NUMPY ? !final_coll : !(s.flags & TG_F_GAME_OVER));
       const uint32_t ocells = lane_cells(cell_tab_l, s.piece, s.rot);
@@ -1323,6 +1499,21 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   if (out_traj && live)
     st_stream(reinterpret_cast<u32x2*>(out_traj + (size_t)step * p.act_stride + env),
               u32x2{__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8)});
+  if (rgb) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();  // the stream wave has applied the locks / clears / resets and drawn the pieces
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    constexpr size_t IMG = (size_t)BG::NPX * 3;
+    const bool lastt = step == nsteps - 1;
+    uint8_t* dst0 = (obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs) + (size_t)base_env * IMG;
+    uint8_t* dst1 = (lastt && obs_traj) ? p.obs + (size_t)base_env * IMG : nullptr;
+    rgb_pack<W, H, BG::GR>(lds, post2, cell_tab + 24, lut_l, lds + BG::OFF_RGB + EPW * 16, 0, ELOG, nlive, lane, dst0, dst1);
+    if (!lastt) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
+  }
   if (dict) {
     // the other three arrays of the dict observation (envs/tetris.py:572-615), while the stream wave packs the board:
     // active_tetromino_mask = bounding box of the native matrix, holder = ones when empty else the held matrix,

@@ -34,7 +34,7 @@ from tetris_gymnasium_amd import _native as N
 from tetris_gymnasium_amd import Engine
 B, K = int(os.environ.get("AB_BATCH", "65536")), int(os.environ.get("AB_STEPS", "512"))
 fn = os.environ.get("AB_RULESET", "numpy") == "functional"
-obs = {"board": N.OBS_BOARD, "dict": N.OBS_DICT, "fn": N.OBS_FN}[os.environ.get("AB_OBS", "fn" if fn else "board")]
+obs = {"board": N.OBS_BOARD, "dict": N.OBS_DICT, "fn": N.OBS_FN, "rgb": N.OBS_RGB}[os.environ.get("AB_OBS", "fn" if fn else "board")]
 acts = np.random.default_rng(0).integers(0, 7 if fn else 8, (K, B)).astype(np.int8)
 for tag, _, _ in variants:  # older builds may lack entry points added later: bind only what all export
     lib = ctypes.CDLL(f"/tmp/libtg_{tag}.so")

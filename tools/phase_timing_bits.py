@@ -13,7 +13,7 @@ from tetris_gymnasium_amd import _native as N
 N.LIB_PATH = out
 from tetris_gymnasium_amd import Engine
 B = 65536
-e = Engine(B, obs_mode={'board': N.OBS_BOARD, 'dict': N.OBS_DICT}[os.environ.get('PT_OBS', 'board')], autoreset=N.AUTORESET_SAME_STEP)
+e = Engine(B, obs_mode={'board': N.OBS_BOARD, 'dict': N.OBS_DICT, 'rgb': N.OBS_RGB}[os.environ.get('PT_OBS', 'board')], autoreset=N.AUTORESET_SAME_STEP)
 e.reset(np.arange(1, B + 1, dtype=np.uint64))
 acts = np.random.default_rng(0).integers(0, 8, (80, B)).astype(np.int8)
 d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts)
