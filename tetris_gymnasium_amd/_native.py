@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libtetris_gym_hip.so")
+LIB_PATH = os.environ.get("TG_LIB") or os.path.join(_PKG, "libtetris_gym_hip.so")  # TG_LIB: the test-only legacy build
 
 RULESET_NUMPY, RULESET_FUNCTIONAL = 0, 1
 OBS_NONE, OBS_BOARD, OBS_DICT, OBS_FN, OBS_RGB = 0, 1, 2, 3, 4

@@ -14,11 +14,13 @@
 #include <vector>
 
 #include "tg_kernel_bits.h"
-#include "tg_kernel_block.h"
 #include "tg_kernel_features.h"
-#include "tg_kernel_lanes.h"
 #include "tg_kernel_placements.h"
-#include "tg_kernels.h"
+#ifdef TG_LEGACY_KERNELS  // test-only build (`make legacy`): the four earlier formulations of the step kernel, selected by TG_KERNEL
+#include "legacy/tg_kernel_block.h"
+#include "legacy/tg_kernel_lanes.h"
+#include "legacy/tg_kernel_wave.h"
+#endif
 
 // ---- board sizes compiled in (W, H).  Extend the list and rebuild to support another size. ----
 #ifndef TG_FOR_EACH_SIZE
@@ -46,8 +48,8 @@ inline int grid_for(int batch) { return (batch + tg::kWavesPerBlock - 1) / tg::k
 int g_step_blocks = 0;  // persistent grid size (blocks); set once per process from the device's CU count
 
 // step kernel selection (TG_KERNEL): 16 = "bits": column-bitmask logic, one env per lane (default, tg_kernel_bits.h);
-// 8 = "block": two-phase workgroup kernel (tg_kernel_block.h); 4 = "quad": 16 envs per wave, 4 lanes per env;
-// 1 = "lanes": 64 envs per wave, one per lane (both tg_kernel_lanes.h); 0 = "wave": one env per wavefront (tg_kernels.h)
+// (legacy build only) 8 = "block": two-phase workgroup kernel (legacy/tg_kernel_block.h); 4 = "quad": 16 envs per wave, 4 lanes per env;
+// 1 = "lanes": 64 envs per wave, one per lane (both legacy/tg_kernel_lanes.h); 0 = "wave": one env per wavefront (legacy/tg_kernel_wave.h)
 int g_kernel_lanes = 16;
 int g_block_waves = 4;  // TG_BLOCK_WAVES: waves per workgroup of the block kernel (4 → 64 envs, 8 → 128 envs)
 int g_stagger = 0;  // TG_STAGGER: odd waves of the lane kernels start this many x64 cycles late
@@ -76,7 +78,7 @@ int bits_feat(const tg::KParams& p) {
 template <int W, int H, int RS>
 void step_name(const tg::KParams& p, char* buf, size_t n) {
   if (p.cols) snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat<W, H, RS>(p));
-  else snprintf(buf, n, "tg::step_kernel%s<%d, %d, %d>", g_kernel_lanes == 8 ? "_block" : (g_kernel_lanes ? "_lanes" : ""), W, H, RS);
+  else snprintf(buf, n, "tg::step_kernel%s<%d, %d, %d>", g_kernel_lanes == 8 ? "_block" : (g_kernel_lanes ? "_lanes" : ""), W, H, RS);  // (legacy build)
 }
 
 template <int W, int H, int RS>
@@ -105,6 +107,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
 #undef TG_LAUNCH_BITS
     return;
   }
+#ifdef TG_LEGACY_KERNELS
   if (g_kernel_lanes == 8 && !p.final_obs) {  // "block": two-phase kernel with workgroup-level slow-path compaction
     if (g_block_waves == 8) {
       using BG = tg::BlockGeo<W, H, 8>;
@@ -136,6 +139,9 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
   int grid = grid_for(p.batch);
   if (g_step_blocks > 0 && grid > g_step_blocks) grid = g_step_blocks;
   hipLaunchKernelGGL((tg::step_kernel<W, H, RS>), dim3(grid), dim3(tg::kBlock), 0, s, p);
+#else
+  (void)s;  // (unreachable: tg_create refuses handles without the column-mask state in the product build)
+#endif
 }
 template <int W, int H, int RS>
 void launch_reset(const tg::ResetParams& p, hipStream_t s) {
@@ -568,6 +574,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     if (const char* e2 = getenv("TG_LDS_PAD")) g_lds_pad = (size_t)atoi(e2);
     if (const char* e4 = getenv("TG_STAGGER")) g_stagger = atoi(e4);
     if (const char* e3 = getenv("TG_GROUPS_PER_WAVE")) g_groups_per_wave = atoi(e3) > 0 ? atoi(e3) : 1;
+#ifdef TG_LEGACY_KERNELS
     if (const char* k = getenv("TG_KERNEL"))
       g_kernel_lanes = strcmp(k, "wave") == 0    ? 0
                        : strcmp(k, "lanes") == 0 ? 1
@@ -576,6 +583,14 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
                        : strcmp(k, "block") == 0 ? 8
                                                  : 16;
     if (const char* bw = getenv("TG_BLOCK_WAVES")) g_block_waves = atoi(bw) == 8 ? 8 : 4;
+#else
+    if (const char* k = getenv("TG_KERNEL"))
+      if (strcmp(k, "bits") != 0) {
+        h->err = std::string("tg_create: TG_KERNEL=") + k + " needs the test-only library with the earlier step kernels "
+                 "(make -C tetris_gymnasium_amd/csrc legacy; TG_LIB=<path>/libtetris_gym_hip_legacy.so)";
+        return bail(TG_EUNSUPPORTED);
+      }
+#endif
     g_step_blocks = per_cu > 0 ? prop.multiProcessorCount * per_cu : -1;
   }
   CRCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));

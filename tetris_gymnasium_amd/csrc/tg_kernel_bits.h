@@ -26,7 +26,7 @@
 #pragma once
 #include <type_traits>
 
-#include "tg_kernel_lanes.h"
+#include "tg_lane.h"
 
 namespace tg {
 
@@ -116,7 +116,7 @@ struct BitsRng {
 // Fisher-Yates positions of Generator.shuffle on a 7-array (numpy/random/_generator.pyx shuffle → random_interval,
 // masked rejection on 32-bit draws; components/tetromino_randomizer.py:42-46, 84) for the lanes in `need`, run on the
 // identity: the result P (7 nibbles) is the permutation with  shuffled[k] = original[P[k]]  for ANY original array.
-// Same vector loop as lane_shuffle7 (tg_kernel_lanes.h): one PCG64 step + two draw attempts per trip.
+// Same vector loop as lane_shuffle7 (legacy/tg_kernel_lanes.h): one PCG64 step + two draw attempts per trip.
 __device__ __forceinline__ void bits_shuffle_perm(BitsRng& g, uint32_t& sig, const bool need) {
   uint64_t s_lo = g.s_lo, s_hi = g.s_hi;
   uint32_t uinteger = g.uinteger, has32 = g.has32;

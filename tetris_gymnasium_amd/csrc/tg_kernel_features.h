@@ -14,7 +14,7 @@
 #pragma once
 #include <type_traits>
 
-#include "tg_kernel_lanes.h"
+#include "tg_lane.h"
 
 namespace tg {
 

@@ -6,10 +6,13 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 if [[ " $* " != *" notest "* ]]; then
   for K in ${TG_KERNELS:-bits block quad lanes wave}; do
+    # (the earlier formulations live in the test-only library: make -C tetris_gymnasium_amd/csrc legacy)
+    [[ $K == bits ]] && unset TG_LIB || export TG_LIB=$PWD/tetris_gymnasium_amd/libtetris_gym_hip_legacy.so
     TG_KERNEL=$K timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu_$K.log 2>&1; echo "pytest[$K] rc=$?"; tail -3 $OUT/pytest_gpu_$K.log
   done
 fi
 for K in ${TG_KERNELS:-bits block quad lanes wave}; do
+  [[ $K == bits ]] && unset TG_LIB || export TG_LIB=$PWD/tetris_gymnasium_amd/libtetris_gym_hip_legacy.so
   TG_KERNEL=$K timeout 600 python bench.py --steps 512 --warmup 64 --no-cpu-baseline > $OUT/bench_$K.json 2> $OUT/bench_$K.err; echo "bench[$K] rc=$?"; cut -c1-330 $OUT/bench_$K.json
 done
 if [[ " $* " != *" nopmc "* ]]; then
