@@ -17,8 +17,8 @@ devices (`--gpus 2` on a 1-GPU box) ranks share devices round-robin: that exerci
 scaling number.
 
 Rank 0 prints ONE JSON line.  At N = 1 the line also carries one block per further BASELINE config (`blocks`:
-config 2 = 4 096 envs, config 5 = 20x40 / queue 7 / grouped action set, the reference's dict observation, the fused
-rollout), each with its own `roofline` and `cpu_baseline`.
+config 2 = 4 096 envs, config 5 = 20x40 / queue 7 / grouped action set, the reference's dict observation, the RGB
+wrapper's image, the fused rollout), each with its own `roofline` and `cpu_baseline`.
 """
 from __future__ import annotations
 
@@ -154,6 +154,8 @@ def alg_bytes_per_step(W, H, obs, Q=4):
     state / action / outputs.  Dict surface: padded board + mask + holder + queue strips written instead of H*W."""
     if obs == "dict":
         return H * W + H * W + (2 * (H + 4) * (W + 8) + 16 + 16 * Q) + 76
+    if obs == "rgb":  # RgbObservation (wrappers/observation.py:38-74): (H+4) x (W+8+4Q) pixels x 3 bytes written
+        return H * W + H * W + 3 * (H + 4) * (W + 8 + 4 * max(Q, 1)) + 76
     return 3 * H * W + 76
 
 
@@ -179,7 +181,7 @@ def cpu_baseline(W, H, Q, B, *, grouped=False, obs="board", budget_s=6.0, action
     `value` is the all-cores rate."""
     from oracle import pyoracle as po
 
-    mode = {"board": po.OBS_BOARD, "dict": po.OBS_DICT}[obs]
+    mode = {"board": po.OBS_BOARD, "dict": po.OBS_DICT, "rgb": po.OBS_RGB}[obs]
     full_B = B
     if grouped:  # the wrapper's step re-derives the legal mask from all 4W placements (wrappers/grouped.py:124-207,
         B = min(B, 8192)  # as the reference does): ~40 us per env-step on one core — sample the first 8 192 envs
@@ -330,7 +332,7 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
         }
         if copy_gbps is not None:
             out["hbm_copy_gbps"] = copy_gbps
-        if want_cpu and D.world == 1 and ruleset == "numpy" and obs in ("board", "dict"):
+        if want_cpu and D.world == 1 and ruleset == "numpy" and obs in ("board", "dict", "rgb"):
             out["cpu_baseline"] = cpu_baseline(W, H, Q, B, grouped=grouped, obs=obs, budget_s=cpu_budget)
     e.dev_free(d_acts)
     e.close()
@@ -379,7 +381,7 @@ def rank_main(args) -> int:
         W, H, Q, grouped = 20, 40, 7, True
     reps = max(5, args.reps)
     want_cpu = not args.no_cpu_baseline
-    head = run_block(D, "config5" if args.config5 else ("dict" if args.obs == "dict" else "config3"), W=W, H=H, Q=Q, B=B,
+    head = run_block(D, "config5" if args.config5 else (args.obs if args.obs in ("dict", "rgb") else "config3"), W=W, H=H, Q=Q, B=B,
                      obs=args.obs, ruleset=args.ruleset, grouped=grouped, steps=args.steps, warmup=args.warmup,
                      reps=reps, fuse=args.fuse, local=local, want_cpu=want_cpu, copy_first=True)
     blocks = {}
@@ -391,6 +393,7 @@ def rank_main(args) -> int:
         blocks["config2"] = run_block(D, "config2", W=10, H=20, Q=4, B=4096, obs="board", grouped=False, **common)
         blocks["config5"] = run_block(D, "config5", W=20, H=40, Q=7, B=65536, obs="board", grouped=True, **common)
         blocks["dict"] = run_block(D, "dict", W=10, H=20, Q=4, B=65536, obs="dict", grouped=False, **common)
+        blocks["rgb"] = run_block(D, "rgb", W=10, H=20, Q=4, B=65536, obs="rgb", grouped=False, **common)
         blocks["fused_rollout"] = run_block(D, "fused8", W=10, H=20, Q=4, B=65536, obs="board", grouped=False, fuse=8,
                                             ruleset="numpy", steps=(ks + 7) // 8 * 8, warmup=64, reps=reps, local=local,
                                             want_cpu=False)

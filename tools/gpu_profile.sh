@@ -14,7 +14,7 @@ for b in $BLOCKS; do
   echo "== $b"; grep -h "step_kernel\|observe_kernel" $OUT/${b}_kt_summary.md | head -3 | cut -c1-140
 done
 for b in $BLOCKS; do
-  case $b in config3|dict|config5)
+  case $b in config3|dict|config5|rgb)
     rocprofv3 --pmc FETCH_SIZE -d $OUT/${b}_f -o f -- python3 bench.py $COMMON --steps 32 --warmup 8 ${ARGS[$b]} > $OUT/${b}_f.log 2>&1
     rocprofv3 --pmc WRITE_SIZE -d $OUT/${b}_w -o w -- python3 bench.py $COMMON --steps 32 --warmup 8 ${ARGS[$b]} > $OUT/${b}_w.log 2>&1
   ;; esac
@@ -43,13 +43,10 @@ for b in blocks:
     ent = {}
     db = f"{out}/{b}_kt/kt_results.db"
     if os.path.exists(db):
-        main_sub = "observe_kernel" if b == "rgb" else "step_kernel"
+        main_sub = "step_kernel"
         t = top(db, main_sub)
         if t:
             ent.update(kernel=t[0], kernel_us=t[2] / 1e3 if t[2] > 1e3 else t[2], calls=t[1], kernel_source=f"profiles/ROUND/{b}_kt_summary.md")
-        if b == "rgb":
-            t2 = top(db, "step_kernel")
-            if t2: ent["step_kernel_us"] = t2[2] / 1e3 if t2[2] > 1e3 else t2[2]
     fdb, wdb = f"{out}/{b}_f/f_results.db", f"{out}/{b}_w/w_results.db"
     if os.path.exists(fdb) and os.path.exists(wdb):
         tr = {}
