@@ -550,3 +550,21 @@ def test_final_observation_same_step_autoreset(mode, fuse, monkeypatch):
         np.testing.assert_array_equal(got[ever], expect[ever], err_msg=f"final obs it={it}")
     assert ever.sum() > B // 2
     e.close()
+
+
+def test_bench_self_launches_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` spawns its own two rank processes (torchrun environment contract, gloo rendezvous on
+    127.0.0.1); on a one-GPU box both ranks share the device.  One JSON line from rank 0: n_gpus 2, 2 x envs, one timing
+    per rank, no data-path collective."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "4",
+                        "--batch", "8192", "--no-cpu-baseline", "--no-blocks"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 2 * 8192 and len(d["per_rank_ms_per_step"]) == 2
+    assert d["config"]["parallelism"] == "env-sharded x2, no collective" and d["value"] > 0
+    assert d["roofline"]["kernel"].startswith("tg::step_kernel_bits<10, 20, 0, 0>")

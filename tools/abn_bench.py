@@ -61,4 +61,7 @@ for rep in range(7):
 for t, (e, d) in eng.items():
     b, r, g = e.get_state()
     crc = zlib.crc32(b.tobytes()) ^ zlib.crc32(np.ascontiguousarray(r["bag"]).tobytes()) ^ zlib.crc32(g["state_lo"].tobytes())
+    o = e.observation()
+    for part in (o.values() if isinstance(o, dict) else [o]):  # (the last observation is part of the checksum)
+        crc ^= zlib.crc32(np.ascontiguousarray(part).tobytes())
     print(f"{t:12s} median {statistics.median(res[t]):6.2f}  min {min(res[t]):6.2f} us/step   state crc {crc:08x}   " + " ".join(f"{x:.2f}" for x in res[t]))
