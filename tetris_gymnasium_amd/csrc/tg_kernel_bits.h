@@ -498,7 +498,7 @@ __device__ __forceinline__ void bits_copy_slab(const uint8_t* src_lds, uint8_t* 
 }
 
 template <int W, int H, int RULESET, int FEAT>
-__global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, const BitsParams bp) {
+__global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | kFeatSample))) ? 3 : 4) void step_kernel_bits(const KParams p, const BitsParams bp) {
   constexpr bool MULTI = (FEAT & kFeatMulti) != 0, TRAJ = (FEAT & kFeatTraj) != 0, DICTK = (FEAT & kFeatDict) != 0,
                  SAMPLE = (FEAT & kFeatSample) != 0, FINAL = (FEAT & kFeatFinal) != 0, RGBK = (FEAT & kFeatRgb) != 0;
   using BG = BitsGeo<W, H>;
@@ -690,7 +690,9 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     __builtin_amdgcn_s_barrier();  // the logic wave has published what happened to every env in this transition
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 #ifndef TG_NO_PRIO_SWAP
-    __builtin_amdgcn_s_setprio(3);  // from here on this wave is the workgroup's critical path
+    // from here on this wave is the workgroup's critical path (NUMPY; with the functional rule-set's in-line threefry the
+    // logic waves of other workgroups on this SIMD are the longer pole: measured 11.4 us with the swap, 10.65 without)
+    if (RULESET == TG_RULESET_NUMPY) __builtin_amdgcn_s_setprio(3);
 #endif
     TG_BITS_STAMP(2);
     // post record of this lane's env: x = lock {cells | val << 16 | place << 24 | clear << 25 | reset << 26},
@@ -941,6 +943,10 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
       *reinterpret_cast<uint4*>(lds + BG::OFF_DICT + BG::GD * BG::PC + i) = make_uint4(0u, 0u, 0u, 0u);
   const uint4* rec4 = reinterpret_cast<const uint4*>(p.rec) + (size_t)env * 2;
   const uint4 ra = rec4[0], rb = rec4[1];
+  // FUNCTIONAL: the jax key travels with the first loads (fetched lazily at the first lock it was a dependent memory
+  // round trip in the middle of the decision logic of practically every wave)
+  uint4 fkey = make_uint4(0u, 0u, 0u, 0u);
+  if (RULESET == TG_RULESET_FUNCTIONAL) fkey = reinterpret_cast<const uint4*>(p.rng + env)[2];
   // the actions of all transitions of this launch, requested up front (int8 rows: one byte per transition and env)
   uint64_t apack = 0;
   int action0 = 0;
@@ -1057,6 +1063,10 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   r.src = p.rng + env;
   r.loaded = false;
   r.dirty = false;
+  if (RULESET == TG_RULESET_FUNCTIONAL) {
+    r.uinteger = fkey.x; r.has32 = fkey.y; r.k0 = fkey.z; r.k1 = fkey.w;
+    r.loaded = true;
+  }
 
   bool cols_dirty_any = false;
   for (int step = 0; step < nsteps; ++step) {
@@ -1113,6 +1123,20 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   const bool pending = p.autoreset == TG_AUTORESET_NEXT_STEP && (s.flags & TG_F_PENDING_RESET);
   bool frozen = RULESET == TG_RULESET_FUNCTIONAL && (s.flags & TG_F_GAME_OVER);
   auto colmask = [&](int piece, int rot) -> uint32_t { return (uint32_t)(col_tab[piece] >> (16 * rot)) & 0xFFFFu; };
+  // Table words (all four rotations) of every piece this transition can involve — the active one, the held one, the next
+  // two of the stream — fetched in ONE LDS batch up front: a lookup at the point of use is a dependent LDS round trip
+  // (~130 cycles of a wave that has nothing else to issue), and there were four of them on the path to the publish.
+  const int up0_ = (int)(s.queue & 0xFF);
+  const int up1_ = Q >= 2 ? (int)((s.queue >> 8) & 0xFF) : (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
+  const int pcH = s.hp < 7 ? s.hp : 0, pc0 = up0_ < 7 ? up0_ : 0, pc1 = up1_ < 7 ? up1_ : 0;
+  const uint64_t tcolC = col_tab[s.piece], tcelC = cell_tab_l[s.piece];
+  uint64_t tcolH = 0, tcelH = 0, tcol0 = 0, tcel0 = 0, tcol1 = 0, tcel1 = 0;
+  if (RULESET == TG_RULESET_NUMPY) {
+    tcolH = col_tab[pcH]; tcelH = cell_tab_l[pcH];
+    tcol0 = col_tab[pc0]; tcel0 = cell_tab_l[pc0];
+    tcol1 = col_tab[pc1]; tcel1 = cell_tab_l[pc1];
+  }
+  auto rot16 = [](const uint64_t t, const int rot) -> uint32_t { return (uint32_t)(t >> (16 * rot)) & 0xFFFFu; };
   // grouped action set (wrappers/grouped.py:209-269): action = column * 4 + rotations → teleport + hard drop; illegal
   // iff a cell of the rotated piece lies outside the playfield columns (collision_with_frame, :104-122)
   int action = action_in;
@@ -1154,13 +1178,13 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   // bag draw, reshuffle from the permutation ring — are owed (`npop`) and applied after the publish, beside the stream
   // wave's tail instead of in front of it.
   int npop = 0;
-  const int up0 = (int)(s.queue & 0xFF);
-  const int up1 = Q >= 2 ? (int)((s.queue >> 8) & 0xFF) : (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
-  if (RULESET == TG_RULESET_NUMPY && __any(swap_eff)) {
+  const int up0 = up0_, up1 = up1_;
+  uint64_t tcolT = tcolC, tcelT = tcelC;  // tables of the tentative piece
+  if (RULESET == TG_RULESET_NUMPY) {  // (no wave-uniform branch: with 64 envs per wave some lane swaps in practically every transition)
     const bool empty = swap_eff && s.hp == TG_NONE;
     if (swap_eff) {
-      if (empty) { tp = up0; tr = 0; tv = up0 + 2; npop = 1; }  // spawn_tetromino; its collision result is ignored
-      else { tp = s.hp; tr = s.hr; tv = s.hv; }
+      if (empty) { tp = up0; tr = 0; tv = up0 + 2; npop = 1; tcolT = tcol0; tcelT = tcel0; }  // spawn_tetromino; its collision result is ignored
+      else { tp = s.hp; tr = s.hr; tv = s.hv; tcolT = tcolH; tcelT = tcelH; }
       s.hp = s.piece; s.hr = s.rot; s.hv = s.val;
       s.flags |= TG_F_HAS_SWAPPED;
       tx = np_spawn_x<W>(tp);
@@ -1186,7 +1210,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     for (int i = 0; i < 6; ++i) w[i] = ONES;
   }
   TG_BITS_STAMP(2);
-  const uint32_t mC = colmask(s.piece, s.rot), mT = colmask(tp, tr);
+  const uint32_t mC = rot16(tcolC, s.rot), mT = rot16(tcolT, tr);
   const int dxT = tx - wb;                 // 0..2 (1 after a swap)
   const uint32_t PT = mT << (4 * dxT);     // nibble i = the tentative piece's cells in window column i
   const uint32_t PC = mC << 4;
@@ -1225,7 +1249,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   int drop_reward = 0;
   uint32_t PF = PC;                 // window-spread column masks of the piece as it ends the move
   int fpiece = s.piece, frot = s.rot;  // ... and its identity (for the uint8 stamp)
-  if (RULESET == TG_RULESET_FUNCTIONAL && __any(hard)) {
+  if (RULESET == TG_RULESET_FUNCTIONAL) {
     // functional/core.py:230-251 hard_drop: step-wise, stops at the first blocked row below y
     const int yd = drop_row_of(PC, s.y);
     if (hard) {
@@ -1237,7 +1261,9 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   const bool moving = stepped && !(RULESET == TG_RULESET_FUNCTIONAL && hard);
   if (RULESET == TG_RULESET_NUMPY && !stepped) final_coll = cC;  // projection rule for an untouched env
   const bool accept = moving && (swap_eff || (check && !cT));
-  if (accept) { s.piece = tp; s.rot = tr; s.x = tx; s.y = ty; s.val = tv; PF = PT; fpiece = tp; frot = tr; }
+  uint64_t tcelF = tcelC;  // cell table word of the piece as it ends the move (of the spawned one after a lock)
+  uint64_t tcolN = tcolC;  // column table word of the piece a lock spawns
+  if (accept) { s.piece = tp; s.rot = tr; s.x = tx; s.y = ty; s.val = tv; PF = PT; fpiece = tp; frot = tr; tcelF = tcelT; }
   const bool coll_here = accept ? cT : cC;
   const bool coll_below = accept ? cT1 : cC1;
   if (RULESET == TG_RULESET_FUNCTIONAL && accept && (e & 4u)) drop_reward = 1;  // soft drop (tetris_fn.py:183-190)
@@ -1267,12 +1293,12 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
       const bool dead = lock && coll_here;  // already colliding: game over, nothing placed (:461-463)
       if (dead) { s.flags |= TG_F_GAME_OVER; reward = 0.0f; }
       place = lock && !coll_here;
-      if (__any(place && hard)) {
+      {  // (no wave-uniform branch: 1 action in 8 is a hard drop, some lane always takes it)
         const int yd = drop_row_of(PF, s.y);  // :445-448 (only hard drops can still move)
         if (place && hard) s.y = yd;
       }
     }
-    lock_cells = lane_cells(cell_tab_l, fpiece, frot);
+    lock_cells = rot16(tcelF, frot);
     lock_x = s.x; lock_y = s.y;
     lock_val = RULESET == TG_RULESET_NUMPY ? s.val : s.piece + 2;  // functional/core.py:103-121 adds piece id
 #pragma unroll
@@ -1315,6 +1341,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     if (RULESET == TG_RULESET_NUMPY) {
       const int np_ = npop ? up1 : up0;  // envs/tetris.py:393-401 (TetrominoQueue.get_next_tetromino: the pop is owed)
       if (place) {
+        tcolN = npop ? tcol1 : tcol0; tcelF = npop ? tcel1 : tcel0;
         s.piece = np_; s.rot = 0; s.val = np_ + 2; s.x = np_spawn_x<W>(np_); s.y = 0;
         npop += 1;
       }
@@ -1340,7 +1367,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
     bool sc;
     {
       constexpr int X0 = (W + 8) / 2 - 2;  // I (and every functional piece) spawns at X0, the others at X0 + 1
-      const uint32_t ms = colmask(s.piece, 0);
+      const uint32_t ms = RULESET == TG_RULESET_NUMPY ? rot16(tcolN, 0) : colmask(s.piece, 0);
       const bool at0 = s.x == X0;
       T hs = 0;
 #pragma unroll
@@ -1476,7 +1503,16 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
                                  (uint32_t)(s.hr & 0xFF) | ((uint32_t)(s.hv & 0xFF) << 8), 0u);
       // publish the payload work of this lane's env to the stream wave
       const bool show = live && (RULESET == TG_RULESET_NUMPY ? !final_coll : !(s.flags & TG_F_GAME_OVER));
-      const uint32_t ocells = lane_cells(cell_tab_l, s.piece, s.rot);
+      uint32_t ocells;
+      if (RULESET == TG_RULESET_NUMPY) {  // (the piece's table word is already here unless a reset has just drawn it)
+        ocells = rot16(tcelF, s.rot);
+        if (__any(do_reset)) {
+          const uint32_t oc2 = lane_cells(cell_tab_l, s.piece, s.rot);
+          if (do_reset) ocells = oc2;
+        }
+      } else {
+        ocells = lane_cells(cell_tab_l, s.piece, s.rot);
+      }
       if (live) post[(step & 1) * EPW + slot] = make_uint4(lock_cells | ((uint32_t)(lock_val & 0xFF) << 16) | ((place ? 1u : 0u) << 24) |
                                   ((do_clear ? 1u : 0u) << 25) | ((do_reset ? 1u : 0u) << 26),
                               (uint32_t)(lock_x & 0xFF) | ((uint32_t)(lock_y & 0xFF) << 8),
@@ -1577,7 +1613,7 @@ __global__ __launch_bounds__(128, 3) void step_kernel_bits(const KParams p, cons
   }
   }  // transitions
 #ifndef TG_NO_PRIO_SWAP
-  __builtin_amdgcn_s_setprio(0);
+  if (RULESET == TG_RULESET_NUMPY) __builtin_amdgcn_s_setprio(0);
 #endif
   // ---- D: per-env stores: first record half, episode statistics, column masks ----
   const bool cols_dirty = cols_dirty_any;

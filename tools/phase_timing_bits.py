@@ -13,9 +13,10 @@ from tetris_gymnasium_amd import _native as N
 N.LIB_PATH = out
 from tetris_gymnasium_amd import Engine
 B = 65536
-e = Engine(B, obs_mode={'board': N.OBS_BOARD, 'dict': N.OBS_DICT, 'rgb': N.OBS_RGB}[os.environ.get('PT_OBS', 'board')], autoreset=N.AUTORESET_SAME_STEP)
+FN = os.environ.get('PT_RULESET') == 'functional'
+e = Engine(B, ruleset=(N.RULESET_FUNCTIONAL if FN else N.RULESET_NUMPY), obs_mode=N.OBS_FN if FN else {'board': N.OBS_BOARD, 'dict': N.OBS_DICT, 'rgb': N.OBS_RGB}[os.environ.get('PT_OBS', 'board')], autoreset=N.AUTORESET_SAME_STEP)
 e.reset(np.arange(1, B + 1, dtype=np.uint64))
-acts = np.random.default_rng(0).integers(0, 8, (80, B)).astype(np.int8)
+acts = np.random.default_rng(0).integers(0, 7 if os.environ.get('PT_RULESET') == 'functional' else 8, (80, B)).astype(np.int8)
 d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts)
 KL = int(os.environ.get('TG_LAST_K', '1'))
 e.step_k_device(d, 80 - KL); e.sync(); e.step_k_device(d + (80 - KL) * B, KL); e.sync()
