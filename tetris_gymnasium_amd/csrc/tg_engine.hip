@@ -1081,6 +1081,11 @@ int tg_timer_stop(tg_handle* h, float* elapsed_ms) {
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  for (int i = 0; i < 4000; ++i) {  // short waits are polled (see tg_sync)
+    const hipError_t q = hipEventQuery(h->ev1);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) return fail(h, TG_EHIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+  }
   HIPCHK(h, hipEventSynchronize(h->ev1));
   HIPCHK(h, hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
   return TG_OK;
