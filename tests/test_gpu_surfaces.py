@@ -320,8 +320,10 @@ def test_rgb_observation_against_reference_frames(golden_dir, name):
             np.testing.assert_array_equal(e.observation()[m], fx["reset_frames"][t][m], err_msg=f"reset frame t={t}")
 
 
-@pytest.mark.parametrize("W,H,Q", [(10, 20, 4), (20, 40, 7), (6, 12, 1), (12, 24, 2)])
+@pytest.mark.parametrize("W,H,Q", [(10, 20, 4), (20, 40, 7), (6, 12, 1), (12, 24, 2),
+                                   (20, 40, 4), (6, 12, 4), (8, 16, 4), (12, 24, 4), (10, 24, 4)])
 def test_rgb_observation_engine_vs_oracle(W, H, Q):
+    """queue_size 4: the image is packed inside the step kernel (both waves); other queue sizes: by the observe kernel."""
     B, T = 300, 120
     e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_RGB, autoreset=N.AUTORESET_SAME_STEP)
     o = po.OracleBatch(B, W, H, queue_size=Q)
