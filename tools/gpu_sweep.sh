@@ -1,11 +1,6 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: bench sweep over TG_BLOCKS_PER_CU (persistent grid size)
-OUT=gpurun_out/${1:-sweep}; mkdir -p $OUT
-for b in ${2:-2 4 6 7 8}; do
-  TG_BLOCKS_PER_CU=$b timeout 300 python bench.py --steps 512 --warmup 64 --no-cpu-baseline > $OUT/bench_bpc$b.json 2>$OUT/err_$b.log
-  python - <<PY
-import json
-d=json.load(open("$OUT/bench_bpc$b.json"))
-print("blocks/CU=$b  value=%.3e  ms/step=%.4f  kernel_ms=%.4f frac=%.3f" % (d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"]))
-PY
+# Runs ON THE GPU BOX: batch sweep of the headline block on one GPU (kernel time by HIP events, median of 7 repetitions)
+for B in 64 4096 16384 32768 65536 131072 262144 524288; do
+  python bench.py --no-cpu-baseline --no-blocks --batch $B --steps 256 --warmup 32 | python3 -c "
+import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('B=%7d  kernel %.2f us  %.3e env steps/s  frac %.3f  resident %s' % ($B, r['kernel_ms']*1e3, $B/(r['kernel_ms']*1e-3), r['frac'], r['resident']))"
 done

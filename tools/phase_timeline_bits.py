@@ -51,3 +51,13 @@ for x in range(8):
     last = max(ends, key=ends.get)
     print(f"XCD {x}: span {max(ends.values()):6d} cycles; last wave to end: {last};  ends rng {ends['rng']} logic {ends['logic']} stream {ends['stream']}"
           f";  step WG start mean {(ss[:, 0] - t0).mean():.0f} max {(ss[:, 0] - t0).max()}")
+# which workgroups end last?  (stream wave end vs launch position)
+t00 = min(tl[:, 0].min(), ts[:, 0].min(), rb[:, :, 0].min())
+end = ts[:, 4] - t00
+start = ts[:, 0] - t00
+order = np.argsort(end)
+print("stream-wave end by workgroup index decile (mean start / mean end / max end, 10 ns ticks):")
+for d in range(10):
+    sl = slice(d * nb // 10, (d + 1) * nb // 10)
+    print(f"  WGs {sl.start:4d}-{sl.stop - 1:4d}: start {start[sl].mean():6.1f}  end {end[sl].mean():6.1f}  max {end[sl].max():5d}")
+print("the 16 last workgroups to end:", sorted(order[-16:].tolist()), " their XCDs:", sorted(((order[-16:] + nr) % 8).tolist()))
