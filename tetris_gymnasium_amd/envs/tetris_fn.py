@@ -6,8 +6,12 @@ carries a private token naming the engine generation that produced it; passing i
 usual rollout loop) skips the host→device upload.  Stock TETROMINOES and the stock 7-bag queue only —
 anything else is rejected explicitly.
 
-RNG note: piece sequences follow jax 0.5.3's threefry split/permutation as restated from its source
-(partitionable scheme); this is not pinned against a live jax (none installable here) — see DESIGN.md.
+PARITY UNPINNED (piece sequences): they follow jax 0.5.3's threefry split / permutation as restated from its source
+(partitionable scheme) and the `jnp.take(-H)` row-0 corner of clear_filled_rows as read from jax semantics; neither is
+pinned against a live jax (none installable in the build container).  `python -m oracle.refgen.make_golden_fn` pins
+them wherever `import jax` works (writes tests/golden/fn_streams.npz, replayed by tests/test_oracle_fn_golden.py and
+tests/test_gpu_fn_golden.py); until that file exists, engine == oracle is all that is verified.  Game logic, rewards and
+observations are pinned by the reference's own known answers (tests/test_oracle_functional.py).
 """
 from __future__ import annotations
 
