@@ -280,18 +280,18 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
     D.barrier()
     e.sync()
     t0 = time.perf_counter()
-    e.timer_start()
     run(warmup, steps)
-    ev_ms = e.timer_stop()  # HIP events on the engine's own stream; synchronises
     e.sync()
     t1 = time.perf_counter()
     D.barrier()
     (elapsed,) = D.max(t1 - t0)
     per_rank_ms = D.gather((t1 - t0) / steps * 1e3)
-    # repetitions of the same timed region, HIP events only: the median is what the roofline figure uses
-    rep_us = [ev_ms / steps * 1e3]
+    # repetitions of the same region timed with HIP events on the engine's own stream (kept out of the wall-clock region
+    # above: two event records and their host round trips are a measurable share of a 20-launch region): the median is
+    # what the roofline figure uses
+    rep_us = []
     k0 = warmup + steps
-    for _ in range(max(0, reps - 1)):
+    for _ in range(max(1, reps)):
         e.timer_start()
         run(k0, steps)
         rep_us.append(e.timer_stop() / steps * 1e3)
