@@ -518,8 +518,16 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
 
   const uint32_t B = (uint32_t)p.batch;
   // role split by blockIdx: the RNG workgroups lead (placing them last measured the same)
+#ifdef TG_RNG_FIRST
   const bool rng_role = (int)blockIdx.x < bp.nrb;
   const uint32_t step_block = blockIdx.x - (uint32_t)bp.nrb, rng_block = blockIdx.x;
+#else
+  // the step workgroups are dispatched first (a grid of this size starts first → last within 0.3-0.7 us, and the step
+  // workgroups are the longer pole since the RNG role produces one entry per launch)
+  const uint32_t n_step = gridDim.x - (uint32_t)bp.nrb;
+  const bool rng_role = blockIdx.x >= n_step;
+  const uint32_t step_block = blockIdx.x, rng_block = blockIdx.x - n_step;
+#endif
   const uint32_t base_env = step_block * (uint32_t)EPW;  // (meaningless in the RNG role)
   const uint32_t nlive = B - base_env < (uint32_t)EPW ? B - base_env : (uint32_t)EPW;
   const bool live = (uint32_t)lane < nlive;

@@ -32,8 +32,8 @@ assert e.lib.tg_debug_phase_times(e.h, buf.ctypes.data_as(C.c_void_p), B // 16) 
 tl = buf[:nb, 0:8].astype(np.int64)    # logic wave stamps 0..7
 ts = buf[:nb, 8:13].astype(np.int64)   # stream wave stamps 0..4
 rb = buf.reshape(-1)[nb * 16: nb * 16 + nr * 4].reshape(nr, 2, 2).astype(np.int64)  # [rng block][wave][start, end]
-step_blk = np.arange(nb) + nr   # blockIdx of step workgroup i
-rng_blk = np.arange(nr)
+step_blk = np.arange(nb)        # blockIdx of step workgroup i (the step workgroups lead the grid)
+rng_blk = np.arange(nr) + nb
 names_l = ["start", "loads done", "window read", "decided", "lock done", "published", "stores done", "end"]
 names_s = ["start", "slab in LDS", "barrier passed", "write-back done", "end"]
 for x in range(8):
@@ -60,4 +60,4 @@ print("stream-wave end by workgroup index decile (mean start / mean end / max en
 for d in range(10):
     sl = slice(d * nb // 10, (d + 1) * nb // 10)
     print(f"  WGs {sl.start:4d}-{sl.stop - 1:4d}: start {start[sl].mean():6.1f}  end {end[sl].mean():6.1f}  max {end[sl].max():5d}")
-print("the 16 last workgroups to end:", sorted(order[-16:].tolist()), " their XCDs:", sorted(((order[-16:] + nr) % 8).tolist()))
+print("the 16 last workgroups to end:", sorted(order[-16:].tolist()), " their XCDs:", sorted((order[-16:] % 8).tolist()))
