@@ -59,7 +59,8 @@ extern "C" {
 
 /* ---- tg_config.flags ---- */
 #define TG_FLAG_EPISODE_STATS 1 /* keep device-side episode return/length (RecordEpisodeStatistics) */
-#define TG_FLAG_FINAL_OBS 2     /* SAME_STEP autoreset: also write the terminal observation to TG_BUF_FINAL_OBS */
+#define TG_FLAG_FINAL_OBS 2     /* SAME_STEP autoreset, TG_OBS_BOARD / TG_OBS_FN: also write the terminal observation to
+                                 * TG_BUF_FINAL_OBS (gymnasium's infos["final_observation"]; valid where terminated) */
 #define TG_FLAG_FEATURES 4      /* allocate the feature buffers used by tg_features */
 
 /* ---- error codes ---- */
@@ -132,7 +133,10 @@ typedef struct tg_rng_rec { /* 48 bytes */
 #define TG_BUF_ACTIONS 2    /* i32 [B] staging buffer used for TG_MEM_HOST actions */
 #define TG_BUF_BOARD 3      /* u8 [B][H][W] state boards */
 #define TG_BUF_REC 4        /* tg_env_rec [B] */
-#define TG_BUF_RNG 5        /* tg_rng_rec [B] */
+#define TG_BUF_RNG 5        /* tg_rng_rec [B].  NUMPY rules: a transition leaves the generator state in the engine's
+                             * look-ahead ring; tg_get_state / tg_fetch / tg_device_ptr of this buffer first enqueue the
+                             * kernel that writes the generators the reference would hold now (tg_sync before reading the
+                             * device pointer from another stream) */
 #define TG_BUF_LEGAL_MASK 6 /* u8 [B][4*W]  grouped legal-action mask (TG_ACTIONS_GROUPED) */
 #define TG_BUF_FINAL_OBS 7  /* SAME_STEP autoreset: observation of the terminal state (valid where terminated) */
 #define TG_BUF_EPISODE 8    /* tg_episode_rec [B] (TG_FLAG_EPISODE_STATS) */
@@ -206,7 +210,8 @@ int tg_fetch(tg_handle* h, int which, void* host_dst, size_t bytes);
 int tg_get_state(tg_handle* h, uint8_t* board, tg_env_rec* rec, tg_rng_rec* rng);
 int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, const tg_rng_rec* rng);
 
-/* Re-pack the observation buffer from the current state without stepping (after tg_set_state). */
+/* Re-pack the observation buffer from the current state without stepping.  (tg_reset and tg_set_state re-pack the DICT /
+ * RGB surfaces themselves: between transitions the step kernel only stores what changed of the holder / queue strips.) */
 int tg_observe(tg_handle* h);
 
 /* Grouped action surface: recompute TG_BUF_LEGAL_MASK and, if boards_dev != NULL, write the wrapper's observation —
