@@ -357,6 +357,48 @@ def test_fused_rollout_equals_single_transitions(fuse, ring_fill, ruleset, W, H,
     e.close()
 
 
+@pytest.mark.parametrize("every", [1, 2, 3])
+@pytest.mark.parametrize("W,H,Q,B,grouped", [(10, 20, 4, 1000, False), (10, 20, 7, 600, True), (6, 12, 2, 500, True)])
+def test_rng_role_every_nth_launch(every, W, H, Q, B, grouped, monkeypatch):
+    """One-transition launches carry the RNG-role workgroups only every TG_RNG_EVERY-th time (the ring parity then flips
+    less often than the consumed-counter parity); whatever the cadence — and with single steps, rollouts, state
+    round trips and masked resets in between — pieces and generator must equal the oracle's."""
+    monkeypatch.setenv("TG_RNG_EVERY", str(every))
+    monkeypatch.setenv("TG_FUSE", "1")
+    na = 4 * W if grouped else 8
+    e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP, grouped=grouped)
+    o = po.OracleBatch(B, W, H, N.RULESET_NUMPY, True, Q)
+    seeds = np.arange(5, 5 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(every * 10 + W)
+
+    def ostep(a):
+        return o.grouped_step(a.astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)[:3] if grouped \
+            else o.step(a.astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+
+    for rnd in range(6):
+        for _ in range(1 + rnd):  # an odd / even number of single launches between the other entry points
+            a = rng.integers(0, na, B).astype(np.int8)
+            got = e.step(a)
+            ro, to, lo = ostep(a)
+            np.testing.assert_array_equal(got[0], ro); np.testing.assert_array_equal(got[1], to)
+        K = (5, 8, 13)[rnd % 3]
+        acts = rng.integers(0, na, (K, B)).astype(np.int8)
+        d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts); e.step_k_device(d, K); e.dev_free(d)
+        for k in range(K):
+            ostep(acts[k])
+        if rnd % 2:
+            e.set_state(*e.get_state())
+        else:
+            m = rng.random(B) < 0.2
+            e.reset(mask=m); o.reset(mask=m)
+        np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_BOARD), err_msg=f"obs round {rnd}")
+        ge, go = _cmp_state(e, o, f"round {rnd}")
+        for f in ("state_lo", "state_hi", "inc_lo", "inc_hi", "uinteger", "has_uint32"):
+            np.testing.assert_array_equal(ge[f], go[f], err_msg=f"rng.{f} round {rnd}")
+    e.close()
+
+
 @pytest.mark.parametrize("fuse", [1, 8])
 @pytest.mark.parametrize("ruleset,obs,B", [(N.RULESET_NUMPY, N.OBS_BOARD, 1500), (N.RULESET_FUNCTIONAL, N.OBS_FN, 640),
                                            (N.RULESET_NUMPY, N.OBS_RGB, 200)])

@@ -42,7 +42,9 @@ struct KParams {
   uint4* ahead;             // bits kernel only: generator states of the permutation ring [B][2][2]
   uint64_t* ring;           // bits kernel only: permutation rings [2][B]
   uint8_t* hbuf;            // bits kernel only: consumed counters [2][B]
-  int ring_cur;             // bits kernel only: launch parity
+  int ring_cur;             // bits kernel only: ring parity (flips with every launch that carries the RNG role)
+  int hbuf_cur;             // bits kernel only: consumed-counter parity (flips with every launch)
+  int rng_role;             // bits kernel only: this launch carries the RNG-role workgroups
   uint32_t ring_stride;     // bits kernel only: elements between the parities of ring / hbuf
   uint32_t cols_bytes;      // bits kernel only: bytes per env of `cols` (host-side shard offsets)
   int nsteps;               // bits kernel only: transitions per launch (tg_step_k), int8 action rows act_stride apart

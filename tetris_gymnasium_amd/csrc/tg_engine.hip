@@ -85,8 +85,8 @@ template <int W, int H, int RS>
 void launch_step(const tg::KParams& p, hipStream_t s) {
   if (p.cols) {  // "bits": the handle carries the column masks / look-ahead permutations
     using BG = tg::BitsGeo<W, H>;
-    const int nrb = RS == TG_RULESET_NUMPY ? (p.batch + 127) / 128 : 0;  // leading RNG workgroups (tg_kernel_bits.h)
-    const tg::BitsParams bp{p.cols, p.ahead, p.ring, p.hbuf, p.ring_cur, nrb, p.ring_stride, p.ring_fill};
+    const int nrb = (RS == TG_RULESET_NUMPY && p.rng_role) ? (p.batch + 127) / 128 : 0;  // RNG-role workgroups (tg_kernel_bits.h)
+    const tg::BitsParams bp{p.cols, p.ahead, p.ring, p.hbuf, p.ring_cur, p.hbuf_cur, nrb, p.ring_stride, p.ring_fill};
     const dim3 grid(nrb + (p.batch + BG::EPW - 1) / BG::EPW);
     constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
     const int feat = bits_feat<W, H, RS>(p);
@@ -211,7 +211,11 @@ struct tg_handle {
   uint4* d_ahead = nullptr; // bits kernel: generator states after the ring's shuffles [B][2 slots][2]
   uint64_t* d_ring = nullptr;  // bits kernel: permutation rings, double-buffered by launch parity [2][B]
   uint8_t* d_hbuf = nullptr;   // bits kernel: consumed counters [2][B]
-  int ring_cur = 0;            // parity the next step launch reads
+  int ring_cur = 0;            // ring parity the next step launch reads
+  int hbuf_cur = 0;            // consumed-counter parity the next step launch reads
+  int rng_every = 3;           // TG_RNG_EVERY: one-transition launches carry the RNG-role workgroups every n-th time (the ring
+                               // looks 3 entries ahead and the consumer shuffles in line when it runs dry): 7.5 -> 7.3 us per launch
+  unsigned launch_no = 0;
   int fuse_max = 8;            // TG_FUSE: transitions per launch in tg_step_k (1..8)
   int ring_fill = tg::kRing - 1;  // TG_RING_FILL (tests): fewer look-ahead permutations → the consumer's in-line shuffle runs
   bool dict_in_kernel = false; // TG_OBS_DICT packed by the bits step kernel itself (no observe launch after a transition)
@@ -367,6 +371,8 @@ tg::KParams step_params(tg_handle* h) {
   p.ring = h->d_ring;
   p.hbuf = h->d_hbuf;
   p.ring_cur = h->ring_cur;
+  p.hbuf_cur = h->hbuf_cur;
+  p.rng_role = 1;
   p.ring_stride = (uint32_t)h->B;
   p.cols_bytes = (uint32_t)h->L.cols_bytes;
   p.nsteps = 1;
@@ -454,6 +460,7 @@ int launch_prepare_bits(tg_handle* h, const uint8_t* d_mask, int force) {
   q.ring = h->d_ring;
   q.hbuf = h->d_hbuf;
   q.cur = h->ring_cur;
+  q.hcur = h->hbuf_cur;
   q.mask = d_mask;
   q.batch = h->B;
   q.ruleset = h->cfg.ruleset;
@@ -470,7 +477,7 @@ int launch_materialize_rng(tg_handle* h) {
   tg::MaterializeParams q{};
   q.rng = (tg_rng_rec*)h->buf[TG_BUF_RNG];
   q.ahead = h->d_ahead;
-  q.hbuf = h->d_hbuf + (size_t)h->ring_cur * (size_t)h->B;
+  q.hbuf = h->d_hbuf + (size_t)h->hbuf_cur * (size_t)h->B;
   q.batch = h->B;
   hipLaunchKernelGGL(tg::bits_materialize_rng_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, q);
   HIPCHK(h, hipGetLastError());
@@ -649,6 +656,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
                         ((cfg->obs_mode == TG_OBS_DICT && L.dict_ok) ||
                          (cfg->obs_mode == TG_OBS_RGB && L.rgb_ok && cfg->queue_size == 4));  // (the in-kernel RGB image is laid out for four queue pieces)
     if (const char* e = getenv("TG_RING_FILL")) { const int v = atoi(e); h->ring_fill = v < 0 ? 0 : (v > tg::kRing - 1 ? tg::kRing - 1 : v); }
+    if (const char* e = getenv("TG_RNG_EVERY")) { const int v = atoi(e); h->rng_every = v < 1 ? 1 : (v > 3 ? 3 : v); }
     if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > 8 ? 8 : v); }
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
     int want = 1;
@@ -773,11 +781,13 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind) {
   } else {
     return fail(h, TG_EINVAL, "tg_step: unknown memory kind %d", kind);
   }
+  p.rng_role = (h->launch_no++ % (unsigned)h->rng_every) == 0;
   {
     int rc = launch_step_all(h, p);
     if (rc != TG_OK) return rc;
   }
-  h->ring_cur ^= 1;
+  if (p.rng_role) h->ring_cur ^= 1;
+  h->hbuf_cur ^= 1;
   HIPCHK(h, hipGetLastError());
   if ((h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) && !h->dict_in_kernel) return launch_observe_dict(h);
   return TG_OK;
@@ -849,6 +859,8 @@ static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, u
       }
       p.nsteps = K - k < fuse ? K - k : fuse;
       p.ring_cur = h->ring_cur;
+      p.hbuf_cur = h->hbuf_cur;
+      p.rng_role = p.nsteps > 1 || (h->launch_no++ % (unsigned)h->rng_every) == 0;
       if (in_kernel) {
         p.obs_traj = obs_traj_dev ? obs_traj_dev + (size_t)k * obs_stride : nullptr;
         p.out_traj = out_traj_dev ? (uint2*)out_traj_dev + (size_t)k * h->B : nullptr;
@@ -856,7 +868,8 @@ static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, u
       }
       int rc = launch_step_all(h, p);
       if (rc != TG_OK) return rc;
-      h->ring_cur ^= 1;
+      if (p.rng_role) h->ring_cur ^= 1;
+      h->hbuf_cur ^= 1;
       if (post_kernel) {  // packed by its own kernel after every transition
         rc = launch_observe_dict(h);
         if (rc != TG_OK) return rc;

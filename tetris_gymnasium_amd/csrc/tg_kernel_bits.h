@@ -187,7 +187,8 @@ struct BitsParams {
   uint64_t* ring;  // [2 parities][B][2]: word 0 = permutations of slots 0 | 1 << 28 (7 nibbles each) | T << 56,
                    //                      word 1 = slots 2 | 3 << 28
   uint8_t* hbuf;   // [2 parities][B]: H (bits 0-6) | inl << 7 (the state after entry H - 1 is in tg_rng_rec, not in `ahead`)
-  int cur;         // parity this launch reads; it writes 1 - cur
+  int cur;         // ring parity this launch reads; the RNG role writes 1 - cur (flips only in launches that carry the RNG role)
+  int hcur;        // consumed-counter parity this launch reads; the logic wave writes 1 - hcur (flips every launch)
   int nrb;         // number of leading RNG workgroups (kRngEnvs envs each)
   uint32_t pstride;  // elements between the two parities of ring / hbuf (the handle's whole batch)
   int fill;          // entries the RNG role keeps ahead in a ring (kRing - 1; tests lower it to exercise the consumer's in-line shuffle)
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
     const uint32_t ee = on ? e : B - 1u;
     const uint4 rw = reinterpret_cast<const uint4*>(bp.ring)[(size_t)bp.cur * bp.pstride + ee];
     uint64_t w0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32), w1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
-    const int Hraw = bp.hbuf[(size_t)bp.cur * bp.pstride + ee];
+    const int Hraw = bp.hbuf[(size_t)bp.hcur * bp.pstride + ee];
     const int Hn = Hraw & 0x7F;
     const bool inl = (Hraw & 0x80) != 0;
 #ifndef TG_RNG_PRIO
@@ -979,7 +980,7 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
     const uint4 rw = reinterpret_cast<const uint4*>(bp.ring)[(size_t)bp.cur * bp.pstride + env];
     ring0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32);
     ring1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
-    Hc = bp.hbuf[(size_t)bp.cur * bp.pstride + env];  // H | inl << 7, split below
+    Hc = bp.hbuf[(size_t)bp.hcur * bp.pstride + env];  // H | inl << 7, split below
   }
   T cv[W];
   {
@@ -1651,7 +1652,7 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
   TG_BITS_STAMP(6);
   // ---- E: consumed counter; the generator state only after an in-line shuffle (otherwise `ahead` holds it) ----
   if (RULESET == TG_RULESET_NUMPY) {
-    if (live) bp.hbuf[(size_t)(1 - bp.cur) * bp.pstride + env] = (uint8_t)(Hc | (inl ? 0x80 : 0));
+    if (live) bp.hbuf[(size_t)(1 - bp.hcur) * bp.pstride + env] = (uint8_t)(Hc | (inl ? 0x80 : 0));
     if (live && g_valid) {
       uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
       rng_out[0] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
@@ -1687,7 +1688,8 @@ struct PrepareParams {
   int batch;
   int ruleset;
   int force;            // refill every ring
-  int cur;              // parity the next launch reads
+  int cur;              // ring parity the next launch reads
+  int hcur;             // consumed-counter parity the next launch reads
 };
 
 template <int W, int H>
@@ -1708,7 +1710,7 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
   uint4* ring4 = reinterpret_cast<uint4*>(p.ring);
   if (!moved) {  // ring untouched: make both parities agree with the one the next launch reads
     ring4[(size_t)(1 - p.cur) * B + env] = ring4[(size_t)p.cur * B + env];
-    p.hbuf[(size_t)(1 - p.cur) * B + env] = p.hbuf[(size_t)p.cur * B + env];
+    p.hbuf[(size_t)(1 - p.hcur) * B + env] = p.hbuf[(size_t)p.hcur * B + env];
     return;
   }
   uint32_t* rec = p.rec + (size_t)env * 8;
