@@ -51,7 +51,9 @@ int g_step_blocks = 0;  // persistent grid size (blocks); set once per process f
 // (legacy build only) 8 = "block": two-phase workgroup kernel (legacy/tg_kernel_block.h); 4 = "quad": 16 envs per wave, 4 lanes per env;
 // 1 = "lanes": 64 envs per wave, one per lane (both legacy/tg_kernel_lanes.h); 0 = "wave": one env per wavefront (legacy/tg_kernel_wave.h)
 int g_kernel_lanes = 16;
+#ifdef TG_LEGACY_KERNELS
 int g_block_waves = 4;  // TG_BLOCK_WAVES: waves per workgroup of the block kernel (4 → 64 envs, 8 → 128 envs)
+#endif
 int g_stagger = 0;  // TG_STAGGER: odd waves of the lane kernels start this many x64 cycles late
 size_t g_lds_pad = 0;       // TG_LDS_PAD: extra dynamic LDS per wave of the lane kernels = occupancy limiter
 int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = lane kernels' pipelined pair of groups per wave (measured slower:

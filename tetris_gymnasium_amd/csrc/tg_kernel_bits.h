@@ -237,6 +237,12 @@ __device__ __forceinline__ void st_dict(V* dst, const V v) {
 #ifndef TG_STATE_ST
 #define TG_STATE_ST 1
 #endif
+// TG_EXP_SKIP (bit mask, timing ablations only — the results are wrong): 1 observation stores, 2 board write-back,
+// 4 record stores, 8 column-mask stores, 16 output store
+#ifndef TG_EXP_SKIP
+#define TG_EXP_SKIP 0
+#endif
+#define TG_SKIP(bit) ((TG_EXP_SKIP & (bit)) != 0 && p.batch >= 0)
 template <typename V>
 __device__ __forceinline__ void st_state(V* dst, const V v) {
   static_assert(sizeof(V) == 16 || sizeof(V) == 8, "state stores are 8 or 16 bytes");
@@ -561,8 +567,14 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
 #define TG_NOW() __builtin_amdgcn_s_memtime()
 #endif
 #define TG_BITS_STAMP(i) tstamp[i] = TG_NOW()
+#ifdef TG_FINE_LOCK  // finer stamps inside the lock path instead of the post-barrier ones: 4 = drop row known, 5 = full rows known, 6 = lock path done, 7 = published
+#define TG_LOCK_STAMP(i) TG_BITS_STAMP(i)
+#endif
 #else
 #define TG_BITS_STAMP(i) do {} while (0)
+#endif
+#ifndef TG_LOCK_STAMP
+#define TG_LOCK_STAMP(i) do {} while (0)
 #endif
   if (rng_role) {
     // =====================================================================================================
@@ -689,6 +701,15 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
       }
     }
     TG_BITS_STAMP(1);
+    // One transition per launch, full workgroup: the slab block stays in the staging registers as it was loaded (B0) and
+    // the board write-back stores exactly the chunks whose bytes changed (a lock: one or two of an env's 13) — a compare
+    // per chunk instead of index arithmetic, and fewer store instructions in the launch's tail.
+    // (Writing the observation twice — B0 from the registers while the logic wave decides, then only the chunks that
+    // differ — was measured: the early stores are free, but the sparse second pass costs more than the full one, 8.0 vs
+    // 7.3 us; plain or nontemporal, 16-byte or whole-line granularity alike.  profiles/r02/ab_early_obs_store.log)
+    constexpr bool ONE = !MULTI;
+    const bool keep_b0 = ONE && full_wave;
+    auto differs = [](const u32x4 a, const u32x4 b) -> bool { return ((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) != 0u; };
     LaneBoard<W, H, 1> bd;
     bd.my = lds + slot * S;
     bd.sub = 0;
@@ -760,6 +781,26 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
       // they are.
       const uint64_t dm = __ballot(dirty_any);
       u32x4* bdst = reinterpret_cast<u32x4*>(p.board + (size_t)base_env * S);
+      if (keep_b0) {
+        u32x4 wv[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const int c = lane + 64 * k;
+          wv[k] = lds4[c < NCH ? c : NCH - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const int c = lane + 64 * k;
+          const bool wput = differs(wv[k], stage[k]);
+          if (c < NCH && wput && !TG_SKIP(2)) {
+#ifdef TG_WB_PLAIN
+            bdst[c] = wv[k];
+#else
+            st_state(&bdst[c], wv[k]);
+#endif
+          }
+        }
+      } else {
       // chunks in flight per lane: all of them in the one-transition kernel; in the transition loop of the fused kernels
       // that would cost 52 registers beside the observation pass's 52 (the kernel spilled)
 #ifdef TG_WBB
@@ -781,7 +822,7 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
           const uint32_t e0 = (16u * c) / (uint32_t)S, e1r = (16u * c + 15u) / (uint32_t)S;
           const uint32_t e1 = e1r < (uint32_t)EPW ? e1r : (uint32_t)EPW - 1u;
           const bool hit = k0 + kk < NIT && c < nchunks && (((dm >> e0) | (dm >> e1)) & 1ull) != 0;
-          if (hit) {
+          if (hit && !TG_SKIP(2)) {
             if (c * 16u + 16u <= nbytes) {
 #ifdef TG_WB_PLAIN
               bdst[c] = wv[kk];
@@ -795,6 +836,7 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
             }
           }
         }
+      }
       }
 #endif
     }
@@ -825,7 +867,7 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
           const int c = lane + 64 * k;
-          if (c < NCH) {
+          if (c < NCH && !TG_SKIP(1)) {
             st_stream(&odst[c], o[k]);
             if (last && obs_traj) st_stream(&odst2[c], o[k]);
           }
@@ -929,8 +971,10 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
     }  // transitions
     TG_BITS_STAMP(4);
 #ifdef TG_PHASE_TIMING
-    if (p.dbg && lane == 0)
+    if (p.dbg && lane == 0) {
       for (int i = 0; i < 5; ++i) p.dbg[(size_t)step_block * 16 + 8 + i] = tstamp[i];
+      p.dbg[(size_t)step_block * 16 + 14] = __builtin_amdgcn_s_getreg(63492);  // HW_ID: where the stream wave ran
+    }
 #endif
     return;
   }
@@ -1257,7 +1301,7 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
   bool lock = false;
   int drop_reward = 0;
   uint32_t PF = PC;                 // window-spread column masks of the piece as it ends the move
-  int fpiece = s.piece, frot = s.rot;  // ... and its identity (for the uint8 stamp)
+  int frot = s.rot;                 // ... and its rotation (for the uint8 stamp)
   if (RULESET == TG_RULESET_FUNCTIONAL) {
     // functional/core.py:230-251 hard_drop: step-wise, stops at the first blocked row below y
     const int yd = drop_row_of(PC, s.y);
@@ -1272,7 +1316,7 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
   const bool accept = moving && (swap_eff || (check && !cT));
   uint64_t tcelF = tcelC;  // cell table word of the piece as it ends the move (of the spawned one after a lock)
   uint64_t tcolN = tcolC;  // column table word of the piece a lock spawns
-  if (accept) { s.piece = tp; s.rot = tr; s.x = tx; s.y = ty; s.val = tv; PF = PT; fpiece = tp; frot = tr; tcelF = tcelT; }
+  if (accept) { s.piece = tp; s.rot = tr; s.x = tx; s.y = ty; s.val = tv; PF = PT; frot = tr; tcelF = tcelT; }
   const bool coll_here = accept ? cT : cC;
   const bool coll_below = accept ? cT1 : cC1;
   if (RULESET == TG_RULESET_FUNCTIONAL && accept && (e & 4u)) drop_reward = 1;  // soft drop (tetris_fn.py:183-190)
@@ -1307,6 +1351,7 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
         if (place && hard) s.y = yd;
       }
     }
+    TG_LOCK_STAMP(4);
     lock_cells = rot16(tcelF, frot);
     lock_x = s.x; lock_y = s.y;
     lock_val = RULESET == TG_RULESET_NUMPY ? s.val : s.piece + 2;  // functional/core.py:103-121 adds piece id
@@ -1326,6 +1371,7 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
     if (!place) full = 0;
     lines = popc_t(full);
     do_clear = lines > 0;
+    TG_LOCK_STAMP(5);
     if (__any(do_clear)) {
       // compaction of the masks: delete the full rows top-down (rows above move down by one each time);
       // NUMPY (envs/tetris.py:500-510): vacated top rows are empty; FUNCTIONAL (functional/core.py:203-214): the
@@ -1407,7 +1453,11 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
     reward = t - old;  // tetris_fn.py:312
   }
 
+#ifdef TG_FINE_LOCK
+  TG_BITS_STAMP(6);
+#else
   TG_BITS_STAMP(4);
+#endif
   // ---- termination / autoreset ----
   if (g_illegal) reward = -0.1f;  // rewards.invalid_action
   const int terminated = (!pending && ((s.flags & TG_F_GAME_OVER) || (g_illegal && p.grouped_term))) ? 1 : 0;
@@ -1527,7 +1577,11 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
                               (uint32_t)(lock_x & 0xFF) | ((uint32_t)(lock_y & 0xFF) << 8),
                               ocells | ((uint32_t)(s.val & 0xFF) << 16) | ((show ? 1u : 0u) << 24),
                               (uint32_t)(s.x & 0xFF) | ((uint32_t)(s.y & 0xFF) << 8) | ((uint32_t)(s.piece & 0xFF) << 16));
+#ifdef TG_FINE_LOCK
+      TG_BITS_STAMP(7);
+#else
       TG_BITS_STAMP(5);
+#endif
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       __builtin_amdgcn_s_barrier();
     }
@@ -1539,7 +1593,7 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
     ep.len += 1;
     if (terminated) { ep.last_ret = ep.ret; ep.last_len = ep.len; ep.ret = 0.0f; ep.len = 0; }
   }
-  if (step == nsteps - 1 && live)  // the outputs of the LAST transition remain in the buffers
+  if (step == nsteps - 1 && live && !TG_SKIP(16))  // the outputs of the LAST transition remain in the buffers
     st_stream(reinterpret_cast<u32x2*>(p.out + env), u32x2{__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8)});
   if (out_traj && live)
     st_stream(reinterpret_cast<u32x2*>(out_traj + (size_t)step * p.act_stride + env),
@@ -1629,7 +1683,7 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
   uint4 oa, ob;
   lane_pack(s, oa, ob);
   uint4* rec_out = reinterpret_cast<uint4*>(p.rec) + (size_t)env * 2;
-  if (live) {
+  if (live && !TG_SKIP(4)) {
     TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out), (u32x4{oa.x, oa.y, oa.z, oa.w}));
     if (p.episode) p.episode[env] = ep;
   }
@@ -1637,7 +1691,7 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
     T nv[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) nv[c] = (T)(colsL[1 + c] & PLAY);
-    if (cols_dirty) {
+    if (cols_dirty && !TG_SKIP(8)) {
       uint2* gc = reinterpret_cast<uint2*>(reinterpret_cast<T*>(bp.cols) + (size_t)env * W);
       if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -1649,7 +1703,9 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
     }
   }
 
+#ifndef TG_FINE_LOCK
   TG_BITS_STAMP(6);
+#endif
   // ---- E: consumed counter; the generator state only after an in-line shuffle (otherwise `ahead` holds it) ----
   if (RULESET == TG_RULESET_NUMPY) {
     if (live) bp.hbuf[(size_t)(1 - bp.hcur) * bp.pstride + env] = (uint8_t)(Hc | (inl ? 0x80 : 0));
@@ -1662,12 +1718,17 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
     uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
     rng_out[2] = make_uint4(r.uinteger, r.has32, r.k0, r.k1);
   }
+#ifndef TG_FINE_LOCK
   TG_BITS_STAMP(7);
-#ifdef TG_PHASE_TIMING
-  if (p.dbg && lane == 0)
-    for (int i = 0; i < 8; ++i) p.dbg[(size_t)step_block * 16 + i] = tstamp[i];
 #endif
-  if (live && (ob.x != rb.x || ob.y != rb.y || ob.z != rb.z || ob.w != rb.w))
+#ifdef TG_PHASE_TIMING
+  if (p.dbg && lane == 0) {
+    for (int i = 0; i < 8; ++i) p.dbg[(size_t)step_block * 16 + i] = tstamp[i];
+    p.dbg[(size_t)step_block * 16 + 13] = __builtin_amdgcn_s_getreg(63492);  // HW_ID (wave / SIMD / CU / SE) of the logic wave
+    p.dbg[(size_t)step_block * 16 + 15] = __builtin_amdgcn_s_getreg(63508);  // XCC_ID
+  }
+#endif
+  if (live && (ob.x != rb.x || ob.y != rb.y || ob.z != rb.z || ob.w != rb.w) && !TG_SKIP(4))
     TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out + 1), (u32x4{ob.x, ob.y, ob.z, ob.w}));
 }
 

@@ -3,7 +3,7 @@
 box-to-box spread on this pool exceeds most kernel changes).  Every variant is a source tree (a copy of csrc under _ab/<tag>/
 or the working tree) plus optional -D flags:
 
-    tools/abn_bench.py tag[=srcdir][:-Dflag[:-Dflag...]][@ENV=value...] ...        env: AB_BATCH, AB_RULESET, AB_OBS, AB_STEPS
+    tools/abn_bench.py tag[=srcdir][:-Dflag[:-Dflag...]][@ENV=value...] ...        env: AB_BATCH, AB_RULESET, AB_OBS, AB_STEPS, AB_ENGINES
 
 @ENV=value pairs are set while the variant's engines are created (knobs tg_create reads, e.g. TG_ALLOC_SKEW).
 
@@ -43,7 +43,7 @@ for tag, _, _ in variants:  # older builds may lack entry points added later: bi
             del N.SYMBOLS[name]
 eng = {}
 for tag, _, _ in variants:
-    for rep in ("", "'"):  # two engines per build: buffer placement varies too
+    for rep in [""] + ["'" * i for i in range(1, int(os.environ.get("AB_ENGINES", "2")))]:  # several engines per build: buffer placement varies too
         N._lib = None
         N.LIB_PATH = f"/tmp/libtg_{tag}.so"
         os.environ.update(envs[tag])
@@ -65,3 +65,6 @@ for t, (e, d) in eng.items():
     for part in (o.values() if isinstance(o, dict) else [o]):  # (the last observation is part of the checksum)
         crc ^= zlib.crc32(np.ascontiguousarray(part).tobytes())
     print(f"{t:12s} median {statistics.median(res[t]):6.2f}  min {min(res[t]):6.2f} us/step   state crc {crc:08x}   " + " ".join(f"{x:.2f}" for x in res[t]))
+for tag, _, _ in variants:
+    ms = [statistics.median(res[t]) for t in eng if t.rstrip("'") == tag]
+    print(f"{tag:12s} mean of the engines' medians {statistics.mean(ms):6.2f}   best {min(ms):6.2f}")
