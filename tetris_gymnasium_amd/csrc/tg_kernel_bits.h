@@ -55,6 +55,15 @@ constexpr ColTable make_col_table() {
 
 __constant__ ColTable c_colmasks = make_col_table();
 
+// cells of every piece at rotation 0 (16 bits each, c_cells' encoding) as two immediates: what a fresh episode shows
+constexpr uint64_t cells_rot0(const int first) {
+  const CellTable t = make_cell_table();
+  uint64_t v = 0;
+  for (int i = 0; i < 4 && first + i < 7; ++i) v |= (t.cells[first + i] & 0xFFFFull) << (16 * i);
+  return v;
+}
+constexpr uint64_t kCells0Lo = cells_rot0(0), kCells0Hi = cells_rot0(4);
+
 template <int H>
 using ColT = std::conditional_t<(H + 6 <= 32), uint32_t, uint64_t>;
 
@@ -505,7 +514,10 @@ __device__ __forceinline__ void bits_copy_slab(const uint8_t* src_lds, uint8_t* 
 }
 
 template <int W, int H, int RULESET, int FEAT>
-__global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | kFeatSample))) ? 3 : 4) void step_kernel_bits(const KParams p, const BitsParams bp) {
+#ifndef TG_ONE_WAVES
+#define TG_ONE_WAVES 4  // waves per SIMD the one-transition kernels are compiled for (4 → 128 VGPRs, 3 → 168)
+#endif
+__global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kFeatSample)) ? 3 : 4) : TG_ONE_WAVES) void step_kernel_bits(const KParams p, const BitsParams bp) {
   constexpr bool MULTI = (FEAT & kFeatMulti) != 0, TRAJ = (FEAT & kFeatTraj) != 0, DICTK = (FEAT & kFeatDict) != 0,
                  SAMPLE = (FEAT & kFeatSample) != 0, FINAL = (FEAT & kFeatFinal) != 0, RGBK = (FEAT & kFeatRgb) != 0;
   using BG = BitsGeo<W, H>;
@@ -1182,13 +1194,7 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
   const int up0_ = (int)(s.queue & 0xFF);
   const int up1_ = Q >= 2 ? (int)((s.queue >> 8) & 0xFF) : (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
   const int pcH = s.hp < 7 ? s.hp : 0, pc0 = up0_ < 7 ? up0_ : 0, pc1 = up1_ < 7 ? up1_ : 0;
-  const uint64_t tcolC = col_tab[s.piece], tcelC = cell_tab_l[s.piece];
-  uint64_t tcolH = 0, tcelH = 0, tcol0 = 0, tcel0 = 0, tcol1 = 0, tcel1 = 0;
-  if (RULESET == TG_RULESET_NUMPY) {
-    tcolH = col_tab[pcH]; tcelH = cell_tab_l[pcH];
-    tcol0 = col_tab[pc0]; tcel0 = cell_tab_l[pc0];
-    tcol1 = col_tab[pc1]; tcel1 = cell_tab_l[pc1];
-  }
+  const int pcC = s.piece;  // (the active piece as the transition starts)
   auto rot16 = [](const uint64_t t, const int rot) -> uint32_t { return (uint32_t)(t >> (16 * rot)) & 0xFFFFu; };
   // grouped action set (wrappers/grouped.py:209-269): action = column * 4 + rotations → teleport + hard drop; illegal
   // iff a cell of the rotated piece lies outside the playfield columns (collision_with_frame, :104-122)
@@ -1232,12 +1238,11 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
   // wave's tail instead of in front of it.
   int npop = 0;
   const int up0 = up0_, up1 = up1_;
-  uint64_t tcolT = tcolC, tcelT = tcelC;  // tables of the tentative piece
+  const bool swap_empty = swap_eff && s.hp == TG_NONE;
   if (RULESET == TG_RULESET_NUMPY) {  // (no wave-uniform branch: with 64 envs per wave some lane swaps in practically every transition)
-    const bool empty = swap_eff && s.hp == TG_NONE;
     if (swap_eff) {
-      if (empty) { tp = up0; tr = 0; tv = up0 + 2; npop = 1; tcolT = tcol0; tcelT = tcel0; }  // spawn_tetromino; its collision result is ignored
-      else { tp = s.hp; tr = s.hr; tv = s.hv; tcolT = tcolH; tcelT = tcelH; }
+      if (swap_empty) { tp = up0; tr = 0; tv = up0 + 2; npop = 1; }  // spawn_tetromino; its collision result is ignored
+      else { tp = s.hp; tr = s.hr; tv = s.hv; }
       s.hp = s.piece; s.hr = s.rot; s.hv = s.val;
       s.flags |= TG_F_HAS_SWAPPED;
       tx = np_spawn_x<W>(tp);
@@ -1258,9 +1263,23 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i) w[i] = colsL[widx[i]];
+  // ... and the table words, requested BEHIND the window (LDS answers in order: the collision tests below start on the
+  // window words while these are still on their way; requested first, their round trip stood in front of the window's)
+  const uint64_t tcolC = col_tab[pcC], tcelC = cell_tab_l[pcC];
+  uint64_t tcolH = 0, tcelH = 0, tcol0 = 0, tcel0 = 0, tcol1 = 0, tcel1 = 0;
+  if (RULESET == TG_RULESET_NUMPY) {
+    tcolH = col_tab[pcH]; tcelH = cell_tab_l[pcH];
+    tcol0 = col_tab[pc0]; tcel0 = cell_tab_l[pc0];
+    tcol1 = col_tab[pc1]; tcel1 = cell_tab_l[pc1];
+  }
   if (oob) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) w[i] = ONES;
+  }
+  uint64_t tcolT = tcolC, tcelT = tcelC;  // tables of the tentative piece
+  if (RULESET == TG_RULESET_NUMPY && swap_eff) {
+    tcolT = swap_empty ? tcol0 : tcolH;
+    tcelT = swap_empty ? tcel0 : tcelH;
   }
   TG_BITS_STAMP(2);
   const uint32_t mC = rot16(tcolC, s.rot), mT = rot16(tcolT, tr);
@@ -1512,79 +1531,88 @@ __global__ __launch_bounds__(128, ((FEAT & kFeatMulti) && (FEAT & (kFeatDict | k
   }
   cols_dirty_any = cols_dirty_any || (live && (place || do_reset));
   if (rgb) early_book = true;  // the image shows the queue and the holder as they are AFTER the transition: bookkeeping first
-  // Two passes so that the bookkeeping exists once in the code: pass 0 publishes (after the bookkeeping when early_book),
-  // pass 1 does the bookkeeping in the normal case — behind the barrier, while the stream wave already works.
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    if (RULESET == TG_RULESET_NUMPY && (pass == 0) == early_book) {
-      // ---- bookkeeping: the owed pops in order (TetrominoQueue.get_next_tetromino, components/tetromino_queue.py:35-42),
-      // then the reset's randomizer / queue / holder state ----
-#pragma unroll 1
-      for (int k = 0; k < 2; ++k) {
-        const bool on = k < npop;
-        if (!__any(on)) break;
-        (void)queue_pop(on);
-      }
-      if (__any(do_reset)) {
-        if (do_reset) {
-#pragma unroll
-          for (int c = 0; c < W; ++c) colsL[1 + c] = FLOOR;
-        }
-        consume_perm(do_reset, true);  // tetromino_queue.py:23-33, tetromino_randomizer.py:87-91
-        if (Q <= 5) {
-          // Q draws fill the queue, the pop takes its head and draws one more: Q + 1 <= 6 draws never wrap the fresh bag
-          if (do_reset) {
-            s.piece = (int)(s.bag & 0xFF);
-            s.queue = (s.bag >> 8) & ((1ULL << (8 * Q)) - 1ULL);
-            s.bidx = Q + 1;
-          }
-        } else {
-          if (do_reset) s.queue = 0;
-          for (int i = 0; i < Q; ++i) {
-            const int t = randomizer_next(do_reset);
-            if (do_reset) s.queue |= (uint64_t)t << (8 * i);
-          }
-          const int first = queue_pop(do_reset);
-          if (do_reset) s.piece = first;
-        }
-        if (do_reset) {
-          s.x = np_spawn_x<W>(s.piece);
-          s.rot = 0; s.y = 0; s.val = s.piece + 2;
-          s.hp = TG_NONE; s.hr = 0; s.hv = 0;
-          s.flags = 0;
-          s.score = 0.0f;
-        }
-      }
+  // The publish exists twice in the code (it is short), the bookkeeping once: normally publish → barrier → bookkeeping
+  // (beside the stream wave's work), with early_book (wave-uniform) the other way round.
+  auto publish = [&]() {
+    if (rgb && live)
+      post2[slot] = make_uint4((uint32_t)s.queue, (uint32_t)((s.queue >> 32) & 0x00FFFFFFu) | ((uint32_t)(s.hp & 0xFF) << 24),
+                               (uint32_t)(s.hr & 0xFF) | ((uint32_t)(s.hv & 0xFF) << 8), 0u);
+    // the payload work of this lane's env for the stream wave
+    const bool show = live && (RULESET == TG_RULESET_NUMPY ? !final_coll : !(s.flags & TG_F_GAME_OVER));
+    uint32_t ocells;
+    if (RULESET == TG_RULESET_NUMPY) {
+      // the piece's table word is already here — unless a reset has just drawn the piece: a new episode starts at
+      // rotation 0, whose cells are compile-time constants (no table round trip in front of the barrier)
+      ocells = rot16(tcelF, s.rot);
+      if (do_reset) ocells = (uint32_t)((s.piece < 4 ? kCells0Lo : kCells0Hi) >> (16 * (s.piece & 3))) & 0xFFFFu;
+    } else {
+      ocells = lane_cells(cell_tab_l, s.piece, s.rot);
     }
-    if (pass == 0) {
-      if (rgb && live)
-        post2[slot] = make_uint4((uint32_t)s.queue, (uint32_t)((s.queue >> 32) & 0x00FFFFFFu) | ((uint32_t)(s.hp & 0xFF) << 24),
-                                 (uint32_t)(s.hr & 0xFF) | ((uint32_t)(s.hv & 0xFF) << 8), 0u);
-      // publish the payload work of this lane's env to the stream wave
-      const bool show = live && (RULESET == TG_RULESET_NUMPY ? !final_coll : !(s.flags & TG_F_GAME_OVER));
-      uint32_t ocells;
-      if (RULESET == TG_RULESET_NUMPY) {  // (the piece's table word is already here unless a reset has just drawn it)
-        ocells = rot16(tcelF, s.rot);
-        if (__any(do_reset)) {
-          const uint32_t oc2 = lane_cells(cell_tab_l, s.piece, s.rot);
-          if (do_reset) ocells = oc2;
+    if (live) post[(step & 1) * EPW + slot] = make_uint4(lock_cells | ((uint32_t)(lock_val & 0xFF) << 16) | ((place ? 1u : 0u) << 24) |
+                                ((do_clear ? 1u : 0u) << 25) | ((do_reset ? 1u : 0u) << 26),
+                            (uint32_t)(lock_x & 0xFF) | ((uint32_t)(lock_y & 0xFF) << 8),
+                            ocells | ((uint32_t)(s.val & 0xFF) << 16) | ((show ? 1u : 0u) << 24),
+                            (uint32_t)(s.x & 0xFF) | ((uint32_t)(s.y & 0xFF) << 8) | ((uint32_t)(s.piece & 0xFF) << 16));
+#ifdef TG_FINE_LOCK
+    TG_BITS_STAMP(7);
+#else
+    TG_BITS_STAMP(5);
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+  };
+  auto bookkeeping = [&]() {
+    // ---- bookkeeping: the owed pops in order (TetrominoQueue.get_next_tetromino, components/tetromino_queue.py:35-42),
+    // then the reset's randomizer / queue / holder state ----
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {
+      const bool on = k < npop;
+      if (!__any(on)) break;
+      (void)queue_pop(on);
+    }
+    if (__any(do_reset)) {
+      if (do_reset) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) colsL[1 + c] = FLOOR;
+      }
+      consume_perm(do_reset, true);  // tetromino_queue.py:23-33, tetromino_randomizer.py:87-91
+      if (Q <= 5) {
+        // Q draws fill the queue, the pop takes its head and draws one more: Q + 1 <= 6 draws never wrap the fresh bag
+        if (do_reset) {
+          s.piece = (int)(s.bag & 0xFF);
+          s.queue = (s.bag >> 8) & ((1ULL << (8 * Q)) - 1ULL);
+          s.bidx = Q + 1;
         }
       } else {
-        ocells = lane_cells(cell_tab_l, s.piece, s.rot);
+        if (do_reset) s.queue = 0;
+        for (int i = 0; i < Q; ++i) {
+          const int t = randomizer_next(do_reset);
+          if (do_reset) s.queue |= (uint64_t)t << (8 * i);
+        }
+        const int first = queue_pop(do_reset);
+        if (do_reset) s.piece = first;
       }
-      if (live) post[(step & 1) * EPW + slot] = make_uint4(lock_cells | ((uint32_t)(lock_val & 0xFF) << 16) | ((place ? 1u : 0u) << 24) |
-                                  ((do_clear ? 1u : 0u) << 25) | ((do_reset ? 1u : 0u) << 26),
-                              (uint32_t)(lock_x & 0xFF) | ((uint32_t)(lock_y & 0xFF) << 8),
-                              ocells | ((uint32_t)(s.val & 0xFF) << 16) | ((show ? 1u : 0u) << 24),
-                              (uint32_t)(s.x & 0xFF) | ((uint32_t)(s.y & 0xFF) << 8) | ((uint32_t)(s.piece & 0xFF) << 16));
-#ifdef TG_FINE_LOCK
-      TG_BITS_STAMP(7);
-#else
-      TG_BITS_STAMP(5);
-#endif
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-      __builtin_amdgcn_s_barrier();
+      if (do_reset) {
+        s.x = np_spawn_x<W>(s.piece);
+        s.rot = 0; s.y = 0; s.val = s.piece + 2;
+        s.hp = TG_NONE; s.hr = 0; s.hv = 0;
+        s.flags = 0;
+        s.score = 0.0f;
+      }
     }
+  };
+  const bool book_first = RULESET == TG_RULESET_NUMPY && early_book;
+  if constexpr (MULTI) {
+    // (the kernels with the transition loop are at their register budget: one publish site, two passes)
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      if (RULESET == TG_RULESET_NUMPY && (pass == 0) == book_first) bookkeeping();
+      if (pass == 0) publish();
+    }
+  } else {
+    if (!book_first) publish();
+    if (RULESET == TG_RULESET_NUMPY) bookkeeping();
+    if (book_first) publish();
   }
   if (pending) {  // the NEXT_STEP reset step belongs to no episode (gymnasium RecordEpisodeStatistics)
     ep.ret = 0.0f; ep.len = 0;
