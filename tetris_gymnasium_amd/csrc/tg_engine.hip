@@ -88,12 +88,20 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
   if (p.cols) {  // "bits": the handle carries the column masks / look-ahead permutations
     using BG = tg::BitsGeo<W, H>;
     const int nrb = (RS == TG_RULESET_NUMPY && p.rng_role) ? (p.batch + 127) / 128 : 0;  // RNG-role workgroups (tg_kernel_bits.h)
-    const tg::BitsParams bp{p.cols, p.ahead, p.ring, p.hbuf, p.ring_cur, p.hbuf_cur, nrb, p.ring_stride, p.ring_fill};
-    const dim3 grid(nrb + (p.batch + BG::EPW - 1) / BG::EPW);
+    const uint4* const ring4 = reinterpret_cast<const uint4*>(p.ring);
+    const tg::BitsParams bp{p.cols, p.ahead,
+                            ring4 + (size_t)p.ring_cur * p.ring_stride, const_cast<uint4*>(ring4) + (size_t)(1 - p.ring_cur) * p.ring_stride,
+                            p.hbuf + (size_t)p.hbuf_cur * p.ring_stride, p.hbuf + (size_t)(1 - p.hbuf_cur) * p.ring_stride,
+                            nrb, p.ring_fill};
+    const int n_step_wgs = (p.batch + BG::EPW - 1) / BG::EPW;
+    const dim3 grid(nrb + n_step_wgs);
     constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
     const int feat = bits_feat<W, H, RS>(p);
     const size_t lds = (feat & D) ? BG::BYTES_DICT : ((feat & R) ? BG::BYTES_RGB : ((feat & F) ? BG::BYTES_FIN : BG::BYTES));
-#define TG_LAUNCH_BITS(FT) hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(128), lds, s, p, bp)
+#define TG_LAUNCH_BITS(FT)                                                                                                  \
+  hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(128), lds, s, p.board, p.rec, p.cols, bp.ring_rd, bp.hbuf_rd, \
+                     p.actions, p.batch, (uint32_t)n_step_wgs | ((p.act_i8 ? 1u : 0u) << 20) | ((uint32_t)(p.nsteps > 0 ? p.nsteps : 0) << 21), \
+                     p, bp)
     if (feat == F) { TG_LAUNCH_BITS(F); return; }
     if (feat == (M | T | F)) { TG_LAUNCH_BITS(M | T | F); return; }
     if constexpr (RS == TG_RULESET_NUMPY) {

@@ -55,6 +55,20 @@ constexpr ColTable make_col_table() {
 
 __constant__ ColTable c_colmasks = make_col_table();
 
+// every column of every piece in every rotation is one vertical run of cells (what the drop below relies on)
+constexpr bool cols_are_runs() {
+  const ColTable t = make_col_table();
+  for (int p = 0; p < 7; ++p)
+    for (int i = 0; i < 16; ++i) {
+      uint32_t n = (uint32_t)(t.cols[p] >> (4 * i)) & 0xFu;
+      if (n == 0) continue;
+      while ((n & 1u) == 0) n >>= 1;
+      if ((n & (n + 1u)) != 0) return false;
+    }
+  return true;
+}
+static_assert(cols_are_runs(), "drop_row_of tests only the lowest cell of a piece column");
+
 // cells of every piece at rotation 0 (16 bits each, c_cells' encoding) as two immediates: what a fresh episode shows
 constexpr uint64_t cells_rot0(const int first) {
   const CellTable t = make_cell_table();
@@ -193,13 +207,16 @@ __device__ __forceinline__ uint64_t bits_apply_perm(const uint32_t sig, const ui
 struct BitsParams {
   void* cols;      // ColT [B][W]
   uint4* ahead;    // [B][4 slots][2]: generator state AFTER the slot's shuffle {state_lo, state_hi} {uinteger, has32, 0, 0}
-  uint64_t* ring;  // [2 parities][B][2]: word 0 = permutations of slots 0 | 1 << 28 (7 nibbles each) | T << 56,
-                   //                      word 1 = slots 2 | 3 << 28
-  uint8_t* hbuf;   // [2 parities][B]: H (bits 0-6) | inl << 7 (the state after entry H - 1 is in tg_rng_rec, not in `ahead`)
-  int cur;         // ring parity this launch reads; the RNG role writes 1 - cur (flips only in launches that carry the RNG role)
-  int hcur;        // consumed-counter parity this launch reads; the logic wave writes 1 - hcur (flips every launch)
-  int nrb;         // number of leading RNG workgroups (kRngEnvs envs each)
-  uint32_t pstride;  // elements between the two parities of ring / hbuf (the handle's whole batch)
+  // ring [2 parities][B][2 x u64]: word 0 = permutations of slots 0 | 1 << 28 (7 nibbles each) | T << 56, word 1 = slots
+  // 2 | 3 << 28.  The launch reads one parity and its RNG role writes the other (it flips only with launches that carry
+  // the RNG role); the host passes both as pointers — the parity arithmetic stood between the logic wave's first loads.
+  const uint4* ring_rd;
+  uint4* ring_wr;
+  // hbuf [2 parities][B]: H (bits 0-6) | inl << 7 (the state after entry H - 1 is in tg_rng_rec, not in `ahead`); read
+  // parity / the parity the logic wave writes (flips every launch)
+  const uint8_t* hbuf_rd;
+  uint8_t* hbuf_wr;
+  int nrb;         // number of RNG workgroups (kRngEnvs envs each)
   int fill;          // entries the RNG role keeps ahead in a ring (kRing - 1; tests lower it to exercise the consumer's in-line shuffle)
 };
 
@@ -517,7 +534,15 @@ template <int W, int H, int RULESET, int FEAT>
 #ifndef TG_ONE_WAVES
 #define TG_ONE_WAVES 4  // waves per SIMD the one-transition kernels are compiled for (4 → 128 VGPRs, 3 → 168)
 #endif
-__global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kFeatSample)) ? 3 : 4) : TG_ONE_WAVES) void step_kernel_bits(const KParams p, const BitsParams bp) {
+__global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kFeatSample)) ? 3 : 4) : TG_ONE_WAVES) void step_kernel_bits(
+    // The arguments every wave needs BEFORE its first global loads, as scalars: the first 14 dwords of the kernel-argument
+    // segment are preloaded into SGPRs by the dispatcher (-mllvm -amdgpu-kernarg-preload-count=16, 14 user SGPRs are free;
+    // struct arguments are not eligible), so the slab / record / ring loads leave without waiting for a scalar load of
+    // the argument block (a memory round trip at the start of every workgroup).  The structs arrive in their shadow.
+    uint8_t* const hot_board, uint32_t* const hot_rec, void* const hot_cols, const uint4* const hot_ring_rd,
+    const uint8_t* const hot_hbuf_rd, const void* const hot_actions, const int hot_batch,
+    const uint32_t hot_misc,  // step workgroups (bits 0-19) | act_i8 << 20 | nsteps << 21
+    const KParams p, const BitsParams bp) {
   constexpr bool MULTI = (FEAT & kFeatMulti) != 0, TRAJ = (FEAT & kFeatTraj) != 0, DICTK = (FEAT & kFeatDict) != 0,
                  SAMPLE = (FEAT & kFeatSample) != 0, FINAL = (FEAT & kFeatFinal) != 0, RGBK = (FEAT & kFeatRgb) != 0;
   using BG = BitsGeo<W, H>;
@@ -535,7 +560,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   const int lane = threadIdx.x & 63;
   const int wave = rfl((int)(threadIdx.x >> 6));
 
-  const uint32_t B = (uint32_t)p.batch;
+  const uint32_t B = (uint32_t)hot_batch;
   // role split by blockIdx: the RNG workgroups lead (placing them last measured the same)
 #ifdef TG_RNG_FIRST
   const bool rng_role = (int)blockIdx.x < bp.nrb;
@@ -543,7 +568,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
 #else
   // the step workgroups are dispatched first (a grid of this size starts first → last within 0.3-0.7 us, and the step
   // workgroups are the longer pole since the RNG role produces one entry per launch)
-  const uint32_t n_step = gridDim.x - (uint32_t)bp.nrb;
+  const uint32_t n_step = hot_misc & 0xFFFFFu;
   const bool rng_role = blockIdx.x >= n_step;
   const uint32_t step_block = blockIdx.x, rng_block = blockIdx.x - n_step;
 #endif
@@ -552,9 +577,17 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   const bool live = (uint32_t)lane < nlive;
   const int slot = live ? lane : (int)nlive - 1;  // dead lanes shadow the last live env (identical, benign LDS writes)
   const uint32_t env = base_env + (uint32_t)slot;
-  const bool need_slab = p.obs_mode == TG_OBS_BOARD || p.obs_mode == TG_OBS_FN;
-  const bool dict = DICTK && BG::DICT_OK && p.obs_mode == TG_OBS_DICT && p.dict_in_kernel;
-  const bool rgb = RGBK && BG::RGB_OK && p.obs_mode == TG_OBS_RGB && p.dict_in_kernel;
+  // What depends on the argument structs (they arrive by scalar loads) is derived in each wave BEHIND its first global
+  // loads: the first use of any struct word is where the wave waits for all of them.
+#define TG_LATE_ARGS()                                                                                            \
+  const bool need_slab = p.obs_mode == TG_OBS_BOARD || p.obs_mode == TG_OBS_FN;                                   \
+  const bool dict = DICTK && BG::DICT_OK && p.obs_mode == TG_OBS_DICT && p.dict_in_kernel;                        \
+  const bool rgb = RGBK && BG::RGB_OK && p.obs_mode == TG_OBS_RGB && p.dict_in_kernel;                            \
+  uint8_t* const obs_traj = TRAJ ? p.obs_traj : nullptr;                                                          \
+  uint2* const out_traj = TRAJ ? p.out_traj : nullptr;                                                            \
+  int8_t* const act_traj = TRAJ ? p.act_traj : nullptr;                                                           \
+  uint8_t* const final_obs = FINAL ? p.final_obs : nullptr;                                                       \
+  (void)need_slab; (void)dict; (void)rgb; (void)obs_traj; (void)out_traj; (void)act_traj; (void)final_obs
   uint4* post2 = reinterpret_cast<uint4*>(lds + BG::OFF_RGB);                      // (RGB instantiations only)
   const uint32_t* lut_l = reinterpret_cast<const uint32_t*>(lds + BG::OFF_TAB + 256);  // colour table (RGB)
   constexpr int ELOG = EPW / 2;  // RGB: the logic wave packs the envs below, the stream wave those from ELOG on
@@ -562,12 +595,10 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   // p.nsteps consecutive transitions in this launch (tg_step_k): records / masks / slabs stay in registers and LDS in
   // between, only actions come in and observations go out per transition; one s_barrier per transition, and the
   // stream wave packs transition k while the logic wave already decides transition k + 1
-  const int nsteps = MULTI ? (p.nsteps > 1 ? p.nsteps : 1) : 1;
-  uint8_t* const obs_traj = TRAJ ? p.obs_traj : nullptr;
-  uint2* const out_traj = TRAJ ? p.out_traj : nullptr;
-  int8_t* const act_traj = TRAJ ? p.act_traj : nullptr;
-  const bool sample_mode = SAMPLE && p.sample_mode;
-  uint8_t* const final_obs = FINAL ? p.final_obs : nullptr;
+  const int hot_nsteps = (int)(hot_misc >> 21);
+  const bool hot_act_i8 = ((hot_misc >> 20) & 1u) != 0;
+  const int nsteps = MULTI ? (hot_nsteps > 1 ? hot_nsteps : 1) : 1;
+  const bool sample_mode = SAMPLE && p.sample_mode;  // (device-side action sampling: the kernels that carry it wait here)
 
 #ifdef TG_PHASE_TIMING
   unsigned long long tstamp[8];  // kept in SGPRs and written at the very end: a store per stamp would itself be waited on
@@ -600,9 +631,9 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     const uint32_t e = rng_block * 128u + threadIdx.x;
     const bool on = e < B;
     const uint32_t ee = on ? e : B - 1u;
-    const uint4 rw = reinterpret_cast<const uint4*>(bp.ring)[(size_t)bp.cur * bp.pstride + ee];
+    const uint4 rw = hot_ring_rd[ee];
     uint64_t w0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32), w1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
-    const int Hraw = bp.hbuf[(size_t)bp.hcur * bp.pstride + ee];
+    const int Hraw = hot_hbuf_rd[ee];
     const int Hn = Hraw & 0x7F;
     const bool inl = (Hraw & 0x80) != 0;
 #ifndef TG_RNG_PRIO
@@ -652,7 +683,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       }
     }
     if (on) {
-      u32x4* rdst = reinterpret_cast<u32x4*>(bp.ring) + (size_t)(1 - bp.cur) * bp.pstride + e;
+      u32x4* rdst = reinterpret_cast<u32x4*>(bp.ring_wr) + e;
       const u32x4 rv = u32x4{(uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32)};
 #ifdef TG_RING_PLAIN
       *rdst = rv;
@@ -688,10 +719,9 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     const uint32_t nchunks = (nbytes + 15u) / 16u;
     uint64_t tab_cells = 0;
     if (lane < 7) tab_cells = c_cells.cells[lane];
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);  // TG_STAGGER: let the logic waves' small loads go first
     u32x4 stage[NIT];
     {
-      const u32x4* gsrc = reinterpret_cast<const u32x4*>(p.board + (size_t)base_env * S);
+      const u32x4* gsrc = reinterpret_cast<const u32x4*>(hot_board + (size_t)base_env * S);
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
         const uint32_t c = (uint32_t)lane + 64u * k;
@@ -713,6 +743,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       }
     }
     TG_BITS_STAMP(1);
+    TG_LATE_ARGS();
     // One transition per launch, full workgroup: the slab block stays in the staging registers as it was loaded (B0) and
     // the board write-back stores exactly the chunks whose bytes changed (a lock: one or two of an env's 13) — a compare
     // per chunk instead of index arithmetic, and fewer store instructions in the launch's tail.
@@ -784,7 +815,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     if (last && __any(dirty_any)) {
 #ifdef TG_WB_PER_LANE
       // board write-back: every changed env's lane copies its own slab (8-byte aligned in LDS and in HBM)
-      if (dirty_any) bits_copy_slab<S, false>(bd.my, p.board + (size_t)env * S);
+      if (dirty_any) bits_copy_slab<S, false>(bd.my, hot_board + (size_t)env * S);
 #else
       // board write-back, chunk-major: lane l of pass k owns the 16-byte chunk l + 64 k of the workgroup's slab block and
       // stores it when it holds bytes of a changed env.  Neighbouring lanes write neighbouring chunks, so a changed
@@ -792,7 +823,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       // bound by line operations, not bytes).  A chunk shared with an unchanged neighbour rewrites that env's bytes as
       // they are.
       const uint64_t dm = __ballot(dirty_any);
-      u32x4* bdst = reinterpret_cast<u32x4*>(p.board + (size_t)base_env * S);
+      u32x4* bdst = reinterpret_cast<u32x4*>(hot_board + (size_t)base_env * S);
       if (keep_b0) {
         u32x4 wv[NIT];
 #pragma unroll
@@ -1003,10 +1034,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   if ((DICTK || RGBK) && lane < 7)
     tab_rows = (uint64_t)c_shapes.mask[lane][0] | ((uint64_t)c_shapes.mask[lane][1] << 16) |
                ((uint64_t)c_shapes.mask[lane][2] << 32) | ((uint64_t)c_shapes.mask[lane][3] << 48);
-  if (dict)  // the mask staging buffer starts all zero (the groups un-stamp what they stamp)
-    for (int i = lane * 16; i < BG::GD * BG::PC; i += 1024)
-      *reinterpret_cast<uint4*>(lds + BG::OFF_DICT + BG::GD * BG::PC + i) = make_uint4(0u, 0u, 0u, 0u);
-  const uint4* rec4 = reinterpret_cast<const uint4*>(p.rec) + (size_t)env * 2;
+  const uint4* rec4 = reinterpret_cast<const uint4*>(hot_rec) + (size_t)env * 2;
   const uint4 ra = rec4[0], rb = rec4[1];
   // FUNCTIONAL: the jax key travels with the first loads (fetched lazily at the first lock it was a dependent memory
   // round trip in the middle of the decision logic of practically every wave)
@@ -1017,31 +1045,28 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   int action0 = 0;
   if (sample_mode) {
     // (actions are drawn per transition below)
-  } else if (p.act_i8) {
+  } else if (hot_act_i8) {
     uint8_t ab[8];  // unconditional loads (row index clamped): all in flight together, no wait between them
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      ab[k] = reinterpret_cast<const uint8_t*>(p.actions)[(size_t)(k < nsteps ? k : nsteps - 1) * p.act_stride + env];
+      ab[k] = reinterpret_cast<const uint8_t*>(hot_actions)[(size_t)(k < nsteps ? k : nsteps - 1) * p.act_stride + env];
 #pragma unroll
     for (int k = 0; k < 8; ++k) apack |= (uint64_t)ab[k] << (8 * k);
   } else {
-    action0 = reinterpret_cast<const int32_t*>(p.actions)[env];
+    action0 = reinterpret_cast<const int32_t*>(hot_actions)[env];
   }
-  // (unconditional load, from the record when there is no statistics buffer: a branch here makes the compiler wait for
-  // the load before it issues the ones below — two memory round trips instead of one)
-  tg_episode_rec ep = *(p.episode ? p.episode + env : reinterpret_cast<const tg_episode_rec*>(rec4));
   uint64_t ring0 = 0, ring1 = 0;
   int Hc = 0;
   if (RULESET == TG_RULESET_NUMPY) {
-    const uint4 rw = reinterpret_cast<const uint4*>(bp.ring)[(size_t)bp.cur * bp.pstride + env];
+    const uint4 rw = hot_ring_rd[env];
     ring0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32);
     ring1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
-    Hc = bp.hbuf[(size_t)bp.hcur * bp.pstride + env];  // H | inl << 7, split below
+    Hc = hot_hbuf_rd[env];  // H | inl << 7, split below
   }
   T cv[W];
   {
     constexpr int NP = (int)(W * sizeof(T) / 8);
-    const uint2* gc = reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(bp.cols) + (size_t)env * W);
+    const uint2* gc = reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(hot_cols) + (size_t)env * W);
     uint2 raw[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) raw[k] = gc[k];
@@ -1051,6 +1076,15 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       else cv[c] = (T)raw[c].x | ((T)raw[c].y << 32);
     }
   }
+  // Episode statistics: the LAST of the first loads — its pointer is not among the preloaded arguments, and nothing needs
+  // the value before the barrier.  (Unconditional, from the record when there is no statistics buffer: a branch would
+  // make the compiler wait for the load right here.)
+  __builtin_amdgcn_sched_barrier(0);  // (the scheduler would lift the pointer test — and with it the wait — above the loads)
+  tg_episode_rec ep = *(p.episode ? p.episode + env : reinterpret_cast<const tg_episode_rec*>(rec4));
+  TG_LATE_ARGS();
+  if (dict)  // the mask staging buffer starts all zero (the groups un-stamp what they stamp)
+    for (int i = lane * 16; i < BG::GD * BG::PC; i += 1024)
+      *reinterpret_cast<uint4*>(lds + BG::OFF_DICT + BG::GD * BG::PC + i) = make_uint4(0u, 0u, 0u, 0u);
   // private copies of the two piece tables for this wave (the stream wave fills cell_tab for itself after its loads)
   uint64_t* cell_tab_l = col_tab + 8;
   if (lane < 7) { cell_tab_l[lane] = tab_cells; col_tab[lane] = tab_cols; }
@@ -1135,7 +1169,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
 
   bool cols_dirty_any = false;
   for (int step = 0; step < nsteps; ++step) {
-  int action_in = p.act_i8 ? (int)(int8_t)(apack >> (8 * step)) : action0;
+  int action_in = hot_act_i8 ? (int)(int8_t)(apack >> (8 * step)) : action0;
   if (RULESET == TG_RULESET_NUMPY && sample_mode) {
     // uniform over the legal placements of the CURRENT piece (wrappers/grouped.py:104-122: legal = inside the frame).
     // Legal columns of a rotation form a range [lo_r, hi_r]; actions are ordered column-major, rotation-minor; the
@@ -1305,13 +1339,26 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   // "piece at row r collides" for every r at once: OR over the piece's cells (k, i) of (column i >> k); the
   // reference's drop loop `while not collision(y + 1): y += 1` (envs/tetris.py:445-448, functional/core.py:243-249)
   // ends at the first blocked row below y
-  auto drop_row_of = [&](const uint32_t P, const int y) -> int {
+  // From a position that does not collide only the LOWEST cell of each piece column can be the first to hit something
+  // (the cells above it move through rows the piece has just left; a column's cells are one run, static_assert above):
+  // 6 terms instead of 24.  `all_cells` = the literal OR over every cell, for a start that already collides (reachable
+  // only through tg_set_state).
+  auto drop_row_of = [&](const uint32_t P, const int y, const bool all_cells) -> int {
     T bm = 0;
+    if (all_cells) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const uint32_t n = (P >> (4 * i)) & 0xFu;
+      for (int i = 0; i < 6; ++i) {
+        const uint32_t n = (P >> (4 * i)) & 0xFu;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) bm |= ((n >> k) & 1u) ? (T)(w[i] >> k) : T(0);
+        for (int k = 0; k < 4; ++k) bm |= ((n >> k) & 1u) ? (T)(w[i] >> k) : T(0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const uint32_t n = (P >> (4 * i)) & 0xFu;
+        const int kb = 31 - (int)__builtin_clz(n | 1u);  // lowest cell of the column = highest bit of the nibble
+        bm |= n ? (T)(w[i] >> kb) : T(0);
+      }
     }
     const int sh = y + 1 < (int)(8 * sizeof(T)) - 1 ? y + 1 : (int)(8 * sizeof(T)) - 1;
     return y + ctz_t((T)((bm | (T(1) << (8 * sizeof(T) - 1))) >> sh));
@@ -1323,7 +1370,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   int frot = s.rot;                 // ... and its rotation (for the uint8 stamp)
   if (RULESET == TG_RULESET_FUNCTIONAL) {
     // functional/core.py:230-251 hard_drop: step-wise, stops at the first blocked row below y
-    const int yd = drop_row_of(PC, s.y);
+    const int yd = drop_row_of(PC, s.y, __any(hard && cC));
     if (hard) {
       drop_reward = 2 * (yd - s.y);
       s.y = yd;
@@ -1366,7 +1413,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       if (dead) { s.flags |= TG_F_GAME_OVER; reward = 0.0f; }
       place = lock && !coll_here;
       {  // (no wave-uniform branch: 1 action in 8 is a hard drop, some lane always takes it)
-        const int yd = drop_row_of(PF, s.y);  // :445-448 (only hard drops can still move)
+        const int yd = drop_row_of(PF, s.y, false);  // :445-448 (only hard drops can still move; `place` = not colliding)
         if (place && hard) s.y = yd;
       }
     }
@@ -1384,6 +1431,33 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     T v[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) v[c] = colsL[1 + c];
+    // spawn the next piece (needs none of the columns: it runs while the reads above are on their way)
+    if (RULESET == TG_RULESET_NUMPY) {
+      const int np_ = npop ? up1 : up0;  // envs/tetris.py:393-401 (TetrominoQueue.get_next_tetromino: the pop is owed)
+      if (place) {
+        tcolN = npop ? tcol1 : tcol0; tcelF = npop ? tcel1 : tcel0;
+        s.piece = np_; s.rot = 0; s.val = np_ + 2; s.x = np_spawn_x<W>(np_); s.y = 0;
+        npop += 1;
+      }
+    }
+    if (RULESET != TG_RULESET_NUMPY) {  // envs/tetris_fn.py:370-413 place_active_tetromino
+      lane_rng_ensure(r);
+      uint32_t a0, a1, b0, b1;
+      threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);  // split(rng_key)[0]
+      const bool refill = place && s.bidx >= 7;
+      if (__any(refill)) {
+        threefry2x32(r.k0, r.k1, 0u, 1u, b0, b1);  // split(rng_key)[1] (functional/queue.py:59-67)
+        const uint64_t nb = jax_permutation7(b0, b1);
+        if (refill) { s.bag = nb; s.bidx = 0; }
+      }
+      if (place) {
+        s.piece = (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
+        s.bidx += 1;
+        r.k0 = a0; r.k1 = a1;
+        r.dirty = true;
+        s.rot = 0; s.val = s.piece + 2; s.x = (W + 8) / 2 - 2; s.y = 0;
+      }
+    }
     T full = PLAY;
 #pragma unroll
     for (int c = 0; c < W; ++c) full &= v[c];
@@ -1411,32 +1485,6 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       }
     }
     if (place) s.flags &= ~TG_F_FULLROW;
-    // spawn the next piece
-    if (RULESET == TG_RULESET_NUMPY) {
-      const int np_ = npop ? up1 : up0;  // envs/tetris.py:393-401 (TetrominoQueue.get_next_tetromino: the pop is owed)
-      if (place) {
-        tcolN = npop ? tcol1 : tcol0; tcelF = npop ? tcel1 : tcel0;
-        s.piece = np_; s.rot = 0; s.val = np_ + 2; s.x = np_spawn_x<W>(np_); s.y = 0;
-        npop += 1;
-      }
-    } else {  // envs/tetris_fn.py:370-413 place_active_tetromino
-      lane_rng_ensure(r);
-      uint32_t a0, a1, b0, b1;
-      threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);  // split(rng_key)[0]
-      const bool refill = place && s.bidx >= 7;
-      if (__any(refill)) {
-        threefry2x32(r.k0, r.k1, 0u, 1u, b0, b1);  // split(rng_key)[1] (functional/queue.py:59-67)
-        const uint64_t nb = jax_permutation7(b0, b1);
-        if (refill) { s.bag = nb; s.bidx = 0; }
-      }
-      if (place) {
-        s.piece = (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
-        s.bidx += 1;
-        r.k0 = a0; r.k1 = a1;
-        r.dirty = true;
-        s.rot = 0; s.val = s.piece + 2; s.x = (W + 8) / 2 - 2; s.y = 0;
-      }
-    }
     // collision of the new piece at its spawn position (rows 0..3 of the columns it spans; static columns)
     bool sc;
     {
@@ -1710,7 +1758,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   const bool cols_dirty = cols_dirty_any;
   uint4 oa, ob;
   lane_pack(s, oa, ob);
-  uint4* rec_out = reinterpret_cast<uint4*>(p.rec) + (size_t)env * 2;
+  uint4* rec_out = reinterpret_cast<uint4*>(hot_rec) + (size_t)env * 2;
   if (live && !TG_SKIP(4)) {
     TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out), (u32x4{oa.x, oa.y, oa.z, oa.w}));
     if (p.episode) p.episode[env] = ep;
@@ -1720,7 +1768,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
 #pragma unroll
     for (int c = 0; c < W; ++c) nv[c] = (T)(colsL[1 + c] & PLAY);
     if (cols_dirty && !TG_SKIP(8)) {
-      uint2* gc = reinterpret_cast<uint2*>(reinterpret_cast<T*>(bp.cols) + (size_t)env * W);
+      uint2* gc = reinterpret_cast<uint2*>(reinterpret_cast<T*>(hot_cols) + (size_t)env * W);
       if constexpr (sizeof(T) == 4) {
 #pragma unroll
         for (int k = 0; k < W / 2; ++k) TG_ST_COLS(reinterpret_cast<u32x2*>(gc + k), (u32x2{(uint32_t)nv[2 * k], (uint32_t)nv[2 * k + 1]}));
@@ -1736,7 +1784,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
 #endif
   // ---- E: consumed counter; the generator state only after an in-line shuffle (otherwise `ahead` holds it) ----
   if (RULESET == TG_RULESET_NUMPY) {
-    if (live) bp.hbuf[(size_t)(1 - bp.hcur) * bp.pstride + env] = (uint8_t)(Hc | (inl ? 0x80 : 0));
+    if (live) bp.hbuf_wr[env] = (uint8_t)(Hc | (inl ? 0x80 : 0));
     if (live && g_valid) {
       uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
       rng_out[0] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));

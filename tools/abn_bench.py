@@ -25,7 +25,7 @@ for a in sys.argv[1:]:
     envs[tag] = dict(x.split("=", 1) for x in kv)
 procs = []
 for tag, src, flags in variants:
-    procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=16",
                                    "-DTG_FOR_EACH_SIZE(X)=X(10,20)", f"-I{os.path.join(ROOT, 'tetris_gymnasium_amd', 'csrc')}", *flags,
                                    "-shared", "-o", f"/tmp/libtg_{tag}.so", os.path.join(src, "tg_engine.hip")],
                                   stderr=subprocess.DEVNULL))
