@@ -8,9 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 src = os.path.join(ROOT, os.environ.get("TL_SRC", "tetris_gymnasium_amd/csrc"), "tg_engine.hip")  # TL_SRC: another source tree (_ab/<tag>)
 out = "/tmp/libtg_phase.so"
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-DTG_PHASE_TIMING",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-DTG_PHASE_TIMING", "-DTG_STAMP_REALTIME",
                        "-DTG_FOR_EACH_SIZE(X)=X(10,20)", "-I" + os.path.join(ROOT, "tetris_gymnasium_amd", "csrc"), *sys.argv[1:], "-shared", "-o", out, src])
-os.environ.setdefault('TG_FUSE', '1')  # steady state of one transition per launch (a fused warm-up leaves an RNG backlog)
+os.environ.setdefault('TG_FUSE', '1')
+os.environ.setdefault('TG_RNG_EVERY', '1')  # the stamped launch carries the RNG-role workgroups (they ride on every third launch otherwise)  # steady state of one transition per launch (a fused warm-up leaves an RNG backlog)
 from tetris_gymnasium_amd import _native as N
 N.LIB_PATH = out
 from tetris_gymnasium_amd import Engine
@@ -32,6 +33,8 @@ assert e.lib.tg_debug_phase_times(e.h, buf.ctypes.data_as(C.c_void_p), B // 16) 
 tl = buf[:nb, 0:8].astype(np.int64)    # logic wave stamps 0..7
 ts = buf[:nb, 8:13].astype(np.int64)   # stream wave stamps 0..4
 rb = buf.reshape(-1)[nb * 16: nb * 16 + nr * 4].reshape(nr, 2, 2).astype(np.int64)  # [rng block][wave][start, end]
+if os.environ.get('TL_DEBUG'):
+    print('min/max per logic stamp', tl.min(axis=0), tl.max(axis=0)); print('stream', ts.min(axis=0), ts.max(axis=0)); print('rng', rb.min(), rb.max(), (rb == 0).sum())
 step_blk = np.arange(nb)        # blockIdx of step workgroup i (the step workgroups lead the grid)
 rng_blk = np.arange(nr) + nb
 names_l = ["start", "loads done", "window read", "decided", "lock done", "published", "stores done", "end"]
