@@ -264,7 +264,8 @@ __device__ __forceinline__ void st_dict(V* dst, const V v) {
 #define TG_STATE_ST 1
 #endif
 // TG_EXP_SKIP (bit mask, timing ablations only — the results are wrong): 1 observation stores, 2 board write-back,
-// 4 record stores, 8 column-mask stores, 16 output store
+// 4 record stores, 8 column-mask stores, 16 output store, 64 the whole observation block of the stream wave, 128 its
+// lock / clear / reset block, 256 the un-draw between the transitions of a launch, 512 the logic wave's bookkeeping
 #ifndef TG_EXP_SKIP
 #define TG_EXP_SKIP 0
 #endif
@@ -759,6 +760,19 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     bool dirty_any = false;  // this lane's env changed its slab in some transition of the launch
     for (int step = 0; step < nsteps; ++step) {
     const bool last = step == nsteps - 1;
+#ifdef TG_PHASE_TIMING
+#ifdef TG_FINE_FUSED_STREAM  // the stream wave's transition nsteps - 2 (no write-back in it): 1 top, 2 barrier passed,
+                             // 3 lock block done, 4 observation stored, 0 un-drawn (end of the iteration)
+#define TG_FS(i) do { if (step == nsteps - 2) TG_BITS_STAMP(i); } while (0)
+    TG_FS(1);
+#else
+#define TG_FS(i) do {} while (0)
+    if (MULTI && last && step > 0) TG_BITS_STAMP(1);  // launches of several transitions: the stamps describe the LAST one
+#endif
+#endif
+#ifndef TG_FS
+#define TG_FS(i) do {} while (0)
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();  // the logic wave has published what happened to every env in this transition
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -767,14 +781,18 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     // logic waves of other workgroups on this SIMD are the longer pole: measured 11.4 us with the swap, 10.65 without)
     if (RULESET == TG_RULESET_NUMPY) __builtin_amdgcn_s_setprio(3);
 #endif
+#ifdef TG_FINE_FUSED_STREAM
+    TG_FS(2);
+#else
     TG_BITS_STAMP(2);
+#endif
     // post record of this lane's env: x = lock {cells | val << 16 | place << 24 | clear << 25 | reset << 26},
     // y = lock {x | y << 8}, z = observation {cells | val << 16 | show << 24}, w = observation {x | y << 8}
     const uint4 po = post[(step & 1) * EPW + slot];
     const bool place = live && ((po.x >> 24) & 1u), do_clear = live && ((po.x >> 25) & 1u), do_reset = live && ((po.x >> 26) & 1u);
     const bool dirty = place || do_reset;
     dirty_any = dirty_any || dirty;
-    if (__any(dirty)) {
+    if (__any(dirty) && !TG_SKIP(128)) {
       bd.stamp(po.x & 0xFFFFu, (int)(po.y & 0xFFu), (int)((po.y >> 8) & 0xFFu), (po.x >> 16) & 0xFFu,
                RULESET == TG_RULESET_FUNCTIONAL, place);
       wave_sync();
@@ -883,8 +901,12 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       }
 #endif
     }
+#ifdef TG_FINE_FUSED_STREAM
+    TG_FS(3);
+#else
     TG_BITS_STAMP(3);
-    if (need_slab) {
+#endif
+    if (need_slab && !TG_SKIP(64)) {
       const bool show = live && ((po.z >> 24) & 1u);
       bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu),
                p.obs_mode == TG_OBS_FN ? 0xFFu : ((po.z >> 16) & 0xFFu), false, show);
@@ -1006,13 +1028,17 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
       }
     }
-    if ((need_slab || dict || rgb) && !last) {  // the slab in LDS is the board again: the drawn piece only ever covers free cells
+    TG_FS(4);
+    if ((need_slab || dict || rgb) && !last && !TG_SKIP(256)) {  // the slab in LDS is the board again: the drawn piece only ever covers free cells
       wave_sync();
       bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu), 0u, false, live && ((po.z >> 24) & 1u));
       wave_sync();
     }
+    TG_FS(0);
     }  // transitions
+#ifndef TG_FINE_FUSED_STREAM
     TG_BITS_STAMP(4);
+#endif
 #ifdef TG_PHASE_TIMING
     if (p.dbg && lane == 0) {
       for (int i = 0; i < 5; ++i) p.dbg[(size_t)step_block * 16 + 8 + i] = tstamp[i];
@@ -1169,6 +1195,9 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
 
   bool cols_dirty_any = false;
   for (int step = 0; step < nsteps; ++step) {
+#ifdef TG_PHASE_TIMING
+  if (MULTI && step == nsteps - 1 && step > 0) TG_BITS_STAMP(1);  // (see the stream wave)
+#endif
   int action_in = hot_act_i8 ? (int)(int8_t)(apack >> (8 * step)) : action0;
   if (RULESET == TG_RULESET_NUMPY && sample_mode) {
     // uniform over the legal placements of the CURRENT piece (wrappers/grouped.py:104-122: legal = inside the frame).
@@ -1654,12 +1683,15 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     // (the kernels with the transition loop are at their register budget: one publish site, two passes)
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-      if (RULESET == TG_RULESET_NUMPY && (pass == 0) == book_first) bookkeeping();
+      if (RULESET == TG_RULESET_NUMPY && (pass == 0) == book_first && !TG_SKIP(512)) bookkeeping();
       if (pass == 0) publish();
+#ifdef TG_FINE_FUSED  // (last transition: 5 = published, 6 = barrier passed, 7 = bookkeeping done / end of the iteration)
+      if (pass == 0 && step == nsteps - 1) TG_BITS_STAMP(6);
+#endif
     }
   } else {
     if (!book_first) publish();
-    if (RULESET == TG_RULESET_NUMPY) bookkeeping();
+    if (RULESET == TG_RULESET_NUMPY && !TG_SKIP(512)) bookkeeping();
     if (book_first) publish();
   }
   if (pending) {  // the NEXT_STEP reset step belongs to no episode (gymnasium RecordEpisodeStatistics)
@@ -1750,6 +1782,9 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       }
     }
   }
+#ifdef TG_FINE_FUSED
+  if (step == nsteps - 1) TG_BITS_STAMP(7);
+#endif
   }  // transitions
 #ifndef TG_NO_PRIO_SWAP
   if (RULESET == TG_RULESET_NUMPY) __builtin_amdgcn_s_setprio(0);
@@ -1779,7 +1814,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     }
   }
 
-#ifndef TG_FINE_LOCK
+#if !defined(TG_FINE_LOCK) && !defined(TG_FINE_FUSED)
   TG_BITS_STAMP(6);
 #endif
   // ---- E: consumed counter; the generator state only after an in-line shuffle (otherwise `ahead` holds it) ----
@@ -1794,7 +1829,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
     rng_out[2] = make_uint4(r.uinteger, r.has32, r.k0, r.k1);
   }
-#ifndef TG_FINE_LOCK
+#if !defined(TG_FINE_LOCK) && !defined(TG_FINE_FUSED)
   TG_BITS_STAMP(7);
 #endif
 #ifdef TG_PHASE_TIMING
