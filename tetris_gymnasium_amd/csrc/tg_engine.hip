@@ -100,7 +100,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     const size_t lds = (feat & D) ? BG::BYTES_DICT : ((feat & R) ? BG::BYTES_RGB : ((feat & F) ? BG::BYTES_FIN : BG::BYTES));
 #define TG_LAUNCH_BITS(FT)                                                                                                  \
   hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(128), lds, s, p.board, p.rec, p.cols, bp.ring_rd, bp.hbuf_rd, \
-                     p.actions, p.batch, (uint32_t)n_step_wgs | ((p.act_i8 ? 1u : 0u) << 20) | ((uint32_t)(p.nsteps > 0 ? p.nsteps : 0) << 21), \
+                     p.actions, p.batch, (uint32_t)n_step_wgs | ((p.act_i8 ? 1u : 0u) << 24) | ((uint32_t)(p.nsteps > 0 ? p.nsteps : 0) << 25), \
                      p, bp)
     if (feat == F) { TG_LAUNCH_BITS(F); return; }
     if (feat == (M | T | F)) { TG_LAUNCH_BITS(M | T | F); return; }

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     // the argument block (a memory round trip at the start of every workgroup).  The structs arrive in their shadow.
     uint8_t* const hot_board, uint32_t* const hot_rec, void* const hot_cols, const uint4* const hot_ring_rd,
     const uint8_t* const hot_hbuf_rd, const void* const hot_actions, const int hot_batch,
-    const uint32_t hot_misc,  // step workgroups (bits 0-19) | act_i8 << 20 | nsteps << 21
+    const uint32_t hot_misc,  // step workgroups (bits 0-23) | act_i8 << 24 | nsteps << 25
     const KParams p, const BitsParams bp) {
   constexpr bool MULTI = (FEAT & kFeatMulti) != 0, TRAJ = (FEAT & kFeatTraj) != 0, DICTK = (FEAT & kFeatDict) != 0,
                  SAMPLE = (FEAT & kFeatSample) != 0, FINAL = (FEAT & kFeatFinal) != 0, RGBK = (FEAT & kFeatRgb) != 0;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
 #else
   // the step workgroups are dispatched first (a grid of this size starts first → last within 0.3-0.7 us, and the step
   // workgroups are the longer pole since the RNG role produces one entry per launch)
-  const uint32_t n_step = hot_misc & 0xFFFFFu;
+  const uint32_t n_step = hot_misc & 0xFFFFFFu;
   const bool rng_role = blockIdx.x >= n_step;
   const uint32_t step_block = blockIdx.x, rng_block = blockIdx.x - n_step;
 #endif
@@ -596,8 +596,8 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   // p.nsteps consecutive transitions in this launch (tg_step_k): records / masks / slabs stay in registers and LDS in
   // between, only actions come in and observations go out per transition; one s_barrier per transition, and the
   // stream wave packs transition k while the logic wave already decides transition k + 1
-  const int hot_nsteps = (int)(hot_misc >> 21);
-  const bool hot_act_i8 = ((hot_misc >> 20) & 1u) != 0;
+  const int hot_nsteps = (int)(hot_misc >> 25);
+  const bool hot_act_i8 = ((hot_misc >> 24) & 1u) != 0;
   const int nsteps = MULTI ? (hot_nsteps > 1 ? hot_nsteps : 1) : 1;
   const bool sample_mode = SAMPLE && p.sample_mode;  // (device-side action sampling: the kernels that carry it wait here)
 
