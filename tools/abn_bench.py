@@ -25,7 +25,9 @@ for a in sys.argv[1:]:
     envs[tag] = dict(x.split("=", 1) for x in kv)
 procs = []
 for tag, src, flags in variants:
-    procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=16",
+    sched = [] if "-default-sched" in flags else ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]  # (variant flag -default-sched: the compiler's default strategy)
+    flags = [f for f in flags if f != "-default-sched"]
+    procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=16", *sched,
                                    "-DTG_FOR_EACH_SIZE(X)=X(10,20)", f"-I{os.path.join(ROOT, 'tetris_gymnasium_amd', 'csrc')}", *flags,
                                    "-shared", "-o", f"/tmp/libtg_{tag}.so", os.path.join(src, "tg_engine.hip")],
                                   stderr=subprocess.DEVNULL))

@@ -2,7 +2,7 @@
 # VGPRs / spills / occupancy of every step-kernel instantiation of a source tree (compile only, no GPU needed)
 # usage: tools/kernel_resources.sh [srcdir] [extra -D flags...]
 SRC=${1:-tetris_gymnasium_amd/csrc}; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-kernarg-preload-count=16 "-DTG_FOR_EACH_SIZE(X)=X(10,20)" -I$SRC -Itetris_gymnasium_amd/csrc "$@" --cuda-device-only -c -o /tmp/tg_res.o $SRC/tg_engine.hip -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-kernarg-preload-count=16 -mllvm -amdgpu-sched-strategy=max-ilp "-DTG_FOR_EACH_SIZE(X)=X(10,20)" -I$SRC -Itetris_gymnasium_amd/csrc "$@" --cuda-device-only -c -o /tmp/tg_res.o $SRC/tg_engine.hip -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys, re
 name = None; row = {}
 for l in sys.stdin:
