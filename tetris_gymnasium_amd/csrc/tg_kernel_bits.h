@@ -1794,10 +1794,36 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   uint4 oa, ob;
   lane_pack(s, oa, ob);
   uint4* rec_out = reinterpret_cast<uint4*>(hot_rec) + (size_t)env * 2;
+#ifndef TG_REC_PER_LANE
+  // Records as whole cache lines (one-transition kernels; -0.15 ... -0.25 us per launch, profiles/r02/ab_rec_lines.log):
+  // lane l of store s writes the 16-byte chunk l + 64 s of the workgroup's record block (= half (chunk & 1) of env
+  // chunk >> 1), fetched from the owning lane by ds_bpermute — stores that cover full lines instead of two stores that
+  // each cover half of every line (and the second half is no longer conditional).
+  const bool rec_lines = !MULTI && nlive == (uint32_t)EPW;
+  constexpr int REC_CHUNKS = 2 * EPW, REC_ST = (REC_CHUNKS + 63) / 64;
+  if (rec_lines && !TG_SKIP(4)) {
+    u32x4* rblk = reinterpret_cast<u32x4*>(hot_rec) + (size_t)base_env * 2;
+#pragma unroll
+    for (int st = 0; st < REC_ST; ++st) {
+      const int chunk = lane + 64 * st;
+      const int src = ((chunk < REC_CHUNKS ? chunk : REC_CHUNKS - 1) >> 1) << 2;
+      const bool hi = (lane & 1) != 0;
+      const uint32_t ax = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)oa.x), bx = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ob.x);
+      const uint32_t ay = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)oa.y), by = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ob.y);
+      const uint32_t az = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)oa.z), bz = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ob.z);
+      const uint32_t aw = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)oa.w), bw = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ob.w);
+      if (chunk < REC_CHUNKS) TG_ST_STATE(rblk + chunk, (u32x4{hi ? bx : ax, hi ? by : ay, hi ? bz : az, hi ? bw : aw}));
+    }
+  }
+  if (live && !rec_lines && !TG_SKIP(4)) TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out), (u32x4{oa.x, oa.y, oa.z, oa.w}));
+  if (live && p.episode && !TG_SKIP(4)) p.episode[env] = ep;
+#else
+  const bool rec_lines = false;
   if (live && !TG_SKIP(4)) {
     TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out), (u32x4{oa.x, oa.y, oa.z, oa.w}));
     if (p.episode) p.episode[env] = ep;
   }
+#endif
   if (__any(cols_dirty)) {
     T nv[W];
 #pragma unroll
@@ -1839,7 +1865,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     p.dbg[(size_t)step_block * 16 + 15] = __builtin_amdgcn_s_getreg(63508);  // XCC_ID
   }
 #endif
-  if (live && (ob.x != rb.x || ob.y != rb.y || ob.z != rb.z || ob.w != rb.w) && !TG_SKIP(4))
+  if (live && !rec_lines && (ob.x != rb.x || ob.y != rb.y || ob.z != rb.z || ob.w != rb.w) && !TG_SKIP(4))
     TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out + 1), (u32x4{ob.x, ob.y, ob.z, ob.w}));
 }
 
