@@ -70,7 +70,7 @@ int bits_feat(const tg::KParams& p) {
   if (p.final_obs) return (p.nsteps > 1 || traj) ? (M | T | F) : F;  // (TG_OBS_BOARD / TG_OBS_FN handles only)
   if (RS == TG_RULESET_NUMPY) {
     if (rgb) return (p.nsteps > 1 || traj || p.sample_mode) ? (M | T | S | R) : R;
-    if (p.sample_mode) return M | T | S;
+    if (p.sample_mode) return p.nsteps > 1 ? (M | T | S) : (T | S);  // (one transition per launch: the kernel without the transition loop)
     if (dict) return (p.nsteps > 1 || traj) ? (M | T | D) : D;
   }
   if (traj) return M | T;
@@ -108,6 +108,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
       if (feat == R) { TG_LAUNCH_BITS(R); return; }
       if (feat == (M | T | S | R)) { TG_LAUNCH_BITS(M | T | S | R); return; }
       if (feat == (M | T | S)) { TG_LAUNCH_BITS(M | T | S); return; }
+      if (feat == (T | S)) { TG_LAUNCH_BITS(T | S); return; }
       if (feat == (M | T | D)) { TG_LAUNCH_BITS(M | T | D); return; }
       if (feat == D) { TG_LAUNCH_BITS(D); return; }
     }
