@@ -861,6 +861,34 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
 #endif
           }
         }
+      } else if (full_wave) {
+        // the kernels with the transition loop, full workgroup: which envs own bytes of a chunk is plain index arithmetic
+        // (the general path below also carries the ragged tail of a partial workgroup inside its loop: ~70 instructions
+        // and three branches per chunk, 4.6k cycles of the stream wave at the end of every launch).  Batches of four
+        // chunks: the loop has no 52 registers to spare.
+#pragma unroll 1
+        for (int k0 = 0; k0 < NIT; k0 += 4) {
+          u32x4 wv[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int c = lane + 64 * (k0 + kk);
+            wv[kk] = lds4[c < NCH ? c : NCH - 1];
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const uint32_t c = (uint32_t)lane + 64u * (uint32_t)(k0 + kk);
+            const uint32_t e0 = (16u * c) / (uint32_t)S, e1r = (16u * c + 15u) / (uint32_t)S;
+            const uint32_t e1 = e1r < (uint32_t)EPW ? e1r : (uint32_t)EPW - 1u;
+            const bool hit = c < (uint32_t)NCH && (((dm >> e0) | (dm >> e1)) & 1ull) != 0;
+            if (hit && !TG_SKIP(2)) {
+#ifdef TG_WB_PLAIN
+              bdst[c] = wv[kk];
+#else
+              st_state(&bdst[c], wv[kk]);
+#endif
+            }
+          }
+        }
       } else {
       // chunks in flight per lane: all of them in the one-transition kernel; in the transition loop of the fused kernels
       // that would cost 52 registers beside the observation pass's 52 (the kernel spilled)
