@@ -807,9 +807,10 @@ __global__ __launch_bounds__(256) void grouped_kernel(const GroupedParams p) {
 }
 
 // stream copy: the practical HBM ceiling reported beside the roofline.  U 16-byte vectors in flight per lane, all loads
-// of a tile issued before its stores; NT = nontemporal stores (tools/ubench/copy_ceiling.hip sweeps the variants)
+// of a tile issued before its stores; NT = nontemporal stores, NTL = nontemporal loads too (tools/ubench/copy_ceiling*.hip
+// sweep the variants: at 1 GiB nontemporal both ways with 16k-64k workgroups reaches 6.3-6.4 TB/s)
 typedef uint32_t copy_vec __attribute__((ext_vector_type(4)));
-template <int U, bool NT>
+template <int U, bool NT, bool NTL = false>
 __global__ __launch_bounds__(256) void stream_copy_kernel(const copy_vec* __restrict__ src, copy_vec* __restrict__ dst,
                                                           size_t n) {
   const size_t tile = (size_t)256 * U;
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const copy_vec* __rest
 #pragma unroll
     for (int k = 0; k < U; ++k) {
       const size_t i = base + (size_t)k * 256 + threadIdx.x;
-      v[k] = src[i < n ? i : n - 1];
+      v[k] = NTL ? __builtin_nontemporal_load(src + (i < n ? i : n - 1)) : src[i < n ? i : n - 1];
     }
 #pragma unroll
     for (int k = 0; k < U; ++k) {

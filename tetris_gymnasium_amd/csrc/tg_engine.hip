@@ -1179,6 +1179,8 @@ int tg_stream_copy_gbps(tg_handle* h, size_t bytes, int iters, float* gbps) {
   timed(tg::stream_copy_kernel<4, true>, 2048);
   timed(tg::stream_copy_kernel<8, true>, 2048);
   timed(tg::stream_copy_kernel<4, true>, 8192);
+  timed(tg::stream_copy_kernel<4, true, true>, 16384);
+  timed(tg::stream_copy_kernel<4, true, true>, 65536);
   (void)hipFree(a);
   (void)hipFree(b);
   if (e != hipSuccess) return fail(h, TG_EHIP, "tg_stream_copy_gbps: %s", hipGetErrorString(e));
