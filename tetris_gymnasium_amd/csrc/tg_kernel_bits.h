@@ -16,13 +16,16 @@
 //   * STREAM WAVE: the uint8 slab is only the payload: it streams HBM → LDS while the logic wave decides, receives
 //     the locked cells / cleared rows / resets after one s_barrier, goes back to the board where it changed and
 //     leaves as the observation (coalesced 16-byte accesses, nontemporal);
-//   * RNG ROLE (leading workgroups of the same launch): numpy's Generator.shuffle draws do not depend on the array
-//     being shuffled (Fisher-Yates positions only), so every env owns a ring of four future bag permutations
-//     (7 nibbles each) produced ahead of their use; consuming one is a byte permute (v_perm_b32).  The generator
-//     state the reference would hold (tg_get_state) stays in tg_rng_rec: it is promoted from the ring entry's
-//     stored state when a permutation is consumed;
+//   * RNG ROLE (trailing workgroups of the same launch, every third one-transition launch): numpy's
+//     Generator.shuffle draws do not depend on the array being shuffled (Fisher-Yates positions only), so every env
+//     owns a ring of four future bag permutations (7 nibbles each) produced ahead of their use; consuming one is a
+//     byte permute (v_perm_b32).  The generator state the reference would hold (tg_get_state) is materialised into
+//     tg_rng_rec on demand from the state stored with the last consumed ring entry;
 //   * tg_step_k / tg_rollout run up to 8 transitions per launch with all of the above resident on chip in between.
-// Bit-identical to the other four step kernels and to the oracle (tests/test_gpu_*.py run against all of them).
+// Round 2: publish before bookkeeping, stores as whole cache lines wherever the layout allows (board
+// chunks by compare, records exchanged between lanes), the arguments the first loads need as preloaded scalars, and a
+// build for instruction-level parallelism (one logic wave per SIMD is a dependent chain: Makefile flags).
+// Bit-identical to the four earlier step kernels (test-only library) and to the oracle (tests/test_gpu_*.py).
 #pragma once
 #include <type_traits>
 
