@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Runs ON THE GPU BOX: long parity soak against the C oracle (test infrastructure): tens of thousands of transitions per
+env so that the mod-128 ring counters wrap many times, across launch kinds (single steps, 1 / 3 / 8 transitions per launch,
+trajectories) and configurations.  usage: python tests/soak_parity.py [steps]   (not collected by pytest: minutes of oracle time)"""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as po
+from tetris_gymnasium_amd import _native as N
+
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+CASES = [  # (W, H, Q, B, grouped, fuse, ruleset)
+    (10, 20, 4, 320, False, 1, N.RULESET_NUMPY), (10, 20, 4, 200, False, 8, N.RULESET_NUMPY), (10, 20, 7, 132, True, 3, N.RULESET_NUMPY),
+    (20, 40, 7, 100, True, 1, N.RULESET_NUMPY), (6, 12, 2, 256, False, 8, N.RULESET_NUMPY), (10, 20, 7, 192, False, 8, N.RULESET_FUNCTIONAL),
+]
+for W, H, Q, B, grouped, fuse, rs in CASES:
+    os.environ["TG_FUSE"] = str(fuse)
+    from tetris_gymnasium_amd import Engine
+    numpy_rules = rs == N.RULESET_NUMPY
+    obs = N.OBS_BOARD if numpy_rules else N.OBS_FN
+    e = Engine(B, W, H, ruleset=rs, queue_size=Q, obs_mode=obs, autoreset=N.AUTORESET_SAME_STEP, grouped=grouped)
+    o = po.OracleBatch(B, W, H, rs, True, Q)
+    seeds = np.arange(11, 11 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(W * 100 + fuse)
+    na = 4 * W if grouped else (8 if numpy_rules else 7)
+    done, CH = 0, 500
+    while done < STEPS:
+        K = min(CH, STEPS - done)
+        acts = rng.integers(0, na, (K, B)).astype(np.int8)
+        d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts); e.step_k_device(d, K); e.dev_free(d)
+        for k in range(K):
+            if grouped: o.grouped_step(acts[k].astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+            else: o.step(acts[k].astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+        done += K
+        be, re_, ge = e.get_state(); bo, ro, go = o.get_state()
+        assert np.array_equal(be, bo), f"board differs after {done} steps"
+        for f in re_.dtype.names:
+            if f != "reserved": assert np.array_equal(re_[f], ro[f]), f"rec.{f} differs after {done} steps"
+        if numpy_rules:
+            for f in ("state_lo", "state_hi", "inc_lo", "inc_hi", "uinteger", "has_uint32"):
+                assert np.array_equal(ge[f], go[f]), f"rng.{f} differs after {done} steps"
+        po_obs = po.OBS_BOARD if numpy_rules else po.OBS_FN
+        assert np.array_equal(e.observation(), o.observe(po_obs)), f"observation differs after {done} steps"
+    print(f"ok  {W}x{H} Q={Q} B={B} grouped={grouped} fuse={fuse} ruleset={rs}: {STEPS} transitions per env")
+    e.close()
