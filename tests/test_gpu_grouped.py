@@ -238,6 +238,7 @@ def test_config5_full_size_against_oracle():
     o = po.OracleBatch(B, W, H, queue_size=Q, nthreads=8)
     seeds = np.arange(1, B + 1, dtype=np.uint64)
     e.reset(seeds); o.reset(seeds)
+    _tall_boards(e, o, every=4)  # 40 placements never fill an empty 20x40 board: a quarter of the envs start near the top
     n_done = n_lock = 0
     for t0 in range(0, T, 20):
         K = min(20, T - t0)
@@ -260,4 +261,64 @@ def test_config5_full_size_against_oracle():
     for f in ("state_lo", "state_hi", "inc_lo", "inc_hi", "uinteger", "has_uint32"):
         np.testing.assert_array_equal(ge[f], go[f], err_msg=f"rng.{f}")
     assert n_lock > B * T // 2  # every grouped step is a hard drop + lock
+    assert n_done > B // 8      # ... and episodes ended: same-step resets (reset shuffle + refilled queue) ran at this grid size
+    e.close()
+
+
+def _tall_boards(e, o, every=1, top=9, seed=3):
+    """Give every `every`-th env (engine and oracle alike) a board whose rows top.. are filled except for two random holes
+    per row (no full rows): random placements then end the episode within a dozen transitions."""
+    board, rec, rng = e.get_state()
+    B, H, W = board.shape
+    g = np.random.default_rng(seed)
+    sel = np.arange(0, B, every)
+    tall = np.full((len(sel), H - top, W), 2, np.uint8)
+    holes = g.integers(0, W, (len(sel), H - top, 2))
+    np.put_along_axis(tall, holes, 0, axis=2)
+    board[sel, top:, :] = tall
+    e.set_state(board=board, rec=rec, rng=rng)
+    o.set_state(board=board, rec=rec, rng=rng)
+
+
+@pytest.mark.parametrize("W,H,Q,B,grouped,ring_fill", [(20, 40, 7, 65536, True, 1), (20, 40, 7, 65536, True, 2),
+                                                         (10, 20, 4, 262144, False, 1), (10, 20, 7, 131072, True, 3)])
+def test_oversubscribed_grid_inline_shuffle_and_resync(W, H, Q, B, grouped, ring_fill, monkeypatch):
+    """Grids larger than the chip's residency (20x40: 4 096 + 512 workgroups; 10x20 above ~87k envs) start their RNG-role
+    workgroups AFTER step workgroups of the same launch have finished.  With a short look-ahead ring (TG_RING_FILL) the
+    logic wave shuffles in line and the RNG role resynchronises from the state that shuffle left — a state the same
+    launch's logic wave must not overwrite (round 2 kept it in tg_rng_rec: a late RNG workgroup then continued from the
+    wrong frontier and the piece sequence silently left the reference's).  Fused rollouts, tall start boards so that
+    episodes end and same-step resets run all the time; pieces, bags, queues and every generator against the oracle."""
+    monkeypatch.setenv("TG_RING_FILL", str(ring_fill))
+    monkeypatch.setenv("TG_FUSE", "8")
+    e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_BOARD, grouped=grouped, autoreset=N.AUTORESET_SAME_STEP)
+    o = po.OracleBatch(B, W, H, queue_size=Q, nthreads=8)
+    seeds = np.arange(1, B + 1, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    _tall_boards(e, o, every=1, top=H // 4)
+    rng = np.random.default_rng(ring_fill)
+    n_done = 0
+    for rnd in range(3):
+        K = (24, 17, 8)[rnd]
+        if grouped:
+            acts, rew, term, lines = e.grouped_rollout(K, seed=9, counter0=100 * rnd)
+        else:
+            acts = rng.integers(0, 8, (K, B)).astype(np.int8)
+            _, rew, term, lines = e.rollout(acts, want_obs=False)
+        for k in range(K):
+            if grouped:
+                ro, to, lo, ill = o.grouped_step(acts[k].astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+                assert not ill.any()
+            else:
+                ro, to, lo = o.step(acts[k].astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+            assert np.array_equal(rew[k], ro) and np.array_equal(term[k], to) and np.array_equal(lines[k], lo), f"round {rnd} k={k}"
+        n_done += int(term.sum())
+        be, re_, ge = e.get_state(); bo, ro2, go = o.get_state()
+        np.testing.assert_array_equal(be, bo)
+        for f in re_.dtype.names:
+            if f != "reserved":
+                np.testing.assert_array_equal(re_[f], ro2[f], err_msg=f"{f} round {rnd}")
+        for f in ("state_lo", "state_hi", "inc_lo", "inc_hi", "uinteger", "has_uint32"):
+            np.testing.assert_array_equal(ge[f], go[f], err_msg=f"rng.{f} round {rnd}")
+    assert n_done > B // 2  # resets (a shuffle each, two with queue_size 7) ran in practically every launch
     e.close()

@@ -41,7 +41,8 @@ struct KParams {
   void* cols;               // bits kernel only: column masks [B][W] (tg_kernel_bits.h); null otherwise
   uint4* ahead;             // bits kernel only: generator states of the permutation ring [B][2][2]
   uint64_t* ring;           // bits kernel only: permutation rings [2][B]
-  uint8_t* hbuf;            // bits kernel only: consumed counters [2][B]
+  uint32_t* hbuf;           // bits kernel only: consumed counters + state location [2][B]
+  uint4* inl;               // bits kernel only: generator states after in-line shuffles [2][B][2]
   int ring_cur;             // bits kernel only: ring parity (flips with every launch that carries the RNG role)
   int hbuf_cur;             // bits kernel only: consumed-counter parity (flips with every launch)
   int rng_role;             // bits kernel only: this launch carries the RNG-role workgroups

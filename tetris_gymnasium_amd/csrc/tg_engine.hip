@@ -87,12 +87,12 @@ template <int W, int H, int RS>
 void launch_step(const tg::KParams& p, hipStream_t s) {
   if (p.cols) {  // "bits": the handle carries the column masks / look-ahead permutations
     using BG = tg::BitsGeo<W, H>;
-    const int nrb = (RS == TG_RULESET_NUMPY && p.rng_role) ? (p.batch + 127) / 128 : 0;  // RNG-role workgroups (tg_kernel_bits.h)
+    const int nrb = p.rng_role ? (p.batch + 127) / 128 : 0;  // RNG-role workgroups (tg_kernel_bits.h)
     const uint4* const ring4 = reinterpret_cast<const uint4*>(p.ring);
     const tg::BitsParams bp{p.cols, p.ahead,
                             ring4 + (size_t)p.ring_cur * p.ring_stride, const_cast<uint4*>(ring4) + (size_t)(1 - p.ring_cur) * p.ring_stride,
                             p.hbuf + (size_t)p.hbuf_cur * p.ring_stride, p.hbuf + (size_t)(1 - p.hbuf_cur) * p.ring_stride,
-                            nrb, p.ring_fill};
+                            p.inl, nrb, p.ring_fill};
     const int n_step_wgs = (p.batch + BG::EPW - 1) / BG::EPW;
     const dim3 grid(nrb + n_step_wgs);
     constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
@@ -221,7 +221,8 @@ struct tg_handle {
   void* d_cols = nullptr;   // bits kernel: column masks [B][W] (device-private acceleration state)
   uint4* d_ahead = nullptr; // bits kernel: generator states after the ring's shuffles [B][2 slots][2]
   uint64_t* d_ring = nullptr;  // bits kernel: permutation rings, double-buffered by launch parity [2][B]
-  uint8_t* d_hbuf = nullptr;   // bits kernel: consumed counters [2][B]
+  uint32_t* d_hbuf = nullptr;  // bits kernel: consumed counters + state location (+ FUNCTIONAL: bag index, chain epoch) [2][B]
+  uint4* d_inl = nullptr;      // bits kernel: generator states after in-line shuffles [2 buffers][B][2]
   int ring_cur = 0;            // ring parity the next step launch reads
   int hbuf_cur = 0;            // consumed-counter parity the next step launch reads
   int rng_every = 3;           // TG_RNG_EVERY: one-transition launches carry the RNG-role workgroups every n-th time (the ring
@@ -381,6 +382,7 @@ tg::KParams step_params(tg_handle* h) {
   p.ahead = h->d_ahead;
   p.ring = h->d_ring;
   p.hbuf = h->d_hbuf;
+  p.inl = h->d_inl;
   p.ring_cur = h->ring_cur;
   p.hbuf_cur = h->hbuf_cur;
   p.rng_role = 1;
@@ -454,6 +456,7 @@ int launch_step_all(tg_handle* h, const tg::KParams& p) {
     if (p.ahead) q.ahead = p.ahead + o * 2 * tg::kRing;
     if (p.ring) q.ring = p.ring + o * 2;
     if (p.hbuf) q.hbuf = p.hbuf + o;
+    if (p.inl) q.inl = p.inl + o * 2;
     h->L.step(q, h->sh_stream[i]);
   }
   return TG_OK;
@@ -484,11 +487,13 @@ int launch_prepare_bits(tg_handle* h, const uint8_t* d_mask, int force) {
 // bits kernel, NUMPY rules: bring TG_BUF_RNG up to date with the generators the reference would hold now (a transition
 // leaves the state in the permutation ring's `ahead` slots, tg_kernel_bits.h)
 int launch_materialize_rng(tg_handle* h) {
-  if (!h->d_cols || h->cfg.ruleset != TG_RULESET_NUMPY) return TG_OK;
+  if (!h->d_cols) return TG_OK;
   tg::MaterializeParams q{};
+  q.ruleset = h->cfg.ruleset;
   q.rng = (tg_rng_rec*)h->buf[TG_BUF_RNG];
   q.ahead = h->d_ahead;
   q.hbuf = h->d_hbuf + (size_t)h->hbuf_cur * (size_t)h->B;
+  q.inl = h->d_inl;
   q.batch = h->B;
   hipLaunchKernelGGL(tg::bits_materialize_rng_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, q);
   HIPCHK(h, hipGetLastError());
@@ -628,10 +633,10 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   {
     h->arena_skew = 0;
     if (const char* e = getenv("TG_ALLOC_SKEW")) h->arena_skew = (size_t)(atol(e) > 0 ? atol(e) : 0);
-    const int n_pieces = TG_BUF_COUNT + 8;
+    const int n_pieces = TG_BUF_COUNT + 9;
     size_t total = 0;
     for (int i = 0; i < TG_BUF_COUNT; ++i) total += sizes[i] + kTailPad + 4096;
-    total += B * sizeof(tg_rng_rec) + 2 * B + B * L.cols_bytes + B * 32 * tg::kRing + 2 * B * 16 + 2 * B + 8 * (kTailPad + 4096);
+    total += B * sizeof(tg_rng_rec) + 2 * B + B * L.cols_bytes + B * 32 * tg::kRing + 2 * B * 16 + 8 * B + 2 * B * 32 + 9 * (kTailPad + 4096);
     total += h->arena_skew * (size_t)n_pieces * (size_t)n_pieces;
     CRCHK(hipMalloc(&h->arena, total));
     h->arena_size = total;
@@ -648,7 +653,8 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     CRCHK(arena_take(h, &h->d_cols, B * L.cols_bytes + kTailPad));
     CRCHK(arena_take(h, (void**)&h->d_ahead, B * 32 * tg::kRing + kTailPad));
     CRCHK(arena_take(h, (void**)&h->d_ring, 2 * B * 16 + kTailPad));
-    CRCHK(arena_take(h, (void**)&h->d_hbuf, 2 * B + kTailPad));
+    CRCHK(arena_take(h, (void**)&h->d_hbuf, 2 * B * sizeof(uint32_t) + kTailPad));
+    CRCHK(arena_take(h, (void**)&h->d_inl, 2 * B * 32 + kTailPad));
   }
 #ifdef TG_PHASE_TIMING
   CRCHK(hipMalloc(&h->dbg, ((B + 15) / 16) * 16 * 8));
@@ -667,6 +673,8 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
                         ((cfg->obs_mode == TG_OBS_DICT && L.dict_ok) ||
                          (cfg->obs_mode == TG_OBS_RGB && L.rgb_ok && cfg->queue_size == 4));  // (the in-kernel RGB image is laid out for four queue pieces)
     if (const char* e = getenv("TG_RING_FILL")) { const int v = atoi(e); h->ring_fill = v < 0 ? 0 : (v > tg::kRing - 1 ? tg::kRing - 1 : v); }
+    // FUNCTIONAL: a ring entry is consumed by every lock (not every seventh as the NUMPY bag permutations): every launch
+    if (cfg->ruleset == TG_RULESET_FUNCTIONAL) h->rng_every = 1;
     if (const char* e = getenv("TG_RNG_EVERY")) { const int v = atoi(e); h->rng_every = v < 1 ? 1 : (v > 3 ? 3 : v); }
     if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > 8 ? 8 : v); }
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)

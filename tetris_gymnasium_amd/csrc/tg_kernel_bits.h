@@ -204,8 +204,13 @@ __device__ __forceinline__ uint64_t bits_apply_perm(const uint32_t sig, const ui
 // (it looks ahead kRing - 1 entries), so "the generator now" = ahead[(H - 1) & 3] — read only by
 // bits_materialize_rng_kernel (before tg_get_state / tg_reset / tg_set_state / a fetch of TG_BUF_RNG) and by the two
 // rare paths below.  No load, no wait and no store of generator state on the transition's path.
-//   ring exhausted → the logic wave shuffles in line, starting from that state; the state after an in-line shuffle goes
-//   to tg_rng_rec and bit 7 of the H byte (`inl`) says so; the RNG role then resynchronises (T := H, frontier = tg_rng_rec).
+//   ring exhausted → the logic wave shuffles in line, starting from that state.  WHERE "the state after entry H - 1" lives
+//   is the `loc` field beside H: kLocAhead (the slot above), kLocRec (tg_rng_rec: after bits_prepare_kernel — a step
+//   launch never writes tg_rng_rec), kLocBuf0 / kLocBuf1 (one of the two in-line buffers `inl`).  The state after an
+//   in-line shuffle goes to the in-line buffer that nobody reads in this launch: both roles read the location named by
+//   the snapshot of the previous launch boundary, so the writer takes the other buffer (kLocBuf0 unless the snapshot
+//   names it).  The RNG role then resynchronises from there (T := H).  Round 2 kept that state in tg_rng_rec itself,
+//   which the RNG role of the SAME launch may read after the logic wave's store once the grid exceeds residency.
 //   `ahead` is written by the RNG role only.
 struct BitsParams {
   void* cols;      // ColT [B][W]
@@ -215,10 +220,12 @@ struct BitsParams {
   // the RNG role); the host passes both as pointers — the parity arithmetic stood between the logic wave's first loads.
   const uint4* ring_rd;
   uint4* ring_wr;
-  // hbuf [2 parities][B]: H (bits 0-6) | inl << 7 (the state after entry H - 1 is in tg_rng_rec, not in `ahead`); read
-  // parity / the parity the logic wave writes (flips every launch)
-  const uint8_t* hbuf_rd;
-  uint8_t* hbuf_wr;
+  // hbuf [2 parities][B]: H (bits 0-7) | loc << 8 (where the state after entry H - 1 is: kLoc*) | bag index << 11
+  // (FUNCTIONAL: which look-ahead position refills the bag) | chain epoch << 16 (FUNCTIONAL: resets so far, mod 256);
+  // read parity / the parity the logic wave writes (flips every launch)
+  const uint32_t* hbuf_rd;
+  uint32_t* hbuf_wr;
+  uint4* inl;      // [2 buffers][B][2]: generator state after an in-line shuffle (layout of an `ahead` slot)
   int nrb;         // number of RNG workgroups (kRngEnvs envs each)
   int fill;          // entries the RNG role keeps ahead in a ring (kRing - 1; tests lower it to exercise the consumer's in-line shuffle)
 };
@@ -226,12 +233,49 @@ struct BitsParams {
 // native 16-byte vector for the slab stream: HIP's uint4 is a struct whose copies become memcpy intrinsics, which
 // kept the staging array in scratch memory (and made the kernel wait for every slab load right after issuing it)
 constexpr int kRing = 4;  // slots per permutation ring: kRing - 1 entries ahead + the last consumed one
-__device__ __forceinline__ int ring_diff(const int a, const int b) { return ((a - b) << 25) >> 25; }  // counters are mod 128
+__device__ __forceinline__ int ring_diff(const int a, const int b) { return ((a - b) << 24) >> 24; }  // counters are mod 256
+// where the generator state (FUNCTIONAL: the key) after the last consumed entry lives (`loc` field of hbuf)
+constexpr int kLocAhead = 0, kLocRec = 1, kLocAheadR = 2, kLocBuf0 = 3, kLocBuf1 = 4;  // (code tests `loc >= kLocBuf0`)
 constexpr int kRngEnvs = 1024;  // envs scanned by one RNG-role workgroup (128 threads x 8)
 
 __device__ __forceinline__ uint32_t ring_get(const uint64_t w0, const uint64_t w1, const int slot) {
   const uint64_t w = (slot & 2) ? w1 : w0;
   return (uint32_t)(w >> (28 * (slot & 1))) & 0x0FFFFFFFu;
+}
+
+// ---- FUNCTIONAL rule-set: the same ring protocol along the jax key chain (envs/tetris_fn.py:370-413, 318-367) ----
+// Every lock replaces the key by c' = split(c)[0] = threefry(c, (0, 0)); a lock that finds the 7-bag used up refills it with
+// permutation(split(c)[1]) (functional/queue.py:59-67); a reset takes permutation(split(c)[0]) as the new bag and
+// R = split(c)[1] as the new key.  So a ring entry describes ONE POSITION of the chain: for the key c at that position
+//   PL = permutation(c')  the bag a reset at this position deals          (21 bits: seven 3-bit pieces)
+//   PR = permutation(R)   the bag a refilling lock at this position deals (only at the position whose lock refills:
+//                         bag index + distance == 7; one field + its slot tag per ring, refills are 7 locks apart)
+//   c', R                 in the entry's `ahead` slot {c'.k0, c'.k1, R.k0, R.k1}: the key after a lock / after a reset.
+// A lock consumes its entry and stays on the chain (loc = kLocAhead: the key is ahead[(H - 1) & 3].c'); a reset consumes
+// its entry and LEAVES the chain (loc = kLocAheadR: the key is that slot's R; the entries beyond describe positions
+// that will never be visited).  Both sides count chains: the consumer's epoch (hbuf) goes up with every reset, the ring
+// carries the epoch its entries were produced for; a ring of another epoch is dead for the consumer, and makes the RNG
+// role start over from the consumer's key (T := H, epoch := the consumer's) — as a ring that ran dry does.  With no
+// usable entry the logic wave runs threefry in line (key in registers, then in an in-line buffer; a plain lock's key
+// step waits until after the publish).
+// Ring record: w0 = PL of slots 0 | 1 << 21 | 2 << 42;  w1 = PL of slot 3 | PR << 21 | PR slot << 42 | PR valid << 44 |
+// epoch << 45 | T << 56.
+// PARITY UNPINNED like every jax-dependent piece of this rule-set; engine == oracle is what tests check.
+__device__ __forceinline__ uint32_t fn_ring_pl(const uint64_t w0, const uint64_t w1, const int slot) {
+  return (uint32_t)((slot & 3) == 3 ? w1 : (w0 >> (21 * (slot & 3)))) & 0x1FFFFFu;
+}
+__device__ __forceinline__ uint32_t fn_pack21(const uint64_t bag) {  // 7 bytes → seven 3-bit fields
+  uint32_t p = 0;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) p |= ((uint32_t)(bag >> (8 * k)) & 7u) << (3 * k);
+  return p;
+}
+__device__ __forceinline__ uint64_t fn_expand21(const uint32_t p) {  // seven 3-bit fields → 7 bytes
+  auto four = [](const uint32_t x) -> uint32_t {  // fields at bits 0, 3, 6, 9 → bytes 0..3
+    const uint32_t t = (x & 0x3Fu) | ((x & 0xFC0u) << 10);
+    return (t & 0x00070007u) | ((t & 0x00380038u) << 5);
+  };
+  return (uint64_t)four(p & 0xFFFu) | ((uint64_t)four((p >> 12) & 0x1FFu) << 32);
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -544,7 +588,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     // struct arguments are not eligible), so the slab / record / ring loads leave without waiting for a scalar load of
     // the argument block (a memory round trip at the start of every workgroup).  The structs arrive in their shadow.
     uint8_t* const hot_board, uint32_t* const hot_rec, void* const hot_cols, const uint4* const hot_ring_rd,
-    const uint8_t* const hot_hbuf_rd, const void* const hot_actions, const int hot_batch,
+    const uint32_t* const hot_hbuf_rd, const void* const hot_actions, const int hot_batch,
     const uint32_t hot_misc,  // step workgroups (bits 0-23) | act_i8 << 24 | nsteps << 25
     const KParams p, const BitsParams bp) {
   constexpr bool MULTI = (FEAT & kFeatMulti) != 0, TRAJ = (FEAT & kFeatTraj) != 0, DICTK = (FEAT & kFeatDict) != 0,
@@ -628,7 +672,6 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     // RNG ROLE (leading workgroups, 128 envs each): refill every ring that holds fewer than kRing permutations.
     // Generator.shuffle on the 7-bag = numpy PCG64 + masked rejection (components/tetromino_randomizer.py:42-46, 84).
     // =====================================================================================================
-    if (RULESET != TG_RULESET_NUMPY) return;
 #ifdef TG_PHASE_TIMING
     const unsigned long long rng_t0 = TG_NOW();
 #endif
@@ -638,8 +681,8 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     const uint4 rw = hot_ring_rd[ee];
     uint64_t w0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32), w1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
     const int Hraw = hot_hbuf_rd[ee];
-    const int Hn = Hraw & 0x7F;
-    const bool inl = (Hraw & 0x80) != 0;
+    const int Hn = Hraw & 0xFF;
+    const int loc = (Hraw >> 8) & 7;
 #ifndef TG_RNG_PRIO
 #define TG_RNG_PRIO 2  // between the stream wave before its barrier (1) and the logic wave (3): A/B in profiles/r02
 #endif
@@ -648,6 +691,115 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     // would otherwise run two shuffles back to back and become the tail of the launch — measured 7.0 us vs 5.8 us for the
     // step workgroups).  Launches of several transitions consume more per env and are long anyway: refill completely.
     const int max_reps = nsteps > 1 ? kRing - 1 : 1;
+    if constexpr (RULESET == TG_RULESET_FUNCTIONAL) {
+#ifndef TG_RNG_PRIO_FN
+#define TG_RNG_PRIO_FN 0  // these waves are dense VALU work nobody waits for inside the launch: below the stream wave (1)
+#endif
+      __builtin_amdgcn_s_setprio(TG_RNG_PRIO_FN);
+      // one entry = one position of the key chain (protocol above): c' = split(c)[0], R = split(c)[1], PL = permutation(c'),
+      // PR = permutation(R) where the lock refills the bag.  Only the lanes whose env consumed an entry need one (a lock: 18 %
+      // of the envs per transition), and a permutation is 1 + 7 threefry blocks — so the seven independent blocks of every
+      // permutation the wave owes are spread over LANES (8 lanes per permutation, 8 permutations per pass: two passes
+      // per launch instead of 16 sparse blocks per lane; the sparse form made these waves the tail of the launch: 15 us).
+      const int bidxH = (Hraw >> 11) & 7;
+      const uint64_t epochH = (uint64_t)((Hraw >> 16) & 0xFF);
+      uint32_t k0 = 0, k1 = 0;
+      bool loaded = false;
+      uint2* a2 = reinterpret_cast<uint2*>(bp.ahead + (size_t)ee * (2 * kRing));  // slot s: a2[4 s] = c', a2[4 s + 1] = R
+      // All four {c', R} pairs travel with the first loads: which one is the frontier depends on T / H / loc (a dependent
+      // round trip otherwise — a second memory phase in front of five dependent threefry blocks made these waves the tail)
+      uint4 slotv[kRing];
+#pragma unroll
+      for (int i = 0; i < kRing; ++i) slotv[i] = *reinterpret_cast<const uint4*>(a2 + 4 * i);
+      uint2* xk = reinterpret_cast<uint2*>(lds + wave * 2048);                    // sort keys of the owed permutations [128]
+      uint32_t* xo = reinterpret_cast<uint32_t*>(lds + wave * 2048 + 1024);       // the permutations [128]
+      for (int rep = 0; rep < max_reps; ++rep) {
+        int Tn = (int)(w1 >> 56) & 0xFF;
+        int d = ring_diff(Tn, Hn);
+        const bool resync = !loaded && (d <= 0 || ((w1 >> 45) & 0xFFULL) != epochH);  // the consumer ran past T, or left the chain
+        if (resync) { Tn = Hn; d = 0; }
+        const bool need = on && d < bp.fill;
+        if (!__any(need)) break;
+        if (need && !loaded) {
+          const int fs = (Tn - 1) & (kRing - 1);  // the key after entry T - 1 ...
+          const uint4 sv = fs == 0 ? slotv[0] : (fs == 1 ? slotv[1] : (fs == 2 ? slotv[2] : slotv[3]));
+          const bool afterR = resync && loc == kLocAheadR;  // ... the consumer's key after a reset,
+          k0 = afterR ? sv.z : sv.x; k1 = afterR ? sv.w : sv.y;
+          const bool elsewhere = resync && (loc == kLocRec || loc >= kLocBuf0);
+          if (__any(elsewhere)) {  // as tg_reset / tg_set_state left it, or after in-line threefry (rare)
+            const uint2* ks = reinterpret_cast<const uint2*>(p.rng + ee) + 5;
+            if (loc >= kLocBuf0) ks = reinterpret_cast<const uint2*>(bp.inl + ((size_t)(loc - kLocBuf0) * p.ring_stride + ee) * 2);
+            if (elsewhere) { const uint2 kk = *ks; k0 = kk.x; k1 = kk.y; }
+          }
+          if (resync) w1 = (w1 & ~((1ULL << 44) | (0xFFULL << 45))) | (epochH << 45);  // (no refill permutation of the chain that was left)
+        }
+        uint32_t c0, c1, r0, r1, sl0, sl1, sr0 = 0, sr1 = 0;
+        threefry2x32(k0, k1, 0u, 0u, c0, c1);
+        threefry2x32(k0, k1, 0u, 1u, r0, r1);
+        const bool refp = need && bidxH + d == 7;  // the lock at this position finds the bag used up
+        threefry2x32(c0, c1, 0u, 1u, sl0, sl1);    // permutation(key): key', sub = split(key); sort keys = bits(sub, 7)
+        if (__any(refp)) threefry2x32(r0, r1, 0u, 1u, sr0, sr1);
+        // task list: PL of every lane in `need`, then PR of every lane in `refp`
+        const uint64_t mN = __ballot(need), mR = __ballot(refp);
+        const int n1 = __popcll(mN), nt = n1 + __popcll(mR);
+        const int q1 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mN >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mN, 0u));
+        const int q2 = n1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mR >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mR, 0u));
+        if (need) xk[q1] = make_uint2(sl0, sl1);
+        if (refp) xk[q2] = make_uint2(sr0, sr1);
+        wave_sync();
+        const int j = lane & 7;
+        // stable rank of element j among the 7 of its 8-lane group (jax sort_key_val on 32 random bits; ties by index) → the
+        // group's permutation as seven 3-bit fields
+        auto group_perm = [&](const uint32_t bits) -> uint32_t {
+          int rank = 0;
+#pragma unroll
+          for (int rr = 1; rr < 7; ++rr) {
+            const int oj = j + rr >= 7 ? j + rr - 7 : j + rr;
+            const uint32_t ob = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & ~7) | oj) << 2, (int)bits);
+            rank += (ob < bits || (ob == bits && oj < j)) ? 1 : 0;
+          }
+          uint32_t pm = j < 7 ? (uint32_t)j << (3 * rank) : 0u;
+          pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+          pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+          pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x141, 0xF, 0xF, true);  // row_half_mirror: the other quad of the 8
+          return pm;
+        };
+        for (int t0 = 0; t0 < nt; t0 += 16) {  // 16 permutations per trip: two independent threefry streams per lane
+          const int ta = t0 + (lane >> 3), tb = ta + 8;
+          const uint2 ka = xk[ta < nt ? ta : 0], kb = xk[tb < nt ? tb : 0];
+          uint32_t a0, a1, b0, b1;
+          threefry2x32(ka.x, ka.y, 0u, (uint32_t)j, a0, a1);
+          threefry2x32(kb.x, kb.y, 0u, (uint32_t)j, b0, b1);
+          const uint32_t pa = group_perm(a0 ^ a1), pb = group_perm(b0 ^ b1);
+          if (j == 0 && ta < nt) xo[ta] = pa;
+          if (j == 0 && tb < nt) xo[tb] = pb;
+        }
+        wave_sync();
+        const uint32_t pl = xo[need ? q1 : 0];
+        const uint32_t pr = xo[refp ? q2 : 0];
+        wave_sync();
+        if (need) {
+          const int sl = Tn & (kRing - 1);
+          *reinterpret_cast<uint4*>(a2 + 4 * sl) = make_uint4(c0, c1, r0, r1);
+          if (sl == 3) w1 = (w1 & ~0x1FFFFFULL) | pl;
+          else w0 = (w0 & ~(0x1FFFFFULL << (21 * sl))) | ((uint64_t)pl << (21 * sl));
+          if (refp) w1 = (w1 & ~(0xFFFFFFULL << 21)) | ((uint64_t)pr << 21) | ((uint64_t)sl << 42) | (1ULL << 44);
+          else if (((w1 >> 42) & 3ULL) == (uint64_t)sl) w1 &= ~(1ULL << 44);  // the slot's previous tenant is gone
+          w1 = (w1 & ~(0xFFULL << 56)) | ((uint64_t)((Tn + 1) & 0xFF) << 56);
+          k0 = c0; k1 = c1;
+          loaded = true;
+        }
+      }
+      if (on) st_state(reinterpret_cast<u32x4*>(bp.ring_wr) + e, u32x4{(uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32)});
+#ifdef TG_PHASE_TIMING
+      if (p.dbg && (threadIdx.x & 63) == 0) {
+        const size_t slot = (size_t)(gridDim.x - bp.nrb) * 16 + (size_t)rng_block * 4 + (threadIdx.x >> 6) * 2;
+        p.dbg[slot] = rng_t0;
+        p.dbg[slot + 1] = TG_NOW();
+      }
+#endif
+      return;
+    }
     BitsRng g;
     g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
     g.uinteger = g.has32 = 0;
@@ -655,19 +807,22 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     uint4* a4 = bp.ahead + (size_t)ee * (2 * kRing);
     const uint4* rng4 = reinterpret_cast<const uint4*>(p.rng + ee);
     for (int rep = 0; rep < max_reps; ++rep) {
-      int Tn = (int)(w0 >> 56) & 0x7F;
+      int Tn = (int)(w0 >> 56) & 0xFF;
       const int d = ring_diff(Tn, Hn);
       const bool need = on && d < bp.fill;
       if (!__any(need)) break;
       if (need && !g.loaded) {
         // frontier = state after entry T - 1 (later entries of this visit continue from the registers).  The consumer may
         // have run past T with in-line shuffles (d <= 0): the entries below H are dead — continue from the consumer's
-        // state (ahead[(H - 1) & 3], or tg_rng_rec when `inl`)
+        // state, wherever `loc` says it is (never a location a step launch writes while this one reads: see above)
         const bool resync = d <= 0;
         if (resync) Tn = Hn;
         const int fs = (Tn - 1) & (kRing - 1);
-        const bool from_rec = resync && inl;
-        const uint4 f0 = *(from_rec ? rng4 : a4 + 2 * fs), f1 = *(from_rec ? rng4 + 2 : a4 + 2 * fs + 1);
+        const uint4* fsrc = a4 + 2 * fs;
+        const uint4* fsrc1 = fsrc + 1;
+        if (resync && loc == kLocRec) { fsrc = rng4; fsrc1 = rng4 + 2; }
+        if (resync && loc >= kLocBuf0) { fsrc = bp.inl + ((size_t)(loc - kLocBuf0) * p.ring_stride + ee) * 2; fsrc1 = fsrc + 1; }
+        const uint4 f0 = *fsrc, f1 = *fsrc1;
         const uint4 gi = rng4[1];
         g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
         g.i_lo = (uint64_t)gi.x | ((uint64_t)gi.y << 32); g.i_hi = (uint64_t)gi.z | ((uint64_t)gi.w << 32);
@@ -683,7 +838,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
         const uint64_t m = 0x0FFFFFFFULL << (28 * (sl & 1)), v = (uint64_t)sig << (28 * (sl & 1));
         if (sl & 2) w1 = (w1 & ~m) | v;
         else w0 = (w0 & ~m) | v;
-        w0 = (w0 & ~(0xFFULL << 56)) | ((uint64_t)((Tn + 1) & 0x7F) << 56);
+        w0 = (w0 & ~(0xFFULL << 56)) | ((uint64_t)((Tn + 1) & 0xFF) << 56);
       }
     }
     if (on) {
@@ -1093,10 +1248,8 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
                ((uint64_t)c_shapes.mask[lane][2] << 32) | ((uint64_t)c_shapes.mask[lane][3] << 48);
   const uint4* rec4 = reinterpret_cast<const uint4*>(hot_rec) + (size_t)env * 2;
   const uint4 ra = rec4[0], rb = rec4[1];
-  // FUNCTIONAL: the jax key travels with the first loads (fetched lazily at the first lock it was a dependent memory
-  // round trip in the middle of the decision logic of practically every wave)
-  uint4 fkey = make_uint4(0u, 0u, 0u, 0u);
-  if (RULESET == TG_RULESET_FUNCTIONAL) fkey = reinterpret_cast<const uint4*>(p.rng + env)[2];
+  // (FUNCTIONAL: the jax key is not among the first loads any more — what a transition needs of the key chain comes
+  // from the look-ahead ring below, as the bag permutations of the NUMPY rule-set do)
   // the actions of all transitions of this launch, requested up front (int8 rows: one byte per transition and env)
   uint64_t apack = 0;
   int action0 = 0;
@@ -1114,11 +1267,11 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   }
   uint64_t ring0 = 0, ring1 = 0;
   int Hc = 0;
-  if (RULESET == TG_RULESET_NUMPY) {
+  {
     const uint4 rw = hot_ring_rd[env];
     ring0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32);
     ring1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
-    Hc = hot_hbuf_rd[env];  // H | inl << 7, split below
+    Hc = hot_hbuf_rd[env];  // H | loc << 8, split below
   }
   T cv[W];
   {
@@ -1162,9 +1315,12 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   // consumer side of the permutation ring (NUMPY).  Consuming an entry is pure register work: a nibble gather from the
   // ring word loaded at launch start; the generator state is not touched (see the protocol above).  g holds the state
   // only after an in-line shuffle (ring exhausted: rare).
-  const int ringT = (int)(ring0 >> 56) & 0x7F;
-  bool inl = (Hc & 0x80) != 0;  // the state after entry H - 1 is in tg_rng_rec (an in-line shuffle produced it)
-  Hc &= 0x7F;
+  const int ringT = (int)((RULESET == TG_RULESET_NUMPY ? ring0 : ring1) >> 56) & 0xFF;
+  const int loc0 = (Hc >> 8) & 7;  // where the state after entry H - 1 is as the launch starts (kLoc*)
+  const int loc_wr = loc0 == kLocBuf0 ? kLocBuf1 : kLocBuf0;  // the in-line buffer this launch may write: the one nobody reads now
+  int loc = loc0;
+  const int epoch0 = (Hc >> 16) & 0xFF;  // (FUNCTIONAL) the chain this env is on
+  Hc &= 0xFF;
   bool g_valid = false, inc_loaded = false;
   BitsRng g;
   g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
@@ -1180,8 +1336,11 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     uint32_t sig = ring_get(ring0, ring1, Hc & (kRing - 1));
     if (__any(fb)) {  // rare: ring exhausted → shuffle in-line, from the state the generator holds right now
       if (fb && !g_valid) {
-        const uint4* a4 = bp.ahead + (size_t)env * (2 * kRing) + 2 * ((Hc - 1) & (kRing - 1));
-        const uint4 f0 = *(inl ? rng4 : a4), f1 = *(inl ? rng4 + 2 : a4 + 1);
+        const uint4* fsrc = bp.ahead + (size_t)env * (2 * kRing) + 2 * ((Hc - 1) & (kRing - 1));
+        const uint4* fsrc1 = fsrc + 1;
+        if (loc == kLocRec) { fsrc = rng4; fsrc1 = rng4 + 2; }
+        if (loc >= kLocBuf0) { fsrc = bp.inl + ((size_t)(loc - kLocBuf0) * p.ring_stride + env) * 2; fsrc1 = fsrc + 1; }
+        const uint4 f0 = *fsrc, f1 = *fsrc1;
         g.s_lo = (uint64_t)f0.x | ((uint64_t)f0.y << 32); g.s_hi = (uint64_t)f0.z | ((uint64_t)f0.w << 32);
         g.uinteger = f1.x; g.has32 = f1.y;
       }
@@ -1191,12 +1350,12 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
         inc_loaded = true;
       }
       bits_shuffle_perm(g, sig, fb);
-      if (fb) { g_valid = true; inl = true; }
+      if (fb) { g_valid = true; loc = loc_wr; }
     }
     const uint64_t nb = bits_apply_perm(sig, from_identity ? 0x06050403020100ULL : s.bag);
     if (need) {
-      s.bag = nb; s.bidx = 0; Hc = (Hc + 1) & 0x7F;
-      if (from_ring) { g_valid = false; inl = false; }
+      s.bag = nb; s.bidx = 0; Hc = (Hc + 1) & 0xFF;
+      if (from_ring) { g_valid = false; loc = kLocAhead; }
     }
   };
   // BagRandomizer.get_next_tetromino (:65-85): eager reshuffle when the 7th piece is drawn
@@ -1213,16 +1372,25 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     if (on) s.queue = (s.queue >> 8) | ((uint64_t)nxt << (8 * (Q - 1)));
     return t;
   };
-  LaneRng r;  // FUNCTIONAL: the jax key (in-line threefry)
-  r.s_lo = r.s_hi = r.i_lo = r.i_hi = 0;
-  r.uinteger = r.has32 = r.k0 = r.k1 = 0;
-  r.src = p.rng + env;
-  r.loaded = false;
-  r.dirty = false;
-  if (RULESET == TG_RULESET_FUNCTIONAL) {
-    r.uinteger = fkey.x; r.has32 = fkey.y; r.k0 = fkey.z; r.k1 = fkey.w;
-    r.loaded = true;
-  }
+  // FUNCTIONAL: consumer side of the key-chain ring.  `ring_ok`: the ring describes the chain this env is on (loc ==
+  // kLocAhead as the launch starts, no reset since).  fk0/fk1 hold the key only while the lane runs threefry in line.
+  int epoch = epoch0;
+  bool ring_ok = RULESET == TG_RULESET_FUNCTIONAL && (int)((ring1 >> 45) & 0xFFULL) == epoch0;
+  bool owe_f0 = false;  // an in-line lock whose key step (rng_key = split(rng_key)[0]) waits until after the publish
+  uint32_t fk0 = 0, fk1 = 0;
+  bool fk_valid = false;
+  int kH = Hc;  // the position whose key `loc` locates (== Hc except while a lock's key step is owed)
+  auto fn_key_ensure = [&](const bool want) {  // the key at position kH, from wherever `loc` says it is (rare path)
+    if (want && !fk_valid) {
+      const uint2* ks = reinterpret_cast<const uint2*>(bp.ahead + (size_t)env * (2 * kRing)) + 4 * ((kH - 1) & (kRing - 1));
+      if (loc == kLocAheadR) ks += 1;
+      if (loc == kLocRec) ks = reinterpret_cast<const uint2*>(p.rng + env) + 5;
+      if (loc >= kLocBuf0) ks = reinterpret_cast<const uint2*>(bp.inl + ((size_t)(loc - kLocBuf0) * p.ring_stride + env) * 2);
+      const uint2 kk = *ks;
+      fk0 = kk.x; fk1 = kk.y;
+      fk_valid = true;
+    }
+  };
 
   bool cols_dirty_any = false;
   for (int step = 0; step < nsteps; ++step) {
@@ -1501,20 +1669,31 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       }
     }
     if (RULESET != TG_RULESET_NUMPY) {  // envs/tetris_fn.py:370-413 place_active_tetromino
-      lane_rng_ensure(r);
-      uint32_t a0, a1, b0, b1;
-      threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);  // split(rng_key)[0]
+      // the lock moves the env one position along its key chain (rng_key = split(rng_key)[0], :399) and, with the bag
+      // used up, deals permutation(split(rng_key)[1]) (functional/queue.py:59-67): both are this position's ring entry
       const bool refill = place && s.bidx >= 7;
-      if (__any(refill)) {
-        threefry2x32(r.k0, r.k1, 0u, 1u, b0, b1);  // split(rng_key)[1] (functional/queue.py:59-67)
-        const uint64_t nb = jax_permutation7(b0, b1);
-        if (refill) { s.bag = nb; s.bidx = 0; }
+      const bool pr_here = ((ring1 >> 44) & 1ULL) != 0 && (int)((ring1 >> 42) & 3ULL) == (Hc & (kRing - 1));
+      const bool via_ring = place && ring_ok && ring_diff(ringT, Hc) > 0 && (!refill || pr_here);
+      const bool inl_lock = place && !via_ring;
+      uint64_t nb = fn_expand21((uint32_t)(ring1 >> 21) & 0x1FFFFFu);
+      // No usable entry (the launches right after a reset / tg_set_state, or the ring ran dry): the key step runs in line —
+      // behind the publish, nothing in front of it needs the key (`owe_f0`) — unless the bag has to be refilled now
+      if (__any(inl_lock && refill)) {
+        fn_key_ensure(inl_lock && refill);
+        uint32_t a0, a1, b0, b1;
+        threefry2x32(fk0, fk1, 0u, 0u, a0, a1);  // split(rng_key)[0]
+        threefry2x32(fk0, fk1, 0u, 1u, b0, b1);  // split(rng_key)[1]
+        const uint64_t nbi = jax_permutation7(b0, b1);
+        if (inl_lock && refill) { nb = nbi; fk0 = a0; fk1 = a1; loc = loc_wr; }
       }
+      if (inl_lock && !refill) owe_f0 = true;  // (loc / kH keep describing the key in front of this lock)
+      if (refill) { s.bag = nb; s.bidx = 0; }
       if (place) {
         s.piece = (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
         s.bidx += 1;
-        r.k0 = a0; r.k1 = a1;
-        r.dirty = true;
+        Hc = (Hc + 1) & 0xFF;
+        if (via_ring) { loc = kLocAhead; fk_valid = false; }  // (the key is the c' of the consumed entry's slot)
+        if (!owe_f0) kH = Hc;
         s.rot = 0; s.val = s.piece + 2; s.x = (W + 8) / 2 - 2; s.y = 0;
       }
     }
@@ -1619,15 +1798,31 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
 #pragma unroll
         for (int c = 0; c < W; ++c) colsL[1 + c] = FLOOR;
       }
-      lane_rng_ensure(r);
-      uint32_t a0, a1, b0, b1;
-      threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);
-      threefry2x32(r.k0, r.k1, 0u, 1u, b0, b1);
-      const uint64_t nb = jax_permutation7(a0, a1);
+      // the reset deals permutation(split(key)[0]) and continues with split(key)[1]: this position's ring entry (PL; the
+      // new key is the R of its `ahead` slot — the env leaves the chain the ring looks ahead on: next epoch)
+      const bool via_ring = do_reset && ring_ok && ring_diff(ringT, Hc) > 0;
+      const bool inl_reset = do_reset && !via_ring;
+      uint64_t nb = fn_expand21(fn_ring_pl(ring0, ring1, Hc & (kRing - 1)));
+      if (__any(inl_reset)) {
+        fn_key_ensure(inl_reset);
+        if (__any(inl_reset && owe_f0)) {  // (the key step of this transition's lock comes first)
+          uint32_t a0, a1;
+          threefry2x32(fk0, fk1, 0u, 0u, a0, a1);
+          if (inl_reset && owe_f0) { fk0 = a0; fk1 = a1; owe_f0 = false; }
+        }
+        uint32_t a0, a1, b0, b1;
+        threefry2x32(fk0, fk1, 0u, 0u, a0, a1);
+        threefry2x32(fk0, fk1, 0u, 1u, b0, b1);
+        const uint64_t nbi = jax_permutation7(a0, a1);
+        if (inl_reset) { nb = nbi; fk0 = b0; fk1 = b1; loc = loc_wr; }
+      }
       if (do_reset) {
         s.bag = nb; s.queue = 0; s.piece = (int)(nb & 0xFF); s.bidx = 1;
-        r.k0 = b0; r.k1 = b1;
-        r.dirty = true;
+        Hc = (Hc + 1) & 0xFF;
+        if (via_ring) { loc = kLocAheadR; fk_valid = false; }
+        kH = Hc;
+        ring_ok = false;
+        epoch = (epoch + 1) & 0xFF;
         s.x = (W + 8) / 2 - 2;
         s.rot = 0; s.y = 0; s.val = s.piece + 2;
         s.hp = TG_NONE; s.hr = 0; s.hv = 0;
@@ -1709,6 +1904,14 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       }
     }
   };
+  auto fn_book = [&]() {  // FUNCTIONAL: the key step an in-line lock owes (beside the stream wave's work)
+    if (__any(owe_f0)) {
+      fn_key_ensure(owe_f0);
+      uint32_t a0, a1;
+      threefry2x32(fk0, fk1, 0u, 0u, a0, a1);  // rng_key = split(rng_key)[0]  (envs/tetris_fn.py:399)
+      if (owe_f0) { fk0 = a0; fk1 = a1; loc = loc_wr; kH = Hc; owe_f0 = false; }
+    }
+  };
   const bool book_first = RULESET == TG_RULESET_NUMPY && early_book;
   if constexpr (MULTI) {
     // (the kernels with the transition loop are at their register budget: one publish site, two passes)
@@ -1716,6 +1919,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     for (int pass = 0; pass < 2; ++pass) {
       if (RULESET == TG_RULESET_NUMPY && (pass == 0) == book_first && !TG_SKIP(512)) bookkeeping();
       if (pass == 0) publish();
+      if (RULESET == TG_RULESET_FUNCTIONAL && pass == 1) fn_book();
 #ifdef TG_FINE_FUSED  // (last transition: 5 = published, 6 = barrier passed, 7 = bookkeeping done / end of the iteration)
       if (pass == 0 && step == nsteps - 1) TG_BITS_STAMP(6);
 #endif
@@ -1724,6 +1928,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     if (!book_first) publish();
     if (RULESET == TG_RULESET_NUMPY && !TG_SKIP(512)) bookkeeping();
     if (book_first) publish();
+    if (RULESET == TG_RULESET_FUNCTIONAL) fn_book();
   }
   if (pending) {  // the NEXT_STEP reset step belongs to no episode (gymnasium RecordEpisodeStatistics)
     ep.ret = 0.0f; ep.len = 0;
@@ -1876,15 +2081,17 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
 #endif
   // ---- E: consumed counter; the generator state only after an in-line shuffle (otherwise `ahead` holds it) ----
   if (RULESET == TG_RULESET_NUMPY) {
-    if (live) bp.hbuf_wr[env] = (uint8_t)(Hc | (inl ? 0x80 : 0));
-    if (live && g_valid) {
-      uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
-      rng_out[0] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
-      *reinterpret_cast<uint2*>(rng_out + 2) = make_uint2(g.uinteger, g.has32);
+    if (live) bp.hbuf_wr[env] = (uint32_t)(Hc | (loc << 8));
+    if (live && g_valid) {  // (loc == loc_wr)
+      uint4* io = bp.inl + ((size_t)(loc_wr - kLocBuf0) * p.ring_stride + env) * 2;
+      io[0] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
+      io[1] = make_uint4(g.uinteger, g.has32, 0u, 0u);
     }
-  } else if (live && r.dirty) {
-    uint4* rng_out = reinterpret_cast<uint4*>(p.rng + env);
-    rng_out[2] = make_uint4(r.uinteger, r.has32, r.k0, r.k1);
+  } else {
+    // FUNCTIONAL: position, where its key is, and the bag index (which look-ahead position refills the bag)
+    if (live) bp.hbuf_wr[env] = (uint32_t)(Hc | (loc << 8) | ((s.bidx & 7) << 11) | (epoch << 16));
+    if (live && fk_valid && loc == loc_wr)
+      bp.inl[((size_t)(loc_wr - kLocBuf0) * p.ring_stride + env) * 2] = make_uint4(fk0, fk1, 0u, 0u);
   }
 #if !defined(TG_FINE_LOCK) && !defined(TG_FINE_FUSED)
   TG_BITS_STAMP(7);
@@ -1912,7 +2119,7 @@ struct PrepareParams {
   void* cols;
   uint4* ahead;
   uint64_t* ring;       // [2][B]
-  uint8_t* hbuf;        // [2][B]
+  uint32_t* hbuf;       // [2][B]
   const uint8_t* mask;  // [B] or null: envs whose generator moved (their ring is refilled)
   int batch;
   int ruleset;
@@ -1933,7 +2140,6 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
     for (int rr = 0; rr < H; ++rr) v |= (T)(b[rr * W + c] != 0 ? 1 : 0) << rr;
     gc[c] = v;
   }
-  if (p.ruleset != TG_RULESET_NUMPY) return;
   const size_t B = (size_t)p.batch;
   const bool moved = p.force || (p.mask ? p.mask[env] != 0 : true);
   uint4* ring4 = reinterpret_cast<uint4*>(p.ring);
@@ -1943,6 +2149,17 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
     return;
   }
   uint32_t* rec = p.rec + (size_t)env * 8;
+  if (p.ruleset != TG_RULESET_NUMPY) {
+    // FUNCTIONAL: an empty ring (T = H = 0) whose key is the one in tg_rng_rec — the RNG role of the first launch
+    // starts the look-ahead from there, the logic wave runs threefry in line until it has
+    const uint4 none = make_uint4(0u, 0u, 0u, 0u);
+    ring4[env] = none;
+    ring4[B + env] = none;
+    const uint32_t hv = (uint32_t)((kLocRec << 8) | ((((rec[2] >> 8) & 0xFFu) > 7u ? 7u : ((rec[2] >> 8) & 7u)) << 11));
+    p.hbuf[env] = hv;
+    p.hbuf[B + env] = hv;
+    return;
+  }
   Rng r;
   r.loaded = false;
   r.dirty = false;
@@ -1960,7 +2177,7 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
   }
   rec[7] = 0;
   // T = kRing - 1, H = 0: entries 0 .. kRing - 2 ahead; "the state after entry -1" = the generator as it stands in
-  // tg_rng_rec (inl = 1), which this kernel leaves where the reference's generator is
+  // tg_rng_rec (loc = kLocRec), which this kernel leaves where the reference's generator is
   uint64_t w[2] = {(uint64_t)(kRing - 1) << 56, 0};
   uint4* a4 = p.ahead + (size_t)env * (2 * kRing);
   for (int sl = 0; sl < kRing - 1; ++sl) {
@@ -1974,8 +2191,8 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
   const uint4 rw = make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
   ring4[env] = rw;
   ring4[B + env] = rw;
-  p.hbuf[env] = 0x80;
-  p.hbuf[B + env] = 0x80;
+  p.hbuf[env] = (uint32_t)(kLocRec << 8);
+  p.hbuf[B + env] = (uint32_t)(kLocRec << 8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1987,16 +2204,25 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
 struct MaterializeParams {
   tg_rng_rec* rng;
   const uint4* ahead;
-  const uint8_t* hbuf;  // the parity the next launch reads
+  const uint32_t* hbuf;  // the parity the next launch reads
+  const uint4* inl;      // in-line buffers [2][B][2]
   int batch;
+  int ruleset;
 };
 
 __global__ __launch_bounds__(256) void bits_materialize_rng_kernel(const MaterializeParams p) {
   const int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= p.batch) return;
   const int Hraw = p.hbuf[env];
-  if (Hraw & 0x80) return;
-  const uint4* a4 = p.ahead + (size_t)env * (2 * kRing) + 2 * (((Hraw & 0x7F) - 1) & (kRing - 1));
+  const int loc = (Hraw >> 8) & 7;
+  if (loc == kLocRec) return;
+  const uint4* a4 = (loc == kLocBuf0 || loc == kLocBuf1) ? p.inl + ((size_t)(loc - kLocBuf0) * p.batch + env) * 2
+                                    : p.ahead + (size_t)env * (2 * kRing) + 2 * (((Hraw & 0xFF) - 1) & (kRing - 1));
+  if (p.ruleset != TG_RULESET_NUMPY) {  // FUNCTIONAL: State.rng_key = the key at the env's position of its chain
+    const uint2 k = reinterpret_cast<const uint2*>(a4)[loc == kLocAheadR ? 1 : 0];
+    reinterpret_cast<uint2*>(p.rng + env)[5] = k;
+    return;
+  }
   const uint4 f0 = a4[0], f1 = a4[1];
   uint4* out = reinterpret_cast<uint4*>(p.rng + env);
   out[0] = f0;

@@ -16,9 +16,10 @@ from tetris_gymnasium_amd import _native as N
 N.LIB_PATH = out
 from tetris_gymnasium_amd import Engine
 B = 65536
-e = Engine(B, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP)
+fn = os.environ.get('TL_RULESET', 'numpy') == 'functional'  # TL_RULESET=functional: the functional rule-set's launch
+e = Engine(B, ruleset=(N.RULESET_FUNCTIONAL if fn else N.RULESET_NUMPY), obs_mode=(N.OBS_FN if fn else N.OBS_BOARD), autoreset=N.AUTORESET_SAME_STEP)
 e.reset(np.arange(1, B + 1, dtype=np.uint64))
-acts = np.random.default_rng(0).integers(0, 8, (80, B)).astype(np.int8)
+acts = np.random.default_rng(0).integers(0, 7 if fn else 8, (80, B)).astype(np.int8)
 d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts)
 e.step_k_device(d, 72); e.sync()
 # launch time of the stamped build (HIP events over 7 launches) and then the one launch whose stamps are read
