@@ -87,17 +87,19 @@ template <int W, int H, int RS>
 void launch_step(const tg::KParams& p, hipStream_t s) {
   if (p.cols) {  // "bits": the handle carries the column masks / look-ahead permutations
     using BG = tg::BitsGeo<W, H>;
-    const int nrb = p.rng_role ? (p.batch + 127) / 128 : 0;  // RNG-role workgroups (tg_kernel_bits.h)
+    const int nrb = (RS == TG_RULESET_NUMPY && p.rng_role) ? (p.batch + 127) / 128 : 0;  // RNG-role workgroups (tg_kernel_bits.h)
     const uint4* const ring4 = reinterpret_cast<const uint4*>(p.ring);
+    // (FUNCTIONAL: hbuf is the look-ahead word array fnw [B] u64 — private to each env's logic wave, no parities)
+    const size_t hrd = RS == TG_RULESET_NUMPY ? (size_t)p.hbuf_cur * p.ring_stride : 0, hwr = RS == TG_RULESET_NUMPY ? (size_t)(1 - p.hbuf_cur) * p.ring_stride : 0;
     const tg::BitsParams bp{p.cols, p.ahead,
                             ring4 + (size_t)p.ring_cur * p.ring_stride, const_cast<uint4*>(ring4) + (size_t)(1 - p.ring_cur) * p.ring_stride,
-                            p.hbuf + (size_t)p.hbuf_cur * p.ring_stride, p.hbuf + (size_t)(1 - p.hbuf_cur) * p.ring_stride,
-                            p.inl, nrb, p.ring_fill};
+                            p.hbuf + hrd, p.hbuf + hwr, p.inl, nrb, p.ring_fill};
     const int n_step_wgs = (p.batch + BG::EPW - 1) / BG::EPW;
     const dim3 grid(nrb + n_step_wgs);
     constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
     const int feat = bits_feat<W, H, RS>(p);
-    const size_t lds = (feat & D) ? BG::BYTES_DICT : ((feat & R) ? BG::BYTES_RGB : ((feat & F) ? BG::BYTES_FIN : BG::BYTES));
+    const size_t lds = RS == TG_RULESET_FUNCTIONAL ? BG::BYTES_FNX
+                       : ((feat & D) ? BG::BYTES_DICT : ((feat & R) ? BG::BYTES_RGB : ((feat & F) ? BG::BYTES_FIN : BG::BYTES)));
 #define TG_LAUNCH_BITS(FT)                                                                                                  \
   hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(128), lds, s, p.board, p.rec, p.cols, bp.ring_rd, bp.hbuf_rd, \
                      p.actions, p.batch, (uint32_t)n_step_wgs | ((p.act_i8 ? 1u : 0u) << 24) | ((uint32_t)(p.nsteps > 0 ? p.nsteps : 0) << 25), \
@@ -455,7 +457,7 @@ int launch_step_all(tg_handle* h, const tg::KParams& p) {
     if (p.cols) q.cols = (uint8_t*)p.cols + o * p.cols_bytes;
     if (p.ahead) q.ahead = p.ahead + o * 2 * tg::kRing;
     if (p.ring) q.ring = p.ring + o * 2;
-    if (p.hbuf) q.hbuf = p.hbuf + o;
+    if (p.hbuf) q.hbuf = p.hbuf + (h->cfg.ruleset == TG_RULESET_NUMPY ? o : 2 * o);  // (FUNCTIONAL: one u64 per env)
     if (p.inl) q.inl = p.inl + o * 2;
     h->L.step(q, h->sh_stream[i]);
   }
@@ -487,9 +489,8 @@ int launch_prepare_bits(tg_handle* h, const uint8_t* d_mask, int force) {
 // bits kernel, NUMPY rules: bring TG_BUF_RNG up to date with the generators the reference would hold now (a transition
 // leaves the state in the permutation ring's `ahead` slots, tg_kernel_bits.h)
 int launch_materialize_rng(tg_handle* h) {
-  if (!h->d_cols) return TG_OK;
+  if (!h->d_cols || h->cfg.ruleset != TG_RULESET_NUMPY) return TG_OK;  // (FUNCTIONAL: the step kernel keeps State.rng_key current)
   tg::MaterializeParams q{};
-  q.ruleset = h->cfg.ruleset;
   q.rng = (tg_rng_rec*)h->buf[TG_BUF_RNG];
   q.ahead = h->d_ahead;
   q.hbuf = h->d_hbuf + (size_t)h->hbuf_cur * (size_t)h->B;
@@ -673,8 +674,6 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
                         ((cfg->obs_mode == TG_OBS_DICT && L.dict_ok) ||
                          (cfg->obs_mode == TG_OBS_RGB && L.rgb_ok && cfg->queue_size == 4));  // (the in-kernel RGB image is laid out for four queue pieces)
     if (const char* e = getenv("TG_RING_FILL")) { const int v = atoi(e); h->ring_fill = v < 0 ? 0 : (v > tg::kRing - 1 ? tg::kRing - 1 : v); }
-    // FUNCTIONAL: a ring entry is consumed by every lock (not every seventh as the NUMPY bag permutations): every launch
-    if (cfg->ruleset == TG_RULESET_FUNCTIONAL) h->rng_every = 1;
     if (const char* e = getenv("TG_RNG_EVERY")) { const int v = atoi(e); h->rng_every = v < 1 ? 1 : (v > 3 ? 3 : v); }
     if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > 8 ? 8 : v); }
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
@@ -974,6 +973,10 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
   // such envs are marked for one full scan.
   std::vector<tg_env_rec> tmp;
   if (board) {
+    if (h->cfg.ruleset == TG_RULESET_FUNCTIONAL)  // (the {-1, 0, 1} observation tells the drawn piece by its top bit: tg_kernel_bits.h bits_bin1)
+      for (size_t i = 0; i < B * h->cells; ++i)
+        if (board[i] >= 0x80)
+          return fail(h, TG_EINVAL, "tg_set_state: board byte %zu is %d; cells of the functional rule-set are 0 or a tetromino value 2..8", i, board[i]);
     HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_BOARD], board, B * h->cells, hipMemcpyHostToDevice, h->stream));
     tmp.resize(B);
     if (rec) std::memcpy(tmp.data(), rec, B * sizeof(tg_env_rec));

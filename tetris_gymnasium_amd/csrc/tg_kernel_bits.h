@@ -128,6 +128,10 @@ struct BitsGeo {
   // the terminal piece of every env that ends its episode in this transition
   static constexpr int OFF_FIN = BYTES;
   static constexpr int BYTES_FIN = BYTES + 2 * EPW * 8;
+  // FUNCTIONAL rule-set (never together with the dict / RGB staging): the logic wave's exchange area for the sorts of the
+  // key-chain look-ahead — uint2 keys [128] | uint32 permutations [128] — behind the FINAL_OBS records
+  static constexpr int OFF_FNX = BYTES_FIN;
+  static constexpr int BYTES_FNX = BYTES_FIN + 128 * 8 + 128 * 4;
   static_assert(W % 2 == 0, "column masks are moved as 8-byte pairs");
 };
 
@@ -220,9 +224,8 @@ struct BitsParams {
   // the RNG role); the host passes both as pointers — the parity arithmetic stood between the logic wave's first loads.
   const uint4* ring_rd;
   uint4* ring_wr;
-  // hbuf [2 parities][B]: H (bits 0-7) | loc << 8 (where the state after entry H - 1 is: kLoc*) | bag index << 11
-  // (FUNCTIONAL: which look-ahead position refills the bag) | chain epoch << 16 (FUNCTIONAL: resets so far, mod 256);
-  // read parity / the parity the logic wave writes (flips every launch)
+  // hbuf [2 parities][B]: H (bits 0-7) | loc << 8 (where the state after entry H - 1 is: kLoc*); read parity / the
+  // parity the logic wave writes (flips every launch).  FUNCTIONAL: the same storage is fnw [B] u64 (no parities)
   const uint32_t* hbuf_rd;
   uint32_t* hbuf_wr;
   uint4* inl;      // [2 buffers][B][2]: generator state after an in-line shuffle (layout of an `ahead` slot)
@@ -235,7 +238,7 @@ struct BitsParams {
 constexpr int kRing = 4;  // slots per permutation ring: kRing - 1 entries ahead + the last consumed one
 __device__ __forceinline__ int ring_diff(const int a, const int b) { return ((a - b) << 24) >> 24; }  // counters are mod 256
 // where the generator state (FUNCTIONAL: the key) after the last consumed entry lives (`loc` field of hbuf)
-constexpr int kLocAhead = 0, kLocRec = 1, kLocAheadR = 2, kLocBuf0 = 3, kLocBuf1 = 4;  // (code tests `loc >= kLocBuf0`)
+constexpr int kLocAhead = 0, kLocRec = 1, kLocBuf0 = 2, kLocBuf1 = 3;  // (code tests `loc >= kLocBuf0`)
 constexpr int kRngEnvs = 1024;  // envs scanned by one RNG-role workgroup (128 threads x 8)
 
 __device__ __forceinline__ uint32_t ring_get(const uint64_t w0, const uint64_t w1, const int slot) {
@@ -243,27 +246,26 @@ __device__ __forceinline__ uint32_t ring_get(const uint64_t w0, const uint64_t w
   return (uint32_t)(w >> (28 * (slot & 1))) & 0x0FFFFFFFu;
 }
 
-// ---- FUNCTIONAL rule-set: the same ring protocol along the jax key chain (envs/tetris_fn.py:370-413, 318-367) ----
-// Every lock replaces the key by c' = split(c)[0] = threefry(c, (0, 0)); a lock that finds the 7-bag used up refills it with
-// permutation(split(c)[1]) (functional/queue.py:59-67); a reset takes permutation(split(c)[0]) as the new bag and
-// R = split(c)[1] as the new key.  So a ring entry describes ONE POSITION of the chain: for the key c at that position
-//   PL = permutation(c')  the bag a reset at this position deals          (21 bits: seven 3-bit pieces)
-//   PR = permutation(R)   the bag a refilling lock at this position deals (only at the position whose lock refills:
-//                         bag index + distance == 7; one field + its slot tag per ring, refills are 7 locks apart)
-//   c', R                 in the entry's `ahead` slot {c'.k0, c'.k1, R.k0, R.k1}: the key after a lock / after a reset.
-// A lock consumes its entry and stays on the chain (loc = kLocAhead: the key is ahead[(H - 1) & 3].c'); a reset consumes
-// its entry and LEAVES the chain (loc = kLocAheadR: the key is that slot's R; the entries beyond describe positions
-// that will never be visited).  Both sides count chains: the consumer's epoch (hbuf) goes up with every reset, the ring
-// carries the epoch its entries were produced for; a ring of another epoch is dead for the consumer, and makes the RNG
-// role start over from the consumer's key (T := H, epoch := the consumer's) — as a ring that ran dry does.  With no
-// usable entry the logic wave runs threefry in line (key in registers, then in an in-line buffer; a plain lock's key
-// step waits until after the publish).
-// Ring record: w0 = PL of slots 0 | 1 << 21 | 2 << 42;  w1 = PL of slot 3 | PR << 21 | PR slot << 42 | PR valid << 44 |
-// epoch << 45 | T << 56.
+// ---- FUNCTIONAL rule-set: look-ahead along the jax key chain (envs/tetris_fn.py:370-413, 318-367) ----
+// With f0(k) = split(k)[0] = threefry(k, (0, 0)), f1(k) = split(k)[1] = threefry(k, (0, 1)) and
+// sort7(s) = the argsort of the seven sort keys threefry(s, (0, j)).x ^ .y   (permutation(k) == sort7(f1(k))):
+//   a lock replaces the key c by f0(c) (:399) and, with the 7-bag used up, deals permutation(f1(c)) (functional/queue.py:59-67);
+//   a reset deals permutation(f0(c)) and continues with the key f1(c) (:318-367).
+// Every env sits at a position n of a key chain c_n, c_{n+1} = f0(c_n), with R_m = f1(c_m):
+//   a lock at n that refills     deals Q0 = sort7(f1(R_n))
+//   a reset at n                 deals S1 = sort7(R_{n+1}), new key R_n            (NEXT_STEP autoreset: the step after the end)
+//   a lock at n + a reset        deals S2 = sort7(R_{n+2}), new key R_{n+1}        (SAME_STEP autoreset)
+// None of this depends on the game, so it is computed AHEAD, by the env's own logic wave, behind its publish (beside the
+// stream wave's tail), for the lanes whose env consumed something — one threefry level (three independent blocks per
+// lane) plus one sort per lock, three levels per reset; the seven blocks of every sort the wave owes are spread over
+// LANES (8 lanes per sort, 16 sorts per trip).  In front of the publish a transition only picks 3-bit pieces out of one
+// 64-bit word.  Round 2 ran threefry in line on every lock (10.3 us per launch, 2.6 us of it in front of the publish); a
+// look-ahead produced by the RNG role (as the NUMPY bag permutations are) reached 8.3 us: its waves were the launch's tail.
+//   fnw  [B] u64: S1 | S2 << 21 | Q0 << 42   (seven 3-bit pieces each; Q0 is meaningful when the bag index is 7)
+//   fnla [B] 128 B: c[4] (c_m in slot m & 3 for m = n+1 .. n+3) | r[4] (R_m in slot m & 3 for m = n .. n+2) | unused;
+//   n mod 4 lives in tg_env_rec.reserved (device-private), the key c_n in tg_rng_rec.key as the reference holds it.
+// bits_prepare_kernel builds all of it from the key after tg_reset / tg_set_state.
 // PARITY UNPINNED like every jax-dependent piece of this rule-set; engine == oracle is what tests check.
-__device__ __forceinline__ uint32_t fn_ring_pl(const uint64_t w0, const uint64_t w1, const int slot) {
-  return (uint32_t)((slot & 3) == 3 ? w1 : (w0 >> (21 * (slot & 3)))) & 0x1FFFFFu;
-}
 __device__ __forceinline__ uint32_t fn_pack21(const uint64_t bag) {  // 7 bytes → seven 3-bit fields
   uint32_t p = 0;
 #pragma unroll
@@ -276,6 +278,25 @@ __device__ __forceinline__ uint64_t fn_expand21(const uint32_t p) {  // seven 3-
     return (t & 0x00070007u) | ((t & 0x00380038u) << 5);
   };
   return (uint64_t)four(p & 0xFFFu) | ((uint64_t)four((p >> 12) & 0x1FFu) << 32);
+}
+// sort7 of one lane (bits_prepare_kernel; the step kernel spreads the seven blocks over lanes)
+__device__ __forceinline__ uint32_t fn_sort7(const uint32_t s0, const uint32_t s1) {
+  uint32_t bits[7];
+#pragma unroll
+  for (uint32_t i = 0; i < 7; ++i) {
+    uint32_t a, b;
+    threefry2x32(s0, s1, 0u, i, a, b);
+    bits[i] = a ^ b;
+  }
+  uint32_t p = 0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) rank += (bits[j] < bits[i] || (bits[j] == bits[i] && j < i)) ? 1 : 0;
+    p |= (uint32_t)i << (3 * rank);
+  }
+  return p;
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -351,11 +372,14 @@ __device__ __forceinline__ void st_state(V* dst, const V v) {
 // Profiles list the kinds of launches separately.
 constexpr int kFeatMulti = 1, kFeatTraj = 2, kFeatDict = 4, kFeatSample = 8, kFeatFinal = 16, kFeatRgb = 32;
 
-// bytes: 0xFF (active) stays -1, other non-zero → 1  (the functional observation, envs/tetris_fn.py:137-158)
+// bytes: 0xFF (active) stays -1, other non-zero → 1  (the functional observation, envs/tetris_fn.py:137-158).  Board cells
+// are 0 or a tetromino value 2..8 (tg_set_state rejects bytes >= 0x80 for this rule-set), so the only byte with its top bit
+// set is the drawn piece: 7 instructions per dword instead of 11 — at 52 dwords per lane this conversion is a fifth of
+// the stream wave's instructions, and the launch is bound by the instructions its two waves issue on their SIMD.
 __device__ __forceinline__ uint32_t bits_bin1(const uint32_t x) {
-  const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
-  const uint32_t ff = ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u;
-  return (nz >> 7) | ((ff >> 7) * 0xFFu);
+  const uint32_t a = x & 0x80808080u;                                              // the active piece's bytes
+  const uint32_t m = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) >> 7) & 0x01010101u;       // 1 where the low seven bits are non-zero
+  return m | a | (a - (a >> 7));                                                   // 0x80 → 0xFF
 }
 
 // Two playfield rows (2 W bytes = 2 W / 4 dwords, row pairs start dword-aligned because W is even) → the same two rows of
@@ -691,115 +715,6 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     // would otherwise run two shuffles back to back and become the tail of the launch — measured 7.0 us vs 5.8 us for the
     // step workgroups).  Launches of several transitions consume more per env and are long anyway: refill completely.
     const int max_reps = nsteps > 1 ? kRing - 1 : 1;
-    if constexpr (RULESET == TG_RULESET_FUNCTIONAL) {
-#ifndef TG_RNG_PRIO_FN
-#define TG_RNG_PRIO_FN 0  // these waves are dense VALU work nobody waits for inside the launch: below the stream wave (1)
-#endif
-      __builtin_amdgcn_s_setprio(TG_RNG_PRIO_FN);
-      // one entry = one position of the key chain (protocol above): c' = split(c)[0], R = split(c)[1], PL = permutation(c'),
-      // PR = permutation(R) where the lock refills the bag.  Only the lanes whose env consumed an entry need one (a lock: 18 %
-      // of the envs per transition), and a permutation is 1 + 7 threefry blocks — so the seven independent blocks of every
-      // permutation the wave owes are spread over LANES (8 lanes per permutation, 8 permutations per pass: two passes
-      // per launch instead of 16 sparse blocks per lane; the sparse form made these waves the tail of the launch: 15 us).
-      const int bidxH = (Hraw >> 11) & 7;
-      const uint64_t epochH = (uint64_t)((Hraw >> 16) & 0xFF);
-      uint32_t k0 = 0, k1 = 0;
-      bool loaded = false;
-      uint2* a2 = reinterpret_cast<uint2*>(bp.ahead + (size_t)ee * (2 * kRing));  // slot s: a2[4 s] = c', a2[4 s + 1] = R
-      // All four {c', R} pairs travel with the first loads: which one is the frontier depends on T / H / loc (a dependent
-      // round trip otherwise — a second memory phase in front of five dependent threefry blocks made these waves the tail)
-      uint4 slotv[kRing];
-#pragma unroll
-      for (int i = 0; i < kRing; ++i) slotv[i] = *reinterpret_cast<const uint4*>(a2 + 4 * i);
-      uint2* xk = reinterpret_cast<uint2*>(lds + wave * 2048);                    // sort keys of the owed permutations [128]
-      uint32_t* xo = reinterpret_cast<uint32_t*>(lds + wave * 2048 + 1024);       // the permutations [128]
-      for (int rep = 0; rep < max_reps; ++rep) {
-        int Tn = (int)(w1 >> 56) & 0xFF;
-        int d = ring_diff(Tn, Hn);
-        const bool resync = !loaded && (d <= 0 || ((w1 >> 45) & 0xFFULL) != epochH);  // the consumer ran past T, or left the chain
-        if (resync) { Tn = Hn; d = 0; }
-        const bool need = on && d < bp.fill;
-        if (!__any(need)) break;
-        if (need && !loaded) {
-          const int fs = (Tn - 1) & (kRing - 1);  // the key after entry T - 1 ...
-          const uint4 sv = fs == 0 ? slotv[0] : (fs == 1 ? slotv[1] : (fs == 2 ? slotv[2] : slotv[3]));
-          const bool afterR = resync && loc == kLocAheadR;  // ... the consumer's key after a reset,
-          k0 = afterR ? sv.z : sv.x; k1 = afterR ? sv.w : sv.y;
-          const bool elsewhere = resync && (loc == kLocRec || loc >= kLocBuf0);
-          if (__any(elsewhere)) {  // as tg_reset / tg_set_state left it, or after in-line threefry (rare)
-            const uint2* ks = reinterpret_cast<const uint2*>(p.rng + ee) + 5;
-            if (loc >= kLocBuf0) ks = reinterpret_cast<const uint2*>(bp.inl + ((size_t)(loc - kLocBuf0) * p.ring_stride + ee) * 2);
-            if (elsewhere) { const uint2 kk = *ks; k0 = kk.x; k1 = kk.y; }
-          }
-          if (resync) w1 = (w1 & ~((1ULL << 44) | (0xFFULL << 45))) | (epochH << 45);  // (no refill permutation of the chain that was left)
-        }
-        uint32_t c0, c1, r0, r1, sl0, sl1, sr0 = 0, sr1 = 0;
-        threefry2x32(k0, k1, 0u, 0u, c0, c1);
-        threefry2x32(k0, k1, 0u, 1u, r0, r1);
-        const bool refp = need && bidxH + d == 7;  // the lock at this position finds the bag used up
-        threefry2x32(c0, c1, 0u, 1u, sl0, sl1);    // permutation(key): key', sub = split(key); sort keys = bits(sub, 7)
-        if (__any(refp)) threefry2x32(r0, r1, 0u, 1u, sr0, sr1);
-        // task list: PL of every lane in `need`, then PR of every lane in `refp`
-        const uint64_t mN = __ballot(need), mR = __ballot(refp);
-        const int n1 = __popcll(mN), nt = n1 + __popcll(mR);
-        const int q1 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mN >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mN, 0u));
-        const int q2 = n1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mR >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mR, 0u));
-        if (need) xk[q1] = make_uint2(sl0, sl1);
-        if (refp) xk[q2] = make_uint2(sr0, sr1);
-        wave_sync();
-        const int j = lane & 7;
-        // stable rank of element j among the 7 of its 8-lane group (jax sort_key_val on 32 random bits; ties by index) → the
-        // group's permutation as seven 3-bit fields
-        auto group_perm = [&](const uint32_t bits) -> uint32_t {
-          int rank = 0;
-#pragma unroll
-          for (int rr = 1; rr < 7; ++rr) {
-            const int oj = j + rr >= 7 ? j + rr - 7 : j + rr;
-            const uint32_t ob = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & ~7) | oj) << 2, (int)bits);
-            rank += (ob < bits || (ob == bits && oj < j)) ? 1 : 0;
-          }
-          uint32_t pm = j < 7 ? (uint32_t)j << (3 * rank) : 0u;
-          pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-          pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-          pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x141, 0xF, 0xF, true);  // row_half_mirror: the other quad of the 8
-          return pm;
-        };
-        for (int t0 = 0; t0 < nt; t0 += 16) {  // 16 permutations per trip: two independent threefry streams per lane
-          const int ta = t0 + (lane >> 3), tb = ta + 8;
-          const uint2 ka = xk[ta < nt ? ta : 0], kb = xk[tb < nt ? tb : 0];
-          uint32_t a0, a1, b0, b1;
-          threefry2x32(ka.x, ka.y, 0u, (uint32_t)j, a0, a1);
-          threefry2x32(kb.x, kb.y, 0u, (uint32_t)j, b0, b1);
-          const uint32_t pa = group_perm(a0 ^ a1), pb = group_perm(b0 ^ b1);
-          if (j == 0 && ta < nt) xo[ta] = pa;
-          if (j == 0 && tb < nt) xo[tb] = pb;
-        }
-        wave_sync();
-        const uint32_t pl = xo[need ? q1 : 0];
-        const uint32_t pr = xo[refp ? q2 : 0];
-        wave_sync();
-        if (need) {
-          const int sl = Tn & (kRing - 1);
-          *reinterpret_cast<uint4*>(a2 + 4 * sl) = make_uint4(c0, c1, r0, r1);
-          if (sl == 3) w1 = (w1 & ~0x1FFFFFULL) | pl;
-          else w0 = (w0 & ~(0x1FFFFFULL << (21 * sl))) | ((uint64_t)pl << (21 * sl));
-          if (refp) w1 = (w1 & ~(0xFFFFFFULL << 21)) | ((uint64_t)pr << 21) | ((uint64_t)sl << 42) | (1ULL << 44);
-          else if (((w1 >> 42) & 3ULL) == (uint64_t)sl) w1 &= ~(1ULL << 44);  // the slot's previous tenant is gone
-          w1 = (w1 & ~(0xFFULL << 56)) | ((uint64_t)((Tn + 1) & 0xFF) << 56);
-          k0 = c0; k1 = c1;
-          loaded = true;
-        }
-      }
-      if (on) st_state(reinterpret_cast<u32x4*>(bp.ring_wr) + e, u32x4{(uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32)});
-#ifdef TG_PHASE_TIMING
-      if (p.dbg && (threadIdx.x & 63) == 0) {
-        const size_t slot = (size_t)(gridDim.x - bp.nrb) * 16 + (size_t)rng_block * 4 + (threadIdx.x >> 6) * 2;
-        p.dbg[slot] = rng_t0;
-        p.dbg[slot + 1] = TG_NOW();
-      }
-#endif
-      return;
-    }
     BitsRng g;
     g.s_lo = g.s_hi = g.i_lo = g.i_hi = 0;
     g.uinteger = g.has32 = 0;
@@ -935,9 +850,14 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     __builtin_amdgcn_s_barrier();  // the logic wave has published what happened to every env in this transition
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 #ifndef TG_NO_PRIO_SWAP
-    // from here on this wave is the workgroup's critical path (NUMPY; with the functional rule-set's in-line threefry the
-    // logic waves of other workgroups on this SIMD are the longer pole: measured 11.4 us with the swap, 10.65 without)
-    if (RULESET == TG_RULESET_NUMPY) __builtin_amdgcn_s_setprio(3);
+    // from here on this wave is the workgroup's critical path (round 2 left the functional rule-set out: its logic waves
+    // ran threefry in line in front of their publish and were the longer pole; that work now sits behind the publish)
+#ifdef TG_FN_NO_SWAP
+    if (RULESET == TG_RULESET_NUMPY)
+#else
+    if (RULESET == TG_RULESET_NUMPY || !MULTI)  // (launches of several functional transitions: the logic wave's look-ahead is on the chain)
+#endif
+    __builtin_amdgcn_s_setprio(3);
 #endif
 #ifdef TG_FINE_FUSED_STREAM
     TG_FS(2);
@@ -1267,11 +1187,15 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   }
   uint64_t ring0 = 0, ring1 = 0;
   int Hc = 0;
-  {
+  uint64_t fnw = 0;  // FUNCTIONAL: the bags this transition may deal (S1 | S2 << 21 | Q0 << 42), see the look-ahead above
+  if (RULESET == TG_RULESET_NUMPY) {
     const uint4 rw = hot_ring_rd[env];
     ring0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32);
     ring1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
     Hc = hot_hbuf_rd[env];  // H | loc << 8, split below
+  } else {
+    const uint2 fw = reinterpret_cast<const uint2*>(hot_hbuf_rd)[env];
+    fnw = (uint64_t)fw.x | ((uint64_t)fw.y << 32);
   }
   T cv[W];
   {
@@ -1315,11 +1239,10 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   // consumer side of the permutation ring (NUMPY).  Consuming an entry is pure register work: a nibble gather from the
   // ring word loaded at launch start; the generator state is not touched (see the protocol above).  g holds the state
   // only after an in-line shuffle (ring exhausted: rare).
-  const int ringT = (int)((RULESET == TG_RULESET_NUMPY ? ring0 : ring1) >> 56) & 0xFF;
+  const int ringT = (int)(ring0 >> 56) & 0xFF;
   const int loc0 = (Hc >> 8) & 7;  // where the state after entry H - 1 is as the launch starts (kLoc*)
   const int loc_wr = loc0 == kLocBuf0 ? kLocBuf1 : kLocBuf0;  // the in-line buffer this launch may write: the one nobody reads now
   int loc = loc0;
-  const int epoch0 = (Hc >> 16) & 0xFF;  // (FUNCTIONAL) the chain this env is on
   Hc &= 0xFF;
   bool g_valid = false, inc_loaded = false;
   BitsRng g;
@@ -1372,31 +1295,25 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     if (on) s.queue = (s.queue >> 8) | ((uint64_t)nxt << (8 * (Q - 1)));
     return t;
   };
-  // FUNCTIONAL: consumer side of the key-chain ring.  `ring_ok`: the ring describes the chain this env is on (loc ==
-  // kLocAhead as the launch starts, no reset since).  fk0/fk1 hold the key only while the lane runs threefry in line.
-  int epoch = epoch0;
-  bool ring_ok = RULESET == TG_RULESET_FUNCTIONAL && (int)((ring1 >> 45) & 0xFFULL) == epoch0;
-  bool owe_f0 = false;  // an in-line lock whose key step (rng_key = split(rng_key)[0]) waits until after the publish
-  uint32_t fk0 = 0, fk1 = 0;
-  bool fk_valid = false;
-  int kH = Hc;  // the position whose key `loc` locates (== Hc except while a lock's key step is owed)
-  auto fn_key_ensure = [&](const bool want) {  // the key at position kH, from wherever `loc` says it is (rare path)
-    if (want && !fk_valid) {
-      const uint2* ks = reinterpret_cast<const uint2*>(bp.ahead + (size_t)env * (2 * kRing)) + 4 * ((kH - 1) & (kRing - 1));
-      if (loc == kLocAheadR) ks += 1;
-      if (loc == kLocRec) ks = reinterpret_cast<const uint2*>(p.rng + env) + 5;
-      if (loc >= kLocBuf0) ks = reinterpret_cast<const uint2*>(bp.inl + ((size_t)(loc - kLocBuf0) * p.ring_stride + env) * 2);
-      const uint2 kk = *ks;
-      fk0 = kk.x; fk1 = kk.y;
-      fk_valid = true;
-    }
-  };
+  // FUNCTIONAL: what this transition consumed of the key-chain look-ahead (made good behind the publish, fn_book below)
+  bool fn_lock = false, fn_reset = false, fn_dirty = false;
 
   bool cols_dirty_any = false;
   for (int step = 0; step < nsteps; ++step) {
 #ifdef TG_PHASE_TIMING
   if (MULTI && step == nsteps - 1 && step > 0) TG_BITS_STAMP(1);  // (see the stream wave)
 #endif
+  // FUNCTIONAL: the look-ahead keys a lock of this transition will continue from — requested now (their address depends on
+  // the record's position counter), consumed behind the publish (fn_book): as a dependent load there they stood in
+  // front of three threefry levels while the memory system was busy with the stream waves' stores (3.3 us)
+  u32x2 pf_c1 = u32x2{0u, 0u}, pf_c3 = pf_c1, pf_r1 = pf_c1;  // (native vectors: HIP's uint2 struct went to scratch memory)
+  if (RULESET == TG_RULESET_FUNCTIONAL) {
+    const u32x2* cs = reinterpret_cast<const u32x2*>(bp.ahead) + (size_t)env * 16;
+    const int n = (int)(s.reserved & 3u);
+    // (an env that only resets in this transition — NEXT_STEP autoreset, the step after its end — continues with R_n)
+    const bool pend = p.autoreset == TG_AUTORESET_NEXT_STEP && (s.flags & TG_F_PENDING_RESET);
+    pf_c1 = cs[(n + 1) & 3]; pf_c3 = cs[(n + 3) & 3]; pf_r1 = cs[4 + ((pend ? n : n + 1) & 3)];
+  }
   int action_in = hot_act_i8 ? (int)(int8_t)(apack >> (8 * step)) : action0;
   if (RULESET == TG_RULESET_NUMPY && sample_mode) {
     // uniform over the legal placements of the CURRENT piece (wrappers/grouped.py:104-122: legal = inside the frame).
@@ -1669,31 +1586,15 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       }
     }
     if (RULESET != TG_RULESET_NUMPY) {  // envs/tetris_fn.py:370-413 place_active_tetromino
-      // the lock moves the env one position along its key chain (rng_key = split(rng_key)[0], :399) and, with the bag
-      // used up, deals permutation(split(rng_key)[1]) (functional/queue.py:59-67): both are this position's ring entry
+      // the lock moves the env one position along its key chain (rng_key = split(rng_key)[0], :399: owed until after the
+      // publish) and, with the bag used up, deals permutation(split(rng_key)[1]) (functional/queue.py:59-67) = Q0
       const bool refill = place && s.bidx >= 7;
-      const bool pr_here = ((ring1 >> 44) & 1ULL) != 0 && (int)((ring1 >> 42) & 3ULL) == (Hc & (kRing - 1));
-      const bool via_ring = place && ring_ok && ring_diff(ringT, Hc) > 0 && (!refill || pr_here);
-      const bool inl_lock = place && !via_ring;
-      uint64_t nb = fn_expand21((uint32_t)(ring1 >> 21) & 0x1FFFFFu);
-      // No usable entry (the launches right after a reset / tg_set_state, or the ring ran dry): the key step runs in line —
-      // behind the publish, nothing in front of it needs the key (`owe_f0`) — unless the bag has to be refilled now
-      if (__any(inl_lock && refill)) {
-        fn_key_ensure(inl_lock && refill);
-        uint32_t a0, a1, b0, b1;
-        threefry2x32(fk0, fk1, 0u, 0u, a0, a1);  // split(rng_key)[0]
-        threefry2x32(fk0, fk1, 0u, 1u, b0, b1);  // split(rng_key)[1]
-        const uint64_t nbi = jax_permutation7(b0, b1);
-        if (inl_lock && refill) { nb = nbi; fk0 = a0; fk1 = a1; loc = loc_wr; }
-      }
-      if (inl_lock && !refill) owe_f0 = true;  // (loc / kH keep describing the key in front of this lock)
+      const uint64_t nb = fn_expand21((uint32_t)(fnw >> 42) & 0x1FFFFFu);
       if (refill) { s.bag = nb; s.bidx = 0; }
       if (place) {
         s.piece = (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
         s.bidx += 1;
-        Hc = (Hc + 1) & 0xFF;
-        if (via_ring) { loc = kLocAhead; fk_valid = false; }  // (the key is the c' of the consumed entry's slot)
-        if (!owe_f0) kH = Hc;
+        fn_lock = true;
         s.rot = 0; s.val = s.piece + 2; s.x = (W + 8) / 2 - 2; s.y = 0;
       }
     }
@@ -1761,7 +1662,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
 
 #ifdef TG_FINE_LOCK
   TG_BITS_STAMP(6);
-#else
+#elif !defined(TG_FINE_FN)
   TG_BITS_STAMP(4);
 #endif
   // ---- termination / autoreset ----
@@ -1798,31 +1699,12 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
 #pragma unroll
         for (int c = 0; c < W; ++c) colsL[1 + c] = FLOOR;
       }
-      // the reset deals permutation(split(key)[0]) and continues with split(key)[1]: this position's ring entry (PL; the
-      // new key is the R of its `ahead` slot — the env leaves the chain the ring looks ahead on: next epoch)
-      const bool via_ring = do_reset && ring_ok && ring_diff(ringT, Hc) > 0;
-      const bool inl_reset = do_reset && !via_ring;
-      uint64_t nb = fn_expand21(fn_ring_pl(ring0, ring1, Hc & (kRing - 1)));
-      if (__any(inl_reset)) {
-        fn_key_ensure(inl_reset);
-        if (__any(inl_reset && owe_f0)) {  // (the key step of this transition's lock comes first)
-          uint32_t a0, a1;
-          threefry2x32(fk0, fk1, 0u, 0u, a0, a1);
-          if (inl_reset && owe_f0) { fk0 = a0; fk1 = a1; owe_f0 = false; }
-        }
-        uint32_t a0, a1, b0, b1;
-        threefry2x32(fk0, fk1, 0u, 0u, a0, a1);
-        threefry2x32(fk0, fk1, 0u, 1u, b0, b1);
-        const uint64_t nbi = jax_permutation7(a0, a1);
-        if (inl_reset) { nb = nbi; fk0 = b0; fk1 = b1; loc = loc_wr; }
-      }
+      // the reset deals permutation(split(key)[0]) and continues with split(key)[1] (owed until after the publish): S1 at
+      // the env's position, S2 behind a lock of this transition
+      const uint64_t nb = fn_expand21((uint32_t)(fnw >> (fn_lock ? 21 : 0)) & 0x1FFFFFu);
       if (do_reset) {
         s.bag = nb; s.queue = 0; s.piece = (int)(nb & 0xFF); s.bidx = 1;
-        Hc = (Hc + 1) & 0xFF;
-        if (via_ring) { loc = kLocAheadR; fk_valid = false; }
-        kH = Hc;
-        ring_ok = false;
-        epoch = (epoch + 1) & 0xFF;
+        fn_reset = true;
         s.x = (W + 8) / 2 - 2;
         s.rot = 0; s.y = 0; s.val = s.piece + 2;
         s.hp = TG_NONE; s.hr = 0; s.hv = 0;
@@ -1858,7 +1740,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
                             (uint32_t)(s.x & 0xFF) | ((uint32_t)(s.y & 0xFF) << 8) | ((uint32_t)(s.piece & 0xFF) << 16));
 #ifdef TG_FINE_LOCK
     TG_BITS_STAMP(7);
-#else
+#elif !defined(TG_FINE_FN)
     TG_BITS_STAMP(5);
 #endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -1904,13 +1786,136 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       }
     }
   };
-  auto fn_book = [&]() {  // FUNCTIONAL: the key step an in-line lock owes (beside the stream wave's work)
-    if (__any(owe_f0)) {
-      fn_key_ensure(owe_f0);
-      uint32_t a0, a1;
-      threefry2x32(fk0, fk1, 0u, 0u, a0, a1);  // rng_key = split(rng_key)[0]  (envs/tetris_fn.py:399)
-      if (owe_f0) { fk0 = a0; fk1 = a1; loc = loc_wr; kH = Hc; owe_f0 = false; }
+  // FUNCTIONAL: make good what this transition consumed of the key-chain look-ahead (protocol at the top of this file),
+  // beside the stream wave's work.  Lanes with a lock: one threefry level (c_{n+4}, R_{n+3}, f1(R_{n+1}) when the next
+  // lock refills) + the sorts S2', Q0'.  Lanes with a reset: three levels from the new key + the sorts S1, S2.
+  auto fn_book = [&]() {
+    const bool ev = fn_lock || fn_reset;
+#ifndef TG_FN_ABL  // timing ablations (results wrong): 1 no reset levels, 2 no sorts, 4 nothing, 8 no level 1
+#define TG_FN_ABL 0
+#endif
+    if ((TG_FN_ABL & 4) && p.batch >= 0) return;
+#ifdef TG_FINE_FN  // (stamps: 3 = fn_book entered, 4 = level 1 done, 5 = reset levels done, 6 = sorts done, 7 = fn_book left)
+#define TG_FN_STAMP(i) TG_BITS_STAMP(i)
+#else
+#define TG_FN_STAMP(i) do {} while (0)
+#endif
+    TG_FN_STAMP(3);
+    if (!__any(ev)) return;
+    uint2* cs = reinterpret_cast<uint2*>(bp.ahead) + (size_t)env * 16;  // c[4] | r[4] | (unused)
+    uint2* rs = cs + 4;
+    const int n = (int)(s.reserved & 3u);
+    const bool lk = fn_lock && !fn_reset;           // stays on its chain: position n + 1
+    const bool needq = lk && s.bidx >= 7;           // ... whose lock will refill the bag
+    // loads (event lanes): the key the lane continues from, the chain's last key, R_{n+1}
+    uint2 ka = make_uint2(pf_c3.x, pf_c3.y), kb = make_uint2(pf_r1.x, pf_r1.y), knew = make_uint2(pf_c1.x, pf_c1.y);
+    if (fn_reset) { knew = kb; ka = kb; }  // R_{n+1} behind a lock of this transition (SAME_STEP), R_n otherwise
+    // level 1
+    uint32_t a0, a1, b0, b1, z0 = 0, z1 = 0;
+    threefry2x32(ka.x, ka.y, 0u, 0u, a0, a1);
+    threefry2x32(ka.x, ka.y, 0u, 1u, b0, b1);
+    if (__any(needq)) threefry2x32(kb.x, kb.y, 0u, 1u, z0, z1);
+    uint32_t t1x = b0, t1y = b1, t2x = z0, t2y = z1;  // sort keys: lock lanes S2' = sort7(R_{n+3}), Q0' = sort7(f1(R_{n+1}))
+#ifdef TG_FINE_FN
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(z0), "+v"(z1));
+#endif
+    TG_FN_STAMP(4);
+    uint2 c1 = make_uint2(a0, a1), r0 = make_uint2(b0, b1), c2 = c1, c3 = c1, r1 = r0, r2 = r0;
+    if (__any(fn_reset) && !((TG_FN_ABL & 1) && p.batch >= 0)) {  // levels 2 and 3 of a fresh chain: c2, R1, then c3, R2
+      uint32_t e0, e1, f0_, f1_, g0, g1, h0, h1;
+      threefry2x32(a0, a1, 0u, 0u, e0, e1);
+      threefry2x32(a0, a1, 0u, 1u, f0_, f1_);
+      threefry2x32(e0, e1, 0u, 0u, g0, g1);
+      threefry2x32(e0, e1, 0u, 1u, h0, h1);
+      c2 = make_uint2(e0, e1); r1 = make_uint2(f0_, f1_); c3 = make_uint2(g0, g1); r2 = make_uint2(h0, h1);
+      if (fn_reset) { t1x = f0_; t1y = f1_; t2x = h0; t2y = h1; }  // S1 = sort7(R_1), S2 = sort7(R_2)
     }
+#ifdef TG_FINE_FN
+    asm volatile("" : "+v"(t1x), "+v"(t1y), "+v"(t2x), "+v"(t2y));
+#endif
+    TG_FN_STAMP(5);
+    // the sorts, seven lanes each: task list = first sort of every event lane, then the second sorts
+    const bool two = needq || fn_reset;
+    const uint64_t m1 = __ballot(ev), m2 = __ballot(two);
+    const int n1 = __popcll(m1), nt = n1 + __popcll(m2);
+    const int q1 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+    const int q2 = n1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+    uint2* xk = reinterpret_cast<uint2*>(lds + BG::OFF_FNX);
+    uint32_t* xo = reinterpret_cast<uint32_t*>(lds + BG::OFF_FNX + 128 * 8);
+    if (ev) xk[q1] = make_uint2(t1x, t1y);
+    if (two) xk[q2] = make_uint2(t2x, t2y);
+    wave_sync();
+    const int j = lane & 7;
+    // stable rank of element j among the 7 of its 8-lane group (jax sort_key_val on 32 random bits; ties by index) → the
+    // group's permutation as seven 3-bit fields.  The other lanes' sort keys come by DPP row rotations (a rotation by r
+    // within the 16-lane row delivers lane - r; for the lanes whose source falls into the neighbouring group the rotation by
+    // r + 8 delivers the same position of their own group): VALU latency instead of six LDS-crossbar round trips
+    // (ds_bpermute: 1 200 of the sort's 2 200 cycles).  The idle eighth lane holds the maximum key: it ranks behind everybody.
+    auto group_perm = [&](const uint32_t bits_in) -> uint32_t {
+      const uint32_t bits = j < 7 ? bits_in : 0xFFFFFFFFu;
+      int rank = 0;
+#ifdef TG_FN_BPERM  // (the LDS-crossbar form, for A/B)
+#pragma unroll
+      for (int rr = 1; rr < 7; ++rr) {
+        const int oj = j + rr >= 7 ? j + rr - 7 : j + rr;
+        const uint32_t ob = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & ~7) | oj) << 2, (int)bits);
+        rank += (ob < bits || (ob == bits && oj < j)) ? 1 : 0;
+      }
+#else
+#define TG_ROR(r) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0x120 + (r), 0xF, 0xF, true)  // row_ror:r
+#define TG_OTHER(r)                                                                    \
+      {                                                                                \
+        const uint32_t near_ = TG_ROR(r), far_ = TG_ROR((r) + 8);                      \
+        const bool same = j >= (r);                       /* lane - r stays in the group */ \
+        const uint32_t ob = same ? near_ : far_;                                       \
+        const int oj = same ? j - (r) : j - (r) + 8;                                   \
+        rank += (ob < bits || (ob == bits && oj < j)) ? 1 : 0;                         \
+      }
+      TG_OTHER(1) TG_OTHER(2) TG_OTHER(3) TG_OTHER(4) TG_OTHER(5) TG_OTHER(6) TG_OTHER(7)
+#undef TG_OTHER
+#undef TG_ROR
+#endif
+      uint32_t pm = j < 7 ? (uint32_t)j << (3 * rank) : 0u;
+      pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+      pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+      pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x141, 0xF, 0xF, true);  // row_half_mirror: the other quad of the 8
+      return pm;
+    };
+    for (int t0 = 0; t0 < (((TG_FN_ABL & 2) && p.batch >= 0) ? 0 : nt); t0 += 16) {  // 16 sorts per trip: two independent threefry streams per lane
+      const int ta = t0 + (lane >> 3), tb = ta + 8;
+      const uint2 xa = xk[ta < nt ? ta : 0], xb = xk[tb < nt ? tb : 0];
+      uint32_t u0, u1, v0, v1;
+      threefry2x32(xa.x, xa.y, 0u, (uint32_t)j, u0, u1);
+      threefry2x32(xb.x, xb.y, 0u, (uint32_t)j, v0, v1);
+      const uint32_t pa = group_perm(u0 ^ u1), pb = group_perm(v0 ^ v1);
+      if (j == 0 && ta < nt) xo[ta] = pa;
+      if (j == 0 && tb < nt) xo[tb] = pb;
+    }
+    wave_sync();
+    uint64_t p1 = xo[ev ? q1 : 0], p2 = xo[two ? q2 : 0];
+    wave_sync();
+#ifdef TG_FINE_FN
+    asm volatile("" : "+v"(p1), "+v"(p2));
+#endif
+    TG_FN_STAMP(6);
+    if (lk) {
+      cs[n & 3] = c1;            // c_{n+4}
+      rs[(n + 3) & 3] = r0;      // R_{n+3}
+      fnw = ((fnw >> 21) & 0x1FFFFFULL) | (p1 << 21) | (needq ? p2 << 42 : 0ULL);
+      s.reserved = (s.reserved & ~3u) | (uint32_t)((n + 1) & 3);
+    }
+    if (fn_reset) {  // a fresh chain, renumbered from position 0
+      cs[1] = c1; cs[2] = c2; cs[3] = c3;
+      rs[0] = r0; rs[1] = r1; rs[2] = r2;
+      fnw = p1 | (p2 << 21);
+      s.reserved &= ~3u;
+    }
+    if (ev && live) {
+      reinterpret_cast<uint2*>(p.rng + env)[5] = knew;  // State.rng_key
+      fn_dirty = true;
+    }
+    fn_lock = false; fn_reset = false;
+    TG_FN_STAMP(7);
   };
   const bool book_first = RULESET == TG_RULESET_NUMPY && early_book;
   if constexpr (MULTI) {
@@ -1919,7 +1924,6 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     for (int pass = 0; pass < 2; ++pass) {
       if (RULESET == TG_RULESET_NUMPY && (pass == 0) == book_first && !TG_SKIP(512)) bookkeeping();
       if (pass == 0) publish();
-      if (RULESET == TG_RULESET_FUNCTIONAL && pass == 1) fn_book();
 #ifdef TG_FINE_FUSED  // (last transition: 5 = published, 6 = barrier passed, 7 = bookkeeping done / end of the iteration)
       if (pass == 0 && step == nsteps - 1) TG_BITS_STAMP(6);
 #endif
@@ -1928,8 +1932,10 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     if (!book_first) publish();
     if (RULESET == TG_RULESET_NUMPY && !TG_SKIP(512)) bookkeeping();
     if (book_first) publish();
-    if (RULESET == TG_RULESET_FUNCTIONAL) fn_book();
   }
+  // (every load result the rest of the transition uses is claimed HERE, in front of the first store behind the publish: on
+  // gfx9 a wait for a load with stores pending is a wait for the stores — vmcnt counts both, and they complete out of order)
+  if (RULESET == TG_RULESET_FUNCTIONAL) asm volatile("" : "+v"(pf_c1), "+v"(pf_c3), "+v"(pf_r1));
   if (pending) {  // the NEXT_STEP reset step belongs to no episode (gymnasium RecordEpisodeStatistics)
     ep.ret = 0.0f; ep.len = 0;
   } else {
@@ -1942,6 +1948,14 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   if (out_traj && live)
     st_stream(reinterpret_cast<u32x2*>(out_traj + (size_t)step * p.act_stride + env),
               u32x2{__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8)});
+  if (RULESET == TG_RULESET_FUNCTIONAL) {
+    // (behind everything that waits for a load of the launch's start — the episode record above: a wait for it behind
+    // fn_book's stores is a wait for those stores, a round trip through a memory system busy with the stream waves' tail)
+#ifndef TG_FN_NO_SWAP
+    if (!MULTI) __builtin_amdgcn_s_setprio(0);  // the look-ahead is nobody's critical path: the stream wave's tail goes first
+#endif
+    fn_book();
+  }
   if (rgb) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();  // the stream wave has applied the locks / clears / resets and drawn the pieces
@@ -2076,7 +2090,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     }
   }
 
-#if !defined(TG_FINE_LOCK) && !defined(TG_FINE_FUSED)
+#if !defined(TG_FINE_LOCK) && !defined(TG_FINE_FUSED) && !defined(TG_FINE_FN)
   TG_BITS_STAMP(6);
 #endif
   // ---- E: consumed counter; the generator state only after an in-line shuffle (otherwise `ahead` holds it) ----
@@ -2087,13 +2101,10 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       io[0] = make_uint4((uint32_t)g.s_lo, (uint32_t)(g.s_lo >> 32), (uint32_t)g.s_hi, (uint32_t)(g.s_hi >> 32));
       io[1] = make_uint4(g.uinteger, g.has32, 0u, 0u);
     }
-  } else {
-    // FUNCTIONAL: position, where its key is, and the bag index (which look-ahead position refills the bag)
-    if (live) bp.hbuf_wr[env] = (uint32_t)(Hc | (loc << 8) | ((s.bidx & 7) << 11) | (epoch << 16));
-    if (live && fk_valid && loc == loc_wr)
-      bp.inl[((size_t)(loc_wr - kLocBuf0) * p.ring_stride + env) * 2] = make_uint4(fk0, fk1, 0u, 0u);
+  } else if (live && fn_dirty) {
+    reinterpret_cast<uint2*>(bp.hbuf_wr)[env] = make_uint2((uint32_t)fnw, (uint32_t)(fnw >> 32));
   }
-#if !defined(TG_FINE_LOCK) && !defined(TG_FINE_FUSED)
+#if !defined(TG_FINE_LOCK) && !defined(TG_FINE_FUSED) && !defined(TG_FINE_FN)
   TG_BITS_STAMP(7);
 #endif
 #ifdef TG_PHASE_TIMING
@@ -2144,20 +2155,35 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
   const bool moved = p.force || (p.mask ? p.mask[env] != 0 : true);
   uint4* ring4 = reinterpret_cast<uint4*>(p.ring);
   if (!moved) {  // ring untouched: make both parities agree with the one the next launch reads
+    if (p.ruleset != TG_RULESET_NUMPY) return;  // (FUNCTIONAL: the look-ahead has no parities)
     ring4[(size_t)(1 - p.cur) * B + env] = ring4[(size_t)p.cur * B + env];
     p.hbuf[(size_t)(1 - p.hcur) * B + env] = p.hbuf[(size_t)p.hcur * B + env];
     return;
   }
   uint32_t* rec = p.rec + (size_t)env * 8;
   if (p.ruleset != TG_RULESET_NUMPY) {
-    // FUNCTIONAL: an empty ring (T = H = 0) whose key is the one in tg_rng_rec — the RNG role of the first launch
-    // starts the look-ahead from there, the logic wave runs threefry in line until it has
-    const uint4 none = make_uint4(0u, 0u, 0u, 0u);
-    ring4[env] = none;
-    ring4[B + env] = none;
-    const uint32_t hv = (uint32_t)((kLocRec << 8) | ((((rec[2] >> 8) & 0xFFu) > 7u ? 7u : ((rec[2] >> 8) & 7u)) << 11));
-    p.hbuf[env] = hv;
-    p.hbuf[B + env] = hv;
+    // FUNCTIONAL: the key-chain look-ahead of the env's position (see the top of this file), renumbered from 0
+    const uint2 key = reinterpret_cast<const uint2*>(p.rng + env)[5];
+    uint2* cs = reinterpret_cast<uint2*>(p.ahead) + (size_t)env * 16;
+    uint2* rs = cs + 4;
+    uint2 c = key, rr[3];
+    for (int m = 0; m < 3; ++m) {
+      uint32_t a0, a1, b0, b1;
+      threefry2x32(c.x, c.y, 0u, 0u, a0, a1);
+      threefry2x32(c.x, c.y, 0u, 1u, b0, b1);
+      rr[m] = make_uint2(b0, b1);
+      rs[m] = rr[m];                   // R_m
+      c = make_uint2(a0, a1);
+      cs[m + 1] = c;                   // c_{m+1}
+    }
+    uint64_t w = (uint64_t)fn_sort7(rr[1].x, rr[1].y) | ((uint64_t)fn_sort7(rr[2].x, rr[2].y) << 21);
+    if (((rec[2] >> 8) & 0xFFu) >= 7u) {  // the next lock refills the bag: Q0 = sort7(f1(R_0))
+      uint32_t z0, z1;
+      threefry2x32(rr[0].x, rr[0].y, 0u, 1u, z0, z1);
+      w |= (uint64_t)fn_sort7(z0, z1) << 42;
+    }
+    reinterpret_cast<uint64_t*>(p.hbuf)[env] = w;
+    rec[7] = 0;
     return;
   }
   Rng r;
@@ -2207,7 +2233,6 @@ struct MaterializeParams {
   const uint32_t* hbuf;  // the parity the next launch reads
   const uint4* inl;      // in-line buffers [2][B][2]
   int batch;
-  int ruleset;
 };
 
 __global__ __launch_bounds__(256) void bits_materialize_rng_kernel(const MaterializeParams p) {
@@ -2218,11 +2243,6 @@ __global__ __launch_bounds__(256) void bits_materialize_rng_kernel(const Materia
   if (loc == kLocRec) return;
   const uint4* a4 = (loc == kLocBuf0 || loc == kLocBuf1) ? p.inl + ((size_t)(loc - kLocBuf0) * p.batch + env) * 2
                                     : p.ahead + (size_t)env * (2 * kRing) + 2 * (((Hraw & 0xFF) - 1) & (kRing - 1));
-  if (p.ruleset != TG_RULESET_NUMPY) {  // FUNCTIONAL: State.rng_key = the key at the env's position of its chain
-    const uint2 k = reinterpret_cast<const uint2*>(a4)[loc == kLocAheadR ? 1 : 0];
-    reinterpret_cast<uint2*>(p.rng + env)[5] = k;
-    return;
-  }
   const uint4 f0 = a4[0], f1 = a4[1];
   uint4* out = reinterpret_cast<uint4*>(p.rng + env);
   out[0] = f0;
