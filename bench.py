@@ -17,8 +17,10 @@ devices (`--gpus 2` on a 1-GPU box) ranks share devices round-robin: that exerci
 scaling number.
 
 Rank 0 prints ONE JSON line.  At N = 1 the line also carries one block per further BASELINE config (`blocks`:
-config 2 = 4 096 envs, config 5 = 20x40 / queue 7 / grouped action set, the reference's dict observation, the RGB
-wrapper's image, the fused rollout), each with its own `roofline` and `cpu_baseline`.
+config 2 = 4 096 envs (one and eight transitions per launch), config 5 = 20x40 / queue 7 / grouped action set, the
+reference's dict observation, the RGB wrapper's image, the fused rollout, the functional rule-set (one and eight
+transitions per launch)), each with its own `roofline` and `cpu_baseline`, and `vector_env`: the rate through the
+gymnasium.vector adapter with host and with device-resident observations.
 """
 from __future__ import annotations
 
@@ -174,25 +176,26 @@ def host_threads() -> int:
     return max(1, min(avail, 64))
 
 
-def cpu_baseline(W, H, Q, B, *, grouped=False, obs="board", budget_s=6.0, action_seed=0):
+def cpu_baseline(W, H, Q, B, *, grouped=False, obs="board", budget_s=6.0, action_seed=0, ruleset="numpy"):
     """SURVEY §8d(i) / BASELINE.md §3: the oracle's C restatement (kind "port") on this host, the SAME workload as the GPU
     block (same B, seeds 1 + i, actions of the same generator, same-step autoreset, observation packed every step),
     timed at 1 thread and at all usable cores on a bounded number of steps (`budget_s` seconds per thread count).
     `value` is the all-cores rate."""
     from oracle import pyoracle as po
 
-    mode = {"board": po.OBS_BOARD, "dict": po.OBS_DICT, "rgb": po.OBS_RGB}[obs]
+    mode = {"board": po.OBS_BOARD, "dict": po.OBS_DICT, "rgb": po.OBS_RGB, "fn": po.OBS_FN}[obs]
+    fn = ruleset == "functional"
     full_B = B
     if grouped:  # the wrapper's step re-derives the legal mask from all 4W placements (wrappers/grouped.py:124-207,
         B = min(B, 8192)  # as the reference does): ~40 us per env-step on one core — sample the first 8 192 envs
     seeds = np.arange(1, B + 1, dtype=np.uint64)
     rng = np.random.default_rng(action_seed)
     T = 64
-    acts = rng.integers(0, 8, (T, B)).astype(np.int32)
+    acts = rng.integers(0, 7 if fn else 8, (T, B)).astype(np.int32)
     res = {}
     cores = host_threads()
     for nt in ([1] if cores == 1 else [1, cores]):
-        o = po.OracleBatch(B, W, H, po.RULESET_NUMPY, True, Q, nthreads=nt)
+        o = po.OracleBatch(B, W, H, po.RULESET_FUNCTIONAL if fn else po.RULESET_NUMPY, True, 7 if fn else Q, nthreads=nt)
         o.reset(seeds)
 
         def one(t):
@@ -224,8 +227,10 @@ def cpu_baseline(W, H, Q, B, *, grouped=False, obs="board", budget_s=6.0, action
             "sample": f"{'first ' if B != full_B else ''}{B} envs x {all_n} steps at {cores} threads, x {one_n} steps at 1 thread: the same workload as the "
                       f"GPU block (C oracle, OpenMP over envs, step + observation pack"
                       f"{'; legal-action draw not timed' if grouped else ''})",
-            "reference_python_single_env": "~3.4k steps/s on one 2.6 GHz Xeon core, measured in the survey container, "
-                                           "not on this host (BASELINE.md §2)"}
+            "reference_python_single_env": "~3.4k steps/s on one 2.6 GHz Xeon core (NumPy Tetris.step), measured in the "
+                                           "survey container, not on this host (BASELINE.md §2)",
+            **({"parity_note": "functional rule-set: the oracle's jax threefry / permutation restatement is parity-unpinned "
+                               "(no jax in the build container, DESIGN §5); engine == oracle is tested"} if fn else {})}
 
 
 def profiled(block: str) -> dict:
@@ -247,9 +252,8 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
     obs_mode = {"board": N.OBS_BOARD, "dict": N.OBS_DICT, "fn": N.OBS_FN, "none": N.OBS_NONE, "rgb": N.OBS_RGB}[obs]
     n_act = 8 if rs == N.RULESET_NUMPY else 7
     lo, hi, seeds = D.shard(B)
-    os.environ["TG_FUSE"] = str(fuse)  # read by tg_create
     e = Engine(B, W, H, ruleset=rs, queue_size=(Q if rs == N.RULESET_NUMPY else 7), obs_mode=obs_mode,
-               autoreset=N.AUTORESET_SAME_STEP, device=local, env_offset=lo, grouped=grouped)
+               autoreset=N.AUTORESET_SAME_STEP, device=local, env_offset=lo, grouped=grouped, fuse=fuse)  # (tg_config.fuse)
     e.reset(seeds)
     copy_gbps = None
     if copy_first:  # the practical ceiling, measured before the timed region (it also brings the clocks up)
@@ -299,6 +303,7 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
     kernel_us = statistics.median(rep_us)
     (kernel_us,) = D.max(kernel_us)
     launches_per_step = 1.0 / fuse
+    rank_devices = [int(x) for x in D.gather(float(local))]  # HIP device ordinal of every rank
     out = None
     if D.rank == 0:
         if fuse == 1:
@@ -307,10 +312,15 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
             bytes_alg = H * W + 1 + (2 * H * W + 64 + 8) / fuse
         achieved = bytes_alg * B / (kernel_us * 1e-6) / 1e9
         prof = profiled(name)
+        # the same time against the bytes the counters saw (committed profile of this block; per launch): the algorithmic
+        # figure charges a board write-back per transition (p_lock = 1.0) that the kernel only does on a lock
+        traffic = prof.get("hbm_bytes_per_launch")
+        measured = None if not traffic else traffic / fuse / (kernel_us * 1e-6) / 1e9
         sym = e.step_kernel_name(fuse, grouped)
         out = {
             "value": throughput(D.world, B, steps, elapsed), "unit": "env steps/s", "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3, "per_rank_ms_per_step": per_rank_ms,
+            "per_rank_device": rank_devices,
             "config": {"workload": (f"Batch {B} envs/GPU, {W}x{H} board, queue_size {Q}, "
                                     + ("grouped action set (column*4+rotation -> teleport + hard drop), legal actions drawn "
                                        "on device inside the step kernel, " if grouped else
@@ -320,7 +330,9 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
                        "parallelism": f"env-sharded x{D.world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": prof.get("hbm_bytes_per_launch"), "traffic_source": prof.get("traffic_source"),
+                         "traffic": traffic, "traffic_source": prof.get("traffic_source"),
+                         "achieved_measured_bytes": measured,
+                         "frac_measured_bytes": None if measured is None else measured / HBM_PEAK_GBPS,
                          "kernel": sym, "kernel_ms": kernel_us * 1e-3 / launches_per_step if fuse > 1 else kernel_us * 1e-3,
                          "kernel_us_per_step_reps": [round(x, 3) for x in rep_us],
                          "kernel_us_rocprof": prof.get("kernel_us"), "rocprof_source": prof.get("kernel_source"),
@@ -332,10 +344,47 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
         }
         if copy_gbps is not None:
             out["hbm_copy_gbps"] = copy_gbps
-        if want_cpu and D.world == 1 and ruleset == "numpy" and obs in ("board", "dict", "rgb"):
-            out["cpu_baseline"] = cpu_baseline(W, H, Q, B, grouped=grouped, obs=obs, budget_s=cpu_budget)
+        if want_cpu and obs in ("board", "dict", "rgb", "fn"):  # (rank 0 only, whatever the number of ranks)
+            out["cpu_baseline"] = cpu_baseline(W, H, Q, B, grouped=grouped, obs=obs, budget_s=cpu_budget, ruleset=ruleset)
+        if ruleset == "functional":
+            out["parity_note"] = "functional rule-set: piece sequence (jax threefry) is parity-unpinned (DESIGN §5)"
     e.dev_free(d_acts)
     e.close()
+    return out
+
+
+def vector_env_block(local, *, B=65536, steps=64, warmup=8):
+    """env steps/s through the gymnasium.vector adapter (TetrisVectorEnv.step, what examples/train_ppo.py:240-245 calls):
+    with the observation copied to host NumPy (the SyncVectorEnv contract) and with the results left on the device as
+    zero-copy views (`step(actions, to_host=False)`).  Wall clock of Python + C ABI + kernels + (for the host form) PCIe;
+    actions are host int32 arrays in both forms.  Never `value`: the PCIe-inclusive rate of the drop-in surface."""
+    from tetris_gymnasium_amd.vector import TetrisVectorEnv
+
+    out = {}
+    rng = np.random.default_rng(0)
+    acts = rng.integers(0, 8, (warmup + steps, B)).astype(np.int32)
+    for kind in ("board", "dict"):
+        v = TetrisVectorEnv(B, observation=kind, autoreset_mode="same_step", devices=(local,))
+        v.reset(seed=1)
+        res = {}
+        for form in ("host", "device"):
+            for t in range(warmup):
+                v.step(acts[t], to_host=(form == "host"))
+            v.engines[0].sync()
+            t0 = time.perf_counter()
+            for t in range(warmup, warmup + steps):
+                v.step(acts[t], to_host=(form == "host"))
+            v.engines[0].sync()
+            dt = time.perf_counter() - t0
+            res[form] = {"value": B * steps / dt, "unit": "env steps/s", "us_per_step": dt / steps * 1e6}
+        obs_bytes = 200 if kind == "board" else 944
+        res["host"]["pcie_bytes_per_env_step"] = obs_bytes + 8 + 4
+        res["device"]["pcie_bytes_per_env_step"] = 4  # the host actions
+        out[kind] = res
+        v.close()
+    out["note"] = (f"TetrisVectorEnv.step at {B} envs on one GPU, {steps} steps after {warmup}: `host` returns NumPy observations "
+                   "(gymnasium contract), `device` returns DeviceArray views (__cuda_array_interface__ / DLPack) and copies "
+                   "nothing back; Python overhead included")
     return out
 
 
@@ -398,9 +447,23 @@ def rank_main(args) -> int:
                                             ruleset="numpy", steps=(ks + 7) // 8 * 8, warmup=64, reps=reps, local=local,
                                             want_cpu=False)
         if blocks["fused_rollout"]:
-            blocks["fused_rollout"]["note"] = ("tg_step_k with TG_FUSE=8: records, column masks and uint8 slabs stay in "
+            blocks["fused_rollout"]["note"] = ("tg_step_k with tg_config.fuse = 8: records, column masks and uint8 slabs stay in "
                                                "registers/LDS across the 8 transitions of a launch; the observation of "
                                                "every transition is still written; reported beside `value`, never as it")
+        # config 2 again with 8 transitions per launch: at 4 096 envs (64 workgroups on 256 CUs) a one-transition launch is
+        # all launch boundary; the fused launch is what a rollout at that batch size should use
+        blocks["config2_fused"] = run_block(D, "config2_fused8", W=10, H=20, Q=4, B=4096, obs="board", grouped=False, fuse=8,
+                                            ruleset="numpy", steps=(ks + 7) // 8 * 8, warmup=64, reps=reps, local=local,
+                                            want_cpu=False)
+        # the functional rule-set (envs/tetris_fn.py step / batched_step: the subsystem north_star names as replaced)
+        fcommon = dict(W=10, H=20, Q=7, B=65536, obs="fn", grouped=False, ruleset="functional", reps=reps, local=local)
+        blocks["functional"] = run_block(D, "functional", steps=ks, warmup=kw, want_cpu=want_cpu, cpu_budget=3.0, **fcommon)
+        blocks["functional_fused"] = run_block(D, "functional_fused8", fuse=8, steps=(ks + 7) // 8 * 8, warmup=64,
+                                               want_cpu=False, **fcommon)
+        try:
+            blocks["vector_env"] = vector_env_block(local)
+        except Exception as ex:  # pragma: no cover - adapter problems must not lose the headline line
+            blocks["vector_env"] = {"error": repr(ex)}
     elif D.world > 1 and not args.no_blocks and std_head:
         pass  # the further configs are single-GPU cases (BASELINE.json configs[1], [4]); config 4 IS this run at N = 8
     if D.rank == 0:
@@ -408,13 +471,17 @@ def rank_main(args) -> int:
                "value": head["value"], "unit": "env steps/s", "n_gpus": D.world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "u8", "data": "synthetic", "config": head["config"],
-               "per_rank_ms_per_step": head["per_rank_ms_per_step"], "roofline": head["roofline"]}
+               "per_rank_ms_per_step": head["per_rank_ms_per_step"], "per_rank_device": head["per_rank_device"],
+               "n_devices_visible": ndev, "roofline": head["roofline"]}
+        if D.world > ndev:
+            out["note"] = (f"{D.world} ranks on {ndev} visible device(s): ranks share devices round-robin — this exercises the "
+                           f"N > 1 path, it is not a scaling measurement")
         if "hbm_copy_gbps" in head:
             out["hbm_copy_gbps"] = head["hbm_copy_gbps"]
         if "cpu_baseline" in head:
             out["cpu_baseline"] = head["cpu_baseline"]
-        if args.ruleset == "functional":
-            out["parity_note"] = "functional rule-set: piece sequence (jax threefry) is parity-unpinned (DESIGN §5)"
+        if "parity_note" in head:
+            out["parity_note"] = head["parity_note"]
         if blocks:
             out["blocks"] = blocks
         print(json.dumps(out), flush=True)

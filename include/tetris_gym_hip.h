@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 1
+#define TG_ABI_VERSION 2 /* 2: tg_config launch knobs, tg_dev_copy, tg_get_state_dev / tg_set_state_dev */
 
 /* ---- rule-sets (the reference contains two different Tetris rule-sets) ---- */
 #define TG_RULESET_NUMPY 0      /* envs/tetris.py (the graded oracle) */
@@ -87,6 +87,14 @@ typedef struct tg_config {
   int32_t grouped_terminate_on_illegal; /* wrappers/grouped.py:49 (default 1) */
   int32_t flags;       /* TG_FLAG_* */
   int32_t reserved;
+  /* launch knobs of the step kernel (0 = default; the environment variables TG_FUSE / TG_RNG_EVERY / TG_RING_FILL override
+   * them — test hooks).  Results never depend on them. */
+  int32_t fuse;         /* transitions per launch of tg_step_k / tg_rollout / tg_grouped_rollout: 1..32, default 8 */
+  int32_t rng_every;    /* NUMPY rules: one-transition launches carry the bag-shuffle look-ahead workgroups every n-th time
+                           (1..3, default 3) */
+  int32_t ring_fill_p1; /* NUMPY rules: 1 + look-ahead bag permutations kept per env (1..4, default 4 = 3 permutations);
+                           smaller values exercise the in-line shuffle of the step kernel */
+  int32_t reserved2;
 } tg_config;
 
 /* ---- per-env state records (tg_get_state / tg_set_state; also the device layout) ----
@@ -188,8 +196,8 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind);
 
 /* K consecutive transitions with pre-generated actions i8 [K][B] resident in DEVICE memory (rollout helper, no host
  * round trip; the outputs of the last transition remain in the buffers, per-episode sums go to TG_BUF_EPISODE when
- * enabled).  The default kernel runs up to TG_FUSE (environment variable, default and maximum 8) transitions per
- * launch with the per-env state resident on chip in between; the observation is written after every transition.
+ * enabled).  The default kernel runs up to tg_config.fuse (default 8) transitions per launch with the per-env state
+ * resident on chip in between; the observation is written after every transition.
  * Results are identical to K calls of tg_step. */
 int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K);
 
@@ -210,6 +218,13 @@ int tg_fetch(tg_handle* h, int which, void* host_dst, size_t bytes);
 int tg_get_state(tg_handle* h, uint8_t* board, tg_env_rec* rec, tg_rng_rec* rng);
 int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, const tg_rng_rec* rng);
 
+/* The same between DEVICE buffers of the caller (layouts as above; any pointer may be NULL), asynchronous on the handle's
+ * stream: what a host program that keeps many states resident (a functional State per call, envs/tetris_fn.py:276-315; a
+ * search that branches) needs instead of a round trip through host memory.  tg_set_state_dev rebuilds the engine's private
+ * acceleration state exactly as tg_set_state does; records are not range-checked (they come from tg_get_state_dev). */
+int tg_get_state_dev(tg_handle* h, uint8_t* board_dev, tg_env_rec* rec_dev, tg_rng_rec* rng_dev);
+int tg_set_state_dev(tg_handle* h, const uint8_t* board_dev, const tg_env_rec* rec_dev, const tg_rng_rec* rng_dev);
+
 /* Re-pack the observation buffer from the current state without stepping.  (tg_reset and tg_set_state re-pack the DICT /
  * RGB surfaces themselves: between transitions the step kernel only stores what changed of the holder / queue strips.) */
 int tg_observe(tg_handle* h);
@@ -229,7 +244,7 @@ int tg_grouped_sample(tg_handle* h, uint32_t seed, uint32_t counter);
  * exactly the action tg_grouped_sample(h, seed, counter0 + k) would draw for the state at that point (so the result
  * equals K x {tg_grouped_sample; tg_step}).  Optional caller-owned DEVICE outputs: the drawn actions i8 [K][B], the
  * observation and output trajectories as in tg_rollout.  The default kernel draws inside the step kernel and runs up
- * to TG_FUSE transitions per launch (BASELINE config 5: 20x40, queue 7, random legal placements). */
+ * to tg_config.fuse transitions per launch (BASELINE config 5: 20x40, queue 7, random legal placements). */
 int tg_grouped_rollout(tg_handle* h, uint32_t seed, uint32_t counter0, int K, int8_t* actions_out_dev,
                        uint8_t* obs_traj_dev, tg_step_out* out_traj_dev);
 
@@ -262,6 +277,8 @@ int tg_dev_alloc(tg_handle* h, size_t bytes, void** ptr);
 int tg_dev_free(tg_handle* h, void* ptr);
 int tg_dev_upload(tg_handle* h, void* dst_dev, const void* src_host, size_t bytes);
 int tg_dev_download(tg_handle* h, void* dst_host, const void* src_dev, size_t bytes);
+/* device → device, asynchronous on the handle's stream (e.g. keep a copy of TG_BUF_OBS before the next transition overwrites it) */
+int tg_dev_copy(tg_handle* h, void* dst_dev, const void* src_dev, size_t bytes);
 
 /* Stream-copy kernel (float4 grid-stride) used by bench.py to report the practical HBM ceiling. */
 int tg_stream_copy_gbps(tg_handle* h, size_t bytes, int iters, float* gbps);

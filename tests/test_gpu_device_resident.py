@@ -1,0 +1,241 @@
+"""Device-resident surfaces: what the engine hands to other GPU code without a trip through host memory, and the
+functional batched API whose values stay on the device until they are read.  torch is used HERE (tests only) as the
+consumer of `__cuda_array_interface__` / DLPack; nothing in tetris_gymnasium_amd imports it."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+from tetris_gymnasium_amd import Engine, _native as N  # noqa: E402
+from tetris_gymnasium_amd import engine as engine_mod  # noqa: E402
+from tetris_gymnasium_amd.envs import tetris_fn as F  # noqa: E402
+from tetris_gymnasium_amd.functional import TETROMINOES, EnvConfig  # noqa: E402
+from tetris_gymnasium_amd.vector import TetrisVectorEnv  # noqa: E402
+
+CFG = EnvConfig(width=10, height=20, padding=4, queue_size=7, gravity_enabled=True)
+
+
+class _D2HCounter:
+    """Counts every device → host transfer the Python layer can make (tg_fetch, tg_dev_download, tg_get_state)."""
+
+    def __init__(self, monkeypatch):
+        self.n = 0
+        for name in ("_fetch", "dev_download", "get_state", "fetch_outputs"):
+            orig = getattr(Engine, name)
+
+            def wrapped(eng, *a, _orig=orig, **k):
+                self.n += 1
+                return _orig(eng, *a, **k)
+
+            monkeypatch.setattr(Engine, name, wrapped)
+
+
+def _keys(B):
+    return np.stack([np.zeros(B, np.uint32), np.arange(1, B + 1, dtype=np.uint32)], axis=1)
+
+
+def test_batched_step_loop_stays_on_the_device(monkeypatch):
+    """1 000 batched_step calls at 65 536 envs: no device → host transfer at all until a leaf is read; then one State costs
+    three downloads, an observation one; values equal the oracle's."""
+    B, T = 65536, 1000
+    keys = _keys(B)
+    o = po.OracleBatch(B, 10, 20, po.RULESET_FUNCTIONAL, nthreads=8)
+    o.reset((keys[:, 0].astype(np.uint64) << np.uint64(32)) | keys[:, 1].astype(np.uint64))
+    F.batched_reset(TETROMINOES, keys, config=CFG)  # (creates the engine)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        new_keys, states, obs = F.batched_reset(TETROMINOES, keys, config=CFG)
+        best = min(best, time.perf_counter() - t0)
+    assert best < 0.05, f"batched_reset of {B} keys took {best * 1e3:.1f} ms of host time"
+    np.testing.assert_array_equal(new_keys[:64], np.array([F.split(k)[0] for k in keys[:64]], np.uint32))
+    cnt = _D2HCounter(monkeypatch)
+    rng = np.random.default_rng(3)
+    acts = rng.integers(0, 7, (T, B)).astype(np.int32)
+    t0 = time.perf_counter()
+    for t in range(T):
+        states, obs, rew, term, info = F.batched_step(TETROMINOES, states, acts[t], config=CFG)
+    loop_s = time.perf_counter() - t0
+    assert cnt.n == 0, f"{cnt.n} device → host transfers inside the loop"
+    assert isinstance(states.board, F.LazyArray) and not states.board.materialized and obs.shape == (B, 20, 10)
+    for t in range(T):
+        ro, to, lo = o.step(acts[t])
+    np.testing.assert_array_equal(np.asarray(rew), ro)
+    assert cnt.n == 1  # reward / terminated / lines share one download
+    np.testing.assert_array_equal(np.asarray(term), to.astype(bool))
+    np.testing.assert_array_equal(np.asarray(info["lines_cleared"]), lo)
+    assert cnt.n == 1
+    np.testing.assert_array_equal(np.asarray(obs), o.observe(po.OBS_FN))
+    assert cnt.n == 2
+    bo, reco, rngo = o.get_state()
+    np.testing.assert_array_equal(states.board[:, :20, 4:14].astype(np.uint8), bo)
+    assert cnt.n == 5  # board + records + keys, once for every leaf of the State
+    np.testing.assert_array_equal(np.asarray(states.x), reco["x"]); np.testing.assert_array_equal(np.asarray(states.score), reco["score"])
+    np.testing.assert_array_equal(np.asarray(states.rng_key), rngo["key"]); np.testing.assert_array_equal(np.asarray(states.queue), reco["bag"])
+    assert cnt.n == 5
+    print(f"batched_step loop: {loop_s / T * 1e6:.0f} us of host time per call at {B} envs; batched_reset {best * 1e3:.1f} ms")
+
+
+def test_old_state_is_restored_device_to_device(monkeypatch):
+    """The functions are pure: a State from earlier can be stepped again (device → device restore from the copy it owns,
+    no host round trip) and gives what it gave the first time."""
+    B = 2048
+    keys = _keys(B)
+    _, s0, _ = F.batched_reset(TETROMINOES, keys, config=CFG)
+    rng = np.random.default_rng(5)
+    acts = rng.integers(0, 7, (30, B)).astype(np.int32)
+    s = s0
+    for t in range(10):
+        s, *_ = F.batched_step(TETROMINOES, s, acts[t], config=CFG)
+    s10 = s
+    firsts = []
+    for t in range(10, 20):
+        s, obs, rew, term, info = F.batched_step(TETROMINOES, s, acts[t], config=CFG)
+        firsts.append((np.asarray(obs), np.asarray(rew), np.asarray(term)))
+    cnt = _D2HCounter(monkeypatch)
+    uploads = []
+    monkeypatch.setattr(Engine, "set_state", lambda *a, **k: uploads.append(1))
+    s = s10  # an old State, never read: goes back device → device
+    for t in range(10, 20):
+        s, obs, rew, term, info = F.batched_step(TETROMINOES, s, acts[t], config=CFG)
+        assert cnt.n == 0 and not uploads
+        for got, exp in zip((np.asarray(obs), np.asarray(rew), np.asarray(term)), firsts[t - 10]):
+            np.testing.assert_array_equal(got, exp)
+    edited = s10.replace(score=np.asarray(s10.score) + np.float32(5))  # an edited State has no device copy: host upload
+    assert edited._token is None and getattr(edited, "_device", None) is None
+
+
+def test_device_array_is_zero_copy_for_torch(monkeypatch):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    B = 4096
+    rng = np.random.default_rng(1)
+    for obs_mode in (N.OBS_BOARD, N.OBS_DICT, N.OBS_RGB):
+        e = Engine(B, 10, 20, obs_mode=obs_mode, autoreset=N.AUTORESET_SAME_STEP, device=0)
+        e.reset(np.arange(1, B + 1, dtype=np.uint64))
+        for _ in range(25):
+            e.step_async(rng.integers(0, 8, B))
+        host_obs, host_out = e.observation(), e.fetch_outputs()
+        cnt = _D2HCounter(monkeypatch)
+        views, out = e.device_array(N.BUF_OBS), e.device_array(N.BUF_STEP_OUT)
+        pairs = list(zip(views.values(), host_obs.values())) if isinstance(views, dict) else [(views, host_obs)]
+        for v, h in pairs:
+            t = torch.as_tensor(v, device="cuda")
+            assert t.data_ptr() == v.ptr and tuple(t.shape) == h.shape and cnt.n == 0
+            t2 = torch.from_dlpack(v)
+            assert t2.data_ptr() == v.ptr and cnt.n == 0
+            assert torch.equal(t, t2)
+            np.testing.assert_array_equal(t.cpu().numpy(), h)
+        for name, h in zip(("reward", "terminated", "lines"), host_out):  # strided views of the 8-byte output records
+            t = torch.as_tensor(out[name], device="cuda")
+            assert t.data_ptr() == out[name].ptr and cnt.n == 0
+            np.testing.assert_array_equal(t.cpu().numpy(), h)
+            np.testing.assert_array_equal(np.asarray(out[name]), h)
+        monkeypatch.undo()
+        e.close()
+
+
+def test_vector_env_device_step_and_device_actions():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    B = 3000
+    rng = np.random.default_rng(2)
+    for kind in ("board", "dict"):
+        a = TetrisVectorEnv(B, observation=kind, autoreset_mode="same_step")
+        b = TetrisVectorEnv(B, observation=kind, autoreset_mode="same_step")
+        a.reset(seed=7); b.reset(seed=7)
+        for t in range(40):
+            act = rng.integers(0, 8, B)
+            obs_h, rew_h, term_h, _, info_h = b.step(act)
+            if t % 2:  # actions already on the device (a policy's output): handed over as a device pointer
+                ta = torch.as_tensor(act.astype(np.int32), device="cuda")
+                torch.cuda.synchronize()
+                obs_d, out_d = a.step(ta.data_ptr(), to_host=False)
+            else:
+                obs_d, out_d = a.step(act, to_host=False)
+            r = torch.as_tensor(out_d["reward"], device="cuda").cpu().numpy()
+            np.testing.assert_array_equal(r.astype(np.float64), rew_h)
+            np.testing.assert_array_equal(torch.as_tensor(out_d["terminated"], device="cuda").cpu().numpy().astype(bool), term_h)
+            for k in (obs_h if isinstance(obs_h, dict) else [None]):
+                got = torch.as_tensor(obs_d[k] if k else obs_d, device="cuda").cpu().numpy()
+                np.testing.assert_array_equal(got, obs_h[k] if k else obs_h)
+        a.close(); b.close()
+
+
+def test_vector_env_final_observation_info():
+    """Same-step autoreset: infos["final_observation"] holds the terminal observation of the envs that ended (gymnasium's
+    convention, examples/train_cnn.py:312-316) — equal to what the oracle shows right before it resets them."""
+    B = 1500
+    v = TetrisVectorEnv(B, observation="board", autoreset_mode="same_step", final_observation=True)
+    o = po.OracleBatch(B, 10, 20)
+    v.reset(seed=1); o.reset(np.arange(1, B + 1, dtype=np.uint64))
+    rng = np.random.default_rng(4)
+    seen = 0
+    for t in range(150):
+        act = rng.integers(0, 8, B)
+        obs, rew, term, trunc, infos = v.step(act)
+        ro, to, lo = o.step(act.astype(np.int32), autoreset=po.AUTORESET_NONE)
+        np.testing.assert_array_equal(term, to.astype(bool))
+        if to.any():
+            m = to.astype(bool)
+            np.testing.assert_array_equal(infos["_final_observation"], m)
+            np.testing.assert_array_equal(infos["final_observation"][m], o.observe(po.OBS_BOARD)[m])
+            seen += int(m.sum())
+            o.reset(mask=to)
+        else:
+            assert "final_observation" not in infos
+        np.testing.assert_array_equal(obs, o.observe(po.OBS_BOARD))
+    assert seen > 100
+    v.close()
+
+
+def test_vector_env_four_shards_on_one_device_equal_one_engine():
+    """The multi-GPU adapter with every shard on device 0 (this pool has one GPU per box): contiguous shards, global seeds,
+    one worker per engine — results independent of the number of shards."""
+    B = 4000
+    one = TetrisVectorEnv(B, observation="board", autoreset_mode="next_step", devices=(0,))
+    four = TetrisVectorEnv(B, observation="board", autoreset_mode="next_step", devices=(0, 0, 0, 0))
+    assert [hi - lo for lo, hi in four.ranges] == [1000] * 4 and len(four.engines) == 4
+    o1, i1 = one.reset(seed=11); o4, i4 = four.reset(seed=11)
+    np.testing.assert_array_equal(o1, o4)
+    rng = np.random.default_rng(6)
+    for t in range(120):
+        act = rng.integers(0, 8, B)
+        r1, r4 = one.step(act), four.step(act)
+        for x, y in zip(r1[:4], r4[:4]):
+            np.testing.assert_array_equal(x, y)
+        assert set(r1[4]) == set(r4[4])
+        for k in r1[4]:
+            if isinstance(r1[4][k], dict):
+                for kk in r1[4][k]:
+                    np.testing.assert_array_equal(r1[4][k][kk], r4[4][k][kk])
+            else:
+                np.testing.assert_array_equal(r1[4][k], r4[4][k])
+    one.close(); four.close()
+
+
+def test_engine_knobs_come_from_the_config_not_the_environment(monkeypatch):
+    """tg_config.fuse / rng_every / ring_fill_p1 (ABI 2) select the launch shape; results never depend on them."""
+    for k in ("TG_FUSE", "TG_RNG_EVERY", "TG_RING_FILL"):
+        monkeypatch.delenv(k, raising=False)
+    B, K = 1500, 37
+    acts = np.random.default_rng(8).integers(0, 8, (K, B)).astype(np.int8)
+    ref = None
+    for fuse, every, fill in ((0, 0, None), (1, 1, 3), (8, 3, 1), (5, 2, 0)):
+        e = Engine(B, 10, 20, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP, fuse=fuse, rng_every=every, ring_fill=fill)
+        assert e.step_kernel_name(fuse or 8).endswith("1>" if (fuse or 8) > 1 else "0>")
+        e.reset(np.arange(1, B + 1, dtype=np.uint64))
+        res = e.rollout(acts)
+        st = e.get_state()
+        got = (res[0], res[1], res[2], res[3], st[0], st[1]["bag"], st[2]["state_lo"])
+        if ref is None:
+            ref = got
+        for g, r in zip(got, ref):
+            np.testing.assert_array_equal(g, r)
+        e.close()

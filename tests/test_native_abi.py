@@ -22,13 +22,13 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared <= set(N.SYMBOLS), "ctypes binding is missing a declared symbol"
-    assert lib.tg_abi_version() == 1
+    assert lib.tg_abi_version() == N.ABI_VERSION == int(re.search(r"#define TG_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_record_layouts_match_header():
     assert N.ENV_REC.itemsize == 32 and N.RNG_REC.itemsize == 48
     assert N.ENV_REC.fields["bag"][1] == 10 and N.ENV_REC.fields["queue"][1] == 17 and N.ENV_REC.fields["score"][1] == 24
-    assert C.sizeof(N.TgConfig) == 16 * 4 and N.STEP_OUT.itemsize == 8
+    assert C.sizeof(N.TgConfig) == 20 * 4 and N.STEP_OUT.itemsize == 8
 
 
 def test_shape_table_matches_reference_matrices():

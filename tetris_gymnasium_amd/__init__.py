@@ -3,6 +3,6 @@
 Python host code calls hand-written HIP (gfx950) through a thin ctypes C ABI.  No PyTorch/Triton/JAX.
 """
 from . import _native  # noqa: F401
-from .engine import Engine, EngineError  # noqa: F401
+from .engine import DeviceArray, Engine, EngineError  # noqa: F401
 
-__all__ = ["Engine", "EngineError"]
+__all__ = ["DeviceArray", "Engine", "EngineError"]

@@ -13,6 +13,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TG_LIB") or os.path.join(_PKG, "libtetris_gym_hip.so")  # TG_LIB: the test-only legacy build
 
+ABI_VERSION = 2  # include/tetris_gym_hip.h TG_ABI_VERSION
 RULESET_NUMPY, RULESET_FUNCTIONAL = 0, 1
 OBS_NONE, OBS_BOARD, OBS_DICT, OBS_FN, OBS_RGB = 0, 1, 2, 3, 4
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = 0, 1, 2
@@ -49,6 +50,8 @@ class TgConfig(C.Structure):
         ("autoreset", C.c_int32), ("action_set", C.c_int32), ("batch", C.c_int32), ("device", C.c_int32),
         ("env_offset", C.c_int32), ("grouped_terminate_on_illegal", C.c_int32), ("flags", C.c_int32),
         ("reserved", C.c_int32),
+        # launch knobs (0 = default): transitions per launch of tg_step_k / tg_rollout, cadence and depth of the NUMPY bag look-ahead
+        ("fuse", C.c_int32), ("rng_every", C.c_int32), ("ring_fill_p1", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 
@@ -69,6 +72,8 @@ SYMBOLS = {
     "tg_fetch": (_i, [_vp, _i, _vp, _sz]),
     "tg_get_state": (_i, [_vp, _vp, _vp, _vp]),
     "tg_set_state": (_i, [_vp, _vp, _vp, _vp]),
+    "tg_get_state_dev": (_i, [_vp, _vp, _vp, _vp]),
+    "tg_set_state_dev": (_i, [_vp, _vp, _vp, _vp]),
     "tg_observe": (_i, [_vp]),
     "tg_grouped_enumerate": (_i, [_vp, _vp]),
     "tg_grouped_sample": (_i, [_vp, C.c_uint32, C.c_uint32]),
@@ -84,6 +89,7 @@ SYMBOLS = {
     "tg_dev_free": (_i, [_vp, _vp]),
     "tg_dev_upload": (_i, [_vp, _vp, _vp, _sz]),
     "tg_dev_download": (_i, [_vp, _vp, _vp, _sz]),
+    "tg_dev_copy": (_i, [_vp, _vp, _vp, _sz]),
     "tg_stream_copy_gbps": (_i, [_vp, _sz, _i, C.POINTER(C.c_float)]),
     "tg_shape_mask": (_i, [_i, _i]),
 }
@@ -112,7 +118,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.tg_abi_version() != 1:
+    if lib.tg_abi_version() != ABI_VERSION:
         raise NativeLibraryError("libtetris_gym_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -673,9 +673,13 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     h->dict_in_kernel = h->d_cols && !(getenv("TG_DICT_KERNEL") && atoi(getenv("TG_DICT_KERNEL")) == 0) &&
                         ((cfg->obs_mode == TG_OBS_DICT && L.dict_ok) ||
                          (cfg->obs_mode == TG_OBS_RGB && L.rgb_ok && cfg->queue_size == 4));  // (the in-kernel RGB image is laid out for four queue pieces)
+    // launch knobs: tg_config (0 = default), overridden by the environment (test hooks)
+    if (cfg->ring_fill_p1 > 0) h->ring_fill = cfg->ring_fill_p1 - 1 > tg::kRing - 1 ? tg::kRing - 1 : cfg->ring_fill_p1 - 1;
+    if (cfg->rng_every > 0) h->rng_every = cfg->rng_every > 3 ? 3 : cfg->rng_every;
+    if (cfg->fuse > 0) h->fuse_max = cfg->fuse > tg::kMaxFuse ? tg::kMaxFuse : cfg->fuse;
     if (const char* e = getenv("TG_RING_FILL")) { const int v = atoi(e); h->ring_fill = v < 0 ? 0 : (v > tg::kRing - 1 ? tg::kRing - 1 : v); }
     if (const char* e = getenv("TG_RNG_EVERY")) { const int v = atoi(e); h->rng_every = v < 1 ? 1 : (v > 3 ? 3 : v); }
-    if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > 8 ? 8 : v); }
+    if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > tg::kMaxFuse ? tg::kMaxFuse : v); }
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
     int want = 1;
     if (const char* e = getenv("TG_STREAMS")) want = atoi(e);
@@ -1015,6 +1019,35 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
   return TG_OK;
 }
 
+int tg_get_state_dev(tg_handle* h, uint8_t* board_dev, tg_env_rec* rec_dev, tg_rng_rec* rng_dev) {
+  if (!h) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
+  const size_t B = (size_t)h->B;
+  if (rng_dev) { int rcm = launch_materialize_rng(h); if (rcm != TG_OK) return rcm; }
+  if (board_dev) HIPCHK(h, hipMemcpyAsync(board_dev, h->buf[TG_BUF_BOARD], B * h->cells, hipMemcpyDeviceToDevice, h->stream));
+  if (rec_dev) HIPCHK(h, hipMemcpyAsync(rec_dev, h->buf[TG_BUF_REC], B * sizeof(tg_env_rec), hipMemcpyDeviceToDevice, h->stream));
+  if (rng_dev) HIPCHK(h, hipMemcpyAsync(rng_dev, h->buf[TG_BUF_RNG], B * sizeof(tg_rng_rec), hipMemcpyDeviceToDevice, h->stream));
+  return TG_OK;
+}
+
+int tg_set_state_dev(tg_handle* h, const uint8_t* board_dev, const tg_env_rec* rec_dev, const tg_rng_rec* rng_dev) {
+  if (!h) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
+  if (!rng_dev) { int rcm = launch_materialize_rng(h); if (rcm != TG_OK) return rcm; }  // the rings are rebuilt from TG_BUF_RNG below
+  const size_t B = (size_t)h->B;
+  if (board_dev) HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_BOARD], board_dev, B * h->cells, hipMemcpyDeviceToDevice, h->stream));
+  if (rec_dev) HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_REC], rec_dev, B * sizeof(tg_env_rec), hipMemcpyDeviceToDevice, h->stream));
+  if (rng_dev) {
+    HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_RNG], rng_dev, B * sizeof(tg_rng_rec), hipMemcpyDeviceToDevice, h->stream));
+    h->rng_valid.assign(B, 1);
+  }
+  { int rc = launch_prepare_bits(h, nullptr, 1); if (rc != TG_OK) return rc; }
+  if (h->cfg.obs_mode != TG_OBS_NONE) return launch_observe_dict(h);  // (the observation of the restored state)
+  return TG_OK;
+}
+
 int tg_observe(tg_handle* h) {
   if (!h) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1157,6 +1190,14 @@ int tg_dev_download(tg_handle* h, void* dst_host, const void* src_dev, size_t by
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   HIPCHK(h, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  return TG_OK;
+}
+
+int tg_dev_copy(tg_handle* h, void* dst_dev, const void* src_dev, size_t bytes) {
+  if (!h || !dst_dev || !src_dev) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
+  if (bytes) HIPCHK(h, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, h->stream));
   return TG_OK;
 }
 

@@ -235,6 +235,7 @@ struct BitsParams {
 
 // native 16-byte vector for the slab stream: HIP's uint4 is a struct whose copies become memcpy intrinsics, which
 // kept the staging array in scratch memory (and made the kernel wait for every slab load right after issuing it)
+constexpr int kMaxFuse = 8;  // transitions per launch (tg_config.fuse): the action bytes of a launch travel in one 64-bit word
 constexpr int kRing = 4;  // slots per permutation ring: kRing - 1 entries ahead + the last consumed one
 __device__ __forceinline__ int ring_diff(const int a, const int b) { return ((a - b) << 24) >> 24; }  // counters are mod 256
 // where the generator state (FUNCTIONAL: the key) after the last consumed entry lives (`loc` field of hbuf)
@@ -1936,6 +1937,9 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   // (every load result the rest of the transition uses is claimed HERE, in front of the first store behind the publish: on
   // gfx9 a wait for a load with stores pending is a wait for the stores — vmcnt counts both, and they complete out of order)
   if (RULESET == TG_RULESET_FUNCTIONAL) asm volatile("" : "+v"(pf_c1), "+v"(pf_c3), "+v"(pf_r1));
+#ifndef TG_NO_EP_CLAIM
+  asm volatile("" : "+v"(ep.ret), "+v"(ep.len), "+v"(ep.last_ret), "+v"(ep.last_len));
+#endif
   if (pending) {  // the NEXT_STEP reset step belongs to no episode (gymnasium RecordEpisodeStatistics)
     ep.ret = 0.0f; ep.len = 0;
   } else {

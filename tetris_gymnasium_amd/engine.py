@@ -12,6 +12,126 @@ class EngineError(RuntimeError):
     pass
 
 
+# ---- device-resident views ------------------------------------------------------------------------------------------
+class _DLDevice(C.Structure):
+    _fields_ = [("device_type", C.c_int), ("device_id", C.c_int)]
+
+
+class _DLDataType(C.Structure):
+    _fields_ = [("code", C.c_uint8), ("bits", C.c_uint8), ("lanes", C.c_uint16)]
+
+
+class _DLTensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("device", _DLDevice), ("ndim", C.c_int), ("dtype", _DLDataType),
+                ("shape", C.POINTER(C.c_int64)), ("strides", C.POINTER(C.c_int64)), ("byte_offset", C.c_uint64)]
+
+
+class _DLManagedTensor(C.Structure):
+    pass
+
+
+_DLDeleter = C.CFUNCTYPE(None, C.POINTER(_DLManagedTensor))
+_DLManagedTensor._fields_ = [("dl_tensor", _DLTensor), ("manager_ctx", C.c_void_p), ("deleter", _DLDeleter)]
+_KDLROCM = 10  # DLDeviceType::kDLROCM
+_dl_live: dict = {}  # address of a handed-out DLManagedTensor → everything that must outlive the capsule
+
+
+@_DLDeleter
+def _dl_deleter(mt):
+    _dl_live.pop(C.addressof(mt.contents), None)
+
+
+_PyCapsule_New = C.pythonapi.PyCapsule_New
+_PyCapsule_New.restype = C.py_object
+_PyCapsule_New.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+
+
+class DeviceArray:
+    """A typed, shaped view of device memory that other GPU libraries take without a copy: `__cuda_array_interface__`
+    (version 3; `torch.as_tensor(view, device="cuda")`, cupy, numba) and `__dlpack__` (`torch.from_dlpack(view)`; device type
+    kDLROCM).  `numpy()` / `np.asarray(view)` download it.  Views of engine buffers (Engine.device_array) alias memory the
+    next transition overwrites — copy on the consumer's side to keep a value; an `owner` (a pooled device buffer) makes the
+    view own its bytes.  Exporting waits for the engine's stream first (`sync=True`), so the consumer reads finished data."""
+
+    def __init__(self, engine, ptr, shape, dtype, strides=None, owner=None, sync=True, readonly=False):
+        self.engine, self.ptr, self.shape, self.dtype = engine, int(ptr), tuple(int(x) for x in shape), np.dtype(dtype)
+        self.strides = None if strides is None else tuple(int(x) for x in strides)
+        self._owner, self._sync, self._readonly = owner, sync, readonly
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def _ready(self):
+        if self._sync:
+            self.engine.sync()
+
+    @property
+    def __cuda_array_interface__(self):
+        self._ready()
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, self._readonly), "version": 3,
+                "strides": self.strides, "descr": [("", self.dtype.str)], "stream": None}
+
+    def __dlpack_device__(self):
+        return (_KDLROCM, int(self.engine.cfg.device))
+
+    def __dlpack__(self, stream=None, **_):
+        self._ready()
+        nd = len(self.shape)
+        shape = (C.c_int64 * nd)(*self.shape)
+        item = self.dtype.itemsize
+        strides = None if self.strides is None else (C.c_int64 * nd)(*[st // item for st in self.strides])
+        code = {"u": 1, "i": 0, "f": 2, "b": 6}[self.dtype.kind]
+        mt = _DLManagedTensor()
+        mt.dl_tensor = _DLTensor(C.c_void_p(self.ptr), _DLDevice(_KDLROCM, int(self.engine.cfg.device)), nd,
+                                 _DLDataType(code, item * 8, 1), shape,
+                                 C.cast(strides, C.POINTER(C.c_int64)) if strides is not None else None, 0)
+        mt.manager_ctx = None
+        mt.deleter = _dl_deleter
+        _dl_live[C.addressof(mt)] = (mt, shape, strides, self)  # the view (and its owner) lives as long as the consumer's tensor
+        return _PyCapsule_New(C.addressof(mt), b"dltensor", None)
+
+    def numpy(self):
+        """Download (waits for the engine's stream)."""
+        if self.strides is None:
+            out = np.empty(self.shape, self.dtype)
+            self.engine.dev_download(self.ptr, out)
+            return out
+        # strided view of a record array: fetch the enclosing bytes once, then view
+        span = sum((n - 1) * st for n, st in zip(self.shape, self.strides)) + self.dtype.itemsize
+        raw = np.empty(span, np.uint8)
+        self.engine.dev_download(self.ptr, raw)
+        return np.lib.stride_tricks.as_strided(raw[: self.dtype.itemsize].view(self.dtype), self.shape, self.strides).copy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, device={self.engine.cfg.device}, ptr=0x{self.ptr:x})"
+
+
+class DeviceBuffer:
+    """A device allocation from the engine's free list (hipMalloc / hipFree cost ~100 us and a stream sync each: buffers of
+    the sizes a loop keeps asking for are recycled).  Returns itself to the list when the last view dies."""
+
+    def __init__(self, engine, nbytes):
+        self.engine, self.nbytes = engine, int(nbytes)
+        free = engine._pool.setdefault(self.nbytes, [])
+        self.ptr = free.pop() if free else engine.dev_alloc(self.nbytes)
+
+    def __del__(self):
+        try:
+            if self.engine.h:
+                self.engine._pool.setdefault(self.nbytes, []).append(self.ptr)
+        except Exception:
+            pass
+
+
 class Engine:
     """Owns `batch` environments on one MI355X.  All arrays in/out are NumPy; state stays on the device.
 
@@ -21,8 +141,12 @@ class Engine:
 
     def __init__(self, batch, width=10, height=20, *, ruleset=N.RULESET_NUMPY, gravity=True, queue_size=None,
                  obs_mode=None, autoreset=N.AUTORESET_NONE, device=0, env_offset=0, padding=4, episode_stats=False,
-                 final_obs=False, grouped=False, terminate_on_illegal=True, features=False):
+                 final_obs=False, grouped=False, terminate_on_illegal=True, features=False, fuse=0, rng_every=0,
+                 ring_fill=None):
+        """fuse / rng_every / ring_fill: launch knobs of the step kernel (tg_config; 0 / None = the defaults 8 / 3 / 3).
+        Results never depend on them."""
         self.lib = N.load()
+        self._pool = {}      # free device buffers by size (DeviceBuffer)
         if queue_size is None:
             queue_size = 4 if ruleset == N.RULESET_NUMPY else 7
         if obs_mode is None:
@@ -36,6 +160,8 @@ class Engine:
         cfg.grouped_terminate_on_illegal = int(bool(terminate_on_illegal))
         cfg.flags = ((N.FLAG_EPISODE_STATS if episode_stats else 0) | (N.FLAG_FINAL_OBS if final_obs else 0)
                      | (N.FLAG_FEATURES if features else 0))
+        cfg.fuse, cfg.rng_every = int(fuse), int(rng_every)
+        cfg.ring_fill_p1 = 0 if ring_fill is None else int(ring_fill) + 1
         self.cfg = cfg
         self.B, self.W, self.H, self.P, self.Q = batch, width, height, padding, queue_size
         self.Wp, self.Hp = width + 2 * padding, height + padding
@@ -50,6 +176,10 @@ class Engine:
     # -- lifetime ------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "h", None):
+            for ptrs in self._pool.values():
+                for p in ptrs:
+                    self.lib.tg_dev_free(self.h, C.c_void_p(p))
+            self._pool = {}
             self.lib.tg_destroy(self.h)
             self.h = None
 
@@ -100,9 +230,10 @@ class Engine:
         a = np.ascontiguousarray(a, dtype=np.int8)
         K = a.shape[0]
         per_env = self.lib.tg_obs_bytes_per_env(C.byref(self.cfg))
-        d_a = self.dev_alloc(a.nbytes)
-        d_o = self.dev_alloc(K * self.B * per_env) if (per_env and want_obs) else None
-        d_r = self.dev_alloc(K * self.B * N.STEP_OUT.itemsize)
+        b_a = DeviceBuffer(self, a.nbytes)  # (scratch from the engine's free list: no hipMalloc / hipFree + sync per call)
+        b_o = DeviceBuffer(self, K * self.B * per_env) if (per_env and want_obs) else None
+        b_r = DeviceBuffer(self, K * self.B * N.STEP_OUT.itemsize)
+        d_a, d_o, d_r = b_a.ptr, (b_o.ptr if b_o else None), b_r.ptr
         try:
             self.dev_upload(d_a, a)
             self._chk(self.lib.tg_rollout(self.h, C.c_void_p(d_a), K, C.c_void_p(d_o) if d_o else None, C.c_void_p(d_r)),
@@ -122,10 +253,7 @@ class Engine:
                 else:
                     obs = raw.reshape(K, self.B * per_env)  # DICT: the engine's flat layout per transition
         finally:
-            self.dev_free(d_a)
-            if d_o:
-                self.dev_free(d_o)
-            self.dev_free(d_r)
+            del b_a, b_o, b_r
         return (obs, np.ascontiguousarray(out["reward"]), np.ascontiguousarray(out["terminated"]),
                 np.ascontiguousarray(out["lines"]))
 
@@ -164,6 +292,62 @@ class Engine:
             return self._fetch(which, np.empty((self.B, self.Hp, self.Wp + self.P * max(1, self.Q), 3), np.uint8))
         raise EngineError("engine was created with obs_mode NONE")
 
+    def device_array(self, which=N.BUF_OBS):
+        """Zero-copy view(s) of an engine-owned buffer for other GPU libraries (DeviceArray: `__cuda_array_interface__` +
+        DLPack): the observation in the shape(s) `observation()` returns (a dict of four views for the dict surface), the
+        last transition's outputs as {"reward" f32[B], "terminated" u8[B], "lines" u8[B]} (strided views of tg_step_out),
+        the legal mask, the boards, the actions buffer.  What a trainer does with `torch.Tensor(next_obs).to(device)`
+        (examples/train_ppo.py:240-245) without the trip through host memory."""
+        ptr, nbytes = self.device_ptr(which)
+        B = self.B
+        if which in (N.BUF_OBS, N.BUF_FINAL_OBS):
+            if self.obs_mode == N.OBS_BOARD:
+                return DeviceArray(self, ptr, (B, self.H, self.W), np.uint8)
+            if self.obs_mode == N.OBS_FN:
+                return DeviceArray(self, ptr, (B, self.H, self.W), np.int8)
+            if self.obs_mode == N.OBS_RGB:
+                return DeviceArray(self, ptr, (B, self.Hp, self.Wp + self.P * max(1, self.Q), 3), np.uint8)
+            if self.obs_mode == N.OBS_DICT:
+                cells, pp = self.Hp * self.Wp, self.P * self.P
+                return {"board": DeviceArray(self, ptr, (B, self.Hp, self.Wp), np.uint8),
+                        "active_tetromino_mask": DeviceArray(self, ptr + B * cells, (B, self.Hp, self.Wp), np.uint8),
+                        "holder": DeviceArray(self, ptr + 2 * B * cells, (B, self.P, self.P), np.uint8),
+                        "queue": DeviceArray(self, ptr + 2 * B * cells + B * pp, (B, self.P, self.P * self.Q), np.uint8)}
+            raise EngineError("engine was created with obs_mode NONE")
+        if which == N.BUF_STEP_OUT:
+            st = N.STEP_OUT.itemsize
+            return {"reward": DeviceArray(self, ptr, (B,), np.float32, strides=(st,)),
+                    "terminated": DeviceArray(self, ptr + 4, (B,), np.uint8, strides=(st,)),
+                    "lines": DeviceArray(self, ptr + 5, (B,), np.uint8, strides=(st,))}
+        if which == N.BUF_LEGAL_MASK:
+            return DeviceArray(self, ptr, (B, 4 * self.W), np.uint8)
+        if which == N.BUF_BOARD:
+            return DeviceArray(self, ptr, (B, self.H, self.W), np.uint8)
+        if which == N.BUF_ACTIONS:
+            return DeviceArray(self, ptr, (B,), np.int32)
+        if which == N.BUF_FEATS:
+            return DeviceArray(self, ptr, (B, self.W + 3), np.uint8)
+        if which == N.BUF_PLACEMENT_FEATS:
+            return DeviceArray(self, ptr, (B, 4 * self.W, self.W + 3), np.uint8)
+        return DeviceArray(self, ptr, (nbytes,), np.uint8)
+
+    def dev_copy(self, dst_ptr, src_ptr, nbytes):
+        """Device → device, asynchronous on the engine's stream."""
+        self._chk(self.lib.tg_dev_copy(self.h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes), "tg_dev_copy")
+
+    def get_state_device(self):
+        """Snapshot of (board, rec, rng) in pooled device buffers (asynchronous; envs/tetris.py:681-708 without the host)."""
+        bufs = (DeviceBuffer(self, self.B * self.H * self.W), DeviceBuffer(self, self.B * N.ENV_REC.itemsize),
+                DeviceBuffer(self, self.B * N.RNG_REC.itemsize))
+        self._chk(self.lib.tg_get_state_dev(self.h, C.c_void_p(bufs[0].ptr), C.c_void_p(bufs[1].ptr), C.c_void_p(bufs[2].ptr)),
+                  "tg_get_state_dev")
+        return bufs
+
+    def set_state_device(self, board=None, rec=None, rng=None):
+        """Restore from device buffers (DeviceBuffer or raw pointers) — the counterpart of get_state_device."""
+        p = [None if b is None else C.c_void_p(b.ptr if isinstance(b, DeviceBuffer) else int(b)) for b in (board, rec, rng)]
+        self._chk(self.lib.tg_set_state_dev(self.h, *p), "tg_set_state_dev")
+
     # -- grouped action surface (wrappers/grouped.py) ---------------------------------------------
     def legal_mask(self):
         """u8 [B, 4*W]: 1 = legal placement (column*4 + rotations) for the current active pieces."""
@@ -174,13 +358,11 @@ class Engine:
         """(legal mask u8[B][4W], boards u8[B][4W][H+p][W+2p]): the observation of GroupedActionsObservations
         (wrappers/grouped.py:124-207) for the current state, built on the device."""
         n = self.B * 4 * self.W * self.Hp * self.Wp
-        d = self.dev_alloc(n)
-        try:
-            self._chk(self.lib.tg_grouped_enumerate(self.h, C.c_void_p(d)), "tg_grouped_enumerate(boards)")
-            boards = np.empty((self.B, 4 * self.W, self.Hp, self.Wp), np.uint8)
-            self._chk(self.lib.tg_dev_download(self.h, N.ptr(boards), C.c_void_p(d), n), "tg_dev_download")
-        finally:
-            self.dev_free(d)
+        buf = DeviceBuffer(self, n)
+        self._chk(self.lib.tg_grouped_enumerate(self.h, C.c_void_p(buf.ptr)), "tg_grouped_enumerate(boards)")
+        boards = np.empty((self.B, 4 * self.W, self.Hp, self.Wp), np.uint8)
+        self._chk(self.lib.tg_dev_download(self.h, N.ptr(boards), C.c_void_p(buf.ptr), n), "tg_dev_download")
+        del buf
         return self._fetch(N.BUF_LEGAL_MASK, np.empty((self.B, 4 * self.W), np.uint8)), boards
 
     def placement_boards_device(self, boards_dev_ptr):
@@ -200,8 +382,8 @@ class Engine:
             self._chk(self.lib.tg_grouped_rollout(self.h, int(seed) & 0xFFFFFFFF, int(counter0) & 0xFFFFFFFF, int(K),
                                                   None, None, None), "tg_grouped_rollout")
             return None
-        d_a = self.dev_alloc(K * self.B)
-        d_r = self.dev_alloc(K * self.B * N.STEP_OUT.itemsize)
+        b_a, b_r = DeviceBuffer(self, K * self.B), DeviceBuffer(self, K * self.B * N.STEP_OUT.itemsize)
+        d_a, d_r = b_a.ptr, b_r.ptr
         try:
             self._chk(self.lib.tg_grouped_rollout(self.h, int(seed) & 0xFFFFFFFF, int(counter0) & 0xFFFFFFFF, int(K),
                                                   C.c_void_p(d_a), None, C.c_void_p(d_r)), "tg_grouped_rollout")
@@ -210,8 +392,7 @@ class Engine:
             self._chk(self.lib.tg_dev_download(self.h, N.ptr(acts), C.c_void_p(d_a), acts.nbytes), "tg_dev_download")
             self._chk(self.lib.tg_dev_download(self.h, N.ptr(out), C.c_void_p(d_r), out.nbytes), "tg_dev_download")
         finally:
-            self.dev_free(d_a)
-            self.dev_free(d_r)
+            del b_a, b_r
         return (acts, np.ascontiguousarray(out["reward"]), np.ascontiguousarray(out["terminated"]),
                 np.ascontiguousarray(out["lines"]))
 

@@ -132,8 +132,7 @@ class Tetris(EnvBase):
         rec["bag_index"] = self.randomizer.index
         p = self.padding
         board = np.ascontiguousarray(self.board[: self.height, p: p + self.width], np.uint8)[None]
-        e.set_state(board=board, rec=rec, rng=self.randomizer.pcg64_state)
-        self._obs_stale = True  # TG_BUF_OBS still holds the observation of the last transition
+        e.set_state(board=board, rec=rec, rng=self.randomizer.pcg64_state)  # (tg_set_state re-packs TG_BUF_OBS itself)
 
     def _pull(self):
         board, rec, rng = self._engine.get_state()
@@ -154,10 +153,8 @@ class Tetris(EnvBase):
         self.randomizer.pcg64_state = rng.copy()
 
     def _obs(self) -> "dict[str, Any]":
-        # after a host-side state upload (set_state, attribute edits pushed by get_state) the observation buffer is
-        # re-packed from the state (tg_observe); after a transition it is what the step kernel wrote
-        o = self._engine.observe() if getattr(self, "_obs_stale", False) else self._engine.observation()
-        self._obs_stale = False
+        # TG_BUF_OBS is what the step kernel wrote (after a transition) or what tg_reset / tg_set_state re-packed
+        o = self._engine.observation()
         return {k: v[0].copy() for k, v in o.items()}
 
     # ---- gymnasium API --------------------------------------------------------------------------
@@ -166,7 +163,6 @@ class Tetris(EnvBase):
         assert self.action_space.contains(action), f"{action!r} ({type(action)}) invalid"
         self._push()
         rew, term, lines = self._engine.step(np.array([int(action)], np.int32))
-        self._obs_stale = False
         self._pull()
         reward = int(rew[0]) if float(rew[0]).is_integer() else float(rew[0])
         return self._obs(), reward, bool(term[0]), False, {"lines_cleared": int(lines[0])}
@@ -178,7 +174,6 @@ class Tetris(EnvBase):
         except TypeError:
             pass
         self._engine.reset(None if not seed else np.array([int(seed)], np.uint64))
-        self._obs_stale = False
         self._pull()
         return self._obs(), {"lines_cleared": 0}
 
@@ -222,7 +217,6 @@ class Tetris(EnvBase):
 
     def set_state(self, state: TetrisState) -> None:
         self._engine.set_state(board=state.board, rec=state.rec, rng=state.rng)
-        self._obs_stale = True
         self._pull()
 
     def render(self):

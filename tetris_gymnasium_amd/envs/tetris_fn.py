@@ -63,7 +63,122 @@ def split(key, num: int = 2) -> np.ndarray:
     return np.array([threefry2x32(key, (0, i)) for i in range(num)], np.uint32)
 
 
+def threefry2x32_batch(k0, k1, c0, c1):
+    """threefry2x32 on uint32 arrays (NumPy wrap-around arithmetic): the batched form of `threefry2x32` above."""
+    k0, k1 = np.asarray(k0, np.uint32), np.asarray(k1, np.uint32)
+    ks = (k0, k1, k0 ^ k1 ^ np.uint32(0x1BD11BDA))
+    x0, x1 = (np.asarray(c0, np.uint32) + ks[0]).astype(np.uint32), (np.asarray(c1, np.uint32) + ks[1]).astype(np.uint32)
+    rots = ((13, 15, 26, 6), (17, 29, 16, 24))
+    for blk in range(5):
+        for r in rots[blk & 1]:
+            x0 = x0 + x1
+            x1 = ((x1 << np.uint32(r)) | (x1 >> np.uint32(32 - r))) ^ x0
+        x0 = x0 + ks[(blk + 1) % 3]
+        x1 = x1 + ks[(blk + 2) % 3] + np.uint32(blk + 1)
+    return x0, x1
+
+
+def split_batch(keys, index: int = 0) -> np.ndarray:
+    """split(key)[index] for every row of keys[B, 2] at once (batched_reset returns split(key)[0] per env: a Python loop over
+    65 536 keys took a second)."""
+    keys = np.asarray(keys, np.uint32).reshape(-1, 2)
+    z = np.zeros(keys.shape[0], np.uint32)
+    x0, x1 = threefry2x32_batch(keys[:, 0], keys[:, 1], z, z + np.uint32(index))
+    return np.stack([x0, x1], axis=1)
+
+
 # ---------------------------------------------------------------------------------------------------
+# Device-resident values of the batched functions.  Like the reference's jax arrays, what batched_reset / batched_step
+# return lives on the device until somebody looks at it: every returned value owns a device copy (pooled buffers,
+# device-to-device on the engine's stream — no synchronisation, no PCIe traffic in a rollout loop) and turns into NumPy
+# on first use (`np.asarray`, indexing, arithmetic, attribute access).  A State handed back to batched_step is restored
+# device-to-device unless it is the one the engine already holds (`_token`).
+class _Source:
+    """One download serving several LazyArray leaves (a State's three buffers, the three fields of tg_step_out)."""
+
+    def __init__(self, fetch):
+        self._fetch, self._vals = fetch, None
+        self.downloads = 0
+
+    def get(self, key):
+        if self._vals is None:
+            self._vals = self._fetch()
+            self._fetch = None  # (drops the device buffers the closure holds)
+            self.downloads += 1
+        return self._vals[key]
+
+
+class LazyArray:
+    """An array that is still on the device.  Behaves like the NumPy array it becomes on first use."""
+
+    def __init__(self, source: _Source, key, shape, dtype, device_view=None):
+        self._source, self._key, self._shape, self._dtype, self._view = source, key, tuple(shape), np.dtype(dtype), device_view
+
+    # cheap metadata: no download
+    shape = property(lambda self: self._shape)
+    dtype = property(lambda self: self._dtype)
+    ndim = property(lambda self: len(self._shape))
+    size = property(lambda self: int(np.prod(self._shape, dtype=np.int64)))
+
+    def __len__(self):
+        return self._shape[0]
+
+    @property
+    def materialized(self) -> bool:
+        return self._source._vals is not None
+
+    def device_view(self):
+        """The DeviceArray behind this value (zero-copy hand-over to torch / cupy), or None once it only exists on the host."""
+        return None if self.materialized else self._view
+
+    def numpy(self) -> np.ndarray:
+        return self._source.get(self._key)
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, i):
+        return self.numpy()[i]
+
+    def __iter__(self):
+        return iter(self.numpy())
+
+    def __getattr__(self, name):  # everything else an ndarray offers (sum, any, astype, reshape, copy, ...)
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return getattr(self.numpy(), name)
+
+    def __repr__(self):
+        return repr(self.numpy()) if self.materialized else f"LazyArray(on device, shape={self._shape}, dtype={self._dtype})"
+
+    def __bool__(self):
+        return bool(self.numpy())
+
+    def __int__(self):
+        return int(self.numpy())
+
+    def __float__(self):
+        return float(self.numpy())
+
+    def __index__(self):
+        return int(self.numpy())
+
+
+def _binop(name):
+    def f(self, other):
+        return getattr(self.numpy(), name)(np.asarray(other) if isinstance(other, LazyArray) else other)
+    return f
+
+
+for _n in ("add", "sub", "mul", "truediv", "floordiv", "mod", "and", "or", "xor", "lt", "le", "gt", "ge", "eq", "ne",
+           "radd", "rsub", "rmul", "rand", "ror", "rxor", "neg", "invert", "abs"):
+    if _n in ("neg", "invert", "abs"):
+        setattr(LazyArray, f"__{_n}__", (lambda nm: lambda self: getattr(self.numpy(), nm)())(f"__{_n}__"))
+    else:
+        setattr(LazyArray, f"__{_n}__", _binop(f"__{_n}__"))
+LazyArray.__hash__ = None
+
 _engines: dict = {}
 _ids = itertools.count(1)
 
@@ -172,32 +287,106 @@ def step(tetrominoes, state: State, action, config, queue_fn=bag_queue_get_next_
             np.bool_(term[0]), {"lines_cleared": np.int32(lines[0])})
 
 
+def _leaves_from_buffers(config, B, board, rec, rng) -> dict:
+    return dict(
+        rng_key=rng["key"].copy(), board=_pad(board, config), active_tetromino=rec["piece"].astype(np.int32),
+        rotation=rec["rot"].astype(np.int32), x=rec["x"].astype(np.int32), y=rec["y"].astype(np.int32),
+        queue=rec["bag"].astype(np.int32), queue_index=rec["bag_index"].astype(np.int32),
+        game_over=(rec["flags"] & N.F_GAME_OVER).astype(bool), score=rec["score"].astype(np.float32))
+
+
+_LEAF_SPEC = {  # leaf → (trailing shape as a function of the config, dtype)
+    "rng_key": (lambda c: (2,), np.uint32), "board": (lambda c: (c.height + c.padding, c.width + 2 * c.padding), np.int8),
+    "active_tetromino": (lambda c: (), np.int32), "rotation": (lambda c: (), np.int32), "x": (lambda c: (), np.int32),
+    "y": (lambda c: (), np.int32), "queue": (lambda c: (7,), np.int32), "queue_index": (lambda c: (), np.int32),
+    "game_over": (lambda c: (), np.bool_), "score": (lambda c: (), np.float32)}
+
+
+def _device_state(slot: _Slot, config) -> State:
+    """The engine's current state as a State whose leaves are still on the device (own device copy: stays valid — and can be
+    handed back to batched_step — however far the engine moves on)."""
+    e = slot.engine
+    bufs = e.get_state_device()
+    B = e.B
+
+    def fetch(bufs=bufs):
+        board = e.dev_download(bufs[0].ptr, np.empty((B, e.H, e.W), np.uint8))
+        rec = e.dev_download(bufs[1].ptr, np.empty(B, N.ENV_REC))
+        rng = e.dev_download(bufs[2].ptr, np.empty(B, N.RNG_REC))
+        return _leaves_from_buffers(config, B, board, rec, rng)
+
+    src = _Source(fetch)
+    st = State(**{k: LazyArray(src, k, (B,) + shp(config), dt) for k, (shp, dt) in _LEAF_SPEC.items()},
+               _token=(slot.id, slot.generation))
+    st._device = (slot.id, bufs, src)  # device copy for a device-to-device restore; dropped with the State
+    return st
+
+
+def _device_outputs(slot: _Slot, config):
+    """(observation, reward, terminated, lines) of the last transition as device-resident values."""
+    from ..engine import DeviceArray, DeviceBuffer
+
+    e = slot.engine
+    B = e.B
+    src_o, n_o = e.device_ptr(N.BUF_OBS)
+    src_r, n_r = e.device_ptr(N.BUF_STEP_OUT)
+    bo, br = DeviceBuffer(e, n_o), DeviceBuffer(e, n_r)
+    e.dev_copy(bo.ptr, src_o, n_o)
+    e.dev_copy(br.ptr, src_r, n_r)
+    so = _Source(lambda bo=bo: {"obs": e.dev_download(bo.ptr, np.empty((B, config.height, config.width), np.int8))})
+
+    def fetch_out(br=br):
+        out = e.dev_download(br.ptr, np.empty(B, N.STEP_OUT))
+        return {"reward": np.ascontiguousarray(out["reward"]), "terminated": out["terminated"].astype(bool),
+                "lines": out["lines"].astype(np.int32)}
+
+    sr = _Source(fetch_out)
+    st = N.STEP_OUT.itemsize
+    obs = LazyArray(so, "obs", (B, config.height, config.width), np.int8,
+                    DeviceArray(e, bo.ptr, (B, config.height, config.width), np.int8, owner=bo))
+    rew = LazyArray(sr, "reward", (B,), np.float32, DeviceArray(e, br.ptr, (B,), np.float32, strides=(st,), owner=br))
+    term = LazyArray(sr, "terminated", (B,), np.bool_, DeviceArray(e, br.ptr + 4, (B,), np.uint8, strides=(st,), owner=br))
+    lines = LazyArray(sr, "lines", (B,), np.int32, DeviceArray(e, br.ptr + 5, (B,), np.uint8, strides=(st,), owner=br))
+    return obs, rew, term, lines
+
+
+def _ensure_resident_batched(slot: _Slot, config, states: State):
+    if states._token == (slot.id, slot.generation):
+        return
+    dev = getattr(states, "_device", None)
+    if dev is not None and dev[0] == slot.id:  # an earlier State of this engine (leaves are immutable): device → device
+        slot.engine.set_state_device(*dev[1])
+        slot.generation += 1
+        return
+    _upload(slot, config, _leaves_of(states, True))
+
+
 def batched_reset(tetrominoes, keys, *, config, create_queue_fn=create_bag_queue,
                   queue_fn=bag_queue_get_next_element, batch_size: int = 1):
     """→ (keys[B,2], states, observations[B,H,W])   (reference envs/tetris_fn.py:438-467; like the reference,
-    `batch_size` is accepted and unused — the batch is keys.shape[0])."""
+    `batch_size` is accepted and unused — the batch is keys.shape[0]).  States and observations stay on the device
+    until read (LazyArray)."""
     _check(tetrominoes, config, create_queue_fn, queue_fn)
     keys = np.asarray(keys, np.uint32).reshape(-1, 2)
     slot = _slot(config, keys.shape[0])
     slot.engine.reset((keys[:, 0].astype(np.uint64) << np.uint64(32)) | keys[:, 1].astype(np.uint64))
     slot.generation += 1
-    leaves = _download(slot, config)
-    new_keys = np.array([split(k)[0] for k in keys], np.uint32)
-    return new_keys, _state_from(leaves, None, (slot.id, slot.generation)), slot.engine.observation()
+    obs = _device_outputs(slot, config)[0]
+    return split_batch(keys, 0), _device_state(slot, config), obs
 
 
 def batched_step(tetrominoes, states: State, actions, *, config, queue_fn=bag_queue_get_next_element):
     """→ (states, observations, rewards f32[B], terminated bool[B], {"lines_cleared": i32[B]})
-    (reference envs/tetris_fn.py:416-435)"""
+    (reference envs/tetris_fn.py:416-435).  Nothing is downloaded and nothing waits for the GPU: every returned value is
+    a LazyArray that owns a device copy and becomes NumPy when it is first read."""
     _check(tetrominoes, config, queue_fn)
     actions = np.asarray(actions, np.int32).reshape(-1)
     slot = _slot(config, actions.shape[0])
-    _ensure_resident(slot, config, states, True)
-    rew, term, lines = slot.engine.step(actions)
+    _ensure_resident_batched(slot, config, states)
+    slot.engine.step_async(actions)
     slot.generation += 1
-    leaves = _download(slot, config)
-    return (_state_from(leaves, None, (slot.id, slot.generation)), slot.engine.observation(), rew, term.astype(bool),
-            {"lines_cleared": lines.astype(np.int32)})
+    obs, rew, term, lines = _device_outputs(slot, config)
+    return _device_state(slot, config), obs, rew, term, {"lines_cleared": lines}
 
 
 def get_observation(board, x, y, active_tetromino, rotation, game_over, tetrominoes, config):

@@ -47,7 +47,11 @@ class TetrisVectorEnv(VectorEnvBase):
     def __init__(self, num_envs: int, width: int = 10, height: int = 20, gravity: bool = True, *,
                  ruleset: str = "numpy", observation: str = "dict", queue_size: int | None = None,
                  autoreset_mode: str = "next_step", devices=(0,), episode_stats: bool = True,
-                 grouped: bool = False, terminate_on_illegal_action: bool = True):
+                 grouped: bool = False, terminate_on_illegal_action: bool = True, final_observation: bool = False):
+        """final_observation: with autoreset_mode="same_step" and a board / functional observation, `infos` of a step in
+        which episodes ended carries "final_observation" (the terminal observation of those envs, the reset observation is
+        what `step` returns) and "_final_observation" — gymnasium's same-step autoreset convention
+        (examples/train_cnn.py:312-316)."""
         self.num_envs = int(num_envs)
         self.width, self.height = width, height
         self.ruleset = N.RULESET_NUMPY if ruleset == "numpy" else N.RULESET_FUNCTIONAL
@@ -62,7 +66,8 @@ class TetrisVectorEnv(VectorEnvBase):
             Engine(hi - lo, width, height, ruleset=self.ruleset, gravity=gravity, queue_size=queue_size,
                    obs_mode=_OBS[observation], autoreset=_AUTORESET[autoreset_mode], device=dev, env_offset=lo,
                    episode_stats=episode_stats, grouped=grouped, terminate_on_illegal=terminate_on_illegal_action,
-                   features=(observation == "placement_features"))
+                   features=(observation == "placement_features"),
+                   final_obs=(bool(final_observation) and autoreset_mode == "same_step" and observation in ("board", "functional")))
             for (lo, hi), dev in zip(self.ranges, devices) if hi > lo
         ]
         self.ranges = [r for r in self.ranges if r[1] > r[0]]
@@ -105,9 +110,12 @@ class TetrisVectorEnv(VectorEnvBase):
             self.action_space = spaces.MultiDiscrete([n_act] * self.num_envs)
             self.observation_space = None
         self._prev_len = np.zeros(self.num_envs, np.uint32)
-        # one host thread per engine (= per device): launches, fetches and the NumPy unpacking of a shard run beside the
-        # other shards' (ctypes releases the GIL inside the C ABI; calls on ONE handle stay serialised on its thread)
+        # one worker per engine (= per device): launches, fetches and the NumPy unpacking of a shard run beside the other
+        # shards' (ctypes releases the GIL inside the C ABI).  _each() submits exactly one job per engine and waits for all
+        # of them, so calls on ONE handle never overlap (the C ABI's contract); which pool thread runs a shard does not
+        # matter — every entry point sets its device itself.
         self._pool = ThreadPoolExecutor(len(self.engines), thread_name_prefix="tg-shard") if len(self.engines) > 1 else None
+        self.final_obs = bool(final_observation) and autoreset_mode == "same_step" and observation in ("board", "functional")
 
     # ---- helpers --------------------------------------------------------------------------------
     def _each(self, fn):
@@ -163,7 +171,38 @@ class TetrisVectorEnv(VectorEnvBase):
             info["board"] = self._cur_feats
         return obs, info
 
-    def step(self, actions):
+    def step_device(self, actions):
+        """One transition whose results STAY ON THE DEVICE: returns (observations, outputs) as zero-copy DeviceArray views of
+        the engines' buffers (`__cuda_array_interface__` / DLPack: `torch.as_tensor(v, device="cuda")`) — observations in the
+        shapes `step` returns (a dict of views for the dict observation), outputs = {"reward" f32, "terminated" u8, "lines"
+        u8}; with several devices one (observations, outputs) pair per shard, in env order.  `actions`: a host array, or
+        per shard a DeviceArray / device pointer to int32[shard size].  Nothing is copied to the host and nothing waits for
+        the GPU; the views alias buffers the next transition overwrites.  What a trainer's rollout loop needs instead of
+        `torch.Tensor(next_obs).to(device)` (examples/train_ppo.py:240-245)."""
+        from .engine import DeviceArray
+
+        if isinstance(actions, (DeviceArray, int)):
+            actions = [actions]
+        dev_actions = isinstance(actions, (list, tuple)) and len(actions) == len(self.engines) and \
+            all(isinstance(a, (DeviceArray, int)) for a in actions)
+        if not dev_actions:
+            actions = np.asarray(actions, np.int32).reshape(self.num_envs)
+
+        def one(k, e, lo, hi):
+            if dev_actions:
+                a = actions[k]
+                e.step_device(a.ptr if isinstance(a, DeviceArray) else a)
+            else:
+                e.step_async(actions[lo:hi])
+            return e.device_array(N.BUF_OBS) if e.obs_mode != N.OBS_NONE else None, e.device_array(N.BUF_STEP_OUT)
+
+        jobs = [(k, e, lo, hi) for k, (e, (lo, hi)) in enumerate(zip(self.engines, self.ranges))]
+        parts = [one(*j) for j in jobs] if self._pool is None else list(self._pool.map(lambda j: one(*j), jobs))
+        return parts[0] if len(parts) == 1 else parts
+
+    def step(self, actions, to_host: bool = True):
+        if not to_host:
+            return self.step_device(actions)
         actions = np.asarray(actions, np.int32).reshape(self.num_envs)
 
         def one(e, lo, hi):  # launch, then collect everything this shard returns, on the shard's own thread
@@ -171,7 +210,8 @@ class TetrisVectorEnv(VectorEnvBase):
             out = e.fetch_outputs()
             ep = e.episode_stats() if (self.episode_stats and out[1].any()) else None
             lm = e.legal_mask() if self.grouped else None
-            return out, ep, lm, self._shard_obs(e)
+            fo = e.final_observation() if (self.final_obs and out[1].any()) else None
+            return out, ep, lm, self._shard_obs(e), fo
 
         parts = self._each(one)
         outs = [p[0] for p in parts]
@@ -194,6 +234,13 @@ class TetrisVectorEnv(VectorEnvBase):
             illegal = np.concatenate([o[0] for o in outs]) < 0
             rewards[illegal] = -0.1  # rewards.invalid_action as a Python float, not float32(-0.1)
         truncations = np.zeros(self.num_envs, bool)
+        if self.final_obs and terminations.any():  # (valid where terminated; zeros elsewhere)
+            fo = np.zeros((self.num_envs, self.height, self.width), np.int8 if self.obs_kind == "functional" else np.uint8)
+            for (lo, hi), p in zip(self.ranges, parts):
+                if p[4] is not None:
+                    fo[lo:hi][terminations[lo:hi]] = p[4][terminations[lo:hi]]
+            infos["final_observation"] = fo
+            infos["_final_observation"] = terminations.copy()
         obs = self._join_obs([p[3] for p in parts])
         if self.obs_kind == "placement_features":
             infos["board"] = self._cur_feats  # wrappers/grouped.py:261-264 info["board"]
