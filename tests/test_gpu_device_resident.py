@@ -101,8 +101,9 @@ def test_old_state_is_restored_device_to_device(monkeypatch):
     monkeypatch.setattr(Engine, "set_state", lambda *a, **k: uploads.append(1))
     s = s10  # an old State, never read: goes back device → device
     for t in range(10, 20):
+        before = cnt.n
         s, obs, rew, term, info = F.batched_step(TETROMINOES, s, acts[t], config=CFG)
-        assert cnt.n == 0 and not uploads
+        assert cnt.n == before and not uploads  # (the call itself moves nothing to or from the host but the actions)
         for got, exp in zip((np.asarray(obs), np.asarray(rew), np.asarray(term)), firsts[t - 10]):
             np.testing.assert_array_equal(got, exp)
     edited = s10.replace(score=np.asarray(s10.score) + np.float32(5))  # an edited State has no device copy: host upload
@@ -135,6 +136,7 @@ def test_device_array_is_zero_copy_for_torch(monkeypatch):
             t = torch.as_tensor(out[name], device="cuda")
             assert t.data_ptr() == out[name].ptr and cnt.n == 0
             np.testing.assert_array_equal(t.cpu().numpy(), h)
+        for name, h in zip(("reward", "terminated", "lines"), host_out):  # ... and their own download path
             np.testing.assert_array_equal(np.asarray(out[name]), h)
         monkeypatch.undo()
         e.close()
