@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libtg_oracle.so")
+# TG_ORACLE_LIB: another build of the same source (the AddressSanitizer / UBSan build of tests/test_oracle_sanitize.py)
+_LIB_PATH = os.environ.get("TG_ORACLE_LIB") or os.path.join(_HERE, "libtg_oracle.so")
 
 RULESET_NUMPY, RULESET_FUNCTIONAL = 0, 1
 OBS_NONE, OBS_BOARD, OBS_DICT, OBS_FN, OBS_RGB = 0, 1, 2, 3, 4
@@ -40,6 +41,8 @@ def build(force: bool = False) -> str:
     """Compile the C restatement (gcc) if the shared object is missing or stale."""
     src = os.path.join(_HERE, "tg_oracle.c")
     hdrs = [os.path.join(_HERE, "tg_oracle.h"), os.path.join(_HERE, "..", "include", "tetris_gym_hip.h")]
+    if os.environ.get("TG_ORACLE_LIB"):
+        return _LIB_PATH
     stale = force or not os.path.exists(_LIB_PATH)
     if not stale:
         t = os.path.getmtime(_LIB_PATH)
