@@ -18,8 +18,10 @@
 #ifndef TETRIS_GYM_HIP_H
 #define TETRIS_GYM_HIP_H
 
+#ifndef __HIPCC_RTC__ /* (the engine's own run-time compilation of further board sizes has these types built in) */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {

@@ -497,3 +497,61 @@ def test_fused_rollout_with_frequent_line_clears(ruleset, fuse, monkeypatch):
         _cmp_state(e, o, f"round {rnd}")
     assert total_lines > B // 4  # hundreds of clears inside the fused groups
     e.close()
+
+
+@pytest.mark.parametrize("W,H,Q,ruleset", [(14, 28, 4, N.RULESET_NUMPY), (10, 22, 4, N.RULESET_NUMPY), (7, 16, 3, N.RULESET_NUMPY),
+                                            (13, 20, 7, N.RULESET_NUMPY), (24, 58, 4, N.RULESET_NUMPY),
+                                            (9, 20, 7, N.RULESET_FUNCTIONAL), (14, 28, 7, N.RULESET_FUNCTIONAL)])
+def test_board_sizes_compiled_at_create(W, H, Q, ruleset):
+    """The reference takes any width / height (envs/tetris.py:77-91, functional/core.py:11-25).  Sizes that are not built
+    into the library are compiled for at tg_create (hiprtc, the same kernel templates; odd widths, heights up to 58, slabs
+    that are not a multiple of 8 bytes): single transitions with the reference's dict observation, then fused rollouts,
+    against the oracle — rewards, observations, boards, records, generators."""
+    numpy_rules = ruleset == N.RULESET_NUMPY
+    B, T = 320, 160
+    obs = N.OBS_DICT if numpy_rules else N.OBS_FN
+    e = Engine(B, W, H, ruleset=ruleset, queue_size=Q, obs_mode=obs, autoreset=N.AUTORESET_SAME_STEP)
+    assert e.step_kernel_name().startswith(f"tg::step_kernel_bits<{W}, {H}, {ruleset},")
+    o = po.OracleBatch(B, W, H, ruleset, True, Q)
+    seeds = np.arange(3, 3 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(W * 100 + H)
+    na = 8 if numpy_rules else 7
+    n_done = 0
+    for t in range(T):
+        a = rng.integers(0, na, B)
+        if t % 3 == 0:
+            a[:] = 5 if numpy_rules else 6  # hard drops: the boards fill up and episodes end
+        got = e.step(a)
+        exp = o.step(a.astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+        for g, x, nm in zip(got, exp, ("reward", "terminated", "lines")):
+            np.testing.assert_array_equal(g, x, err_msg=f"{nm} t={t}")
+        n_done += int(exp[1].sum())
+        if t % 8 == 0 or t == T - 1:
+            eo, oo = e.observation(), o.observe(po.OBS_DICT if numpy_rules else po.OBS_FN)
+            if numpy_rules:
+                oo = po.split_dict_obs(oo, B, H + 4, W + 8, 4, Q) if not isinstance(oo, dict) else oo
+                for k in eo:
+                    np.testing.assert_array_equal(eo[k], oo[k], err_msg=f"obs[{k}] t={t}")
+            else:
+                np.testing.assert_array_equal(eo, oo, err_msg=f"obs t={t}")
+    assert n_done > 0
+    for K in (5, 16):
+        acts = rng.integers(0, na, (K, B)).astype(np.int8)
+        _, rew, term, lines = e.rollout(acts, want_obs=False)
+        for k in range(K):
+            ro, to, lo = o.step(acts[k].astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+            assert np.array_equal(rew[k], ro) and np.array_equal(term[k], to) and np.array_equal(lines[k], lo), f"K={K} k={k}"
+    ge, go = _cmp_state(e, o, "final")
+    fields = ("state_lo", "state_hi", "inc_lo", "inc_hi", "uinteger", "has_uint32") if numpy_rules else ("key",)
+    for f in fields:
+        np.testing.assert_array_equal(ge[f], go[f], err_msg=f"rng.{f}")
+    e.close()
+
+
+def test_board_size_that_cannot_be_compiled_is_refused():
+    from tetris_gymnasium_amd import EngineError
+    with pytest.raises(EngineError, match="multiple of 4"):
+        Engine(8, 7, 14)
+    with pytest.raises(EngineError, match="outside"):
+        Engine(8, 10, 60)

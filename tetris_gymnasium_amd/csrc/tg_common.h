@@ -5,8 +5,13 @@
 // ceiling kernel.  The step kernel itself is tg_kernel_bits.h; its earlier formulations live in legacy/ (test-only build).
 // Integer / byte work only: no MFMA.  Bound: HBM (see DESIGN.md for bytes per env-step).
 #pragma once
+#ifndef __HIPCC_RTC__  // (hiprtc, which compiles board sizes that are not built in at tg_create, brings its own runtime declarations)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+using __hip_internal::int8_t; using __hip_internal::uint8_t; using __hip_internal::int16_t; using __hip_internal::uint16_t;
+using __hip_internal::int32_t; using __hip_internal::uint32_t; using __hip_internal::int64_t; using __hip_internal::uint64_t;
+#endif
 
 #include "../../include/tetris_gym_hip.h"
 #include "tg_tables.h"

@@ -4,12 +4,21 @@
 // (board u8[B][H][W] | tg_env_rec[B] | tg_rng_rec[B]); outputs stay on the device until fetched.
 // There is NO CPU fallback: every entry point that computes launches a HIP kernel.
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <mutex>
 #include <new>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -31,14 +40,16 @@ namespace {
 
 thread_local std::string g_create_err;
 
+// The kernels of one board size: template instantiations built into the library (TG_FOR_EACH_SIZE) or, for any other
+// size, a module compiled by hiprtc at tg_create (rtc_launchers below).  Callables so that both fit one interface.
 struct Launchers {
-  void (*features)(const tg::FeatureParams&, hipStream_t);
-  void (*step)(const tg::KParams&, hipStream_t);
-  void (*step_name)(const tg::KParams&, char*, size_t);
-  void (*reset)(const tg::ResetParams&, hipStream_t);
-  void (*observe)(const tg::ObserveParams&, hipStream_t);
-  void (*prepare)(const tg::PrepareParams&, hipStream_t);
-  void (*placements)(const tg::PlacementParams&, hipStream_t);
+  std::function<void(const tg::FeatureParams&, hipStream_t)> features;
+  std::function<void(const tg::KParams&, hipStream_t)> step;
+  std::function<void(const tg::KParams&, char*, size_t)> step_name;
+  std::function<void(const tg::ResetParams&, hipStream_t)> reset;
+  std::function<void(const tg::ObserveParams&, hipStream_t)> observe;
+  std::function<void(const tg::PrepareParams&, hipStream_t)> prepare;
+  std::function<void(const tg::PlacementParams&, hipStream_t)> placements;
   size_t cols_bytes;  // per env: column masks of the bits kernel
   bool dict_ok, rgb_ok;  // the bits kernel packs TG_OBS_DICT / TG_OBS_RGB itself for this board size
 };
@@ -60,12 +71,10 @@ int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = lane kernels' pipelined p
                             // the prefetched inputs spill), 1 = off
 
 // which instantiation of the bits kernel a launch with these parameters uses (FEAT flags, tg_kernel_bits.h)
-template <int W, int H, int RS>
-int bits_feat(const tg::KParams& p) {
-  using BG = tg::BitsGeo<W, H>;
+int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok) {
   constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
-  const bool dict = p.obs_mode == TG_OBS_DICT && p.dict_in_kernel && BG::DICT_OK;
-  const bool rgb = p.obs_mode == TG_OBS_RGB && p.dict_in_kernel && BG::RGB_OK;
+  const bool dict = p.obs_mode == TG_OBS_DICT && p.dict_in_kernel && dict_ok;
+  const bool rgb = p.obs_mode == TG_OBS_RGB && p.dict_in_kernel && rgb_ok;
   const bool traj = p.obs_traj || p.out_traj || p.act_traj;
   if (p.final_obs) return (p.nsteps > 1 || traj) ? (M | T | F) : F;  // (TG_OBS_BOARD / TG_OBS_FN handles only)
   if (RS == TG_RULESET_NUMPY) {
@@ -75,6 +84,11 @@ int bits_feat(const tg::KParams& p) {
   }
   if (traj) return M | T;
   return p.nsteps > 1 ? M : 0;
+}
+
+template <int W, int H, int RS>
+int bits_feat(const tg::KParams& p) {
+  return bits_feat_rt(p, RS, tg::BitsGeo<W, H>::DICT_OK, tg::BitsGeo<W, H>::RGB_OK);
 }
 
 template <int W, int H, int RS>
@@ -192,6 +206,190 @@ bool find_launchers(int W, int H, int ruleset, Launchers* out) {
   TG_FOR_EACH_SIZE(X)
 #undef X
   return false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Board sizes that are not built in: the same kernel templates, instantiated for (W, H) by hiprtc when the first handle of
+// that size is created (reference envs/tetris.py:77-91 / functional/core.py:11-25 accept any width / height).  In-process
+// compilation — nothing is exec'ed (a process that has touched the GPU must not start another program on this pool) —
+// from the headers that ship next to the library (csrc/; TG_CSRC_DIR overrides), with the flags of the Makefile.  The
+// code object is cached on disk (TG_CACHE_DIR, default ~/.cache/tetris_gym_hip) under a hash of the headers, so only the
+// first process pays the compile (tens of seconds for the ~16 instantiations of a size).
+// ---------------------------------------------------------------------------------------------------------------------
+struct RtcSize {
+  hipModule_t mod = nullptr;
+  std::map<int, hipFunction_t> step;  // by FEAT
+  hipFunction_t reset = nullptr, observe = nullptr, prepare = nullptr, features = nullptr, placements = nullptr;
+  int W = 0, H = 0, RS = 0;
+  int geo[12] = {};  // EPW, BYTES, BYTES_DICT, BYTES_RGB, BYTES_FIN, BYTES_FNX, DICT_OK, RGB_OK, cols_bytes, placements lds
+};
+std::mutex g_rtc_mu;
+std::map<std::string, RtcSize*> g_rtc;  // "dev:W:H:RS" → module (lives as long as the process)
+
+std::string csrc_dir() {
+  if (const char* e = getenv("TG_CSRC_DIR")) return e;
+  Dl_info info;
+  if (dladdr((const void*)&csrc_dir, &info) && info.dli_fname) {
+    std::string lib = info.dli_fname;
+    const size_t k = lib.rfind('/');
+    return (k == std::string::npos ? std::string(".") : lib.substr(0, k)) + "/csrc";
+  }
+  return "csrc";
+}
+
+std::vector<int> rtc_feats(int RS) {
+  constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
+  if (RS == TG_RULESET_NUMPY) return {0, M, M | T, F, M | T | F, D, M | T | D, T | S, M | T | S, R, M | T | S | R};
+  return {0, M, M | T, F, M | T | F};
+}
+
+uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
+  for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+  return h;
+}
+
+// compile (or load from the cache) the kernels of one size; returns an error text or "" on success
+std::string rtc_build(int device, int W, int H, int RS, RtcSize** out) {
+  char keyb[64];
+  snprintf(keyb, sizeof keyb, "%d:%d:%d:%d", device, W, H, RS);
+  std::lock_guard<std::mutex> lock(g_rtc_mu);
+  auto it = g_rtc.find(keyb);
+  if (it != g_rtc.end()) { *out = it->second; return ""; }
+  const std::string dir = csrc_dir();
+  std::string all;  // the headers, for the cache key
+  for (const char* f : {"tg_common.h", "tg_lane.h", "tg_tables.h", "tg_kernel_bits.h", "tg_kernel_features.h", "tg_kernel_placements.h",
+                        "../../include/tetris_gym_hip.h"}) {
+    std::ifstream in(dir + "/" + f, std::ios::binary);
+    if (!in) return "kernel source " + dir + "/" + f + " not found (set TG_CSRC_DIR to tetris_gymnasium_amd/csrc)";
+    std::stringstream ss; ss << in.rdbuf(); all += ss.str();
+  }
+  std::vector<std::string> names;
+  char nb[128];
+  for (int ft : rtc_feats(RS)) { snprintf(nb, sizeof nb, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, ft); names.push_back(nb); }
+  snprintf(nb, sizeof nb, "tg::reset_kernel<%d, %d, %d>", W, H, RS); names.push_back(nb);
+  snprintf(nb, sizeof nb, "tg::observe_kernel<%d, %d>", W, H); names.push_back(nb);
+  snprintf(nb, sizeof nb, "tg::bits_prepare_kernel<%d, %d>", W, H); names.push_back(nb);
+  snprintf(nb, sizeof nb, "tg::features_kernel<%d, %d>", W, H); names.push_back(nb);
+  snprintf(nb, sizeof nb, "tg::placements_kernel<%d, %d>", W, H); names.push_back(nb);
+  char srcb[1024];
+  snprintf(srcb, sizeof srcb,
+           "#include \"tg_kernel_bits.h\"\n#include \"tg_kernel_features.h\"\n#include \"tg_kernel_placements.h\"\n"
+           "typedef tg::BitsGeo<%d, %d> TgBG;\n"
+           "extern \"C\" __constant__ int tg_rtc_geo[12] = {TgBG::EPW, TgBG::BYTES, TgBG::BYTES_DICT, TgBG::BYTES_RGB, TgBG::BYTES_FIN, "
+           "TgBG::BYTES_FNX, TgBG::DICT_OK ? 1 : 0, TgBG::RGB_OK ? 1 : 0, (int)tg::bits_cols_bytes<%d, %d>(), "
+           "(int)tg::placements_lds_bytes<%d, %d>(), 0, 0};\n", W, H, W, H, W, H);
+  const std::string src = srcb;
+  const std::vector<std::string> optv = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + dir, "-mllvm", "-amdgpu-kernarg-preload-count=16",
+                                         "-mllvm", "-amdgpu-sched-strategy=max-ilp"};
+  std::string keytext = all + src;
+  for (auto& o : optv) keytext += o;
+  for (auto& n : names) keytext += n;
+  char hashb[32];
+  snprintf(hashb, sizeof hashb, "%016llx", (unsigned long long)fnv1a(keytext));
+  std::string cdir = getenv("TG_CACHE_DIR") ? getenv("TG_CACHE_DIR") : (std::string(getenv("HOME") ? getenv("HOME") : "/tmp") + "/.cache/tetris_gym_hip");
+  const std::string cfile = cdir + "/" + std::to_string(W) + "x" + std::to_string(H) + "_" + std::to_string(RS) + "_" + hashb + ".bin";
+  std::string code;
+  std::vector<std::string> lowered;
+  {  // cache: lowered names (one per line) | blank line | code object
+    std::ifstream in(cfile, std::ios::binary);
+    if (in) {
+      std::string line;
+      while (std::getline(in, line) && !line.empty()) lowered.push_back(line);
+      std::stringstream ss; ss << in.rdbuf(); code = ss.str();
+      if (lowered.size() != names.size() || code.empty()) { lowered.clear(); code.clear(); }
+    }
+  }
+  if (code.empty()) {
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "tg_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return "hiprtcCreateProgram failed";
+    for (auto& n : names) hiprtcAddNameExpression(prog, n.c_str());
+    std::vector<const char*> opts;
+    for (auto& o : optv) opts.push_back(o.c_str());
+    const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+    if (r != HIPRTC_SUCCESS) {
+      size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
+      std::string log(ls, 0); if (ls) hiprtcGetProgramLog(prog, &log[0]);
+      hiprtcDestroyProgram(&prog);
+      const size_t e = log.find("error:");
+      return std::string("compiling the kernels for this board size failed: ") + (e == std::string::npos ? log.substr(0, 300) : log.substr(e, 300));
+    }
+    for (auto& n : names) { const char* low = nullptr; hiprtcGetLoweredName(prog, n.c_str(), &low); lowered.push_back(low ? low : ""); }
+    size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
+    code.resize(cs);
+    hiprtcGetCode(prog, &code[0]);
+    hiprtcDestroyProgram(&prog);
+    mkdir((std::string(getenv("HOME") ? getenv("HOME") : "/tmp") + "/.cache").c_str(), 0755);
+    mkdir(cdir.c_str(), 0755);
+    const std::string tmp = cfile + ".tmp" + std::to_string((long)getpid());
+    std::ofstream o(tmp, std::ios::binary);
+    if (o) {
+      for (auto& l : lowered) o << l << "\n";
+      o << "\n";
+      o.write(code.data(), (std::streamsize)code.size());
+      o.close();
+      rename(tmp.c_str(), cfile.c_str());
+    }
+  }
+  RtcSize* rs = new RtcSize();
+  rs->W = W; rs->H = H; rs->RS = RS;
+  if (hipModuleLoadData(&rs->mod, code.data()) != hipSuccess) { delete rs; return "hipModuleLoadData failed for the compiled kernels"; }
+  size_t k = 0;
+  auto fn = [&](hipFunction_t* f) { return hipModuleGetFunction(f, rs->mod, lowered[k++].c_str()) == hipSuccess; };
+  bool ok = true;
+  for (int ft : rtc_feats(RS)) { hipFunction_t f = nullptr; ok = fn(&f) && ok; rs->step[ft] = f; }
+  ok = fn(&rs->reset) && ok; ok = fn(&rs->observe) && ok; ok = fn(&rs->prepare) && ok; ok = fn(&rs->features) && ok; ok = fn(&rs->placements) && ok;
+  hipDeviceptr_t gp = nullptr; size_t gb = 0;
+  ok = ok && hipModuleGetGlobal(&gp, &gb, rs->mod, "tg_rtc_geo") == hipSuccess && gb == sizeof(rs->geo) &&
+       hipMemcpy(rs->geo, gp, sizeof(rs->geo), hipMemcpyDeviceToHost) == hipSuccess;
+  if (!ok) { delete rs; return "the compiled module lacks an expected kernel"; }
+  g_rtc[keyb] = rs;
+  *out = rs;
+  return "";
+}
+
+template <typename P>
+void rtc_launch(hipFunction_t f, dim3 grid, dim3 block, size_t lds, hipStream_t s, const P& p) {
+  void* args[] = {const_cast<P*>(&p)};
+  (void)hipModuleLaunchKernel(f, grid.x, 1, 1, block.x, 1, 1, (unsigned)lds, s, args, nullptr);
+}
+
+Launchers rtc_launchers(const RtcSize* r) {
+  Launchers L;
+  const int EPW = r->geo[0], W = r->W, H = r->H, RS = r->RS;
+  const bool dict_ok = r->geo[6] != 0, rgb_ok = r->geo[7] != 0;
+  L.cols_bytes = (size_t)r->geo[8];
+  L.dict_ok = dict_ok; L.rgb_ok = rgb_ok;
+  L.step = [=](const tg::KParams& p, hipStream_t s) {
+    constexpr int D = tg::kFeatDict, F = tg::kFeatFinal, R = tg::kFeatRgb;
+    const int nrb = (RS == TG_RULESET_NUMPY && p.rng_role) ? (p.batch + 127) / 128 : 0;
+    const uint4* const ring4 = reinterpret_cast<const uint4*>(p.ring);
+    const size_t hrd = RS == TG_RULESET_NUMPY ? (size_t)p.hbuf_cur * p.ring_stride : 0, hwr = RS == TG_RULESET_NUMPY ? (size_t)(1 - p.hbuf_cur) * p.ring_stride : 0;
+    tg::BitsParams bp{p.cols, p.ahead, ring4 + (size_t)p.ring_cur * p.ring_stride, const_cast<uint4*>(ring4) + (size_t)(1 - p.ring_cur) * p.ring_stride,
+                      p.hbuf + hrd, p.hbuf + hwr, p.inl, nrb, p.ring_fill};
+    const int n_step_wgs = (p.batch + EPW - 1) / EPW;
+    const int feat = bits_feat_rt(p, RS, dict_ok, rgb_ok);
+    const size_t lds = RS == TG_RULESET_FUNCTIONAL ? r->geo[5] : ((feat & D) ? r->geo[2] : ((feat & R) ? r->geo[3] : ((feat & F) ? r->geo[4] : r->geo[1])));
+    auto it = r->step.find(feat);
+    if (it == r->step.end()) return;
+    uint8_t* a0 = p.board; uint32_t* a1 = p.rec; void* a2 = p.cols; const uint4* a3 = bp.ring_rd; const uint32_t* a4 = bp.hbuf_rd;
+    const void* a5 = p.actions; int a6 = p.batch;
+    uint32_t a7 = (uint32_t)n_step_wgs | ((p.act_i8 ? 1u : 0u) << 24) | ((uint32_t)(p.nsteps > 0 ? p.nsteps : 0) << 25);
+    tg::KParams kp = p;
+    void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &kp, &bp};
+    (void)hipModuleLaunchKernel(it->second, (unsigned)(nrb + n_step_wgs), 1, 1, 128, 1, 1, (unsigned)lds, s, args, nullptr);
+  };
+  L.step_name = [=](const tg::KParams& p, char* buf, size_t n) {
+    snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat_rt(p, RS, dict_ok, rgb_ok));
+  };
+  L.reset = [=](const tg::ResetParams& p, hipStream_t s) { rtc_launch(r->reset, dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p); };
+  L.observe = [=](const tg::ObserveParams& p, hipStream_t s) {
+    const int per_block = tg::kWavesPerBlock * tg::kObserveEnvsPerWave;
+    rtc_launch(r->observe, dim3((p.batch + per_block - 1) / per_block), dim3(tg::kBlock), 0, s, p);
+  };
+  L.prepare = [=](const tg::PrepareParams& p, hipStream_t s) { rtc_launch(r->prepare, dim3((p.batch + 255) / 256), dim3(256), 0, s, p); };
+  L.features = [=](const tg::FeatureParams& p, hipStream_t s) { rtc_launch(r->features, dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p); };
+  L.placements = [=](const tg::PlacementParams& p, hipStream_t s) { rtc_launch(r->placements, dim3(grid_for(p.batch)), dim3(tg::kBlock), (size_t)r->geo[9], s, p); };
+  return L;
 }
 
 std::string built_sizes() {
@@ -558,14 +756,27 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   if (cfg->action_set == TG_ACTIONS_GROUPED && cfg->ruleset != TG_RULESET_NUMPY)
     return fail(nullptr, TG_EINVAL, "tg_create: the grouped action set wraps the NUMPY rule-set (wrappers/grouped.py)");
   Launchers L{};
-  if (!find_launchers(cfg->width, cfg->height, cfg->ruleset, &L))
-    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: board %dx%d not compiled in (built sizes: %s)", cfg->width,
-                cfg->height, built_sizes().c_str());
+  const bool built_in = find_launchers(cfg->width, cfg->height, cfg->ruleset, &L);
+  if (!built_in && (cfg->width < 4 || cfg->width > 32 || cfg->height < 4 || cfg->height > 58))
+    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: board %dx%d outside 4..32 x 4..58 (row masks are 32 bits, column masks 64)",
+                cfg->width, cfg->height);
+  if (!built_in && (cfg->width * cfg->height) % 4 != 0)
+    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: board %dx%d: width * height must be a multiple of 4 (an env's uint8 slab is "
+                "cleared and copied in dwords)", cfg->width, cfg->height);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, TG_EHIP, "tg_create: no HIP device available (this engine has no CPU fallback)");
   if (cfg->device < 0 || cfg->device >= ndev)
     return fail(nullptr, TG_EINVAL, "tg_create: device %d out of range (0..%d)", cfg->device, ndev - 1);
+  if (!built_in) {  // any other size: the same kernels, compiled for it now (or taken from the on-disk cache)
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, TG_EHIP, "tg_create: hipSetDevice failed");
+    RtcSize* rs = nullptr;
+    const std::string err = rtc_build(cfg->device, cfg->width, cfg->height, cfg->ruleset, &rs);
+    if (!err.empty())
+      return fail(nullptr, TG_EUNSUPPORTED, "tg_create: board %dx%d is not built in (%s) and %s", cfg->width, cfg->height,
+                  built_sizes().c_str(), err.c_str());
+    L = rtc_launchers(rs);
+  }
 
   tg_handle* h = new (std::nothrow) tg_handle();
   if (!h) return fail(nullptr, TG_ENOMEM, "tg_create: out of host memory");

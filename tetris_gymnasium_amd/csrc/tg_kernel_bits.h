@@ -27,7 +27,9 @@
 // build for instruction-level parallelism (one logic wave per SIMD is a dependent chain: Makefile flags).
 // Bit-identical to the four earlier step kernels (test-only library) and to the oracle (tests/test_gpu_*.py).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <type_traits>
+#endif
 
 #include "tg_lane.h"
 
@@ -81,17 +83,22 @@ constexpr uint64_t cells_rot0(const int first) {
 }
 constexpr uint64_t kCells0Lo = cells_rot0(0), kCells0Hi = cells_rot0(4);
 
+template <bool C, typename A, typename B> struct pick_t { typedef A type; };
+template <typename A, typename B> struct pick_t<false, A, B> { typedef B type; };
 template <int H>
-using ColT = std::conditional_t<(H + 6 <= 32), uint32_t, uint64_t>;
+using ColT = typename pick_t<(H + 6 <= 32), uint32_t, uint64_t>::type;
 
 __device__ __forceinline__ int ctz_t(uint32_t v) { return (int)__builtin_ctz(v); }
 __device__ __forceinline__ int ctz_t(uint64_t v) { return (int)__builtin_ctzll(v); }
 __device__ __forceinline__ int popc_t(uint32_t v) { return (int)__popc(v); }
 __device__ __forceinline__ int popc_t(uint64_t v) { return (int)__popcll(v); }
 
+// column-mask words per env in HBM: the masks travel as 8-byte pairs, so an odd number of 32-bit masks is padded by one
+template <int W, int H>
+constexpr int bits_cols_words() { return sizeof(ColT<H>) == 4 ? W + (W & 1) : W; }
 // bytes per env of the column-mask buffer
 template <int W, int H>
-constexpr size_t bits_cols_bytes() { return (size_t)W * sizeof(ColT<H>); }
+constexpr size_t bits_cols_bytes() { return (size_t)bits_cols_words<W, H>() * sizeof(ColT<H>); }
 
 // dynamic LDS of one wave of step_kernel_bits.  EPW envs per wave (one per lane; on large boards fewer than 64 so that
 // the wave's slab block still fits the staging registers — the idle lanes only help streaming the slabs)
@@ -114,7 +121,7 @@ struct BitsGeo {
   static constexpr int GD = 16;
   static constexpr int OFF_DICT = BYTES;
   static constexpr int BYTES_DICT = BYTES + 2 * GD * PC;
-  static constexpr bool DICT_OK = PC % 16 == 0 && EPW % GD == 0 && H % 2 == 0;
+  static constexpr bool DICT_OK = PC % 16 == 0 && EPW % GD == 0 && H % 2 == 0 && W % 2 == 0;  // (row pairs as whole dwords)
   // TG_OBS_RGB packed in the kernel (queue_size 4): uint4 post2[EPW] {queue bytes | holder} published by the logic wave,
   // then one id-image staging buffer of GR envs per wave.  Image row = padded board row | 4 queue pieces x 4 columns.
   static constexpr int RS = W + 8 + 16;
@@ -123,7 +130,7 @@ struct BitsGeo {
   static constexpr int GR = 4;
   static constexpr int OFF_RGB = BYTES;
   static constexpr int BYTES_RGB = BYTES + EPW * 16 + 2 * GR * IDB;
-  static constexpr bool RGB_OK = NPX % 4 == 0 && H % 2 == 0 && (EPW / 2) % GR == 0;
+  static constexpr bool RGB_OK = NPX % 4 == 0 && H % 2 == 0 && W % 2 == 0 && (EPW / 2) % GR == 0;
   // TG_FLAG_FINAL_OBS (observation BOARD / FN only, never together with the dict staging): uint2 [2][EPW] behind BYTES —
   // the terminal piece of every env that ends its episode in this transition
   static constexpr int OFF_FIN = BYTES;
@@ -132,7 +139,8 @@ struct BitsGeo {
   // key-chain look-ahead — uint2 keys [128] | uint32 permutations [128] — behind the FINAL_OBS records
   static constexpr int OFF_FNX = BYTES_FIN;
   static constexpr int BYTES_FNX = BYTES_FIN + 128 * 8 + 128 * 4;
-  static_assert(W % 2 == 0, "column masks are moved as 8-byte pairs");
+  static constexpr int WC = bits_cols_words<W, H>();  // column-mask words per env in HBM
+  static_assert(S % 4 == 0, "W*H must be a multiple of 4 (an env's slab is cleared and copied in dwords)");
 };
 
 
@@ -581,9 +589,15 @@ __device__ __forceinline__ void dict_mask_group(uint8_t* buf, const uint4* post_
 // batch in flight before its 16-byte stores.  BIN: through the functional observation's byte map.
 template <int S, bool BIN>
 __device__ __forceinline__ void bits_copy_slab(const uint8_t* src_lds, uint8_t* dst) {
+  if constexpr (S % 8 != 0) {  // (slabs of such sizes start at 4-byte alignment only: dword by dword; the terminal observation is rare)
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src_lds);
+    uint32_t* d4 = reinterpret_cast<uint32_t*>(dst);
+#pragma unroll 4
+    for (int u = 0; u < S / 4; ++u) d4[u] = BIN ? bits_bin1(s4[u]) : s4[u];
+    return;
+  }
   const u32x2* src = reinterpret_cast<const u32x2*>(src_lds);
   constexpr int NU = S / 8, UB = NU <= 32 ? NU : 20;
-  static_assert(S % 8 == 0, "slabs are copied in 8-byte units, stored in pairs");
 #pragma unroll 1
   for (int u0 = 0; u0 < NU; u0 += UB) {
     u32x2 t2[UB];
@@ -1200,8 +1214,8 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   }
   T cv[W];
   {
-    constexpr int NP = (int)(W * sizeof(T) / 8);
-    const uint2* gc = reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(hot_cols) + (size_t)env * W);
+    constexpr int NP = (int)(BG::WC * sizeof(T) / 8);
+    const uint2* gc = reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(hot_cols) + (size_t)env * BG::WC);
     uint2 raw[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) raw[k] = gc[k];
@@ -2083,10 +2097,11 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
 #pragma unroll
     for (int c = 0; c < W; ++c) nv[c] = (T)(colsL[1 + c] & PLAY);
     if (cols_dirty && !TG_SKIP(8)) {
-      uint2* gc = reinterpret_cast<uint2*>(reinterpret_cast<T*>(hot_cols) + (size_t)env * W);
+      uint2* gc = reinterpret_cast<uint2*>(reinterpret_cast<T*>(hot_cols) + (size_t)env * BG::WC);
       if constexpr (sizeof(T) == 4) {
 #pragma unroll
         for (int k = 0; k < W / 2; ++k) TG_ST_COLS(reinterpret_cast<u32x2*>(gc + k), (u32x2{(uint32_t)nv[2 * k], (uint32_t)nv[2 * k + 1]}));
+        if constexpr (W % 2 == 1) TG_ST_COLS(reinterpret_cast<u32x2*>(gc + W / 2), (u32x2{(uint32_t)nv[W - 1], 0u}));
       } else {
 #pragma unroll
         for (int c = 0; c < W; ++c) TG_ST_COLS(reinterpret_cast<u32x2*>(gc + c), (u32x2{(uint32_t)nv[c], (uint32_t)((uint64_t)nv[c] >> 32)}));
@@ -2149,12 +2164,13 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
   const int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= p.batch) return;
   const uint8_t* b = p.board + (size_t)env * W * H;
-  T* gc = reinterpret_cast<T*>(p.cols) + (size_t)env * W;
+  T* gc = reinterpret_cast<T*>(p.cols) + (size_t)env * bits_cols_words<W, H>();
   for (int c = 0; c < W; ++c) {
     T v = 0;
     for (int rr = 0; rr < H; ++rr) v |= (T)(b[rr * W + c] != 0 ? 1 : 0) << rr;
     gc[c] = v;
   }
+  if (bits_cols_words<W, H>() > W) gc[W] = 0;
   const size_t B = (size_t)p.batch;
   const bool moved = p.force || (p.mask ? p.mask[env] != 0 : true);
   uint4* ring4 = reinterpret_cast<uint4*>(p.ring);

@@ -12,7 +12,9 @@
 // bit masks: landing row = min over the piece's cells of ctz(column mask >> ...), completed rows = row masks |
 // piece bits == full, compaction = bit surgery on the column masks, features = ctz / popcount.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <type_traits>
+#endif
 
 #include "tg_lane.h"
 
@@ -28,7 +30,7 @@ struct FeatureParams {
 
 template <int H>
 struct ColMask {
-  using type = typename std::conditional<(H + 1 <= 32), uint32_t, uint64_t>::type;
+  using type = typename pick_t<(H + 1 <= 32), uint32_t, uint64_t>::type;
 };
 
 template <typename M>

@@ -7,7 +7,9 @@
 // np.rot90(native, k=r) inside the native n x n box (envs/tetris.py:429-443,
 // functional/tetrominoes.py:82-106).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 namespace tg {
 
