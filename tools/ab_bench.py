@@ -14,7 +14,7 @@ for tag, flags in (("A", fa), ("B", fb)):
     root = os.environ.get("AB_SRC_" + tag, ROOT)  # (another source tree for this side, e.g. an older commit's csrc)
     src = os.path.join(root, "tetris_gymnasium_amd", "csrc", "tg_engine.hip")
     procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-                                   "-DTG_FOR_EACH_SIZE(X)=X(10,20)", *flags, "-shared", "-o", f"/tmp/libtg_{tag}.so", src]))
+                                   "-DTG_FOR_EACH_SIZE(X)=X(10,20)", *flags, "-lhiprtc", "-shared", "-o", f"/tmp/libtg_{tag}.so", src]))
 assert all(p.wait() == 0 for p in procs)
 from tetris_gymnasium_amd import _native as N
 from tetris_gymnasium_amd import Engine

@@ -29,7 +29,7 @@ for tag, src, flags in variants:
     flags = [f for f in flags if f != "-default-sched"]
     procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=16", *sched,
                                    "-DTG_FOR_EACH_SIZE(X)=X(10,20)", f"-I{os.path.join(ROOT, 'tetris_gymnasium_amd', 'csrc')}", *flags,
-                                   "-shared", "-o", f"/tmp/libtg_{tag}.so", os.path.join(src, "tg_engine.hip")],
+                                   "-lhiprtc", "-shared", "-o", f"/tmp/libtg_{tag}.so", os.path.join(src, "tg_engine.hip")],
                                   stderr=subprocess.DEVNULL))
 assert all(p.wait() == 0 for p in procs), "a variant failed to compile"
 from tetris_gymnasium_amd import _native as N

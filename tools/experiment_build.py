@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 flags = sys.argv[1:]
 out = "/tmp/libtg_exp.so"
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DTG_FOR_EACH_SIZE(X)=X(10,20)", *(["-DTG_LEGACY_KERNELS"] if os.environ.get("TG_KERNEL", "bits") != "bits" else []), *flags, "-shared", "-o", out,
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DTG_FOR_EACH_SIZE(X)=X(10,20)", *(["-DTG_LEGACY_KERNELS"] if os.environ.get("TG_KERNEL", "bits") != "bits" else []), *flags, "-lhiprtc", "-shared", "-o", out,
                        os.path.join(ROOT, "tetris_gymnasium_amd", "csrc", "tg_engine.hip")])
 from tetris_gymnasium_amd import _native as N
 N.LIB_PATH = out

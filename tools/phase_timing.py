@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 src = os.path.join(ROOT, "tetris_gymnasium_amd", "csrc", "tg_engine.hip")
 out = "/tmp/libtg_phase.so"
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DTG_PHASE_TIMING", "-DTG_LEGACY_KERNELS", "-shared", "-o", out, src])
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DTG_PHASE_TIMING", "-DTG_LEGACY_KERNELS", "-lhiprtc", "-shared", "-o", out, src])
 from tetris_gymnasium_amd import _native as N
 N.LIB_PATH = out
 from tetris_gymnasium_amd import Engine

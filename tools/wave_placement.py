@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 src = os.path.join(ROOT, "tetris_gymnasium_amd", "csrc", "tg_engine.hip")
 out = "/tmp/libtg_place.so"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-DTG_PHASE_TIMING",
-                       "-DTG_FOR_EACH_SIZE(X)=X(10,20)", *sys.argv[1:], "-shared", "-o", out, src])
+                       "-DTG_FOR_EACH_SIZE(X)=X(10,20)", *sys.argv[1:], "-lhiprtc", "-shared", "-o", out, src])
 os.environ.setdefault("TG_FUSE", "1")
 os.environ.setdefault('TG_RNG_EVERY', '1')  # the stamped launch carries the RNG-role workgroups (they ride on every third launch otherwise)
 from tetris_gymnasium_amd import _native as N
