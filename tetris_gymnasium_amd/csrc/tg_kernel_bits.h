@@ -120,7 +120,8 @@ struct BitsGeo {
   static constexpr int PC = (W + 8) * (H + 4);
   static constexpr int GD = 16;
   static constexpr int OFF_DICT = BYTES;
-  static constexpr int BYTES_DICT = BYTES + 2 * GD * PC;
+  static constexpr int OFF_OLDPW = BYTES + 2 * GD * PC;  // uint32 [EPW]: the box TG_BUF_OBS's mask array shows per env
+  static constexpr int BYTES_DICT = OFF_OLDPW + EPW * 4;
   static constexpr bool DICT_OK = PC % 16 == 0 && EPW % GD == 0 && H % 2 == 0 && W % 2 == 0;  // (row pairs as whole dwords)
   // TG_OBS_RGB packed in the kernel (queue_size 4): uint4 post2[EPW] {queue bytes | holder} published by the logic wave,
   // then one id-image staging buffer of GR envs per wave.  Image row = padded board row | 4 queue pieces x 4 columns.
@@ -573,12 +574,82 @@ __device__ __forceinline__ void dict_mask_group(uint8_t* buf, const uint4* post_
 #pragma unroll
   for (int i = 0; i < CT; ++i) {
     const int c = lane + 64 * i;
+#ifdef TG_ABL_NO_MASK  // (timing ablation: the mask array is not stored at all)
+    if (nlive_g > 9999u)
+#endif
     if (c < NCHG && (uint32_t)c / (PC / 16) < nlive_g) {
       st_dict(reinterpret_cast<u32x4*>(dst0 + 16 * (size_t)c), v[i]);
       if (dst1) st_dict(reinterpret_cast<u32x4*>(dst1 + 16 * (size_t)c), v[i]);
     }
   }
   wave_sync();
+#pragma unroll
+  for (int i = 0; i < ST; ++i)
+    if (addr[i] >= 0) buf[addr[i]] = 0;
+  wave_sync();
+}
+
+// The same into TG_BUF_OBS, which keeps its content from transition to transition: only the 16-byte chunks that the box
+// of the previous observation (`oldpw`, to be cleared) or the new one covers are stored — at most five contiguous chunks
+// each at 10x20 (a box spans (n - 1) Wp + n <= 58 bytes), typically seven of an env's 27 altogether.  The full array is 28 MB of the
+// 62 MB a dict observation writes per transition at 65 536 envs, and that transition is bound by its stores: without the
+// mask stores it takes 12.1 instead of 17.1 us.  MEASURED AND REJECTED (-DTG_DICT_INCR_MASK, profiles/r03/
+// ab_dict_incremental_mask.log): the ~7 scattered 16-byte chunks per env cost 18.0 us per transition against 17.1 us for
+// the whole array as one contiguous full-line stream — partial-line stores are several times dearer per byte here.
+template <int W, int H, int GD>
+__device__ __forceinline__ void dict_mask_group_incr(uint8_t* buf, const uint4* post_g, uint32_t* oldpw_g, const uint32_t nlive_g,
+                                                     const int lane, uint8_t* dst) {
+  constexpr int WP = W + 8, HP = H + 4, PC = WP * HP, ST = GD * 16 / 64;
+  constexpr int NB = (3 * WP + 4 + 15) / 16 + 1;  // 16-byte chunks a box can touch: it spans at most 3 Wp + 4 bytes (five at 10x20)
+  constexpr int NT = GD * 2 * NB, TT = (NT + 63) / 64;
+  int addr[ST];
+  uint32_t pws[ST];
+#pragma unroll
+  for (int i = 0; i < ST; ++i) pws[i] = post_g[(lane + 64 * i) >> 4].w;
+#pragma unroll
+  for (int i = 0; i < ST; ++i) {
+    const int t = lane + 64 * i;
+    const int el = t >> 4, k = (t >> 2) & 3, c = t & 3;
+    const uint32_t pw = pws[i];
+    const int x = (int)(pw & 0xFFu), y = (int)((pw >> 8) & 0xFFu), pc = (int)((pw >> 16) & 0xFFu);
+    const int n = pc == 0 ? 4 : (pc == 1 ? 2 : 3);
+    const bool ok = (uint32_t)el < nlive_g && k < n && c < n && y + k < HP && x + c < WP;
+    addr[i] = ok ? el * PC + (y + k) * WP + x + c : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < ST; ++i)
+    if (addr[i] >= 0) buf[addr[i]] = 1;
+  wave_sync();
+  // tasks (env of the group, j): j < NB the chunks of the old box, j >= NB those of the new one that the old range does not hold
+  auto range = [&](const uint32_t pw, int& q0, int& q1) {
+    const int x = (int)(pw & 0xFFu), y = (int)((pw >> 8) & 0xFFu), pc = (int)((pw >> 16) & 0xFFu);
+    const int n = pc == 0 ? 4 : (pc == 1 ? 2 : 3);
+    const int kr = (HP - y < n ? HP - y : n) - 1, kc = (WP - x < n ? WP - x : n) - 1;  // rows / columns of the box inside the array
+    q0 = (y * WP + x) >> 4;
+    q1 = (kr < 0 || kc < 0) ? -1 : (((y + kr) * WP + x + kc) >> 4);
+  };
+  u32x4 v[TT];
+  int qq[TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
+    const int t = lane + 64 * i;
+    const int el = t / (2 * NB), j = t - el * (2 * NB);
+    const int e = el < GD ? el : GD - 1;
+    const uint32_t po = oldpw_g[e], pn = post_g[e].w;
+    int o0, o1, n0, n1;
+    range(po, o0, o1);
+    range(pn, n0, n1);
+    const bool isnew = j >= NB;
+    const int q = (isnew ? n0 : o0) + (isnew ? j - NB : j);
+    const bool ok = t < NT && (uint32_t)el < nlive_g && q <= (isnew ? n1 : o1) && !(isnew && q >= o0 && q <= o1);
+    qq[i] = ok ? e * (PC / 16) + q : -1;
+    v[i] = reinterpret_cast<const u32x4*>(buf)[ok ? e * (PC / 16) + q : 0];
+  }
+#pragma unroll
+  for (int i = 0; i < TT; ++i)
+    if (qq[i] >= 0) st_dict(reinterpret_cast<u32x4*>(dst + 16 * (size_t)qq[i]), v[i]);
+  wave_sync();
+  if (lane < GD && (uint32_t)lane < nlive_g) oldpw_g[lane] = post_g[lane].w;  // what TG_BUF_OBS shows from now on
 #pragma unroll
   for (int i = 0; i < ST; ++i)
     if (addr[i] >= 0) buf[addr[i]] = 0;
@@ -1249,6 +1320,9 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   // ---- B: rule logic (per lane, branch-free except wave-uniform any() branches) ----
   LaneS s;
   lane_unpack(s, ra, rb);
+  if (DICTK) {  // the box TG_BUF_OBS's mask array shows: the env's piece as the launch starts (tg_reset / tg_set_state re-pack it)
+    reinterpret_cast<uint32_t*>(lds + BG::OFF_OLDPW)[slot] = (uint32_t)(s.x & 0xFF) | ((uint32_t)(s.y & 0xFF) << 8) | ((uint32_t)(s.piece & 0xFF) << 16);
+  }
   const int Q = p.queue_size;
   const int grav = p.gravity;
   // consumer side of the permutation ring (NUMPY).  Consuming an entry is pure register work: a nibble gather from the
@@ -1998,10 +2072,20 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
                         (step == nsteps - 1 && obs_traj) ? p.obs : nullptr};
     constexpr int GD = BG::GD;
     uint8_t* grpm = lds + BG::OFF_DICT + GD * BG::PC;  // all zero between groups (zeroed at launch start, un-stamped by every group)
-    for (int g0 = 0; g0 < EPW; g0 += GD)
-      dict_mask_group<W, H, GD>(grpm, post + (step & 1) * EPW + g0, nlive > (uint32_t)g0 ? nlive - (uint32_t)g0 : 0u, lane,
+    uint32_t* oldpw = reinterpret_cast<uint32_t*>(lds + BG::OFF_OLDPW);
+    for (int g0 = 0; g0 < EPW; g0 += GD) {
+      const uint32_t nlg = nlive > (uint32_t)g0 ? nlive - (uint32_t)g0 : 0u;
+#ifdef TG_DICT_INCR_MASK  // (measured and rejected, see dict_mask_group_incr: sparse 16-byte stores cost more than the full stream)
+      // a trajectory slot is fresh memory and gets the whole array; TG_BUF_OBS only what changed
+      if (obs_traj) dict_mask_group<W, H, GD>(grpm, post + (step & 1) * EPW + g0, nlg, lane, dsts[0] + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC, nullptr);
+      if (!obs_traj || step == nsteps - 1)
+        dict_mask_group_incr<W, H, GD>(grpm, post + (step & 1) * EPW + g0, oldpw + g0, nlg, lane, p.obs + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC);
+#else
+      dict_mask_group<W, H, GD>(grpm, post + (step & 1) * EPW + g0, nlg, lane,
                                 dsts[0] + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC,
                                 dsts[1] ? dsts[1] + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC : nullptr);
+#endif
+    }
     // holder and queue strips change only with a hold, a spawn or a reset: TG_BUF_OBS keeps the strips of the previous
     // transition (tg_reset / tg_observe / tg_set_state re-pack it completely), so only those envs store them; a
     // trajectory slot is fresh memory and gets every env's strips
