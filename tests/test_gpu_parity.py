@@ -33,12 +33,28 @@ class EngineBackend:
         self.e.set_state(**kw)
 
 
+class EngineInStepObsBackend(EngineBackend):
+    """The same, but the dict observation is what the STEP KERNEL packed (TG_BUF_OBS as the transition left it: board and
+    mask arrays written by its two waves, holder / queue strips stored only when they change) — the surface that is
+    benchmarked — instead of a re-pack by the observe kernel.  After a reset / set_state the engine re-packs anyway."""
+
+    def observe_dict(self):
+        return self.e.observation()
+
+
 TRACES = ["trace_10x20_g1", "trace_10x20_g0", "trace_20x40_g1", "trace_6x12_g1", "clears_10x20", "clears_20x40"]
 
 
 @pytest.mark.parametrize("name", TRACES)
 def test_engine_replays_reference_trace(golden_dir, name):
     replay.replay_trace(EngineBackend, replay.load(golden_dir, name))
+
+
+@pytest.mark.parametrize("name", TRACES)
+def test_engine_replays_reference_trace_with_the_in_step_observation(golden_dir, name):
+    """Every reference-generated observation checksum of the traces against the observation the step kernel itself packs."""
+    be = replay.replay_trace(EngineInStepObsBackend, replay.load(golden_dir, name))
+    assert be.e.dict_in_kernel() or name.startswith("trace_6x12")  # (sizes whose padded board is not a multiple of 16 bytes use the observe kernel)
 
 
 def _cmp_state(e, o, msg=""):

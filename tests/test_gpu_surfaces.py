@@ -570,3 +570,21 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 2 * 8192 and len(d["per_rank_ms_per_step"]) == 2
     assert d["config"]["parallelism"] == "env-sharded x2, no collective" and d["value"] > 0
     assert d["roofline"]["kernel"].startswith("tg::step_kernel_bits<10, 20, 0, 0>")
+
+
+def test_bench_four_ranks_on_one_gpu_carry_cpu_baseline_and_device_list():
+    """`python bench.py --gpus 4` on a one-GPU box: four rank processes share device 0 (the N > 1 path, not a scaling
+    number — the line says so), rank 0 still times the CPU baseline, every rank reports its device ordinal."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "16", "--warmup", "4",
+                        "--batch", "4096", "--no-blocks"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 4 and d["config"]["total_envs"] == 4 * 4096 and len(d["per_rank_ms_per_step"]) == 4
+    assert d["per_rank_device"] == [r % d["n_devices_visible"] for r in range(4)]
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    if d["n_devices_visible"] < 4:
+        assert "not a scaling measurement" in d["note"]

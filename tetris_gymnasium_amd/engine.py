@@ -473,6 +473,13 @@ class Engine:
         self._chk(self.lib.tg_timer_stop(self.h, C.byref(ms)), "tg_timer_stop")
         return ms.value
 
+    def dict_in_kernel(self) -> bool:
+        """True when the step kernel packs this engine's dict / RGB observation itself (FEAT bit 4 / 32 of the instantiation)."""
+        if self.obs_mode not in (N.OBS_DICT, N.OBS_RGB):
+            return False
+        feat = int(self.step_kernel_name().rstrip(">").split(",")[-1])
+        return bool(feat & (4 | 32))
+
     def step_kernel_name(self, transitions_per_launch=1, sampled=False, trajectory=False) -> str:
         """Symbol of the step-kernel instantiation the corresponding entry point launches (as rocprofv3 lists it)."""
         buf = C.create_string_buffer(128)
