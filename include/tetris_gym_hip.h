@@ -91,7 +91,7 @@ typedef struct tg_config {
   int32_t reserved;
   /* launch knobs of the step kernel (0 = default; the environment variables TG_FUSE / TG_RNG_EVERY / TG_RING_FILL override
    * them — test hooks).  Results never depend on them. */
-  int32_t fuse;         /* transitions per launch of tg_step_k / tg_rollout / tg_grouped_rollout: 1..32, default 8 */
+  int32_t fuse;         /* transitions per launch of tg_step_k / tg_rollout / tg_grouped_rollout: 1..8, default 8 */
   int32_t rng_every;    /* NUMPY rules: one-transition launches carry the bag-shuffle look-ahead workgroups every n-th time
                            (1..3, default 3) */
   int32_t ring_fill_p1; /* NUMPY rules: 1 + look-ahead bag permutations kept per env (1..4, default 4 = 3 permutations);
