@@ -101,6 +101,28 @@ class NativeLibraryError(RuntimeError):
     pass
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same soname as /opt/rocm's): if this
+    library loads the system copy first and torch is imported later, torch loads its bundled copy beside it and finds no GPU
+    ("No HIP GPUs are available") — and zero-copy hand-over (`DeviceArray`) needs both sides in one runtime anyway.  So when a
+    torch installation is present (looked up, never imported), its bundled runtime is loaded first and this library's
+    dependency on libamdhip64.so.7 resolves to it; whichever of torch / this package comes first then works.
+    TG_HIP_RUNTIME=system keeps the system runtime (then import torch and touch torch.cuda BEFORE creating engines)."""
+    if os.environ.get("TG_HIP_RUNTIME", "auto") == "system":
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # a broken / non-ROCm torch installation must not keep the engine from loading
+        pass
+
+
 def load() -> C.CDLL:
     """Load the HIP engine.  Raises NativeLibraryError (never falls back) when it is unavailable."""
     global _lib
@@ -110,6 +132,7 @@ def load() -> C.CDLL:
         raise NativeLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
             f"`make -C tetris_gymnasium_amd/csrc` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    _share_torch_hip_runtime()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64 missing
