@@ -25,6 +25,10 @@
 // Round 2: publish before bookkeeping, stores as whole cache lines wherever the layout allows (board
 // chunks by compare, records exchanged between lanes), the arguments the first loads need as preloaded scalars, and a
 // build for instruction-level parallelism (one logic wave per SIMD is a dependent chain: Makefile flags).
+// Round 3: where the generator state after an in-line shuffle lives is a field (`loc`) beside the consumed counter, and the
+// in-line buffer written is never the one this launch's readers were pointed at (round 2 had a race there); the functional
+// rule-set's jax key chain is looked ahead by the env's own logic wave behind its publish (protocol in front of the kernel);
+// a wave issues one instruction per ~4.8 cycles whatever its ILP (tools/ubench/valu_issue.hip): instruction COUNT is the lever.
 // Bit-identical to the four earlier step kernels (test-only library) and to the oracle (tests/test_gpu_*.py).
 #pragma once
 #ifndef __HIPCC_RTC__
