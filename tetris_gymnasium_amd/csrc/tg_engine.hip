@@ -70,9 +70,18 @@ size_t g_lds_pad = 0;       // TG_LDS_PAD: extra dynamic LDS per wave of the lan
 int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = lane kernels' pipelined pair of groups per wave (measured slower:
                             // the prefetched inputs spill), 1 = off
 
+int g_simds = 1024;  // SIMDs of the device (4 per CU), set by tg_create
+int g_wide = 1;      // TG_WIDE=0: never pick the instantiations compiled for 2 waves per SIMD (kFeatWide)
+
 // which instantiation of the bits kernel a launch with these parameters uses (FEAT flags, tg_kernel_bits.h)
-int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok) {
+int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw) {
   constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
+  // FUNCTIONAL, plain launches: when every workgroup of the launch is resident at 2 waves per SIMD anyway, the instantiation
+  // compiled for that occupancy (256 VGPRs instead of 128) is the shorter instruction stream (8.4 -> 8.0 us at 65 536 envs;
+  // beyond residency the 4-waves build wins: profiles/r03/ab_select_waves.log)
+  if (RS == TG_RULESET_FUNCTIONAL && g_wide && !p.final_obs && !(p.obs_traj || p.out_traj || p.act_traj) &&
+      (p.batch + epw - 1) / epw * 2 <= 2 * g_simds)
+    return (p.nsteps > 1 ? M : 0) | tg::kFeatWide;
   const bool dict = p.obs_mode == TG_OBS_DICT && p.dict_in_kernel && dict_ok;
   const bool rgb = p.obs_mode == TG_OBS_RGB && p.dict_in_kernel && rgb_ok;
   const bool traj = p.obs_traj || p.out_traj || p.act_traj;
@@ -88,7 +97,7 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
 
 template <int W, int H, int RS>
 int bits_feat(const tg::KParams& p) {
-  return bits_feat_rt(p, RS, tg::BitsGeo<W, H>::DICT_OK, tg::BitsGeo<W, H>::RGB_OK);
+  return bits_feat_rt(p, RS, tg::BitsGeo<W, H>::DICT_OK, tg::BitsGeo<W, H>::RGB_OK, tg::BitsGeo<W, H>::EPW);
 }
 
 template <int W, int H, int RS>
@@ -127,6 +136,10 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
       if (feat == (T | S)) { TG_LAUNCH_BITS(T | S); return; }
       if (feat == (M | T | D)) { TG_LAUNCH_BITS(M | T | D); return; }
       if (feat == D) { TG_LAUNCH_BITS(D); return; }
+    }
+    if constexpr (RS == TG_RULESET_FUNCTIONAL) {
+      if (feat == tg::kFeatWide) { TG_LAUNCH_BITS(tg::kFeatWide); return; }
+      if (feat == (M | tg::kFeatWide)) { TG_LAUNCH_BITS(M | tg::kFeatWide); return; }
     }
     if (feat == (M | T)) TG_LAUNCH_BITS(M | T);
     else if (feat == M) TG_LAUNCH_BITS(M);
@@ -240,7 +253,7 @@ std::string csrc_dir() {
 std::vector<int> rtc_feats(int RS) {
   constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
   if (RS == TG_RULESET_NUMPY) return {0, M, M | T, F, M | T | F, D, M | T | D, T | S, M | T | S, R, M | T | S | R};
-  return {0, M, M | T, F, M | T | F};
+  return {0, M, M | T, F, M | T | F, tg::kFeatWide, M | tg::kFeatWide};
 }
 
 uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
@@ -367,7 +380,7 @@ Launchers rtc_launchers(const RtcSize* r) {
     tg::BitsParams bp{p.cols, p.ahead, ring4 + (size_t)p.ring_cur * p.ring_stride, const_cast<uint4*>(ring4) + (size_t)(1 - p.ring_cur) * p.ring_stride,
                       p.hbuf + hrd, p.hbuf + hwr, p.inl, nrb, p.ring_fill};
     const int n_step_wgs = (p.batch + EPW - 1) / EPW;
-    const int feat = bits_feat_rt(p, RS, dict_ok, rgb_ok);
+    const int feat = bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW);
     const size_t lds = RS == TG_RULESET_FUNCTIONAL ? r->geo[5] : ((feat & D) ? r->geo[2] : ((feat & R) ? r->geo[3] : ((feat & F) ? r->geo[4] : r->geo[1])));
     auto it = r->step.find(feat);
     if (it == r->step.end()) return;
@@ -379,7 +392,7 @@ Launchers rtc_launchers(const RtcSize* r) {
     (void)hipModuleLaunchKernel(it->second, (unsigned)(nrb + n_step_wgs), 1, 1, 128, 1, 1, (unsigned)lds, s, args, nullptr);
   };
   L.step_name = [=](const tg::KParams& p, char* buf, size_t n) {
-    snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat_rt(p, RS, dict_ok, rgb_ok));
+    snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW));
   };
   L.reset = [=](const tg::ResetParams& p, hipStream_t s) { rtc_launch(r->reset, dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p); };
   L.observe = [=](const tg::ObserveParams& p, hipStream_t s) {
@@ -827,6 +840,8 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
       }
 #endif
     g_step_blocks = per_cu > 0 ? prop.multiProcessorCount * per_cu : -1;
+    g_simds = 4 * prop.multiProcessorCount;
+    if (const char* w = getenv("TG_WIDE")) g_wide = atoi(w) != 0;
   }
   CRCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CRCHK(hipEventCreate(&h->ev0));

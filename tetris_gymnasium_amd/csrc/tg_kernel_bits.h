@@ -385,6 +385,9 @@ __device__ __forceinline__ void st_state(V* dst, const V v) {
 //   kFeatRgb    TG_OBS_RGB (RgbObservation, wrappers/observation.py:38-74) packed by the two waves
 // Profiles list the kinds of launches separately.
 constexpr int kFeatMulti = 1, kFeatTraj = 2, kFeatDict = 4, kFeatSample = 8, kFeatFinal = 16, kFeatRgb = 32;
+// kFeatWide: the same code compiled for 2 waves per SIMD (up to 256 VGPRs) — picked by the host when the whole launch is
+// resident at that occupancy anyway (FUNCTIONAL rule-set, plain launches: tg_engine.hip bits_feat_rt)
+constexpr int kFeatWide = 64;
 
 // bytes: 0xFF (active) stays -1, other non-zero → 1  (the functional observation, envs/tetris_fn.py:137-158).  Board cells
 // are 0 or a tetromino value 2..8 (tg_set_state rejects bytes >= 0x80 for this rule-set), so the only byte with its top bit
@@ -696,7 +699,10 @@ template <int W, int H, int RULESET, int FEAT>
 #ifndef TG_ONE_WAVES
 #define TG_ONE_WAVES 4  // waves per SIMD the one-transition kernels are compiled for (4 → 128 VGPRs, 3 → 168)
 #endif
-__global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kFeatSample)) ? 3 : 4) : TG_ONE_WAVES) void step_kernel_bits(
+#ifndef TG_MULTI_WAVES
+#define TG_MULTI_WAVES 3  // ... the kernels of several transitions per launch (NUMPY: at 4 the plain one spilled 12 registers: 2.90 -> 2.73 us per transition)
+#endif
+__global__ __launch_bounds__(128, (FEAT & kFeatWide) ? 2 : (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kFeatSample)) ? 3 : (RULESET == TG_RULESET_NUMPY ? TG_MULTI_WAVES : 4)) : TG_ONE_WAVES) void step_kernel_bits(
     // The arguments every wave needs BEFORE its first global loads, as scalars: the first 14 dwords of the kernel-argument
     // segment are preloaded into SGPRs by the dispatcher (-mllvm -amdgpu-kernarg-preload-count=16, 14 user SGPRs are free;
     // struct arguments are not eligible), so the slab / record / ring loads leave without waiting for a scalar load of
@@ -1476,16 +1482,21 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     const int col = action_in >> 2, nrot = (s.rot + (action_in & 3)) & 3;
     const int nx = col + 4 - (s.piece == 0 ? 2 : 1);  // x + padding - matrix.shape[1] // 2
     const uint32_t cg = colmask(s.piece, nrot);
+    // (selects and bitwise bool algebra from here to the publish: a lane-varying `if` or a short-circuit && / || becomes an
+    // exec-mask region — s_and_saveexec / s_cbranch_execz / s_or exec — which costs a wave ~45 cycles more than the same
+    // work as v_cndmask, profiles/r03/salu_issue.log; there were ~25 of them on the way to the barrier)
     bool legal = (unsigned)action_in < (unsigned)(4 * W);
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      legal = legal && (((cg >> (4 * c)) & 0xFu) == 0 || (unsigned)(nx + c - 4) < (unsigned)W);
-    if (!pending) {
-      if (legal) { s.x = nx; s.rot = nrot; action = 5; }
-      else { g_illegal = true; action = 7; if (p.grouped_term) frozen = true; }
-    }
+      legal = legal & ((((cg >> (4 * c)) & 0xFu) == 0) | ((unsigned)(nx + c - 4) < (unsigned)W));
+    const bool g_ok = !pending & legal;
+    g_illegal = !pending & !legal;
+    s.x = g_ok ? nx : s.x;
+    s.rot = g_ok ? nrot : s.rot;
+    action = g_ok ? 5 : (g_illegal ? 7 : action);
+    frozen = frozen | (g_illegal & (p.grouped_term != 0));
   }
-  const bool stepped = live && !pending && !frozen;
+  const bool stepped = live & !pending & !frozen;
 
   // action → tentative placement (branch-free LUT)
   uint32_t e;
@@ -1500,9 +1511,9 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   int ty = s.y + (int)((e >> 2) & 1u);
   int tr = (s.rot + (int)((e >> 3) & 3u)) & 3;
   const bool check = (e & 0x20u) != 0;
-  const bool hard = stepped && (e & 0x40u) != 0;
+  const bool hard = stepped & ((e & 0x40u) != 0);
   // swap (envs/tetris.py:242-252, components/tetromino_holder.py:31-49)
-  const bool swap_eff = RULESET == TG_RULESET_NUMPY && stepped && (e & 0x80u) && !(s.flags & TG_F_HAS_SWAPPED);
+  const bool swap_eff = RULESET == TG_RULESET_NUMPY && (stepped & ((e & 0x80u) != 0) & !(s.flags & TG_F_HAS_SWAPPED));
   // NUMPY: the visible queue is consumed lazily.  A transition takes at most two pieces from the env's stream (a hold
   // with an empty holder, then a lock's spawn); WHICH pieces is known without touching the randomizer: the head of the
   // queue, then its second entry (queue_size 1: the bag entry the first pop draws).  The pops themselves — queue shift,
@@ -1510,27 +1521,33 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   // wave's tail instead of in front of it.
   int npop = 0;
   const int up0 = up0_, up1 = up1_;
-  const bool swap_empty = swap_eff && s.hp == TG_NONE;
+  const bool swap_empty = swap_eff & (s.hp == TG_NONE);
   if (RULESET == TG_RULESET_NUMPY) {  // (no wave-uniform branch: with 64 envs per wave some lane swaps in practically every transition)
-    if (swap_eff) {
-      if (swap_empty) { tp = up0; tr = 0; tv = up0 + 2; npop = 1; }  // spawn_tetromino; its collision result is ignored
-      else { tp = s.hp; tr = s.hr; tv = s.hv; }
-      s.hp = s.piece; s.hr = s.rot; s.hv = s.val;
-      s.flags |= TG_F_HAS_SWAPPED;
-      tx = np_spawn_x<W>(tp);
-      ty = 0;
-    }
+    // swap_empty: spawn_tetromino (its collision result is ignored); otherwise the held piece comes back
+    tp = swap_eff ? (swap_empty ? up0 : s.hp) : tp;
+    tr = swap_eff ? (swap_empty ? 0 : s.hr) : tr;
+    tv = swap_eff ? (swap_empty ? up0 + 2 : s.hv) : tv;
+    npop = swap_empty ? 1 : 0;
+    s.hp = swap_eff ? s.piece : s.hp;
+    s.hr = swap_eff ? s.rot : s.hr;
+    s.hv = swap_eff ? s.val : s.hv;
+    s.flags |= swap_eff ? TG_F_HAS_SWAPPED : 0;
+    tx = swap_eff ? np_spawn_x<W>(tp) : tx;
+    ty = swap_eff ? 0 : ty;
   }
 
   // the six columns around the piece: padded columns wb .. wb+5 (the current piece spans wb+1 .. wb+4, a tentative
   // one wb+dxT .. wb+dxT+3 with dxT in 0..2).  An out-of-range position (only by tg_set_state) collides everywhere.
   const int wb = (swap_eff ? tx : s.x) - 1;
-  const bool oob = (unsigned)wb > (unsigned)(W + 2) || (unsigned)s.y > (unsigned)H;
+  const bool oob = ((unsigned)wb > (unsigned)(W + 2)) | ((unsigned)s.y > (unsigned)H);
+  // (out of range: all six window words are the bedrock column; so are those of a dead lane, which shares its slot with the
+  // last live env — the lock's unconditional write-back below must not restore what that env has just changed)
+  const int wbo = (oob | !live) ? -16 : wb;
   T w[6];
   int widx[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    const int j = wb + i - 3;  // padded column → LDS index: playfield column c sits at 1 + c, bedrock at 0 and W + 1
+    const int j = wbo + i - 3;  // padded column → LDS index: playfield column c sits at 1 + c, bedrock at 0 and W + 1
     widx[i] = j < 0 ? 0 : (j > W + 1 ? W + 1 : j);
   }
 #pragma unroll
@@ -1544,14 +1561,10 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     tcol0 = col_tab[pc0]; tcel0 = cell_tab_l[pc0];
     tcol1 = col_tab[pc1]; tcel1 = cell_tab_l[pc1];
   }
-  if (oob) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) w[i] = ONES;
-  }
   uint64_t tcolT = tcolC, tcelT = tcelC;  // tables of the tentative piece
-  if (RULESET == TG_RULESET_NUMPY && swap_eff) {
-    tcolT = swap_empty ? tcol0 : tcolH;
-    tcelT = swap_empty ? tcel0 : tcelH;
+  if (RULESET == TG_RULESET_NUMPY) {
+    tcolT = swap_eff ? (swap_empty ? tcol0 : tcolH) : tcolC;
+    tcelT = swap_eff ? (swap_empty ? tcel0 : tcelH) : tcelC;
   }
   TG_BITS_STAMP(2);
   const uint32_t mC = rot16(tcolC, s.rot), mT = rot16(tcolT, tr);
@@ -1608,33 +1621,29 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   int frot = s.rot;                 // ... and its rotation (for the uint8 stamp)
   if (RULESET == TG_RULESET_FUNCTIONAL) {
     // functional/core.py:230-251 hard_drop: step-wise, stops at the first blocked row below y
-    const int yd = drop_row_of(PC, s.y, __any(hard && cC));
-    if (hard) {
-      drop_reward = 2 * (yd - s.y);
-      s.y = yd;
-      lock = grav || action == 6;  // blocked below by construction → should_lock iff gravity (tetris_fn.py:247-264)
-    }
+    const int yd = drop_row_of(PC, s.y, __any(hard & cC));
+    drop_reward = hard ? 2 * (yd - s.y) : 0;
+    s.y = hard ? yd : s.y;
+    lock = hard & ((grav != 0) | (action == 6));  // blocked below by construction → should_lock iff gravity (tetris_fn.py:247-264)
   }
-  const bool moving = stepped && !(RULESET == TG_RULESET_FUNCTIONAL && hard);
-  if (RULESET == TG_RULESET_NUMPY && !stepped) final_coll = cC;  // projection rule for an untouched env
-  const bool accept = moving && (swap_eff || (check && !cT));
+  const bool moving = stepped & !(RULESET == TG_RULESET_FUNCTIONAL && hard);
+  const bool accept = moving & (swap_eff | (check & !cT));
   uint64_t tcelF = tcelC;  // cell table word of the piece as it ends the move (of the spawned one after a lock)
   uint64_t tcolN = tcolC;  // column table word of the piece a lock spawns
-  if (accept) { s.piece = tp; s.rot = tr; s.x = tx; s.y = ty; s.val = tv; PF = PT; frot = tr; tcelF = tcelT; }
+  s.piece = accept ? tp : s.piece; s.rot = accept ? tr : s.rot; s.x = accept ? tx : s.x; s.y = accept ? ty : s.y;
+  s.val = accept ? tv : s.val; PF = accept ? PT : PF; frot = accept ? tr : frot; tcelF = accept ? tcelT : tcelF;
   const bool coll_here = accept ? cT : cC;
   const bool coll_below = accept ? cT1 : cC1;
-  if (RULESET == TG_RULESET_FUNCTIONAL && accept && (e & 4u)) drop_reward = 1;  // soft drop (tetris_fn.py:183-190)
-  if (moving) {
+  if (RULESET == TG_RULESET_FUNCTIONAL) drop_reward = (accept & ((e & 4u) != 0)) ? 1 : drop_reward;  // soft drop (tetris_fn.py:183-190)
+  {
+    const bool gq = moving & (grav != 0) & !hard;  // envs/tetris.py:259-264; functional/core.py:150-182 + tetris_fn.py:242-247
+    const bool fall = gq & !coll_below;
+    s.y += fall ? 1 : 0;
     if (RULESET == TG_RULESET_NUMPY) {
-      final_coll = coll_here;
-      lock = hard;
-      if (grav && !hard) {  // envs/tetris.py:259-264
-        if (!coll_below) { s.y += 1; final_coll = false; }
-        else lock = true;
-      }
-    } else if (grav) {  // functional/core.py:150-182 + tetris_fn.py:242-247
-      if (!coll_below) s.y += 1;
-      else lock = true;
+      lock = moving & (hard | (gq & coll_below));
+      final_coll = moving ? (coll_here & !fall) : cC;  // (!moving: the projection rule for an untouched env)
+    } else {
+      lock = lock | (gq & coll_below);
     }
   }
 
@@ -1647,12 +1656,12 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   if (__any(lock)) {
     place = lock;
     if (RULESET == TG_RULESET_NUMPY) {  // envs/tetris.py:450-479 commit_active_tetromino
-      const bool dead = lock && coll_here;  // already colliding: game over, nothing placed (:461-463)
-      if (dead) { s.flags |= TG_F_GAME_OVER; reward = 0.0f; }
-      place = lock && !coll_here;
+      const bool dead = lock & coll_here;  // already colliding: game over, nothing placed (:461-463; the reward is still 0)
+      s.flags |= dead ? TG_F_GAME_OVER : 0;
+      place = lock & !coll_here;
       {  // (no wave-uniform branch: 1 action in 8 is a hard drop, some lane always takes it)
         const int yd = drop_row_of(PF, s.y, false);  // :445-448 (only hard drops can still move; `place` = not colliding)
-        if (place && hard) s.y = yd;
+        s.y = (place & hard) ? yd : s.y;
       }
     }
     TG_LOCK_STAMP(4);
@@ -1661,8 +1670,10 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     lock_val = RULESET == TG_RULESET_NUMPY ? s.val : s.piece + 2;  // functional/core.py:103-121 adds piece id
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const uint32_t n = (PF >> (4 * i)) & 0xFu;
-      if (place && n != 0 && !oob) colsL[widx[i]] = (T)(w[i] | ((T)n << s.y));
+      // (unconditional: a lane that places nothing writes the word back; a piece that does not collide has no cell on
+      // a bedrock word, and an out-of-range one sees six of them)
+      const uint32_t n = place ? (PF >> (4 * i)) & 0xFu : 0u;
+      colsL[widx[i]] = (T)(w[i] | ((T)n << s.y));
     }
     wave_sync();
     // full rows: AND over the playfield columns (whole-board scan, envs/tetris.py:493-494, functional/core.py:198-201)
@@ -1672,29 +1683,26 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     // spawn the next piece (needs none of the columns: it runs while the reads above are on their way)
     if (RULESET == TG_RULESET_NUMPY) {
       const int np_ = npop ? up1 : up0;  // envs/tetris.py:393-401 (TetrominoQueue.get_next_tetromino: the pop is owed)
-      if (place) {
-        tcolN = npop ? tcol1 : tcol0; tcelF = npop ? tcel1 : tcel0;
-        s.piece = np_; s.rot = 0; s.val = np_ + 2; s.x = np_spawn_x<W>(np_); s.y = 0;
-        npop += 1;
-      }
+      tcolN = place ? (npop ? tcol1 : tcol0) : tcolN; tcelF = place ? (npop ? tcel1 : tcel0) : tcelF;
+      s.piece = place ? np_ : s.piece; s.rot = place ? 0 : s.rot; s.val = place ? np_ + 2 : s.val;
+      s.x = place ? np_spawn_x<W>(np_) : s.x; s.y = place ? 0 : s.y;
+      npop += place ? 1 : 0;
     }
     if (RULESET != TG_RULESET_NUMPY) {  // envs/tetris_fn.py:370-413 place_active_tetromino
       // the lock moves the env one position along its key chain (rng_key = split(rng_key)[0], :399: owed until after the
       // publish) and, with the bag used up, deals permutation(split(rng_key)[1]) (functional/queue.py:59-67) = Q0
-      const bool refill = place && s.bidx >= 7;
+      const bool refill = place & (s.bidx >= 7);
       const uint64_t nb = fn_expand21((uint32_t)(fnw >> 42) & 0x1FFFFFu);
-      if (refill) { s.bag = nb; s.bidx = 0; }
-      if (place) {
-        s.piece = (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF);
-        s.bidx += 1;
-        fn_lock = true;
-        s.rot = 0; s.val = s.piece + 2; s.x = (W + 8) / 2 - 2; s.y = 0;
-      }
+      s.bag = refill ? nb : s.bag; s.bidx = refill ? 0 : s.bidx;
+      s.piece = place ? (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF) : s.piece;
+      s.bidx += place ? 1 : 0;
+      fn_lock = fn_lock | place;
+      s.rot = place ? 0 : s.rot; s.val = place ? s.piece + 2 : s.val; s.x = place ? (W + 8) / 2 - 2 : s.x; s.y = place ? 0 : s.y;
     }
     T full = PLAY;
 #pragma unroll
     for (int c = 0; c < W; ++c) full &= v[c];
-    if (!place) full = 0;
+    full = place ? full : T(0);
     lines = popc_t(full);
     do_clear = lines > 0;
     TG_LOCK_STAMP(5);
@@ -1717,7 +1725,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
         if (do_clear) { v[c] = (T)(x | FLOOR); colsL[1 + c] = v[c]; }
       }
     }
-    if (place) s.flags &= ~TG_F_FULLROW;
+    s.flags &= place ? ~TG_F_FULLROW : ~0;
     // collision of the new piece at its spawn position (rows 0..3 of the columns it spans; static columns)
     bool sc;
     {
@@ -1733,24 +1741,20 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       sc = hs != 0;
     }
     if (RULESET == TG_RULESET_NUMPY) {
-      if (place) {
-        reward = (float)(lines * lines * W + 1);  // score + rewards.alife
-        if (sc) { s.flags |= TG_F_GAME_OVER; reward = 0.0f; }
-        else s.flags &= ~TG_F_GAME_OVER;
-        s.flags &= ~TG_F_HAS_SWAPPED;
-        final_coll = sc;
-      }
+      reward = (place & !sc) ? (float)(lines * lines * W + 1) : 0.0f;  // score + rewards.alife; 0 when the spawn collides
+      s.flags = place ? ((s.flags & ~(TG_F_GAME_OVER | TG_F_HAS_SWAPPED)) | (sc ? TG_F_GAME_OVER : 0)) : s.flags;
+      final_coll = place ? sc : final_coll;
     } else {
-      if (place && sc) s.flags |= TG_F_GAME_OVER;
+      s.flags |= (place & sc) ? TG_F_GAME_OVER : 0;
     }
   }
-  if (RULESET == TG_RULESET_FUNCTIONAL && stepped) {
+  if (RULESET == TG_RULESET_FUNCTIONAL) {
     const int lock_reward = lock ? (lines == 4 ? 800 : (lines > 0 ? lines * 200 - 100 : 0)) : 0;  // core.py:124-146
     const float old = s.score;
     float t = old + (float)drop_reward;
     t = t + (float)lock_reward;
-    s.score = t;
-    reward = t - old;  // tetris_fn.py:312
+    s.score = stepped ? t : old;
+    reward = stepped ? t - old : reward;  // tetris_fn.py:312
   }
 
 #ifdef TG_FINE_LOCK
@@ -1759,10 +1763,10 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
   TG_BITS_STAMP(4);
 #endif
   // ---- termination / autoreset ----
-  if (g_illegal) reward = -0.1f;  // rewards.invalid_action
-  const int terminated = (!pending && ((s.flags & TG_F_GAME_OVER) || (g_illegal && p.grouped_term))) ? 1 : 0;
-  const bool do_reset = live && (pending || (terminated && p.autoreset == TG_AUTORESET_SAME_STEP));
-  if (terminated && p.autoreset == TG_AUTORESET_NEXT_STEP && !pending) s.flags |= TG_F_PENDING_RESET;
+  reward = g_illegal ? -0.1f : reward;  // rewards.invalid_action
+  const int terminated = (!pending & (((s.flags & TG_F_GAME_OVER) != 0) | (g_illegal & (p.grouped_term != 0)))) ? 1 : 0;
+  const bool do_reset = live & (pending | ((terminated != 0) & (p.autoreset == TG_AUTORESET_SAME_STEP)));
+  s.flags |= ((terminated != 0) & (p.autoreset == TG_AUTORESET_NEXT_STEP) & !pending) ? TG_F_PENDING_RESET : 0;
   if (FINAL && final_obs && live) {  // the terminal piece, before the reset replaces it (TG_FLAG_FINAL_OBS)
     const bool fin = do_reset && terminated;
     const bool showf = fin && (RULESET == TG_RULESET_NUMPY ? !final_coll : false);
@@ -1780,13 +1784,11 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
     if (RULESET == TG_RULESET_NUMPY) {
       const int Hr = Hc + ((s.bidx + npop >= 7) ? 1 : 0);
       const bool have = ring_diff(ringT, Hr) > 0;
-      early_book = __any(do_reset && !have);
-      if (do_reset) {
-        s.piece = (int)(ring_get(ring0, ring1, Hr & (kRing - 1)) & 0xFu);
-        s.x = np_spawn_x<W>(s.piece);
-        s.rot = 0; s.y = 0; s.val = s.piece + 2;
-        final_coll = false;
-      }
+      early_book = __any(do_reset & !have);
+      s.piece = do_reset ? (int)(ring_get(ring0, ring1, Hr & (kRing - 1)) & 0xFu) : s.piece;
+      s.x = do_reset ? np_spawn_x<W>(s.piece) : s.x;
+      s.rot = do_reset ? 0 : s.rot; s.y = do_reset ? 0 : s.y; s.val = do_reset ? s.piece + 2 : s.val;
+      final_coll = final_coll & !do_reset;
     } else {  // envs/tetris_fn.py:318-367
       if (do_reset) {
 #pragma unroll
@@ -1795,19 +1797,18 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       // the reset deals permutation(split(key)[0]) and continues with split(key)[1] (owed until after the publish): S1 at
       // the env's position, S2 behind a lock of this transition
       const uint64_t nb = fn_expand21((uint32_t)(fnw >> (fn_lock ? 21 : 0)) & 0x1FFFFFu);
-      if (do_reset) {
-        s.bag = nb; s.queue = 0; s.piece = (int)(nb & 0xFF); s.bidx = 1;
-        fn_reset = true;
-        s.x = (W + 8) / 2 - 2;
-        s.rot = 0; s.y = 0; s.val = s.piece + 2;
-        s.hp = TG_NONE; s.hr = 0; s.hv = 0;
-        s.flags = 0;
-        s.score = 0.0f;
-        final_coll = false;
-      }
+      s.bag = do_reset ? nb : s.bag; s.queue = do_reset ? 0 : s.queue; s.piece = do_reset ? (int)(nb & 0xFF) : s.piece;
+      s.bidx = do_reset ? 1 : s.bidx;
+      fn_reset = fn_reset | do_reset;
+      s.x = do_reset ? (W + 8) / 2 - 2 : s.x;
+      s.rot = do_reset ? 0 : s.rot; s.y = do_reset ? 0 : s.y; s.val = do_reset ? s.piece + 2 : s.val;
+      s.hp = do_reset ? TG_NONE : s.hp; s.hr = do_reset ? 0 : s.hr; s.hv = do_reset ? 0 : s.hv;
+      s.flags = do_reset ? 0 : s.flags;
+      s.score = do_reset ? 0.0f : s.score;
+      final_coll = final_coll & !do_reset;
     }
   }
-  cols_dirty_any = cols_dirty_any || (live && (place || do_reset));
+  cols_dirty_any = cols_dirty_any | (live & (place | do_reset));
   if (rgb) early_book = true;  // the image shows the queue and the holder as they are AFTER the transition: bookkeeping first
   // The publish exists twice in the code (it is short), the bookkeeping once: normally publish → barrier → bookkeeping
   // (beside the stream wave's work), with early_book (wave-uniform) the other way round.
@@ -1816,13 +1817,13 @@ __global__ __launch_bounds__(128, (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kF
       post2[slot] = make_uint4((uint32_t)s.queue, (uint32_t)((s.queue >> 32) & 0x00FFFFFFu) | ((uint32_t)(s.hp & 0xFF) << 24),
                                (uint32_t)(s.hr & 0xFF) | ((uint32_t)(s.hv & 0xFF) << 8), 0u);
     // the payload work of this lane's env for the stream wave
-    const bool show = live && (RULESET == TG_RULESET_NUMPY ? !final_coll : !(s.flags & TG_F_GAME_OVER));
+    const bool show = live & (RULESET == TG_RULESET_NUMPY ? !final_coll : !(s.flags & TG_F_GAME_OVER));
     uint32_t ocells;
     if (RULESET == TG_RULESET_NUMPY) {
       // the piece's table word is already here — unless a reset has just drawn the piece: a new episode starts at
       // rotation 0, whose cells are compile-time constants (no table round trip in front of the barrier)
       ocells = rot16(tcelF, s.rot);
-      if (do_reset) ocells = (uint32_t)((s.piece < 4 ? kCells0Lo : kCells0Hi) >> (16 * (s.piece & 3))) & 0xFFFFu;
+      ocells = do_reset ? (uint32_t)((s.piece < 4 ? kCells0Lo : kCells0Hi) >> (16 * (s.piece & 3))) & 0xFFFFu : ocells;
     } else {
       ocells = lane_cells(cell_tab_l, s.piece, s.rot);
     }
