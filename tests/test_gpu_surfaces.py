@@ -569,7 +569,7 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 2 * 8192 and len(d["per_rank_ms_per_step"]) == 2
     assert d["config"]["parallelism"] == "env-sharded x2, no collective" and d["value"] > 0
-    assert d["roofline"]["kernel"].startswith("tg::step_kernel_bits<10, 20, 0, 0>")
+    assert d["roofline"]["kernel"].startswith("tg::step_kernel_bits<10, 20, 0, ")  # (the FEAT flags depend on the batch size)
 
 
 def test_bench_four_ranks_on_one_gpu_carry_cpu_baseline_and_device_list():

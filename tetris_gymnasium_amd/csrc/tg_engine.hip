@@ -71,10 +71,24 @@ int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = lane kernels' pipelined p
                             // the prefetched inputs spill), 1 = off
 
 int g_simds = 1024;  // SIMDs of the device (4 per CU), set by tg_create
-int g_wide = 1;      // TG_WIDE=0: never pick the instantiations compiled for 2 waves per SIMD (kFeatWide)
+int g_split = 1;     // TG_SPLIT=0: never pick the instantiations with two stream waves per workgroup (kFeatSplit)
+int g_wide = 1;      // TG_WIDE=0: never pick the instantiations compiled for fewer waves per SIMD (kFeatWide)
 
 // which instantiation of the bits kernel a launch with these parameters uses (FEAT flags, tg_kernel_bits.h)
-int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw) {
+int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw);
+int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw, const bool split_ok) {
+  constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj;
+  const int feat = bits_feat_base(p, RS, dict_ok, rgb_ok, epw);
+  // two stream waves per workgroup (kFeatSplit) while all workgroups of the launch — the RNG role's included — are resident
+  // with three waves each at the occupancy the instantiation is compiled for
+  const int base = feat & ~tg::kFeatWide;
+  if (!g_split || !split_ok || RS != TG_RULESET_NUMPY || !(base == 0 || base == M || base == (M | T))) return feat;
+  const int per_simd = tg::bits_waves_per_simd(RS, feat);
+  const long cap = (long)(g_simds / 4) * (4 * per_simd / 3);
+  const long wgs = (p.batch + epw - 1) / epw + ((RS == TG_RULESET_NUMPY && p.rng_role) ? (p.batch + 127) / 128 : 0);
+  return wgs <= cap ? (feat | tg::kFeatSplit) : feat;
+}
+int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw) {
   constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
   // FUNCTIONAL, plain launches: when every workgroup of the launch is resident at 2 waves per SIMD anyway, the instantiation
   // compiled for that occupancy (256 VGPRs instead of 128) is the shorter instruction stream (8.4 -> 8.0 us at 65 536 envs;
@@ -97,7 +111,7 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
 
 template <int W, int H, int RS>
 int bits_feat(const tg::KParams& p) {
-  return bits_feat_rt(p, RS, tg::BitsGeo<W, H>::DICT_OK, tg::BitsGeo<W, H>::RGB_OK, tg::BitsGeo<W, H>::EPW);
+  return bits_feat_rt(p, RS, tg::BitsGeo<W, H>::DICT_OK, tg::BitsGeo<W, H>::RGB_OK, tg::BitsGeo<W, H>::EPW, tg::BitsGeo<W, H>::SPLIT_OK);
 }
 
 template <int W, int H, int RS>
@@ -124,7 +138,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     const size_t lds = RS == TG_RULESET_FUNCTIONAL ? BG::BYTES_FNX
                        : ((feat & D) ? BG::BYTES_DICT : ((feat & R) ? BG::BYTES_RGB : ((feat & F) ? BG::BYTES_FIN : BG::BYTES)));
 #define TG_LAUNCH_BITS(FT)                                                                                                  \
-  hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(128), lds, s, p.board, p.rec, p.cols, bp.ring_rd, bp.hbuf_rd, \
+  hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(64 * (1 + tg::bits_stream_waves<W, H>(FT))), lds, s, p.board, p.rec, p.cols, bp.ring_rd, bp.hbuf_rd, \
                      p.actions, p.batch, (uint32_t)n_step_wgs | ((p.act_i8 ? 1u : 0u) << 24) | ((uint32_t)(p.nsteps > 0 ? p.nsteps : 0) << 25), \
                      p, bp)
     if (feat == F) { TG_LAUNCH_BITS(F); return; }
@@ -140,6 +154,12 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     if constexpr (RS == TG_RULESET_FUNCTIONAL) {
       if (feat == tg::kFeatWide) { TG_LAUNCH_BITS(tg::kFeatWide); return; }
       if (feat == (M | tg::kFeatWide)) { TG_LAUNCH_BITS(M | tg::kFeatWide); return; }
+    }
+    if constexpr (BG::SPLIT_OK && RS == TG_RULESET_NUMPY) {
+      constexpr int P = tg::kFeatSplit;
+      if (feat == (P | M | T)) { TG_LAUNCH_BITS(P | M | T); return; }
+      if (feat == (P | M)) { TG_LAUNCH_BITS(P | M); return; }
+      if (feat == P) { TG_LAUNCH_BITS(P); return; }
     }
     if (feat == (M | T)) TG_LAUNCH_BITS(M | T);
     else if (feat == M) TG_LAUNCH_BITS(M);
@@ -252,8 +272,9 @@ std::string csrc_dir() {
 
 std::vector<int> rtc_feats(int RS) {
   constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
-  if (RS == TG_RULESET_NUMPY) return {0, M, M | T, F, M | T | F, D, M | T | D, T | S, M | T | S, R, M | T | S | R};
-  return {0, M, M | T, F, M | T | F, tg::kFeatWide, M | tg::kFeatWide};
+  constexpr int P = tg::kFeatSplit, Wd = tg::kFeatWide;
+  if (RS == TG_RULESET_NUMPY) return {0, M, M | T, F, M | T | F, D, M | T | D, T | S, M | T | S, R, M | T | S | R, P, P | M, P | M | T};
+  return {0, M, M | T, F, M | T | F, Wd, M | Wd};
 }
 
 uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
@@ -380,7 +401,8 @@ Launchers rtc_launchers(const RtcSize* r) {
     tg::BitsParams bp{p.cols, p.ahead, ring4 + (size_t)p.ring_cur * p.ring_stride, const_cast<uint4*>(ring4) + (size_t)(1 - p.ring_cur) * p.ring_stride,
                       p.hbuf + hrd, p.hbuf + hwr, p.inl, nrb, p.ring_fill};
     const int n_step_wgs = (p.batch + EPW - 1) / EPW;
-    const int feat = bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW);
+    const bool split_ok = EPW == 64 && (32 * W * H) % 16 == 0;  // (BitsGeo::SPLIT_OK)
+    const int feat = bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, split_ok);
     const size_t lds = RS == TG_RULESET_FUNCTIONAL ? r->geo[5] : ((feat & D) ? r->geo[2] : ((feat & R) ? r->geo[3] : ((feat & F) ? r->geo[4] : r->geo[1])));
     auto it = r->step.find(feat);
     if (it == r->step.end()) return;
@@ -389,10 +411,11 @@ Launchers rtc_launchers(const RtcSize* r) {
     uint32_t a7 = (uint32_t)n_step_wgs | ((p.act_i8 ? 1u : 0u) << 24) | ((uint32_t)(p.nsteps > 0 ? p.nsteps : 0) << 25);
     tg::KParams kp = p;
     void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &kp, &bp};
-    (void)hipModuleLaunchKernel(it->second, (unsigned)(nrb + n_step_wgs), 1, 1, 128, 1, 1, (unsigned)lds, s, args, nullptr);
+    // (threads per workgroup: tg::bits_stream_waves of this size and instantiation)
+    (void)hipModuleLaunchKernel(it->second, (unsigned)(nrb + n_step_wgs), 1, 1, (feat & tg::kFeatSplit) ? 192 : 128, 1, 1, (unsigned)lds, s, args, nullptr);
   };
   L.step_name = [=](const tg::KParams& p, char* buf, size_t n) {
-    snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW));
+    snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, EPW == 64 && (32 * W * H) % 16 == 0));
   };
   L.reset = [=](const tg::ResetParams& p, hipStream_t s) { rtc_launch(r->reset, dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p); };
   L.observe = [=](const tg::ObserveParams& p, hipStream_t s) {
@@ -842,6 +865,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     g_step_blocks = per_cu > 0 ? prop.multiProcessorCount * per_cu : -1;
     g_simds = 4 * prop.multiProcessorCount;
     if (const char* w = getenv("TG_WIDE")) g_wide = atoi(w) != 0;
+    if (const char* w = getenv("TG_SPLIT")) g_split = atoi(w) != 0;
   }
   CRCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CRCHK(hipEventCreate(&h->ev0));

@@ -145,6 +145,9 @@ struct BitsGeo {
   static constexpr int OFF_FNX = BYTES_FIN;
   static constexpr int BYTES_FNX = BYTES_FIN + 128 * 8 + 128 * 4;
   static constexpr int WC = bits_cols_words<W, H>();  // column-mask words per env in HBM
+  // two stream waves per workgroup (each owns half of the envs and their slabs: no exchange between them) when the halves
+  // are whole 16-byte chunks
+  static constexpr bool SPLIT_OK = EPW == 64 && ((EPW / 2) * S) % 16 == 0;
   static_assert(S % 4 == 0, "W*H must be a multiple of 4 (an env's slab is cleared and copied in dwords)");
 };
 
@@ -365,6 +368,21 @@ __device__ __forceinline__ void st_state(V* dst, const V v) {
   }
 }
 #define TG_ST_STATE(ptr, val) st_state(ptr, val)
+// A PREDICATED 16-byte state store without an exec-mask region: a raw-buffer store whose offset lies outside the
+// descriptor's num_records is dropped by the hardware.  `if (c) store` costs a wave s_and_saveexec + s_cbranch_execz +
+// s_or exec around every store (the compiler keeps the skip branch for memory instructions): 13 of them per lane in the
+// board write-back = 1 416 cycles of issue against 865 this way (tools/ubench/buffer_store_oob.hip, profiles/r03/).
+// `base` = a wave-uniform address, `bytes` what may be written behind it (< 2 GiB), `off` the lane's byte offset.
+// (The same idea for the piece stamps in LDS — cells that are not drawn go to a dump dword of the lane — is SLOWER, 6.39 ->
+// 6.54 us: few lanes draw, and an LDS store of 64 active lanes costs more than the exec-mask region around one of 10.)
+#ifndef TG_NO_BUFFER_ST
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t st_window(void* base, const uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);  // (gfx9 raw buffer: 32-bit data format, no swizzle)
+}
+__device__ __forceinline__ void st_state_if(const __amdgpu_buffer_rsrc_t win, const uint32_t off, const u32x4 v, const bool on) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, win, on ? off : 0x80000000u, 0, TG_STATE_ST == 1 ? 2 : 0);  // (aux 2 = nontemporal)
+}
+#endif
 #ifdef TG_COLS_NT
 #define TG_ST_COLS(ptr, val) st_state(ptr, val)
 #else
@@ -385,9 +403,20 @@ __device__ __forceinline__ void st_state(V* dst, const V v) {
 //   kFeatRgb    TG_OBS_RGB (RgbObservation, wrappers/observation.py:38-74) packed by the two waves
 // Profiles list the kinds of launches separately.
 constexpr int kFeatMulti = 1, kFeatTraj = 2, kFeatDict = 4, kFeatSample = 8, kFeatFinal = 16, kFeatRgb = 32;
-// kFeatWide: the same code compiled for 2 waves per SIMD (up to 256 VGPRs) — picked by the host when the whole launch is
+// kFeatWide: the same code compiled for fewer waves per SIMD (TG_WIDE_WAVES: more VGPRs) — picked by the host when the whole launch is
 // resident at that occupancy anyway (FUNCTIONAL rule-set, plain launches: tg_engine.hip bits_feat_rt)
 constexpr int kFeatWide = 64;
+// kFeatSplit: TWO stream waves per step workgroup (192 threads).  The uint8 payload work is proportional to bytes, not to
+// envs: split over two waves it is the same number of instructions in half the time per wave.  Picked by the host while
+// every workgroup of the launch is still resident with three waves each (up to ~40 000 envs): 4.7 -> 4.3 us at 8 192 envs,
+// 5.7 -> 5.3 at 32 768; at 65 536 the 3-wave workgroups no longer fit beside the RNG role's and the launch is slower
+// (profiles/r03/ab_stream_waves.log).  NUMPY rule-set only (FUNCTIONAL: its logic wave is the long pole, no gain at any batch
+// size); not for the instantiations whose stream wave shares staging buffers with the logic wave.
+constexpr int kFeatSplit = 128;
+template <int W, int H>
+constexpr int bits_stream_waves(const int feat) {
+  return ((feat & kFeatSplit) && BitsGeo<W, H>::SPLIT_OK && !(feat & (kFeatDict | kFeatSample | kFeatFinal | kFeatRgb | kFeatWide))) ? 2 : 1;
+}
 
 // bytes: 0xFF (active) stays -1, other non-zero → 1  (the functional observation, envs/tetris_fn.py:137-158).  Board cells
 // are 0 or a tetromino value 2..8 (tg_set_state rejects bytes >= 0x80 for this rule-set), so the only byte with its top bit
@@ -695,14 +724,24 @@ __device__ __forceinline__ void bits_copy_slab(const uint8_t* src_lds, uint8_t* 
   }
 }
 
-template <int W, int H, int RULESET, int FEAT>
 #ifndef TG_ONE_WAVES
 #define TG_ONE_WAVES 4  // waves per SIMD the one-transition kernels are compiled for (4 → 128 VGPRs, 3 → 168)
 #endif
 #ifndef TG_MULTI_WAVES
 #define TG_MULTI_WAVES 3  // ... the kernels of several transitions per launch (NUMPY: at 4 the plain one spilled 12 registers: 2.90 -> 2.73 us per transition)
 #endif
-__global__ __launch_bounds__(128, (FEAT & kFeatWide) ? 2 : (FEAT & kFeatMulti) ? ((FEAT & (kFeatDict | kFeatSample)) ? 3 : (RULESET == TG_RULESET_NUMPY ? TG_MULTI_WAVES : 4)) : TG_ONE_WAVES) void step_kernel_bits(
+#ifndef TG_WIDE_WAVES
+#define TG_WIDE_WAVES 2  // ... the kFeatWide instantiations (FUNCTIONAL, up to 65 536 envs: one logic + one stream wave per SIMD)
+#endif
+constexpr int bits_waves_per_simd(const int ruleset, const int feat) {
+  return (feat & kFeatWide) ? TG_WIDE_WAVES
+         : (feat & kFeatMulti) ? ((feat & (kFeatDict | kFeatSample)) ? 3 : (ruleset == TG_RULESET_NUMPY ? TG_MULTI_WAVES : 4))
+                               : TG_ONE_WAVES;
+}
+template <int W, int H, int RULESET, int FEAT>
+__global__ __attribute__((amdgpu_flat_work_group_size(64 * (1 + bits_stream_waves<W, H>(FEAT)), 64 * (1 + bits_stream_waves<W, H>(FEAT))),
+                          amdgpu_waves_per_eu(bits_waves_per_simd(RULESET, FEAT), bits_waves_per_simd(RULESET, FEAT))))
+void step_kernel_bits(
     // The arguments every wave needs BEFORE its first global loads, as scalars: the first 14 dwords of the kernel-argument
     // segment are preloaded into SGPRs by the dispatcher (-mllvm -amdgpu-kernarg-preload-count=16, 14 user SGPRs are free;
     // struct arguments are not eligible), so the slab / record / ring loads leave without waiting for a scalar load of
@@ -715,7 +754,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatWide) ? 2 : (FEAT & kFeatMulti) ?
                  SAMPLE = (FEAT & kFeatSample) != 0, FINAL = (FEAT & kFeatFinal) != 0, RGBK = (FEAT & kFeatRgb) != 0;
   using BG = BitsGeo<W, H>;
   using T = ColT<H>;
-  constexpr int S = BG::S, EPW = BG::EPW, NCH = BG::NCH, NIT = BG::NIT, CST = BG::CST;
+  [[maybe_unused]] constexpr int S = BG::S, EPW = BG::EPW, NCH = BG::NCH, NIT = BG::NIT, CST = BG::CST;
   constexpr T ONES = ~T(0);
   constexpr T FLOOR = (T)(ONES << H);  // rows >= H are bedrock (envs/tetris.py:632-641)
   constexpr T PLAY = (T)~FLOOR;
@@ -787,6 +826,13 @@ __global__ __launch_bounds__(128, (FEAT & kFeatWide) ? 2 : (FEAT & kFeatMulti) ?
 #ifndef TG_LOCK_STAMP
 #define TG_LOCK_STAMP(i) do {} while (0)
 #endif
+  // A role ends with s_endpgm, not with a return: a return joins the function's single exit, and the wait-count pass then
+  // treats the RNG role's loads as possibly pending where the logic wave starts — depending on register allocation it put
+  // an s_waitcnt vmcnt(0) between the logic wave's table loads and its record loads (6.4 -> 6.9 us per launch).
+// (The builtin does not cut the edge either — the code behind it still "falls through" to the common join — so the role
+// waits for its own memory operations first: nothing is pending on that edge any more.  The launch cannot complete before
+// those stores anyway.)
+#define TG_ROLE_END() do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_endpgm(); } while (0)
   if (rng_role) {
     // =====================================================================================================
     // RNG ROLE (leading workgroups, 128 envs each): refill every ring that holds fewer than kRing permutations.
@@ -795,6 +841,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatWide) ? 2 : (FEAT & kFeatMulti) ?
 #ifdef TG_PHASE_TIMING
     const unsigned long long rng_t0 = TG_NOW();
 #endif
+    if (bits_stream_waves<W, H>(FEAT) > 1 && threadIdx.x >= 128) TG_ROLE_END();  // (a third wave of the workgroup has no RNG range)
     const uint32_t e = rng_block * 128u + threadIdx.x;
     const bool on = e < B;
     const uint32_t ee = on ? e : B - 1u;
@@ -868,7 +915,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatWide) ? 2 : (FEAT & kFeatMulti) ?
       p.dbg[slot + 1] = TG_NOW();
     }
 #endif
-    return;
+    TG_ROLE_END();
   }
 #ifdef TG_WG_STAGGER
   // experiment: half of the step workgroups start late (k x 512 cycles) so that their load / store bursts fall into the
@@ -878,12 +925,39 @@ __global__ __launch_bounds__(128, (FEAT & kFeatWide) ? 2 : (FEAT & kFeatMulti) ?
 #endif
   TG_BITS_STAMP(0);
 
-  if (wave == 1) {
+  // (the stream block out of line: the logic wave's code comes first, straight behind the common prologue)
+  if (__builtin_expect(wave >= 1, 0)) {
     // =====================================================================================================
-    // STREAM WAVE: the uint8 payload.  Slab block HBM → LDS while the logic wave decides; afterwards the locked
+    // STREAM WAVE(S): the uint8 payload.  Slab block HBM → LDS while the logic wave decides; afterwards the locked
     // cells / cleared rows / resets are applied, changed slabs go back to the board, and the observation leaves.
+    // With two stream waves each owns EPS = EPW / 2 envs (lane l < EPS serves env sbase + l) and their NCHS chunks; the
+    // names below shadow the workgroup's: everything in this block is relative to the wave's own env range.
     // =====================================================================================================
     __builtin_amdgcn_s_setprio(1);
+    constexpr int NSW = bits_stream_waves<W, H>(FEAT);
+    constexpr int EPW_WG = BG::EPW, EPS = EPW_WG / NSW, NCHS = NSW == 1 ? BG::NCH : EPS * S / 16;
+    const uint32_t sbase = NSW == 1 ? 0u : (uint32_t)(wave - 1) * (uint32_t)EPS;
+    const uint32_t nlive_wg = nlive, base_env_wg = base_env;
+    uint8_t* const lds_wg = lds;
+    u32x4* const lds4_wg = lds4;
+    uint4* const post_wg = post;
+    constexpr int EPW = EPS, NCH = NCHS, NIT = (NCHS + 63) / 64;
+    const uint32_t nlive = nlive_wg > sbase ? (nlive_wg - sbase < (uint32_t)EPS ? nlive_wg - sbase : (uint32_t)EPS) : 0u;
+    if (NSW > 1 && nlive == 0u) {  // (ragged last workgroup: no env in this wave's range — only the barriers)
+      for (int step = 0; step < nsteps; ++step) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+      }
+      TG_ROLE_END();
+    }
+    const uint32_t base_env = base_env_wg + sbase;
+    const bool live = (uint32_t)lane < nlive;
+    const int slot = live ? lane : (int)nlive - 1;
+    const uint32_t env = base_env + (uint32_t)slot;
+    (void)env;
+    uint8_t* const lds = lds_wg + (size_t)sbase * S;
+    u32x4* const lds4 = lds4_wg + (NSW == 1 ? 0 : (wave - 1) * NCHS);
+    uint4* const post = post_wg + sbase;
     const bool full_wave = nlive == (uint32_t)EPW;
     const uint32_t nbytes = nlive * (uint32_t)S;
     const uint32_t nchunks = (nbytes + 15u) / 16u;
@@ -962,7 +1036,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatWide) ? 2 : (FEAT & kFeatMulti) ?
 #endif
     // post record of this lane's env: x = lock {cells | val << 16 | place << 24 | clear << 25 | reset << 26},
     // y = lock {x | y << 8}, z = observation {cells | val << 16 | show << 24}, w = observation {x | y << 8}
-    const uint4 po = post[(step & 1) * EPW + slot];
+    const uint4 po = post[(step & 1) * EPW_WG + slot];
     const bool place = live && ((po.x >> 24) & 1u), do_clear = live && ((po.x >> 25) & 1u), do_reset = live && ((po.x >> 26) & 1u);
     const bool dirty = place || do_reset;
     dirty_any = dirty_any || dirty;
@@ -1023,6 +1097,14 @@ __global__ __launch_bounds__(128, (FEAT & kFeatWide) ? 2 : (FEAT & kFeatMulti) ?
           const int c = lane + 64 * k;
           wv[k] = lds4[c < NCH ? c : NCH - 1];
         }
+#if !defined(TG_NO_BUFFER_ST) && !defined(TG_WB_PLAIN)
+        const __amdgpu_buffer_rsrc_t win = st_window(bdst, (uint32_t)NCH * 16u);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const int c = lane + 64 * k;
+          st_state_if(win, 16u * (uint32_t)c, wv[k], c < NCH && differs(wv[k], stage[k]) && !TG_SKIP(2));
+        }
+#else
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
           const int c = lane + 64 * k;
@@ -1035,6 +1117,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatWide) ? 2 : (FEAT & kFeatMulti) ?
 #endif
           }
         }
+#endif
       } else if (full_wave) {
         // the kernels with the transition loop, full workgroup: which envs own bytes of a chunk is plain index arithmetic
         // (the general path below also carries the ragged tail of a partial workgroup inside its loop: ~70 instructions
@@ -1054,6 +1137,9 @@ __global__ __launch_bounds__(128, (FEAT & kFeatWide) ? 2 : (FEAT & kFeatMulti) ?
             const uint32_t e0 = (16u * c) / (uint32_t)S, e1r = (16u * c + 15u) / (uint32_t)S;
             const uint32_t e1 = e1r < (uint32_t)EPW ? e1r : (uint32_t)EPW - 1u;
             const bool hit = c < (uint32_t)NCH && (((dm >> e0) | (dm >> e1)) & 1ull) != 0;
+#if !defined(TG_NO_BUFFER_ST) && !defined(TG_WB_PLAIN)
+            st_state_if(st_window(bdst, (uint32_t)NCH * 16u), 16u * c, wv[kk], hit && !TG_SKIP(2));
+#else
             if (hit && !TG_SKIP(2)) {
 #ifdef TG_WB_PLAIN
               bdst[c] = wv[kk];
@@ -1061,6 +1147,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatWide) ? 2 : (FEAT & kFeatMulti) ?
               st_state(&bdst[c], wv[kk]);
 #endif
             }
+#endif
           }
         }
       } else {
@@ -1134,6 +1221,15 @@ __global__ __launch_bounds__(128, (FEAT & kFeatWide) ? 2 : (FEAT & kFeatMulti) ?
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
           const int c = lane + 64 * k;
+#if !defined(TG_NO_BUFFER_ST) && !defined(TG_NO_NT) && !defined(TG_NO_OBS_TAIL_BUF)
+          if (64 * k + 63 >= NCH) {  // the last, partial pass: the window drops the lanes behind the block (no exec-mask region)
+            if (!TG_SKIP(1)) {
+              __builtin_amdgcn_raw_buffer_store_b128(o[k], st_window(odst, (uint32_t)NCH * 16u), 16u * (uint32_t)c, 0, 2);
+              if (last && obs_traj) __builtin_amdgcn_raw_buffer_store_b128(o[k], st_window(odst2, (uint32_t)NCH * 16u), 16u * (uint32_t)c, 0, 2);
+            }
+            continue;
+          }
+#endif
           if (c < NCH && !TG_SKIP(1)) {
             st_stream(&odst[c], o[k]);
             if (last && obs_traj) st_stream(&odst2[c], o[k]);
@@ -1247,7 +1343,7 @@ __global__ __launch_bounds__(128, (FEAT & kFeatWide) ? 2 : (FEAT & kFeatMulti) ?
       p.dbg[(size_t)step_block * 16 + 14] = __builtin_amdgcn_s_getreg(63492);  // HW_ID: where the stream wave ran
     }
 #endif
-    return;
+    TG_ROLE_END();
   }
 
   // =======================================================================================================
