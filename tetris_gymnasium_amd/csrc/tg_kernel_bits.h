@@ -934,6 +934,14 @@ void step_kernel_bits(
     // names below shadow the workgroup's: everything in this block is relative to the wave's own env range.
     // =====================================================================================================
     __builtin_amdgcn_s_setprio(1);
+    // One transition per launch: the slab loads leave ~2 000 cycles late.  The launch starts with every wave of the grid
+    // loading at once, and the stream waves' 13 KB per workgroup queue in front of the logic waves' records — which are the
+    // start of the critical path, while the slabs are not needed before the publish (6.41 -> 6.28 us, FUNCTIONAL 8.38 ->
+    // 8.29; 16 x 64 cycles: half of that; 48: nothing.  profiles/r03/ab_stream_delay.log)
+#ifndef TG_STREAM_DELAY
+#define TG_STREAM_DELAY 32
+#endif
+    if (!MULTI && TG_STREAM_DELAY > 0) __builtin_amdgcn_s_sleep(TG_STREAM_DELAY);
     constexpr int NSW = bits_stream_waves<W, H>(FEAT);
     constexpr int EPW_WG = BG::EPW, EPS = EPW_WG / NSW, NCHS = NSW == 1 ? BG::NCH : EPS * S / 16;
     const uint32_t sbase = NSW == 1 ? 0u : (uint32_t)(wave - 1) * (uint32_t)EPS;
