@@ -143,7 +143,13 @@ struct BitsGeo {
   // FUNCTIONAL rule-set (never together with the dict / RGB staging): the logic wave's exchange area for the sorts of the
   // key-chain look-ahead — uint2 keys [128] | uint32 permutations [128] — behind the FINAL_OBS records
   static constexpr int OFF_FNX = BYTES_FIN;
-  static constexpr int BYTES_FNX = BYTES_FIN + 128 * 8 + 128 * 4;
+  // ... and behind them (-DTG_FN_DENSE only) the task list of the dense threefry levels: uint4 {key, counter word 1} [192] | uint2 results [192]
+  static constexpr int OFF_FNT = BYTES_FIN + 128 * 8 + 128 * 4;
+#ifdef TG_FN_DENSE
+  static constexpr int BYTES_FNX = OFF_FNT + 192 * 16 + 192 * 8;
+#else
+  static constexpr int BYTES_FNX = OFF_FNT;
+#endif
   static constexpr int WC = bits_cols_words<W, H>();  // column-mask words per env in HBM
   // two stream waves per workgroup (each owns half of the envs and their slabs: no exchange between them) when the halves
   // are whole 16-byte chunks
@@ -427,6 +433,27 @@ __device__ __forceinline__ uint32_t bits_bin1(const uint32_t x) {
   const uint32_t m = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) >> 7) & 0x01010101u;       // 1 where the low seven bits are non-zero
   return m | a | (a - (a >> 7));                                                   // 0x80 → 0xFF
 }
+
+// The same map for four dwords in 17 instructions instead of 28: per byte  min(sign-extended byte, 1)  as a signed 16-bit
+// SDWA minimum written back into its byte (0 → 0, 2..8 → 1, 0xFF = -1 → -1).  The four dwords are interleaved so that three
+// instructions separate two partial writes of the same register (gfx940+: a VALU write with dst_sel needs a wait state
+// before the register is read again; inline assembly is outside the compiler's hazard recogniser — back to back the third
+// byte came out wrong), and the trailing s_nop covers whatever the compiler places behind the block.
+// Checked against bits_bin1 on 65 536 random dwords (profiles/r03/ab_bin4_sdwa.log) and by the FUNCTIONAL parity tests.
+#ifndef TG_NO_SDWA_BIN
+__device__ __forceinline__ u32x4 bits_bin4(const u32x4 v) {
+  uint32_t a = v.x, b = v.y, c = v.z, d = v.w;
+#define TG_R(B) "v_min_i16_sdwa %0, sext(%0), %4 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:WORD_0\n\t" \
+                "v_min_i16_sdwa %1, sext(%1), %4 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:WORD_0\n\t" \
+                "v_min_i16_sdwa %2, sext(%2), %4 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:WORD_0\n\t" \
+                "v_min_i16_sdwa %3, sext(%3), %4 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:WORD_0\n\t"
+  asm(TG_R(0) TG_R(1) TG_R(2) TG_R(3) "s_nop 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(1u));
+#undef TG_R
+  return u32x4{a, b, c, d};
+}
+#else
+__device__ __forceinline__ u32x4 bits_bin4(const u32x4 v) { return u32x4{bits_bin1(v.x), bits_bin1(v.y), bits_bin1(v.z), bits_bin1(v.w)}; }
+#endif
 
 // Two playfield rows (2 W bytes = 2 W / 4 dwords, row pairs start dword-aligned because W is even) → the same two rows of
 // the padded board (bedrock | row | bedrock, W + 8 bytes each; envs/tetris.py:632-641).  Both rows map source byte → output
@@ -1224,7 +1251,7 @@ void step_kernel_bits(
         }
         if (fn) {
 #pragma unroll
-          for (int k = 0; k < NIT; ++k) o[k] = u32x4{bin1(o[k].x), bin1(o[k].y), bin1(o[k].z), bin1(o[k].w)};
+          for (int k = 0; k < NIT; ++k) o[k] = bits_bin4(o[k]);
         }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -2008,11 +2035,47 @@ void step_kernel_bits(
     // loads (event lanes): the key the lane continues from, the chain's last key, R_{n+1}
     uint2 ka = make_uint2(pf_c3.x, pf_c3.y), kb = make_uint2(pf_r1.x, pf_r1.y), knew = make_uint2(pf_c1.x, pf_c1.y);
     if (fn_reset) { knew = kb; ka = kb; }  // R_{n+1} behind a lock of this transition (SAME_STEP), R_n otherwise
+    // -DTG_FN_DENSE (off): the threefry blocks of the levels as a task list in LDS — only the event lanes (one in seven of the
+    // wave, one in sixty for a reset) have keys to advance, but a block costs the wave the same ~110 instructions however few
+    // lanes want it; the event lanes post {key, counter}, lane t runs task t, the owners read the results back: one block per
+    // level instead of two or three.  Measured: 8.07 -> 7.96 us per launch at 65 536 envs (within the engine-to-engine
+    // spread), but 4.13 -> 4.22 per fused transition and 5.80 -> 5.91 at 4 096 envs — the three LDS exchanges are latency on
+    // the logic wave's chain where that chain is what the launch waits for (profiles/r03/ab_functional_dense.log).
+    const uint64_t m1 = __ballot(ev);
+    const int n1 = __popcll(m1);
+    const int q1 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+#ifdef TG_FN_DENSE
+    uint4* tq = reinterpret_cast<uint4*>(lds + BG::OFF_FNT);
+    uint2* tr = reinterpret_cast<uint2*>(lds + BG::OFF_FNT + 192 * 16);
+    auto run_tasks = [&](const int ntask) {  // (ntask is wave-uniform)
+      wave_sync();
+      for (int t0 = 0; t0 < ntask; t0 += 64) {
+        const int t = t0 + lane;
+        const uint4 tk = tq[t < ntask ? t : 0];
+        uint32_t o0, o1;
+        threefry2x32(tk.x, tk.y, 0u, tk.z, o0, o1);
+        if (t < ntask) tr[t] = make_uint2(o0, o1);
+      }
+      wave_sync();
+    };
+#endif
     // level 1
-    uint32_t a0, a1, b0, b1, z0 = 0, z1 = 0;
+    uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0, z0 = 0, z1 = 0;
+#ifndef TG_FN_DENSE
     threefry2x32(ka.x, ka.y, 0u, 0u, a0, a1);
     threefry2x32(ka.x, ka.y, 0u, 1u, b0, b1);
     if (__any(needq)) threefry2x32(kb.x, kb.y, 0u, 1u, z0, z1);
+#else
+    {
+      const uint64_t mq = __ballot(needq);
+      const int qq = 2 * n1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
+      if (ev) { tq[2 * q1] = make_uint4(ka.x, ka.y, 0u, 0u); tq[2 * q1 + 1] = make_uint4(ka.x, ka.y, 1u, 0u); }
+      if (needq) tq[qq] = make_uint4(kb.x, kb.y, 1u, 0u);
+      run_tasks(2 * n1 + __popcll(mq));
+      const uint2 ra = tr[ev ? 2 * q1 : 0], rb = tr[ev ? 2 * q1 + 1 : 0], rz = tr[needq ? qq : 0];
+      a0 = ra.x; a1 = ra.y; b0 = rb.x; b1 = rb.y; z0 = rz.x; z1 = rz.y;
+    }
+#endif
     uint32_t t1x = b0, t1y = b1, t2x = z0, t2y = z1;  // sort keys: lock lanes S2' = sort7(R_{n+3}), Q0' = sort7(f1(R_{n+1}))
 #ifdef TG_FINE_FN
     asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(z0), "+v"(z1));
@@ -2021,10 +2084,24 @@ void step_kernel_bits(
     uint2 c1 = make_uint2(a0, a1), r0 = make_uint2(b0, b1), c2 = c1, c3 = c1, r1 = r0, r2 = r0;
     if (__any(fn_reset) && !((TG_FN_ABL & 1) && p.batch >= 0)) {  // levels 2 and 3 of a fresh chain: c2, R1, then c3, R2
       uint32_t e0, e1, f0_, f1_, g0, g1, h0, h1;
+#ifndef TG_FN_DENSE
       threefry2x32(a0, a1, 0u, 0u, e0, e1);
       threefry2x32(a0, a1, 0u, 1u, f0_, f1_);
       threefry2x32(e0, e1, 0u, 0u, g0, g1);
       threefry2x32(e0, e1, 0u, 1u, h0, h1);
+#else
+      const uint64_t mr = __ballot(fn_reset);
+      const int nr = __popcll(mr);
+      const int qr = 2 * (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mr, 0u));
+      if (fn_reset) { tq[qr] = make_uint4(a0, a1, 0u, 0u); tq[qr + 1] = make_uint4(a0, a1, 1u, 0u); }
+      run_tasks(2 * nr);
+      const uint2 re = tr[fn_reset ? qr : 0], rf = tr[fn_reset ? qr + 1 : 0];
+      e0 = re.x; e1 = re.y; f0_ = rf.x; f1_ = rf.y;
+      if (fn_reset) { tq[qr] = make_uint4(e0, e1, 0u, 0u); tq[qr + 1] = make_uint4(e0, e1, 1u, 0u); }
+      run_tasks(2 * nr);
+      const uint2 rg = tr[fn_reset ? qr : 0], rh = tr[fn_reset ? qr + 1 : 0];
+      g0 = rg.x; g1 = rg.y; h0 = rh.x; h1 = rh.y;
+#endif
       c2 = make_uint2(e0, e1); r1 = make_uint2(f0_, f1_); c3 = make_uint2(g0, g1); r2 = make_uint2(h0, h1);
       if (fn_reset) { t1x = f0_; t1y = f1_; t2x = h0; t2y = h1; }  // S1 = sort7(R_1), S2 = sort7(R_2)
     }
@@ -2034,9 +2111,8 @@ void step_kernel_bits(
     TG_FN_STAMP(5);
     // the sorts, seven lanes each: task list = first sort of every event lane, then the second sorts
     const bool two = needq || fn_reset;
-    const uint64_t m1 = __ballot(ev), m2 = __ballot(two);
-    const int n1 = __popcll(m1), nt = n1 + __popcll(m2);
-    const int q1 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+    const uint64_t m2 = __ballot(two);
+    const int nt = n1 + __popcll(m2);
     const int q2 = n1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
     uint2* xk = reinterpret_cast<uint2*>(lds + BG::OFF_FNX);
     uint32_t* xo = reinterpret_cast<uint32_t*>(lds + BG::OFF_FNX + 128 * 8);
@@ -2082,11 +2158,15 @@ void step_kernel_bits(
     for (int t0 = 0; t0 < (((TG_FN_ABL & 2) && p.batch >= 0) ? 0 : nt); t0 += 16) {  // 16 sorts per trip: two independent threefry streams per lane
       const int ta = t0 + (lane >> 3), tb = ta + 8;
       const uint2 xa = xk[ta < nt ? ta : 0], xb = xk[tb < nt ? tb : 0];
-      uint32_t u0, u1, v0, v1;
+      uint32_t u0, u1, v0 = 0, v1 = 0;
       threefry2x32(xa.x, xa.y, 0u, (uint32_t)j, u0, u1);
-      threefry2x32(xb.x, xb.y, 0u, (uint32_t)j, v0, v1);
-      const uint32_t pa = group_perm(u0 ^ u1), pb = group_perm(v0 ^ v1);
+      const uint32_t pa = group_perm(u0 ^ u1);
       if (j == 0 && ta < nt) xo[ta] = pa;
+#ifndef TG_FN_BOTH_STREAMS
+      if (nt - t0 <= 8) break;  // (eight sorts or fewer left: the second stream would be ~130 instructions for nobody)
+#endif
+      threefry2x32(xb.x, xb.y, 0u, (uint32_t)j, v0, v1);
+      const uint32_t pb = group_perm(v0 ^ v1);
       if (j == 0 && tb < nt) xo[tb] = pb;
     }
     wave_sync();
