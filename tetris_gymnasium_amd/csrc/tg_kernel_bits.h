@@ -28,7 +28,11 @@
 // Round 3: where the generator state after an in-line shuffle lives is a field (`loc`) beside the consumed counter, and the
 // in-line buffer written is never the one this launch's readers were pointed at (round 2 had a race there); the functional
 // rule-set's jax key chain is looked ahead by the env's own logic wave behind its publish (protocol in front of the kernel);
-// a wave issues one instruction per ~4.8 cycles whatever its ILP (tools/ubench/valu_issue.hip): instruction COUNT is the lever.
+// a wave issues one instruction per ~4.8 cycles whatever its ILP (tools/ubench/valu_issue.hip): instruction COUNT is the lever;
+// exec-mask regions and branches cost 15-45 cycles beyond their instructions (tools/ubench/salu_issue.hip): the decision path is
+// selects, predicated global stores are raw-buffer stores with the predicate in the offset; the roles end with s_waitcnt 0 +
+// s_endpgm (a return joins the function exit and the wait-count pass then sees the other roles' loads pending at the logic
+// wave's start); small and medium batches run two stream waves per workgroup (kFeatSplit, picked by the host).
 // Bit-identical to the four earlier step kernels (test-only library) and to the oracle (tests/test_gpu_*.py).
 #pragma once
 #ifndef __HIPCC_RTC__

@@ -38,7 +38,11 @@ def top(db, sub):
     rows = con.execute("select name, total_calls, average from top_kernels").fetchall()
     rows = [r for r in rows if sub in r[0]]
     rows.sort(key=lambda r: -r[1] * r[2])
-    return rows[0] if rows else None
+    if not rows: return None
+    # a block may alternate between instantiations of the step kernel (launches with and without the RNG role's workgroups
+    # pick different FEAT flags): the name of the one with the most time, calls and mean duration over all of them
+    calls = sum(r[1] for r in rows)
+    return (rows[0][0], calls, sum(r[1] * r[2] for r in rows) / calls, [(r[0].split("(")[0], r[1], r[2]) for r in rows])
 latest = {}
 for b in blocks:
     ent = {}
@@ -48,6 +52,7 @@ for b in blocks:
         t = top(db, main_sub)
         if t:
             ent.update(kernel=t[0], kernel_us=t[2] / 1e3 if t[2] > 1e3 else t[2], calls=t[1], kernel_source=f"profiles/ROUND/{b}_kt_summary.md")
+            if len(t[3]) > 1: ent["instantiations"] = [{"kernel": n, "calls": c, "avg_us": (a / 1e3 if a > 1e3 else a)} for n, c, a in t[3]]
     fdb, wdb = f"{out}/{b}_f/f_results.db", f"{out}/{b}_w/w_results.db"
     if os.path.exists(fdb) and os.path.exists(wdb):
         tr = {}
