@@ -1,6 +1,8 @@
 """GPU parity tests proper: the HIP engine (through the C ABI) against (a) golden vectors generated from
 the reference NumPy env and (b) the CPU oracle on identical seeds and actions.  Bit-exact: boards,
 rewards, terminated, lines, observations, piece/queue/bag/RNG state."""
+import os
+
 import numpy as np
 import pytest
 
@@ -97,6 +99,45 @@ def test_numpy_rules_engine_vs_oracle(W, H, Q, gravity, autoreset):
             for k in ("state_lo", "state_hi", "inc_lo", "inc_hi", "uinteger", "has_uint32"):
                 np.testing.assert_array_equal(ge[k], go[k], err_msg=f"rng.{k} t={t}")
     assert done_total > B  # several episodes per env ended (reset/autoreset path exercised)
+
+
+@pytest.mark.parametrize("B", [1, 31, 32, 33, 36, 60, 63, 64, 65, 100, 128 + 40])
+@pytest.mark.parametrize("ruleset", [N.RULESET_NUMPY, N.RULESET_FUNCTIONAL])
+def test_ragged_batches_one_and_eight_transitions_per_launch(B, ruleset, monkeypatch):
+    """The last workgroup of a batch that is no multiple of 64: dead lanes share the LDS slot of the last live env, and with
+    two stream waves per workgroup (the instantiation small NUMPY batches pick) the second wave owns envs 32..63 of the
+    workgroup — none (B % 64 <= 32: it only passes the barriers), some, or all of them.  One transition per launch and the
+    fused rollout, both against the oracle; TG_SPLIT=0 (one stream wave) must give the same."""
+    fn = ruleset == N.RULESET_FUNCTIONAL
+    obs, po_obs, na = (N.OBS_FN, po.OBS_FN, 7) if fn else (N.OBS_BOARD, po.OBS_BOARD, 8)
+    T = 160
+    acts = np.random.default_rng(B).integers(0, na, (T, B)).astype(np.int8)
+    seeds = np.arange(7, 7 + B, dtype=np.uint64)
+    o = po.OracleBatch(B, 10, 20, ruleset)
+    o.reset(seeds)
+    exp = []
+    for t in range(T):
+        r, d, l = o.step(acts[t].astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+        exp.append((r.copy(), d.copy(), l.copy(), o.observe(po_obs).copy()))
+    e = Engine(B, 10, 20, ruleset=ruleset, obs_mode=obs, autoreset=N.AUTORESET_SAME_STEP)
+    if not fn and os.environ.get("TG_SPLIT") != "0":
+        assert int(e.step_kernel_name().rstrip(">").split(",")[-1]) & 128  # two stream waves per workgroup
+    e.reset(seeds)
+    for t in range(T):
+        r, d, l = e.step(acts[t])
+        for g, x, name in zip((r, d, l, e.observation()), exp[t], ("reward", "terminated", "lines", "obs")):
+            np.testing.assert_array_equal(g, x, err_msg=f"{name} t={t}")
+    _cmp_state(e, o, "one transition per launch")
+    if B % 4:  # (tg_rollout packs int8 action rows: batch must be a multiple of 4)
+        e.close()
+        return
+    e.reset(seeds)
+    res = e.rollout(acts)  # 8 transitions per launch, trajectory outputs
+    for t in range(T):
+        np.testing.assert_array_equal(res[0][t], exp[t][3], err_msg=f"rollout obs t={t}")
+        np.testing.assert_array_equal(res[1][t], exp[t][0], err_msg=f"rollout reward t={t}")
+    _cmp_state(e, o, "fused rollout")
+    e.close()
 
 
 @pytest.mark.parametrize("W,H,gravity", [(10, 20, True), (10, 20, False), (20, 40, True), (6, 12, True)])
