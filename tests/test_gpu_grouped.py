@@ -107,8 +107,9 @@ def test_placement_features_against_reference_fixture(golden_dir, name):
     np.testing.assert_array_equal(e.legal_mask(), fx["masks"])
 
 
-def test_placement_features_engine_vs_oracle_random_states():
-    B, W, H = 512, 10, 20
+@pytest.mark.parametrize("W,H", [(10, 20), (7, 14), (6, 9)])
+def test_placement_features_engine_vs_oracle_random_states(W, H):
+    B = 512
     e = Engine(B, W, H, obs_mode=N.OBS_BOARD, grouped=True, features=True, autoreset=N.AUTORESET_SAME_STEP)
     o = po.OracleBatch(B, W, H)
     seeds = np.arange(3, 3 + B, dtype=np.uint64)
@@ -117,7 +118,7 @@ def test_placement_features_engine_vs_oracle_random_states():
     for t in range(40):
         if t % 8 == 0:  # dense stacks: placements that clear 1-4 rows
             b = rng.integers(2, 9, (B, H, W)).astype(np.uint8)
-            b[:, : rng.integers(8, 16)] = 0
+            b[:, : rng.integers(2 * H // 5, 4 * H // 5)] = 0
             for i in range(B):
                 g = rng.integers(0, W - 3); b[i, :, g:g + rng.integers(1, 4)] = 0
             e.set_state(board=b); o.set_state(board=b)
@@ -166,7 +167,7 @@ def test_placement_boards_reference_csv(golden_dir):
     np.testing.assert_array_equal(boards[0, 5 * 4 + 1], fx["csv_board"])
 
 
-@pytest.mark.parametrize("W,H,Q", [(10, 20, 4), (20, 40, 7), (10, 24, 4), (6, 12, 2)])
+@pytest.mark.parametrize("W,H,Q", [(10, 20, 4), (20, 40, 7), (10, 24, 4), (6, 12, 2), (7, 14, 4), (5, 9, 2)])
 def test_placement_boards_engine_vs_oracle_random_states(W, H, Q):
     B = 384
     e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_BOARD, grouped=True, autoreset=N.AUTORESET_SAME_STEP)

@@ -558,11 +558,13 @@ def test_fused_rollout_with_frequent_line_clears(ruleset, fuse, monkeypatch):
 
 @pytest.mark.parametrize("W,H,Q,ruleset", [(14, 28, 4, N.RULESET_NUMPY), (10, 22, 4, N.RULESET_NUMPY), (7, 16, 3, N.RULESET_NUMPY),
                                             (13, 20, 7, N.RULESET_NUMPY), (24, 58, 4, N.RULESET_NUMPY),
-                                            (9, 20, 7, N.RULESET_FUNCTIONAL), (14, 28, 7, N.RULESET_FUNCTIONAL)])
+                                            (7, 14, 4, N.RULESET_NUMPY), (5, 9, 2, N.RULESET_NUMPY), (6, 7, 1, N.RULESET_NUMPY),
+                                            (9, 20, 7, N.RULESET_FUNCTIONAL), (14, 28, 7, N.RULESET_FUNCTIONAL),
+                                            (7, 14, 7, N.RULESET_FUNCTIONAL)])
 def test_board_sizes_compiled_at_create(W, H, Q, ruleset):
     """The reference takes any width / height (envs/tetris.py:77-91, functional/core.py:11-25).  Sizes that are not built
     into the library are compiled for at tg_create (hiprtc, the same kernel templates; odd widths, heights up to 58, slabs
-    that are not a multiple of 8 bytes): single transitions with the reference's dict observation, then fused rollouts,
+    that are not a multiple of 8, 4 or 2 bytes — 7x14 = 98, 6x7 = 42, 5x9 = 45): single transitions with the reference's dict observation, then fused rollouts,
     against the oracle — rewards, observations, boards, records, generators."""
     numpy_rules = ruleset == N.RULESET_NUMPY
     B, T = 320, 160
@@ -608,7 +610,5 @@ def test_board_sizes_compiled_at_create(W, H, Q, ruleset):
 
 def test_board_size_that_cannot_be_compiled_is_refused():
     from tetris_gymnasium_amd import EngineError
-    with pytest.raises(EngineError, match="multiple of 4"):
-        Engine(8, 7, 14)
     with pytest.raises(EngineError, match="outside"):
         Engine(8, 10, 60)

@@ -321,9 +321,10 @@ def test_rgb_observation_against_reference_frames(golden_dir, name):
 
 
 @pytest.mark.parametrize("W,H,Q", [(10, 20, 4), (20, 40, 7), (6, 12, 1), (12, 24, 2),
-                                   (20, 40, 4), (6, 12, 4), (8, 16, 4), (12, 24, 4), (10, 24, 4)])
+                                   (20, 40, 4), (6, 12, 4), (8, 16, 4), (12, 24, 4), (10, 24, 4), (7, 14, 4), (5, 9, 2)])
 def test_rgb_observation_engine_vs_oracle(W, H, Q):
-    """queue_size 4: the image is packed inside the step kernel (both waves); other queue sizes: by the observe kernel."""
+    """queue_size 4: the image is packed inside the step kernel (both waves); other queue sizes — and sizes whose image is no
+    whole number of pixel quads (7x14, 5x9: compiled at tg_create) — by the observe kernel."""
     B, T = 300, 120
     e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_RGB, autoreset=N.AUTORESET_SAME_STEP)
     o = po.OracleBatch(B, W, H, queue_size=Q)
@@ -502,7 +503,7 @@ def test_rollout_entry_points_reject_bad_arguments():
     e.close()
 
 
-@pytest.mark.parametrize("mode", ["numpy", "functional", "grouped", "numpy_20x40"])
+@pytest.mark.parametrize("mode", ["numpy", "functional", "grouped", "numpy_20x40", "numpy_7x14", "functional_7x14"])
 @pytest.mark.parametrize("fuse", [1, 8])
 def test_final_observation_same_step_autoreset(mode, fuse, monkeypatch):
     """TG_FLAG_FINAL_OBS (what gymnasium's same-step autoreset reports as infos["final_observation"], consumed by
@@ -511,9 +512,9 @@ def test_final_observation_same_step_autoreset(mode, fuse, monkeypatch):
     step kernel's stream wave before the reset zeroes the slab.  Oracle: step without autoreset, observe, reset the
     terminated envs (running generators)."""
     monkeypatch.setenv("TG_FUSE", str(fuse))
-    W, H, Q = (20, 40, 7) if mode == "numpy_20x40" else (10, 20, 4)
+    W, H, Q = (20, 40, 7) if mode == "numpy_20x40" else ((7, 14, 4) if mode.endswith("7x14") else (10, 20, 4))  # (7x14: 98-byte slabs)
     B = 1536
-    fn = mode == "functional"
+    fn = mode.startswith("functional")
     grouped = mode == "grouped"
     ruleset, obs, po_obs = (N.RULESET_FUNCTIONAL, N.OBS_FN, po.OBS_FN) if fn else (N.RULESET_NUMPY, N.OBS_BOARD, po.OBS_BOARD)
     e = Engine(B, W, H, ruleset=ruleset, queue_size=(7 if fn else Q), obs_mode=obs, autoreset=N.AUTORESET_SAME_STEP,

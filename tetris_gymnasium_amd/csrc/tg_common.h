@@ -98,16 +98,40 @@ __device__ __forceinline__ void wave_sync() {
 template <int W, int H>
 struct Geo {
   static constexpr int CELLS = W * H;
-  static constexpr int NDW = CELLS / 4;
+  static constexpr int NDW = (CELLS + 3) / 4;             // dwords of an env's slab (the last one partial when CELLS % 4 != 0)
   static constexpr int DPL = (NDW + 63) / 64;             // dwords per lane
   static constexpr int SLAB = ((CELLS + 15) / 16) * 16;   // slab bytes
   static constexpr int LDS_SLAB = 256 * DPL;              // LDS bytes per wave (whole dword-per-lane passes)
   static constexpr int WP = W + 8;
   static constexpr int HP = H + 4;
-  static_assert(CELLS % 4 == 0, "W*H must be a multiple of 4 (dword-per-lane slab transfers)");
   static_assert(H + 4 <= 64, "one row per lane: H + padding must fit a wave");
   static_assert(W <= 32, "row masks are 32-bit");
 };
+
+// Dword idx of an env's uint8 slab in HBM.  With W * H not a multiple of 4 the slabs start at 2- or 1-byte alignment (global
+// memory takes unaligned dword accesses) and the last dword is partial: a load reads into the next env's slab (the buffers
+// carry tail padding; the bytes land behind the slab in LDS, where nobody looks), a store writes the tail byte by byte.
+typedef uint32_t u32_a2 __attribute__((aligned(2)));
+typedef uint32_t u32_a1 __attribute__((aligned(1)));
+template <int CELLS>
+__device__ __forceinline__ uint32_t slab_ld(const uint8_t* base, const int idx) {
+  if constexpr (CELLS % 4 == 0) return reinterpret_cast<const uint32_t*>(base)[idx];
+  else if constexpr (CELLS % 2 == 0) return reinterpret_cast<const u32_a2*>(base)[idx];
+  else return reinterpret_cast<const u32_a1*>(base)[idx];
+}
+template <int CELLS>
+__device__ __forceinline__ void slab_st(uint8_t* base, const int idx, const uint32_t v) {
+  if constexpr (CELLS % 4 == 0) {
+    reinterpret_cast<uint32_t*>(base)[idx] = v;
+  } else {
+    if (4 * idx + 4 <= CELLS) {
+      if constexpr (CELLS % 2 == 0) reinterpret_cast<u32_a2*>(base)[idx] = v;
+      else reinterpret_cast<u32_a1*>(base)[idx] = v;
+    } else {
+      for (int b = 0; 4 * idx + b < CELLS; ++b) base[4 * idx + b] = (uint8_t)(v >> (8 * b));
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // numpy PCG64 (restated from numpy/random/src/pcg64/pcg64.h; pinned by tests through the oracle)
@@ -446,7 +470,6 @@ __device__ __forceinline__ void emit_obs(uint8_t* slab, int lane, uint8_t* dst_e
   if (show) stamp<W, H>(slab, lane, shape, x, y, mode == TG_OBS_FN ? 0xFFu : (uint32_t)val, false);
   wave_sync();
   const uint32_t* slab_dw = reinterpret_cast<const uint32_t*>(slab);
-  uint32_t* dst = reinterpret_cast<uint32_t*>(dst_env);
 #pragma unroll
   for (int k = 0; k < G::DPL; ++k) {
     const int idx = lane + 64 * k;
@@ -457,7 +480,7 @@ __device__ __forceinline__ void emit_obs(uint8_t* slab, int lane, uint8_t* dst_e
         const uint32_t ff = ((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u;
         v = (nz >> 7) | ((ff >> 7) * 0xFFu);
       }
-      dst[idx] = v;
+      slab_st<G::CELLS>(dst_env, idx, v);
     }
   }
 }
@@ -527,11 +550,11 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const ResetParams p) {
   rng_load(r, reseed ? p.new_rng + env : p.rng + env);
   r.dirty = true;
   env_reset<W, H, RULESET>(s, r, p.rng + env, slab_dw, lane, p.queue_size);
-  uint32_t* gboard = reinterpret_cast<uint32_t*>(p.board + (size_t)env * G::CELLS);
+  uint8_t* gboard = p.board + (size_t)env * G::CELLS;
 #pragma unroll
   for (int k = 0; k < G::DPL; ++k) {
     const int idx = lane + 64 * k;
-    if (idx < G::NDW) gboard[idx] = 0u;
+    if (idx < G::NDW) slab_st<G::CELLS>(gboard, idx, 0u);
   }
   emit_obs<W, H>(slab, lane, p.obs + (size_t)env * G::CELLS, p.obs_mode, true, c_shapes.mask[s.piece][0], s.x, 0,
                  s.val);
@@ -651,6 +674,12 @@ __device__ __forceinline__ void observe_env(const ObserveParams& p, const int en
       dst[3 * q + 1] = (c4[1] >> 8) | (c4[2] << 16);
       dst[3 * q + 2] = (c4[2] >> 16) | (c4[3] << 8);
     }
+    if (NPX % 4 != 0 && lane < NPX % 4) {  // (an image that is no whole number of pixel quads: the last pixels byte by byte)
+      const int px = NPX / 4 * 4 + lane;
+      const uint32_t id = img[px], c = lut[id <= 8 ? id : 8];
+      uint8_t* d8 = reinterpret_cast<uint8_t*>(dst) + 3 * px;
+      d8[0] = (uint8_t)c; d8[1] = (uint8_t)(c >> 8); d8[2] = (uint8_t)(c >> 16);
+    }
     if (wide) {
       wave_sync();
       for (int i = lane * 16; i < NPX * 3; i += 1024)
@@ -669,10 +698,15 @@ __device__ __forceinline__ void observe_env(const ObserveParams& p, const int en
       *reinterpret_cast<uint4*>(o_board + i) = *reinterpret_cast<const uint4*>(img + i);
       *reinterpret_cast<uint4*>(o_mask + i) = *reinterpret_cast<const uint4*>(msk + i);
     }
-  } else {
+  } else if constexpr (PC % 4 == 0) {
     for (int i = lane * 4; i < PC; i += 256) {
       *reinterpret_cast<uint32_t*>(o_board + i) = *reinterpret_cast<const uint32_t*>(img + i);
       *reinterpret_cast<uint32_t*>(o_mask + i) = *reinterpret_cast<const uint32_t*>(msk + i);
+    }
+  } else {  // (padded boards that are no whole dwords, e.g. 15 x 18: an env's arrays start at 2- or 1-byte alignment)
+    for (int i = lane; i < PC; i += 64) {
+      o_board[i] = img[i];
+      o_mask[i] = msk[i];
     }
   }
   if (lane < 16) {  // holder: ones when empty, else the held matrix (keeps its rotation and values)
@@ -708,9 +742,9 @@ __global__ __launch_bounds__(kBlock) void observe_kernel(const ObserveParams p) 
 #pragma unroll
   for (int j = 0; j < NE; ++j) {
     const int env = env0 + j < p.batch ? env0 + j : p.batch - 1;
-    const uint32_t* gboard = reinterpret_cast<const uint32_t*>(p.board + (size_t)env * G::CELLS);
+    const uint8_t* gboard = p.board + (size_t)env * G::CELLS;
 #pragma unroll
-    for (int k = 0; k < G::DPL; ++k) bv[j][k] = gboard[lane + 64 * k];  // (buffers carry tail padding: unmasked)
+    for (int k = 0; k < G::DPL; ++k) bv[j][k] = slab_ld<G::CELLS>(gboard, lane + 64 * k);  // (buffers carry tail padding: unmasked)
     const uint4* r4 = reinterpret_cast<const uint4*>(p.rec + (size_t)env * 8);
     ra[j] = r4[0];
     rb[j] = r4[1];

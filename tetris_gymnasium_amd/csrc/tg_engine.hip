@@ -796,9 +796,6 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   if (!built_in && (cfg->width < 4 || cfg->width > 32 || cfg->height < 4 || cfg->height > 58))
     return fail(nullptr, TG_EUNSUPPORTED, "tg_create: board %dx%d outside 4..32 x 4..58 (row masks are 32 bits, column masks 64)",
                 cfg->width, cfg->height);
-  if (!built_in && (cfg->width * cfg->height) % 4 != 0)
-    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: board %dx%d: width * height must be a multiple of 4 (an env's uint8 slab is "
-                "cleared and copied in dwords)", cfg->width, cfg->height);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, TG_EHIP, "tg_create: no HIP device available (this engine has no CPU fallback)");

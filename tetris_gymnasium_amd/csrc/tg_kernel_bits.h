@@ -158,7 +158,6 @@ struct BitsGeo {
   // two stream waves per workgroup (each owns half of the envs and their slabs: no exchange between them) when the halves
   // are whole 16-byte chunks
   static constexpr bool SPLIT_OK = EPW == 64 && ((EPW / 2) * S) % 16 == 0;
-  static_assert(S % 4 == 0, "W*H must be a multiple of 4 (an env's slab is cleared and copied in dwords)");
 };
 
 
@@ -727,6 +726,14 @@ __device__ __forceinline__ void dict_mask_group_incr(uint8_t* buf, const uint4* 
 // batch in flight before its 16-byte stores.  BIN: through the functional observation's byte map.
 template <int S, bool BIN>
 __device__ __forceinline__ void bits_copy_slab(const uint8_t* src_lds, uint8_t* dst) {
+  if constexpr (S % 4 != 0) {  // (slabs at 2- or 1-byte alignment: byte by byte; the terminal observation is rare)
+#pragma unroll 4
+    for (int u = 0; u < S; ++u) {
+      const uint8_t v = src_lds[u];
+      dst[u] = BIN ? (uint8_t)(v >= 0x80u ? 0xFFu : (v ? 1u : 0u)) : v;
+    }
+    return;
+  }
   if constexpr (S % 8 != 0) {  // (slabs of such sizes start at 4-byte alignment only: dword by dword; the terminal observation is rare)
     const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src_lds);
     uint32_t* d4 = reinterpret_cast<uint32_t*>(dst);
@@ -1112,8 +1119,13 @@ void step_kernel_bits(
       while (todo) {  // cooperative zero of a reset env's slab
         const int l = (int)__builtin_ctzll(todo);
         todo &= todo - 1;
-        uint32_t* sw = reinterpret_cast<uint32_t*>(lds + l * S);
-        for (int i = lane; i < S / 4; i += 64) sw[i] = 0u;
+        if constexpr (S % 4 == 0) {
+          uint32_t* sw = reinterpret_cast<uint32_t*>(lds + l * S);
+          for (int i = lane; i < S / 4; i += 64) sw[i] = 0u;
+        } else {  // (slabs of such sizes start at 2- or 1-byte alignment)
+          uint8_t* sb = lds + l * S;
+          for (int i = lane; i < S; i += 64) sb[i] = 0u;
+        }
       }
       wave_sync();
     }

@@ -88,10 +88,10 @@ __global__ __launch_bounds__(kBlock) void features_kernel(const FeatureParams p)
   uint32_t* rm = reinterpret_cast<uint32_t*>(base + OFF_RM);
   uint8_t* ft = base + OFF_FT;
 
-  const uint32_t* gboard = reinterpret_cast<const uint32_t*>(p.board + (size_t)env * G::CELLS);
+  const uint8_t* gboard = p.board + (size_t)env * G::CELLS;
   uint32_t* slab_dw = reinterpret_cast<uint32_t*>(slab);
 #pragma unroll
-  for (int k = 0; k < G::DPL; ++k) slab_dw[lane + 64 * k] = gboard[lane + 64 * k];
+  for (int k = 0; k < G::DPL; ++k) slab_dw[lane + 64 * k] = slab_ld<G::CELLS>(gboard, lane + 64 * k);
   EnvS s;
   rec_unpack(s, p.rec + (size_t)env * 8);
   wave_sync();

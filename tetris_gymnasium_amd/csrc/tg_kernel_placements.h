@@ -32,8 +32,8 @@ __global__ __launch_bounds__(kBlock) void placements_kernel(const PlacementParam
   using M = typename ColMask<H>::type;
   constexpr int WP = G::WP, HP = G::HP, PB = WP * HP, NA = 4 * W;
   constexpr int UNIT = (PB % 16 == 0) ? 16 : 4;  // bytes per lane per store
-  constexpr int NU = PB / UNIT;                  // units per placement board
-  static_assert(PB % 4 == 0, "padded boards are moved in dwords");
+  constexpr int NU = (PB + UNIT - 1) / UNIT;     // units per placement board (the last one partial when PB % 4 != 0: such
+                                                 // boards start at 2- or 1-byte alignment in HBM; slab_st writes the tail)
   // per wave: slab | column masks | row masks | padded base board | scratch board | placement descriptors
   constexpr int PBA = ((PB + 15) / 16) * 16;
   constexpr int OFF_CM = G::LDS_SLAB, OFF_RM = OFF_CM + W * 8, OFF_PB = OFF_RM + ((H * 4 + 15) / 16) * 16;
@@ -51,10 +51,10 @@ __global__ __launch_bounds__(kBlock) void placements_kernel(const PlacementParam
   uint8_t* sb = base + OFF_SB;
   uint4* desc = reinterpret_cast<uint4*>(base + OFF_DS);
 
-  const uint32_t* gboard = reinterpret_cast<const uint32_t*>(p.board + (size_t)env * G::CELLS);
+  const uint8_t* gboard = p.board + (size_t)env * G::CELLS;
   uint32_t* slab_dw = reinterpret_cast<uint32_t*>(slab);
 #pragma unroll
-  for (int k = 0; k < G::DPL; ++k) slab_dw[lane + 64 * k] = gboard[lane + 64 * k];
+  for (int k = 0; k < G::DPL; ++k) slab_dw[lane + 64 * k] = slab_ld<G::CELLS>(gboard, lane + 64 * k);
   EnvS s;
   rec_unpack(s, p.rec + (size_t)env * 8);
   wave_sync();
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void placements_kernel(const PlacementParam
         }
         uint8_t* out = dst + (size_t)a * PB + o;
         if constexpr (UNIT == 16) *reinterpret_cast<uint4*>(out) = make_uint4(v[0], v[1], v[2], v[3]);
-        else *reinterpret_cast<uint32_t*>(out) = v[0];
+        else slab_st<PB>(dst + (size_t)a * PB, o / 4, v[0]);
       }
     }
   }
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void placements_kernel(const PlacementParam
     }
     wave_sync();
     uint8_t* out = dst + (size_t)a * PB;
-    for (int o = lane * 4; o < PB; o += 256) *reinterpret_cast<uint32_t*>(out + o) = *reinterpret_cast<const uint32_t*>(sb + o);
+    for (int o = lane * 4; o < PB; o += 256) slab_st<PB>(out, o / 4, *reinterpret_cast<const uint32_t*>(sb + o));
     wave_sync();
   }
 }
