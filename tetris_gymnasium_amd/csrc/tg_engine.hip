@@ -82,7 +82,8 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
   // two stream waves per workgroup (kFeatSplit) while all workgroups of the launch — the RNG role's included — are resident
   // with three waves each at the occupancy the instantiation is compiled for
   const int base = feat & ~tg::kFeatWide;
-  if (!g_split || !split_ok || RS != TG_RULESET_NUMPY || !(base == 0 || base == M || base == (M | T))) return feat;
+  if (!g_split || !split_ok || RS != TG_RULESET_NUMPY ||
+      !(base == 0 || base == M || base == (M | T) || base == tg::kFeatDict || base == (M | T | tg::kFeatDict))) return feat;
   const int per_simd = tg::bits_waves_per_simd(RS, feat);
   const long cap = (long)(g_simds / 4) * (4 * per_simd / 3);
   const long wgs = (p.batch + epw - 1) / epw + ((RS == TG_RULESET_NUMPY && p.rng_role) ? (p.batch + 127) / 128 : 0);
@@ -136,7 +137,8 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
     const int feat = bits_feat<W, H, RS>(p);
     const size_t lds = RS == TG_RULESET_FUNCTIONAL ? BG::BYTES_FNX
-                       : ((feat & D) ? BG::BYTES_DICT : ((feat & R) ? BG::BYTES_RGB : ((feat & F) ? BG::BYTES_FIN : BG::BYTES)));
+                       : ((feat & D) ? ((feat & tg::kFeatSplit) ? BG::BYTES_DICT_SPLIT : BG::BYTES_DICT)
+                                     : ((feat & R) ? BG::BYTES_RGB : ((feat & F) ? BG::BYTES_FIN : BG::BYTES)));
 #define TG_LAUNCH_BITS(FT)                                                                                                  \
   hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(64 * (1 + tg::bits_stream_waves<W, H>(FT))), lds, s, p.board, p.rec, p.cols, bp.ring_rd, bp.hbuf_rd, \
                      p.actions, p.batch, (uint32_t)n_step_wgs | ((p.act_i8 ? 1u : 0u) << 24) | ((uint32_t)(p.nsteps > 0 ? p.nsteps : 0) << 25), \
@@ -157,6 +159,8 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     }
     if constexpr (BG::SPLIT_OK && RS == TG_RULESET_NUMPY) {
       constexpr int P = tg::kFeatSplit;
+      if (feat == (P | D)) { TG_LAUNCH_BITS(P | D); return; }
+      if (feat == (P | M | T | D)) { TG_LAUNCH_BITS(P | M | T | D); return; }
       if (feat == (P | M | T)) { TG_LAUNCH_BITS(P | M | T); return; }
       if (feat == (P | M)) { TG_LAUNCH_BITS(P | M); return; }
       if (feat == P) { TG_LAUNCH_BITS(P); return; }
@@ -273,7 +277,7 @@ std::string csrc_dir() {
 std::vector<int> rtc_feats(int RS) {
   constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
   constexpr int P = tg::kFeatSplit, Wd = tg::kFeatWide;
-  if (RS == TG_RULESET_NUMPY) return {0, M, M | T, F, M | T | F, D, M | T | D, T | S, M | T | S, R, M | T | S | R, P, P | M, P | M | T};
+  if (RS == TG_RULESET_NUMPY) return {0, M, M | T, F, M | T | F, D, M | T | D, T | S, M | T | S, R, M | T | S | R, P, P | M, P | M | T, P | D, P | M | T | D};
   return {0, M, M | T, F, M | T | F, Wd, M | Wd};
 }
 
@@ -403,7 +407,9 @@ Launchers rtc_launchers(const RtcSize* r) {
     const int n_step_wgs = (p.batch + EPW - 1) / EPW;
     const bool split_ok = EPW == 64 && (32 * W * H) % 16 == 0;  // (BitsGeo::SPLIT_OK)
     const int feat = bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, split_ok);
-    const size_t lds = RS == TG_RULESET_FUNCTIONAL ? r->geo[5] : ((feat & D) ? r->geo[2] : ((feat & R) ? r->geo[3] : ((feat & F) ? r->geo[4] : r->geo[1])));
+    const size_t lds = RS == TG_RULESET_FUNCTIONAL ? r->geo[5]
+                       : ((feat & D) ? r->geo[2] + ((feat & tg::kFeatSplit) ? 16 * (W + 8) * (H + 4) : 0)  // (BYTES_DICT_SPLIT: + GD * PC)
+                                     : ((feat & R) ? r->geo[3] : ((feat & F) ? r->geo[4] : r->geo[1])));
     auto it = r->step.find(feat);
     if (it == r->step.end()) return;
     uint8_t* a0 = p.board; uint32_t* a1 = p.rec; void* a2 = p.cols; const uint4* a3 = bp.ring_rd; const uint32_t* a4 = bp.hbuf_rd;

@@ -130,6 +130,8 @@ struct BitsGeo {
   static constexpr int OFF_DICT = BYTES;
   static constexpr int OFF_OLDPW = BYTES + 2 * GD * PC;  // uint32 [EPW]: the box TG_BUF_OBS's mask array shows per env
   static constexpr int BYTES_DICT = OFF_OLDPW + EPW * 4;
+  static constexpr int OFF_DICT2 = BYTES_DICT;             // (kFeatSplit: the second stream wave's board staging buffer)
+  static constexpr int BYTES_DICT_SPLIT = BYTES_DICT + GD * PC;
   static constexpr bool DICT_OK = PC % 16 == 0 && EPW % GD == 0 && H % 2 == 0 && W % 2 == 0;  // (row pairs as whole dwords)
   // TG_OBS_RGB packed in the kernel (queue_size 4): uint4 post2[EPW] {queue bytes | holder} published by the logic wave,
   // then one id-image staging buffer of GR envs per wave.  Image row = padded board row | 4 queue pieces x 4 columns.
@@ -424,7 +426,8 @@ constexpr int kFeatWide = 64;
 constexpr int kFeatSplit = 128;
 template <int W, int H>
 constexpr int bits_stream_waves(const int feat) {
-  return ((feat & kFeatSplit) && BitsGeo<W, H>::SPLIT_OK && !(feat & (kFeatDict | kFeatSample | kFeatFinal | kFeatRgb | kFeatWide))) ? 2 : 1;
+  return ((feat & kFeatSplit) && BitsGeo<W, H>::SPLIT_OK && !(feat & (kFeatSample | kFeatFinal | kFeatRgb | kFeatWide)) &&
+          (!(feat & kFeatDict) || (BitsGeo<W, H>::DICT_OK && (BitsGeo<W, H>::EPW / 2) % BitsGeo<W, H>::GD == 0))) ? 2 : 1;
 }
 
 // bytes: 0xFF (active) stays -1, other non-zero → 1  (the functional observation, envs/tetris_fn.py:137-158).  Board cells
@@ -1311,7 +1314,7 @@ void step_kernel_bits(
       bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu), (po.z >> 16) & 0xFFu, false,
                live && ((po.z >> 24) & 1u));
       wave_sync();
-      uint8_t* grp = lds + BG::OFF_DICT;
+      uint8_t* grp = lds_wg + ((NSW == 2 && wave == 2) ? BG::OFF_DICT2 : BG::OFF_DICT);  // (this wave's staging buffer)
       uint8_t* dst0 = obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs;
       uint8_t* dst1 = (last && obs_traj) ? p.obs : nullptr;
       constexpr int GD = BG::GD, NPAIR = HP / 2, NS = 2 * W / 4, ND = 2 * WP / 4;
