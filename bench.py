@@ -355,9 +355,10 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
 
 def vector_env_block(local, *, B=65536, steps=64, warmup=8):
     """env steps/s through the gymnasium.vector adapter (TetrisVectorEnv.step, what examples/train_ppo.py:240-245 calls):
-    with the observation copied to host NumPy (the SyncVectorEnv contract) and with the results left on the device as
-    zero-copy views (`step(actions, to_host=False)`).  Wall clock of Python + C ABI + kernels + (for the host form) PCIe;
-    actions are host int32 arrays in both forms.  Never `value`: the PCIe-inclusive rate of the drop-in surface."""
+    with the observation copied to host NumPy (the SyncVectorEnv contract), with the results left on the device as
+    zero-copy views (`step(actions, to_host=False)`, actions still a host int32 array), and with the actions on the device
+    too (a device pointer per step: what a policy running on the GPU hands over).  Wall clock of Python + C ABI + kernels
+    + PCIe where there is any.  Never `value`: the rate of the drop-in surface."""
     from tetris_gymnasium_amd.vector import TetrisVectorEnv
 
     out = {}
@@ -367,24 +368,31 @@ def vector_env_block(local, *, B=65536, steps=64, warmup=8):
         v = TetrisVectorEnv(B, observation=kind, autoreset_mode="same_step", devices=(local,))
         v.reset(seed=1)
         res = {}
-        for form in ("host", "device"):
+        e0 = v.engines[0]
+        d_acts = e0.dev_alloc(acts.nbytes)  # the third form: the policy's actions are on the device already (int32 [T][B])
+        e0.dev_upload(d_acts, acts)
+        for form in ("host", "device", "device_actions"):
+            act = (lambda t: d_acts + t * B * 4) if form == "device_actions" else (lambda t: acts[t])
             for t in range(warmup):
-                v.step(acts[t], to_host=(form == "host"))
-            v.engines[0].sync()
+                v.step(act(t), to_host=(form == "host"))
+            e0.sync()
             t0 = time.perf_counter()
             for t in range(warmup, warmup + steps):
-                v.step(acts[t], to_host=(form == "host"))
-            v.engines[0].sync()
+                v.step(act(t), to_host=(form == "host"))
+            e0.sync()
             dt = time.perf_counter() - t0
             res[form] = {"value": B * steps / dt, "unit": "env steps/s", "us_per_step": dt / steps * 1e6}
+        e0.dev_free(d_acts)
         obs_bytes = 200 if kind == "board" else 944
         res["host"]["pcie_bytes_per_env_step"] = obs_bytes + 8 + 4
         res["device"]["pcie_bytes_per_env_step"] = 4  # the host actions
+        res["device_actions"]["pcie_bytes_per_env_step"] = 0
         out[kind] = res
         v.close()
     out["note"] = (f"TetrisVectorEnv.step at {B} envs on one GPU, {steps} steps after {warmup}: `host` returns NumPy observations "
                    "(gymnasium contract), `device` returns DeviceArray views (__cuda_array_interface__ / DLPack) and copies "
-                   "nothing back; Python overhead included")
+                   "nothing back, `device_actions` additionally takes the actions from a device pointer; Python overhead "
+                   "included")
     return out
 
 

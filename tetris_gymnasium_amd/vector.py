@@ -115,6 +115,7 @@ class TetrisVectorEnv(VectorEnvBase):
         # of them, so calls on ONE handle never overlap (the C ABI's contract); which pool thread runs a shard does not
         # matter — every entry point sets its device itself.
         self._pool = ThreadPoolExecutor(len(self.engines), thread_name_prefix="tg-shard") if len(self.engines) > 1 else None
+        self._dev_views = {}  # shard -> (observation view(s), outputs views) of step_device
         self.final_obs = bool(final_observation) and autoreset_mode == "same_step" and observation in ("board", "functional")
 
     # ---- helpers --------------------------------------------------------------------------------
@@ -194,7 +195,11 @@ class TetrisVectorEnv(VectorEnvBase):
                 e.step_device(a.ptr if isinstance(a, DeviceArray) else a)
             else:
                 e.step_async(actions[lo:hi])
-            return e.device_array(N.BUF_OBS) if e.obs_mode != N.OBS_NONE else None, e.device_array(N.BUF_STEP_OUT)
+            views = self._dev_views.get(k)  # (the engine's buffers never move: the views are built once per shard)
+            if views is None:
+                views = self._dev_views[k] = (e.device_array(N.BUF_OBS) if e.obs_mode != N.OBS_NONE else None,
+                                              e.device_array(N.BUF_STEP_OUT))
+            return views
 
         jobs = [(k, e, lo, hi) for k, (e, (lo, hi)) in enumerate(zip(self.engines, self.ranges))]
         parts = [one(*j) for j in jobs] if self._pool is None else list(self._pool.map(lambda j: one(*j), jobs))
@@ -267,6 +272,7 @@ class TetrisVectorEnv(VectorEnvBase):
         if self._pool is not None:
             self._pool.shutdown(wait=True)
             self._pool = None
+        self._dev_views = {}
         for e in self.engines:
             e.close()
         self.engines = []
