@@ -371,26 +371,28 @@ def vector_env_block(local, *, B=65536, steps=64, warmup=8):
         e0 = v.engines[0]
         d_acts = e0.dev_alloc(acts.nbytes)  # the third form: the policy's actions are on the device already (int32 [T][B])
         e0.dev_upload(d_acts, acts)
-        for form in ("host", "device", "device_actions"):
+        for form in ("host", "host_pinned", "device", "device_actions"):
+            if form == "host_pinned":  # (gymnasium's copy=False: views of rotating page-locked buffers)
+                e0.use_pinned_observations(2)
             act = (lambda t: d_acts + t * B * 4) if form == "device_actions" else (lambda t: acts[t])
             for t in range(warmup):
-                v.step(act(t), to_host=(form == "host"))
+                v.step(act(t), to_host=form.startswith("host"))
             e0.sync()
             t0 = time.perf_counter()
             for t in range(warmup, warmup + steps):
-                v.step(act(t), to_host=(form == "host"))
+                v.step(act(t), to_host=form.startswith("host"))
             e0.sync()
             dt = time.perf_counter() - t0
             res[form] = {"value": B * steps / dt, "unit": "env steps/s", "us_per_step": dt / steps * 1e6}
         e0.dev_free(d_acts)
         obs_bytes = 200 if kind == "board" else 944
-        res["host"]["pcie_bytes_per_env_step"] = obs_bytes + 8 + 4
+        res["host"]["pcie_bytes_per_env_step"] = res["host_pinned"]["pcie_bytes_per_env_step"] = obs_bytes + 8 + 4
         res["device"]["pcie_bytes_per_env_step"] = 4  # the host actions
         res["device_actions"]["pcie_bytes_per_env_step"] = 0
         out[kind] = res
         v.close()
     out["note"] = (f"TetrisVectorEnv.step at {B} envs on one GPU, {steps} steps after {warmup}: `host` returns NumPy observations "
-                   "(gymnasium contract), `device` returns DeviceArray views (__cuda_array_interface__ / DLPack) and copies "
+                   "(gymnasium contract; `host_pinned`: copy=False, views of page-locked buffers), `device` returns DeviceArray views (__cuda_array_interface__ / DLPack) and copies "
                    "nothing back, `device_actions` additionally takes the actions from a device pointer; Python overhead "
                    "included")
     return out

@@ -277,6 +277,11 @@ int tg_num_actions(const tg_config* cfg);
 /* Device memory helpers so a ctypes-only host program needs no other GPU library. */
 int tg_dev_alloc(tg_handle* h, size_t bytes, void** ptr);
 int tg_dev_free(tg_handle* h, void* ptr);
+/* Page-locked host memory (hipHostMalloc): a tg_fetch / tg_dev_download into it is one DMA at PCIe rate instead of a staged
+ * copy through the runtime's bounce buffers — what the host-NumPy observation path of the gymnasium.vector adapter uses
+ * (TetrisVectorEnv(copy=False); replaces the per-step `np.stack` of SyncVectorEnv, gymnasium/vector/sync_vector_env.py). */
+int tg_host_alloc(tg_handle* h, size_t bytes, void** ptr);
+int tg_host_free(tg_handle* h, void* ptr);
 int tg_dev_upload(tg_handle* h, void* dst_dev, const void* src_host, size_t bytes);
 int tg_dev_download(tg_handle* h, void* dst_host, const void* src_dev, size_t bytes);
 /* device → device, asynchronous on the handle's stream (e.g. keep a copy of TG_BUF_OBS before the next transition overwrites it) */

@@ -242,3 +242,31 @@ def test_engine_knobs_come_from_the_config_not_the_environment(monkeypatch):
         for g, r in zip(got, ref):
             np.testing.assert_array_equal(g, r)
         e.close()
+
+
+@pytest.mark.parametrize("kind", ["board", "dict"])
+def test_vector_env_copy_false_returns_pinned_views_with_the_same_content(kind):
+    """TetrisVectorEnv(copy=False) = gymnasium's SyncVectorEnv(copy=False): observations are views of two rotating
+    page-locked host buffers (tg_host_alloc).  Same content as copy=True at every step; an array stays intact for one
+    further step and is reused by the one after."""
+    B = 1000
+    a = TetrisVectorEnv(B, observation=kind, autoreset_mode="same_step", copy=True)
+    b = TetrisVectorEnv(B, observation=kind, autoreset_mode="same_step", copy=False)
+    oa, _ = a.reset(seed=3); ob, _ = b.reset(seed=3)
+    first = (lambda o: o["board"] if isinstance(o, dict) else o)
+    rng = np.random.default_rng(1)
+    prev, prev_copy = None, None
+    seen_ptrs = set()
+    for t in range(6):
+        act = rng.integers(0, 8, B)
+        oa, ra, ta, _, _ = a.step(act)
+        ob, rb, tb, _, _ = b.step(act)
+        for k in (oa if isinstance(oa, dict) else [None]):
+            np.testing.assert_array_equal(ob[k] if k else ob, oa[k] if k else oa, err_msg=f"obs[{k}] t={t}")
+        np.testing.assert_array_equal(rb, ra); np.testing.assert_array_equal(tb, ta)
+        if prev is not None:
+            np.testing.assert_array_equal(prev, prev_copy, err_msg="the previous step's view was overwritten one step later")
+        prev, prev_copy = first(ob), first(ob).copy()
+        seen_ptrs.add(first(ob).__array_interface__["data"][0])
+    assert len(seen_ptrs) == 2  # two slots, rotating
+    a.close(); b.close()

@@ -87,6 +87,8 @@ SYMBOLS = {
     "tg_num_actions": (_i, [C.POINTER(TgConfig)]),
     "tg_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "tg_dev_free": (_i, [_vp, _vp]),
+    "tg_host_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "tg_host_free": (_i, [_vp, _vp]),
     "tg_dev_upload": (_i, [_vp, _vp, _vp, _sz]),
     "tg_dev_download": (_i, [_vp, _vp, _vp, _sz]),
     "tg_dev_copy": (_i, [_vp, _vp, _vp, _sz]),

@@ -1419,6 +1419,22 @@ int tg_dev_alloc(tg_handle* h, size_t bytes, void** ptr) {
   return TG_OK;
 }
 
+int tg_host_alloc(tg_handle* h, size_t bytes, void** ptr) {
+  if (!h || !ptr) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return TG_OK;
+}
+
+int tg_host_free(tg_handle* h, void* ptr) {
+  if (!h) return TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipHostFree(ptr));
+  return TG_OK;
+}
+
 int tg_dev_free(tg_handle* h, void* ptr) {
   if (!h) return TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));

@@ -147,6 +147,7 @@ class Engine:
         Results never depend on them."""
         self.lib = N.load()
         self._pool = {}      # free device buffers by size (DeviceBuffer)
+        self._pinned, self._pinned_ptrs, self._pin_slots = {}, [], 0  # page-locked host buffers (use_pinned_observations)
         if queue_size is None:
             queue_size = 4 if ruleset == N.RULESET_NUMPY else 7
         if obs_mode is None:
@@ -180,6 +181,10 @@ class Engine:
                 for p in ptrs:
                     self.lib.tg_dev_free(self.h, C.c_void_p(p))
             self._pool = {}
+            self._pinned = {}
+            for p in self._pinned_ptrs:
+                self.lib.tg_host_free(self.h, C.c_void_p(p))
+            self._pinned_ptrs = []
             self.lib.tg_destroy(self.h)
             self.h = None
 
@@ -263,7 +268,7 @@ class Engine:
         return self.fetch_outputs()
 
     def fetch_outputs(self):
-        out = np.empty(self.B, N.STEP_OUT)
+        out = self._host_array((self.B,), N.STEP_OUT, "out")
         self._chk(self.lib.tg_fetch(self.h, N.BUF_STEP_OUT, N.ptr(out), out.nbytes), "tg_fetch(step_out)")
         return (np.ascontiguousarray(out["reward"]), np.ascontiguousarray(out["terminated"]),
                 np.ascontiguousarray(out["lines"]))
@@ -273,15 +278,36 @@ class Engine:
         self._chk(self.lib.tg_fetch(self.h, which, N.ptr(arr), arr.nbytes), f"tg_fetch({which})")
         return arr
 
+    def use_pinned_observations(self, slots=2):
+        """observation() / fetch_outputs() return views of `slots` rotating page-locked host buffers instead of fresh NumPy
+        arrays: the device-to-host copy is one DMA at PCIe rate and nothing is allocated per call.  A returned array is
+        overwritten `slots` calls later (gymnasium's `copy=False`); the buffers live until close()."""
+        self._pin_slots = max(2, int(slots))
+
+    def _host_array(self, shape, dtype, tag):
+        """a host array for a fetch: fresh (default) or the next page-locked slot of its kind"""
+        if not getattr(self, "_pin_slots", 0):
+            return np.empty(shape, dtype)
+        ring = self._pinned.setdefault((tag, tuple(shape), np.dtype(dtype).str), [])
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if len(ring) < self._pin_slots:
+            p = C.c_void_p()
+            self._chk(self.lib.tg_host_alloc(self.h, nbytes, C.byref(p)), "tg_host_alloc")
+            self._pinned_ptrs.append(p.value)
+            ring.append(np.ctypeslib.as_array((C.c_uint8 * max(nbytes, 1)).from_address(p.value))[:nbytes].view(dtype).reshape(shape))
+            return ring[-1]
+        ring.append(ring.pop(0))
+        return ring[-1]
+
     def observation(self, which=N.BUF_OBS):
         """The observation buffer of the engine's obs_mode as NumPy array(s)."""
         if self.obs_mode == N.OBS_BOARD:
-            return self._fetch(which, np.empty((self.B, self.H, self.W), np.uint8))
+            return self._fetch(which, self._host_array((self.B, self.H, self.W), np.uint8, which))
         if self.obs_mode == N.OBS_FN:
-            return self._fetch(which, np.empty((self.B, self.H, self.W), np.int8))
+            return self._fetch(which, self._host_array((self.B, self.H, self.W), np.int8, which))
         if self.obs_mode == N.OBS_DICT:
             cells, pp, B = self.Hp * self.Wp, self.P * self.P, self.B
-            flat = self._fetch(which, np.empty(B * (2 * cells + pp + pp * self.Q), np.uint8))
+            flat = self._fetch(which, self._host_array((B * (2 * cells + pp + pp * self.Q),), np.uint8, which))
             o = 0
             board = flat[o:o + B * cells].reshape(B, self.Hp, self.Wp); o += B * cells
             mask = flat[o:o + B * cells].reshape(B, self.Hp, self.Wp); o += B * cells
@@ -289,7 +315,7 @@ class Engine:
             queue = flat[o:o + B * pp * self.Q].reshape(B, self.P, self.P * self.Q)
             return {"board": board, "active_tetromino_mask": mask, "holder": holder, "queue": queue}
         if self.obs_mode == N.OBS_RGB:
-            return self._fetch(which, np.empty((self.B, self.Hp, self.Wp + self.P * max(1, self.Q), 3), np.uint8))
+            return self._fetch(which, self._host_array((self.B, self.Hp, self.Wp + self.P * max(1, self.Q), 3), np.uint8, which))
         raise EngineError("engine was created with obs_mode NONE")
 
     def device_array(self, which=N.BUF_OBS):

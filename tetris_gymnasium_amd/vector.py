@@ -47,8 +47,13 @@ class TetrisVectorEnv(VectorEnvBase):
     def __init__(self, num_envs: int, width: int = 10, height: int = 20, gravity: bool = True, *,
                  ruleset: str = "numpy", observation: str = "dict", queue_size: int | None = None,
                  autoreset_mode: str = "next_step", devices=(0,), episode_stats: bool = True,
-                 grouped: bool = False, terminate_on_illegal_action: bool = True, final_observation: bool = False):
-        """final_observation: with autoreset_mode="same_step" and a board / functional observation, `infos` of a step in
+                 grouped: bool = False, terminate_on_illegal_action: bool = True, final_observation: bool = False,
+                 copy: bool = True):
+        """copy=False (gymnasium's SyncVectorEnv(copy=False), gymnasium/vector/sync_vector_env.py): the observations `reset` /
+        `step` return are views of rotating page-locked host buffers — valid until the next-but-one call — instead of fresh
+        NumPy arrays: the device-to-host copy becomes one DMA at PCIe rate and nothing is allocated per step (single-device
+        envs; with several shards the parts are still concatenated into a fresh array).
+        final_observation: with autoreset_mode="same_step" and a board / functional observation, `infos` of a step in
         which episodes ended carries "final_observation" (the terminal observation of those envs, the reset observation is
         what `step` returns) and "_final_observation" — gymnasium's same-step autoreset convention
         (examples/train_cnn.py:312-316)."""
@@ -116,6 +121,9 @@ class TetrisVectorEnv(VectorEnvBase):
         # matter — every entry point sets its device itself.
         self._pool = ThreadPoolExecutor(len(self.engines), thread_name_prefix="tg-shard") if len(self.engines) > 1 else None
         self._dev_views = {}  # shard -> (observation view(s), outputs views) of step_device
+        if not copy:
+            for e in self.engines:
+                e.use_pinned_observations(2)
         self.final_obs = bool(final_observation) and autoreset_mode == "same_step" and observation in ("board", "functional")
 
     # ---- helpers --------------------------------------------------------------------------------
@@ -139,6 +147,8 @@ class TetrisVectorEnv(VectorEnvBase):
         if self.obs_kind == "placement_features":
             self._cur_feats = np.concatenate([p[1] for p in parts])
         obs = [p[0] for p in parts]
+        if len(obs) == 1:  # one shard: its arrays ARE the result (a concatenate of one part would copy 13 MB per step for nothing)
+            return obs[0]
         if isinstance(obs[0], dict):
             return {k: np.concatenate([o[k] for o in obs]) for k in obs[0]}
         return np.concatenate(obs)
