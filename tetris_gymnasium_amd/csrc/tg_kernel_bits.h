@@ -1555,13 +1555,24 @@ void step_kernel_bits(
   // FUNCTIONAL: the look-ahead keys a lock of this transition will continue from — requested now (their address depends on
   // the record's position counter), consumed behind the publish (fn_book): as a dependent load there they stood in
   // front of three threefry levels while the memory system was busy with the stream waves' stores (3.3 us)
+  // One transition per launch, large batches (round 3, second half): requested by EVERY lane they pull the env's whole
+  // 128-byte look-ahead block in with every launch — 8.4 MB of the 46 MB a launch of 65 536 envs moves, for the one env in
+  // seven that locks.  Beyond the batch whose working set the Infinity Cache holds that is what the launch waits for: there
+  // the keys are requested behind the publish, by the event lanes only, and claimed in front of the first store (the logic
+  // wave ends 1.4 us before its stream wave: it can wait).  98 304 envs 11.5 -> 9.9 us, 131 072 18.2 -> 16.6, 524 288
+  // 57.9 -> 52.0; at 65 536 the same, at 4 096 +2 % — hence the threshold (profiles/r03/ab_functional_late_prefetch.log).
+#ifndef TG_FN_PREFETCH_ALL
+  const bool fn_prefetch_late = RULESET == TG_RULESET_FUNCTIONAL && !MULTI && hot_batch > 49152;
+#else
+  constexpr bool fn_prefetch_late = false;
+#endif
   u32x2 pf_c1 = u32x2{0u, 0u}, pf_c3 = pf_c1, pf_r1 = pf_c1;  // (native vectors: HIP's uint2 struct went to scratch memory)
-  if (RULESET == TG_RULESET_FUNCTIONAL) {
+  const int fn_n0 = (int)(s.reserved & 3u);
+  // (an env that only resets in this transition — NEXT_STEP autoreset, the step after its end — continues with R_n)
+  const bool fn_pend0 = p.autoreset == TG_AUTORESET_NEXT_STEP && (s.flags & TG_F_PENDING_RESET);
+  if (RULESET == TG_RULESET_FUNCTIONAL && !fn_prefetch_late) {
     const u32x2* cs = reinterpret_cast<const u32x2*>(bp.ahead) + (size_t)env * 16;
-    const int n = (int)(s.reserved & 3u);
-    // (an env that only resets in this transition — NEXT_STEP autoreset, the step after its end — continues with R_n)
-    const bool pend = p.autoreset == TG_AUTORESET_NEXT_STEP && (s.flags & TG_F_PENDING_RESET);
-    pf_c1 = cs[(n + 1) & 3]; pf_c3 = cs[(n + 3) & 3]; pf_r1 = cs[4 + ((pend ? n : n + 1) & 3)];
+    pf_c1 = cs[(fn_n0 + 1) & 3]; pf_c3 = cs[(fn_n0 + 3) & 3]; pf_r1 = cs[4 + ((fn_pend0 ? fn_n0 : fn_n0 + 1) & 3)];
   }
   int action_in = hot_act_i8 ? (int)(int8_t)(apack >> (8 * step)) : action0;
   if (RULESET == TG_RULESET_NUMPY && sample_mode) {
@@ -2232,6 +2243,10 @@ void step_kernel_bits(
   }
   // (every load result the rest of the transition uses is claimed HERE, in front of the first store behind the publish: on
   // gfx9 a wait for a load with stores pending is a wait for the stores — vmcnt counts both, and they complete out of order)
+  if (fn_prefetch_late && (fn_lock | fn_reset)) {
+    const u32x2* cs = reinterpret_cast<const u32x2*>(bp.ahead) + (size_t)env * 16;
+    pf_c1 = cs[(fn_n0 + 1) & 3]; pf_c3 = cs[(fn_n0 + 3) & 3]; pf_r1 = cs[4 + ((fn_pend0 ? fn_n0 : fn_n0 + 1) & 3)];
+  }
   if (RULESET == TG_RULESET_FUNCTIONAL) asm volatile("" : "+v"(pf_c1), "+v"(pf_c3), "+v"(pf_r1));
 #ifndef TG_NO_EP_CLAIM
   asm volatile("" : "+v"(ep.ret), "+v"(ep.len), "+v"(ep.last_ret), "+v"(ep.last_len));
