@@ -512,6 +512,35 @@ def test_baseline_batch_sizes_against_oracle(B, T):
     e.close()
 
 
+@pytest.mark.parametrize("autoreset", [N.AUTORESET_SAME_STEP, N.AUTORESET_NEXT_STEP])
+@pytest.mark.parametrize("B", [49152, 65536 + 40])
+def test_functional_large_batches_one_transition_per_launch(B, autoreset):
+    """FUNCTIONAL rule-set on both sides of the batch size (49 152 envs) above which the one-transition kernel requests
+    the look-ahead keys behind the publish, by the event lanes only (NEXT_STEP: an env that only resets continues with
+    R_n, not R_{n+1}); hard-drop-heavy actions so that locks, bag refills and resets are frequent.  Every transition's
+    outputs, the last observation and the full state incl. the jax keys against the oracle."""
+    T = 120
+    e = Engine(B, 10, 20, ruleset=N.RULESET_FUNCTIONAL, queue_size=7, obs_mode=N.OBS_FN, autoreset=autoreset)
+    o = po.OracleBatch(B, 10, 20, po.RULESET_FUNCTIONAL, True, 7, nthreads=8)
+    seeds = np.arange(5, 5 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(B)
+    n_done = 0
+    for t in range(T):
+        a = rng.integers(0, 7, B)
+        a[rng.random(B) < 0.4] = 6
+        got = e.step(a)
+        exp = o.step(a.astype(np.int32), autoreset=autoreset)
+        for g, x, nm in zip(got, exp, ("reward", "terminated", "lines")):
+            assert np.array_equal(g, x), f"{nm} t={t}"
+        n_done += int(exp[1].sum())
+    np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_FN))
+    ge, go = _cmp_state(e, o, "final")
+    np.testing.assert_array_equal(ge["key"], go["key"], err_msg="rng.key")
+    assert n_done > B // 2
+    e.close()
+
+
 @pytest.mark.parametrize("ruleset", [N.RULESET_NUMPY, N.RULESET_FUNCTIONAL])
 @pytest.mark.parametrize("fuse", [1, 8])
 def test_fused_rollout_with_frequent_line_clears(ruleset, fuse, monkeypatch):
