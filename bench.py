@@ -17,8 +17,8 @@ devices (`--gpus 2` on a 1-GPU box) ranks share devices round-robin: that exerci
 scaling number.
 
 Rank 0 prints ONE JSON line.  At N = 1 the line also carries one block per further BASELINE config (`blocks`:
-config 2 = 4 096 envs (one and eight transitions per launch), config 5 = 20x40 / queue 7 / grouped action set, the
-reference's dict observation, the RGB wrapper's image, the fused rollout, the functional rule-set (one and eight
+config 2 = 4 096 envs (one and sixteen transitions per launch), config 5 = 20x40 / queue 7 / grouped action set, the
+reference's dict observation, the RGB wrapper's image, the fused rollout, the functional rule-set (one and sixteen
 transitions per launch)), each with its own `roofline` and `cpu_baseline`, and `vector_env`: the rate through the
 gymnasium.vector adapter with host and with device-resident observations.
 """
@@ -453,22 +453,22 @@ def rank_main(args) -> int:
         blocks["config5"] = run_block(D, "config5", W=20, H=40, Q=7, B=65536, obs="board", grouped=True, **common)
         blocks["dict"] = run_block(D, "dict", W=10, H=20, Q=4, B=65536, obs="dict", grouped=False, **common)
         blocks["rgb"] = run_block(D, "rgb", W=10, H=20, Q=4, B=65536, obs="rgb", grouped=False, **common)
-        blocks["fused_rollout"] = run_block(D, "fused8", W=10, H=20, Q=4, B=65536, obs="board", grouped=False, fuse=8,
-                                            ruleset="numpy", steps=(ks + 7) // 8 * 8, warmup=64, reps=reps, local=local,
+        blocks["fused_rollout"] = run_block(D, "fused16", W=10, H=20, Q=4, B=65536, obs="board", grouped=False, fuse=16,
+                                            ruleset="numpy", steps=(ks + 15) // 16 * 16, warmup=64, reps=reps, local=local,
                                             want_cpu=False)
         if blocks["fused_rollout"]:
-            blocks["fused_rollout"]["note"] = ("tg_step_k with tg_config.fuse = 8: records, column masks and uint8 slabs stay in "
-                                               "registers/LDS across the 8 transitions of a launch; the observation of "
+            blocks["fused_rollout"]["note"] = ("tg_step_k with tg_config.fuse = 16 (the default): records, column masks and uint8 slabs stay in "
+                                               "registers/LDS across the 16 transitions of a launch; the observation of "
                                                "every transition is still written; reported beside `value`, never as it")
-        # config 2 again with 8 transitions per launch: at 4 096 envs (64 workgroups on 256 CUs) a one-transition launch is
+        # config 2 again with 16 transitions per launch: at 4 096 envs (64 workgroups on 256 CUs) a one-transition launch is
         # all launch boundary; the fused launch is what a rollout at that batch size should use
-        blocks["config2_fused"] = run_block(D, "config2_fused8", W=10, H=20, Q=4, B=4096, obs="board", grouped=False, fuse=8,
-                                            ruleset="numpy", steps=(ks + 7) // 8 * 8, warmup=64, reps=reps, local=local,
+        blocks["config2_fused"] = run_block(D, "config2_fused16", W=10, H=20, Q=4, B=4096, obs="board", grouped=False, fuse=16,
+                                            ruleset="numpy", steps=(ks + 15) // 16 * 16, warmup=64, reps=reps, local=local,
                                             want_cpu=False)
         # the functional rule-set (envs/tetris_fn.py step / batched_step: the subsystem north_star names as replaced)
         fcommon = dict(W=10, H=20, Q=7, B=65536, obs="fn", grouped=False, ruleset="functional", reps=reps, local=local)
         blocks["functional"] = run_block(D, "functional", steps=ks, warmup=kw, want_cpu=want_cpu, cpu_budget=3.0, **fcommon)
-        blocks["functional_fused"] = run_block(D, "functional_fused8", fuse=8, steps=(ks + 7) // 8 * 8, warmup=64,
+        blocks["functional_fused"] = run_block(D, "functional_fused16", fuse=16, steps=(ks + 15) // 16 * 16, warmup=64,
                                                want_cpu=False, **fcommon)
         try:
             blocks["vector_env"] = vector_env_block(local)

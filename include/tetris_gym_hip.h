@@ -91,7 +91,7 @@ typedef struct tg_config {
   int32_t reserved;
   /* launch knobs of the step kernel (0 = default; the environment variables TG_FUSE / TG_RNG_EVERY / TG_RING_FILL override
    * them — test hooks).  Results never depend on them. */
-  int32_t fuse;         /* transitions per launch of tg_step_k / tg_rollout / tg_grouped_rollout: 1..8, default 8 */
+  int32_t fuse;         /* transitions per launch of tg_step_k / tg_rollout / tg_grouped_rollout: 1..16, default 16 */
   int32_t rng_every;    /* NUMPY rules: one-transition launches carry the bag-shuffle look-ahead workgroups every n-th time
                            (1..3, default 3) */
   int32_t ring_fill_p1; /* NUMPY rules: 1 + look-ahead bag permutations kept per env (1..4, default 4 = 3 permutations);
@@ -198,7 +198,7 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind);
 
 /* K consecutive transitions with pre-generated actions i8 [K][B] resident in DEVICE memory (rollout helper, no host
  * round trip; the outputs of the last transition remain in the buffers, per-episode sums go to TG_BUF_EPISODE when
- * enabled).  The default kernel runs up to tg_config.fuse (default 8) transitions per launch with the per-env state
+ * enabled).  The default kernel runs up to tg_config.fuse (default 16) transitions per launch with the per-env state
  * resident on chip in between; the observation is written after every transition.
  * Results are identical to K calls of tg_step. */
 int tg_step_k(tg_handle* h, const int8_t* actions_dev, int K);

@@ -11,8 +11,8 @@ from tetris_gymnasium_amd import _native as N
 
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 CASES = [  # (W, H, Q, B, grouped, fuse, ruleset)
-    (10, 20, 4, 320, False, 1, N.RULESET_NUMPY), (10, 20, 4, 200, False, 8, N.RULESET_NUMPY), (10, 20, 7, 132, True, 3, N.RULESET_NUMPY),
-    (20, 40, 7, 100, True, 1, N.RULESET_NUMPY), (6, 12, 2, 256, False, 8, N.RULESET_NUMPY), (10, 20, 7, 192, False, 8, N.RULESET_FUNCTIONAL),
+    (10, 20, 4, 320, False, 1, N.RULESET_NUMPY), (10, 20, 4, 200, False, 16, N.RULESET_NUMPY), (10, 20, 7, 132, True, 3, N.RULESET_NUMPY),
+    (20, 40, 7, 100, True, 1, N.RULESET_NUMPY), (6, 12, 2, 256, False, 8, N.RULESET_NUMPY), (10, 20, 7, 192, False, 16, N.RULESET_FUNCTIONAL),
     (7, 14, 4, 168, False, 1, N.RULESET_NUMPY), (7, 14, 7, 100, False, 8, N.RULESET_FUNCTIONAL),  # 98-byte slabs, ragged batches
 ]
 for W, H, Q, B, grouped, fuse, rs in CASES:

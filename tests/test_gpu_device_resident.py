@@ -229,10 +229,10 @@ def test_engine_knobs_come_from_the_config_not_the_environment(monkeypatch):
     B, K = 1500, 37
     acts = np.random.default_rng(8).integers(0, 8, (K, B)).astype(np.int8)
     ref = None
-    for fuse, every, fill in ((0, 0, None), (1, 1, 3), (8, 3, 1), (5, 2, 0)):
+    for fuse, every, fill in ((0, 0, None), (1, 1, 3), (8, 3, 1), (5, 2, 0), (16, 3, 2), (11, 1, 3)):
         e = Engine(B, 10, 20, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP, fuse=fuse, rng_every=every, ring_fill=fill)
-        feat = int(e.step_kernel_name(fuse or 8).rstrip(">").split(",")[-1])  # FEAT flags: bit 0 = several transitions per launch
-        assert (feat & 1) == (1 if (fuse or 8) > 1 else 0)
+        feat = int(e.step_kernel_name(fuse or 16).rstrip(">").split(",")[-1])  # FEAT flags: bit 0 = several transitions per launch
+        assert (feat & 1) == (1 if (fuse or 16) > 1 else 0)
         e.reset(np.arange(1, B + 1, dtype=np.uint64))
         res = e.rollout(acts)
         st = e.get_state()

@@ -360,7 +360,7 @@ def test_sharded_streams_engine_vs_oracle(ruleset, B, monkeypatch):
     e.close()
 
 
-@pytest.mark.parametrize("fuse,ring_fill", [(1, 4), (2, 4), (4, 4), (8, 4), (8, 1), (3, 0)])
+@pytest.mark.parametrize("fuse,ring_fill", [(1, 4), (2, 4), (4, 4), (8, 4), (8, 1), (3, 0), (16, 4), (16, 1), (11, 4)])
 @pytest.mark.parametrize("ruleset,W,H,Q,B,autoreset,grouped", [
     (N.RULESET_NUMPY, 10, 20, 4, 1000, N.AUTORESET_SAME_STEP, False),
     (N.RULESET_NUMPY, 10, 20, 4, 4096, N.AUTORESET_NEXT_STEP, False),
@@ -456,7 +456,7 @@ def test_rng_role_every_nth_launch(every, W, H, Q, B, grouped, monkeypatch):
     e.close()
 
 
-@pytest.mark.parametrize("fuse", [1, 8])
+@pytest.mark.parametrize("fuse", [1, 8, 16])
 @pytest.mark.parametrize("ruleset,obs,B", [(N.RULESET_NUMPY, N.OBS_BOARD, 1500), (N.RULESET_FUNCTIONAL, N.OBS_FN, 640),
                                            (N.RULESET_NUMPY, N.OBS_RGB, 200)])
 def test_rollout_trajectory_equals_stepwise(fuse, ruleset, obs, B, monkeypatch):
@@ -542,7 +542,7 @@ def test_functional_large_batches_one_transition_per_launch(B, autoreset):
 
 
 @pytest.mark.parametrize("ruleset", [N.RULESET_NUMPY, N.RULESET_FUNCTIONAL])
-@pytest.mark.parametrize("fuse", [1, 8])
+@pytest.mark.parametrize("fuse", [1, 8, 16])
 def test_fused_rollout_with_frequent_line_clears(ruleset, fuse, monkeypatch):
     """Dense stacks (full rows except a narrow gap) + hard-drop-heavy actions: line clears (mask compaction in the logic
     wave, cooperative uint8 row compaction in the stream wave, the functional rule-set's row-0 quirk) happen all the time

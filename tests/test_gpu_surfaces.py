@@ -504,7 +504,7 @@ def test_rollout_entry_points_reject_bad_arguments():
 
 
 @pytest.mark.parametrize("mode", ["numpy", "functional", "grouped", "numpy_20x40", "numpy_7x14", "functional_7x14"])
-@pytest.mark.parametrize("fuse", [1, 8])
+@pytest.mark.parametrize("fuse", [1, 8, 16])
 def test_final_observation_same_step_autoreset(mode, fuse, monkeypatch):
     """TG_FLAG_FINAL_OBS (what gymnasium's same-step autoreset reports as infos["final_observation"], consumed by
     examples/train_cnn.py:312-316): when an env ends its episode and resets inside the same transition, TG_BUF_OBS holds
@@ -526,7 +526,7 @@ def test_final_observation_same_step_autoreset(mode, fuse, monkeypatch):
     n_act = 4 * W if grouped else (7 if fn else 8)
     expect = np.zeros((B, H, W), np.int8 if fn else np.uint8)
     ever = np.zeros(B, bool)
-    K = 8 if fuse > 1 else 1
+    K = fuse if fuse > 1 else 1
     for it in range(320 // K if mode != "numpy_20x40" else 480 // K):
         acts = rng.integers(0, n_act, (K, B))
         if not grouped:

@@ -470,7 +470,7 @@ struct tg_handle {
   int rng_every = 3;           // TG_RNG_EVERY: one-transition launches carry the RNG-role workgroups every n-th time (the ring
                                // looks 3 entries ahead and the consumer shuffles in line when it runs dry): 7.5 -> 7.3 us per launch
   unsigned launch_no = 0;
-  int fuse_max = 8;            // TG_FUSE: transitions per launch in tg_step_k (1..8)
+  int fuse_max = tg::kMaxFuse; // TG_FUSE: transitions per launch in tg_step_k (1..16)
   int ring_fill = tg::kRing - 1;  // TG_RING_FILL (tests): fewer look-ahead permutations → the consumer's in-line shuffle runs
   bool dict_in_kernel = false; // TG_OBS_DICT packed by the bits step kernel itself (no observe launch after a transition)
   // TG_STREAMS=n (default 1) spreads the step launches of one transition over n streams (contiguous env shards).

@@ -262,7 +262,10 @@ struct BitsParams {
 
 // native 16-byte vector for the slab stream: HIP's uint4 is a struct whose copies become memcpy intrinsics, which
 // kept the staging array in scratch memory (and made the kernel wait for every slab load right after issuing it)
-constexpr int kMaxFuse = 8;  // transitions per launch (tg_config.fuse): the action bytes of a launch travel in one 64-bit word
+#ifndef TG_MAX_FUSE
+#define TG_MAX_FUSE 16
+#endif
+constexpr int kMaxFuse = TG_MAX_FUSE;  // transitions per launch (tg_config.fuse): the action bytes of a launch travel in one or two 64-bit words
 constexpr int kRing = 4;  // slots per permutation ring: kRing - 1 entries ahead + the last consumed one
 __device__ __forceinline__ int ring_diff(const int a, const int b) { return ((a - b) << 24) >> 24; }  // counters are mod 256
 // where the generator state (FUNCTIONAL: the key) after the last consumed entry lives (`loc` field of hbuf)
@@ -1417,7 +1420,7 @@ void step_kernel_bits(
   // (FUNCTIONAL: the jax key is not among the first loads any more — what a transition needs of the key chain comes
   // from the look-ahead ring below, as the bag permutations of the NUMPY rule-set do)
   // the actions of all transitions of this launch, requested up front (int8 rows: one byte per transition and env)
-  uint64_t apack = 0;
+  uint64_t apack = 0, apack1 = 0;
   int action0 = 0;
   if (sample_mode) {
     // (actions are drawn per transition below)
@@ -1428,6 +1431,14 @@ void step_kernel_bits(
       ab[k] = reinterpret_cast<const uint8_t*>(hot_actions)[(size_t)(k < nsteps ? k : nsteps - 1) * p.act_stride + env];
 #pragma unroll
     for (int k = 0; k < 8; ++k) apack |= (uint64_t)ab[k] << (8 * k);
+    if (kMaxFuse > 8 && MULTI && nsteps > 8) {  // (launches of more than eight transitions: a second word)
+      uint8_t ac[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        ac[k] = reinterpret_cast<const uint8_t*>(hot_actions)[(size_t)(8 + k < nsteps ? 8 + k : nsteps - 1) * p.act_stride + env];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) apack1 |= (uint64_t)ac[k] << (8 * k);
+    }
   } else {
     action0 = reinterpret_cast<const int32_t*>(hot_actions)[env];
   }
@@ -1574,7 +1585,7 @@ void step_kernel_bits(
     const u32x2* cs = reinterpret_cast<const u32x2*>(bp.ahead) + (size_t)env * 16;
     pf_c1 = cs[(fn_n0 + 1) & 3]; pf_c3 = cs[(fn_n0 + 3) & 3]; pf_r1 = cs[4 + ((fn_pend0 ? fn_n0 : fn_n0 + 1) & 3)];
   }
-  int action_in = hot_act_i8 ? (int)(int8_t)(apack >> (8 * step)) : action0;
+  int action_in = hot_act_i8 ? (int)(int8_t)(((kMaxFuse > 8 && step >= 8) ? apack1 : apack) >> (8 * (step & 7))) : action0;
   if (RULESET == TG_RULESET_NUMPY && sample_mode) {
     // uniform over the legal placements of the CURRENT piece (wrappers/grouped.py:104-122: legal = inside the frame).
     // Legal columns of a rotation form a range [lo_r, hi_r]; actions are ordered column-major, rotation-minor; the

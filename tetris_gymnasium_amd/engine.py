@@ -143,7 +143,7 @@ class Engine:
                  obs_mode=None, autoreset=N.AUTORESET_NONE, device=0, env_offset=0, padding=4, episode_stats=False,
                  final_obs=False, grouped=False, terminate_on_illegal=True, features=False, fuse=0, rng_every=0,
                  ring_fill=None):
-        """fuse / rng_every / ring_fill: launch knobs of the step kernel (tg_config; 0 / None = the defaults 8 / 3 / 3).
+        """fuse / rng_every / ring_fill: launch knobs of the step kernel (tg_config; 0 / None = the defaults 16 / 3 / 3).
         Results never depend on them."""
         self.lib = N.load()
         self._pool = {}      # free device buffers by size (DeviceBuffer)

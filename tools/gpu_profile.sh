@@ -1,13 +1,13 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: the round's profile set → gpurun_out/<tag>/ (copy the summaries + latest.json into profiles/<round>/).
-#   per block (config3 = headline, config2, config5, dict, fused8, rgb, functional, functional_fused8, config2_fused8): rocprofv3
+#   per block (config3 = headline, config2, config5, dict, fused16, rgb, functional, functional_fused16, config2_fused16): rocprofv3
 #   --kernel-trace --stats of the bench block's command
 #   config3 / dict / config5 / rgb / functional: HBM traffic (FETCH_SIZE, WRITE_SIZE in separate --pmc passes, calibrated on the stream-copy kernel)
 #   config3: two SQ_* counter passes
 # usage: tools/gpu_profile.sh <tag> [blocks...]
-TAG=${1:-prof}; shift; BLOCKS=${@:-config3 config2 config5 dict fused8 rgb functional functional_fused8 config2_fused8}
+TAG=${1:-prof}; shift; BLOCKS=${@:-config3 config2 config5 dict fused16 rgb functional functional_fused16 config2_fused16}
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-declare -A ARGS=( [config3]="" [config2]="--batch 4096" [config5]="--config5" [dict]="--obs dict" [fused8]="--fuse 8" [rgb]="--obs rgb" [functional]="--ruleset functional --obs fn" [functional_fused8]="--ruleset functional --obs fn --fuse 8" [config2_fused8]="--batch 4096 --fuse 8" )
+declare -A ARGS=( [config3]="" [config2]="--batch 4096" [config5]="--config5" [dict]="--obs dict" [fused16]="--fuse 16" [rgb]="--obs rgb" [functional]="--ruleset functional --obs fn" [functional_fused16]="--ruleset functional --obs fn --fuse 16" [config2_fused16]="--batch 4096 --fuse 16" )
 COMMON="--no-cpu-baseline --no-blocks --steps 128 --warmup 16"
 for b in $BLOCKS; do
   rocprofv3 --kernel-trace --stats -d $OUT/${b}_kt -o kt -- python3 bench.py $COMMON ${ARGS[$b]} > $OUT/${b}_kt.log 2>&1
