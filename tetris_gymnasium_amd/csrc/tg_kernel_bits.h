@@ -21,7 +21,7 @@
 //     owns a ring of four future bag permutations (7 nibbles each) produced ahead of their use; consuming one is a
 //     byte permute (v_perm_b32).  The generator state the reference would hold (tg_get_state) is materialised into
 //     tg_rng_rec on demand from the state stored with the last consumed ring entry;
-//   * tg_step_k / tg_rollout run up to 8 transitions per launch with all of the above resident on chip in between.
+//   * tg_step_k / tg_rollout run up to 16 transitions per launch with all of the above resident on chip in between.
 // Round 2: publish before bookkeeping, stores as whole cache lines wherever the layout allows (board
 // chunks by compare, records exchanged between lanes), the arguments the first loads need as preloaded scalars, and a
 // build for instruction-level parallelism (one logic wave per SIMD is a dependent chain: Makefile flags).

@@ -222,7 +222,7 @@ class Engine:
         self._chk(self.lib.tg_step_k(self.h, C.c_void_p(actions_dev_ptr), int(k)), "tg_step_k")
 
     def rollout(self, actions, want_obs=True):
-        """K transitions with the given actions int8[K][B] in one call (tg_rollout: the default kernel runs up to 8 per
+        """K transitions with the given actions int8[K][B] in one call (tg_rollout: the default kernel runs up to 16 per
         launch with the state resident on chip).  Returns (obs[K][B]..., reward f32[K][B], terminated u8[K][B],
         lines u8[K][B]) — what K calls of step() + observation() would have returned."""
         a = np.asarray(actions)

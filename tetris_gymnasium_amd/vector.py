@@ -262,7 +262,7 @@ class TetrisVectorEnv(VectorEnvBase):
         return obs, rewards, terminations, truncations, infos
 
     def rollout(self, actions):
-        """K transitions for pre-generated actions [K][num_envs] in one call per device (tg_rollout: up to 8 transitions
+        """K transitions for pre-generated actions [K][num_envs] in one call per device (tg_rollout: up to 16 transitions
         per launch, state resident on chip).  Returns (obs[K][num_envs]..., rewards, terminations, lines) — the
         trajectory a `for k: envs.step(actions[k])` loop would have produced (autoreset as configured)."""
         actions = np.asarray(actions)
