@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The device-resident tests hand engine buffers to torch tensors inside THIS process, engine first and torch later: that is
+# the case the opt-in TG_HIP_RUNTIME=torch exists for (_native._share_torch_hip_runtime; the default is the system runtime
+# the engine was built against).  The SONAME check there still applies.
+os.environ.setdefault("TG_HIP_RUNTIME", "torch")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")

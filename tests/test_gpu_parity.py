@@ -541,6 +541,52 @@ def test_functional_large_batches_one_transition_per_launch(B, autoreset):
     e.close()
 
 
+@pytest.mark.parametrize("lazy", [0, 1, 2])
+@pytest.mark.parametrize("autoreset", [N.AUTORESET_SAME_STEP, N.AUTORESET_NEXT_STEP])
+@pytest.mark.parametrize("fuse", [1, 16])
+def test_functional_reset_bags_sorted_ahead_or_in_line(lazy, autoreset, fuse, monkeypatch):
+    """FUNCTIONAL rule-set (envs/tetris_fn.py:318-367, functional/queue.py:20-35): the bag a reset deals is sorted AHEAD only by
+    a lock that leaves the stack within reach of the spawn rows (rows 0-5: tg_kernel_bits.h fn_hi); TG_FN_LAZY=1 never sorts
+    ahead, so every episode end takes the in-line sort, TG_FN_LAZY=2 always sorts ahead (round 3).  All three against the
+    oracle — outputs of every transition, observation, state and jax keys — from fresh resets and from uploaded tall
+    boards (tg_set_state rebuilds the whole look-ahead), hard-drop-heavy so that episodes end all the time."""
+    monkeypatch.setenv("TG_FN_LAZY", str(lazy))
+    monkeypatch.setenv("TG_FUSE", str(fuse))
+    B, W, H = 1500, 10, 20
+    e = Engine(B, W, H, ruleset=N.RULESET_FUNCTIONAL, queue_size=7, obs_mode=N.OBS_FN, autoreset=autoreset)
+    o = po.OracleBatch(B, W, H, po.RULESET_FUNCTIONAL, True, 7)
+    seeds = np.arange(900, 900 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(17 * lazy + fuse + autoreset)
+    n_done = 0
+    for phase in range(3):
+        if phase == 1:  # tall stacks: filled from row 3 / 5 / 7 down except one column — the very next lock can end the game
+            b, r, g = o.get_state()
+            for i in range(B):
+                top = 3 + 2 * (i % 3)
+                b[i, top:, :] = 2 + (i % 7)
+                b[i, top:, i % W] = 0
+            o.set_state(board=b, rec=r, rng=g); e.set_state(board=b, rec=r, rng=g)
+        for K in (1, 7, 16, 40):
+            acts = rng.integers(0, 7, (K, B)).astype(np.int8)
+            acts[rng.random((K, B)) < 0.45] = 6
+            d = e.dev_alloc(acts.nbytes)
+            e.dev_upload(d, acts)
+            e.step_k_device(d, K)
+            for k in range(K):
+                ro, to, lo = o.step(acts[k].astype(np.int32), autoreset=autoreset)
+                n_done += int(to.sum())
+            got = e.fetch_outputs()
+            for g_, x, nm in zip(got, (ro, to, lo), ("reward", "terminated", "lines")):
+                np.testing.assert_array_equal(g_, x, err_msg=f"{nm} phase={phase} K={K}")
+            np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_FN), err_msg=f"obs phase={phase} K={K}")
+            ge, go = _cmp_state(e, o, f"phase={phase} K={K}")
+            np.testing.assert_array_equal(ge["key"], go["key"], err_msg=f"rng_key phase={phase} K={K}")
+            e.dev_free(d)
+    assert n_done > B  # every env ended at least one episode on average
+    e.close()
+
+
 @pytest.mark.parametrize("ruleset", [N.RULESET_NUMPY, N.RULESET_FUNCTIONAL])
 @pytest.mark.parametrize("fuse", [1, 8, 16])
 def test_fused_rollout_with_frequent_line_clears(ruleset, fuse, monkeypatch):

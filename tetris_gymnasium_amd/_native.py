@@ -103,14 +103,27 @@ class NativeLibraryError(RuntimeError):
     pass
 
 
+HIP_RUNTIME = "system"  # which libamdhip64 the engine runs on: "system" (what it was built and tested against) or the path preloaded
+
+
 def _share_torch_hip_runtime():
-    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same soname as /opt/rocm's): if this
+    """One HIP runtime per process.  A PyTorch-ROCm wheel bundles its own libamdhip64.so (same soname as /opt/rocm's): if this
     library loads the system copy first and torch is imported later, torch loads its bundled copy beside it and finds no GPU
-    ("No HIP GPUs are available") — and zero-copy hand-over (`DeviceArray`) needs both sides in one runtime anyway.  So when a
-    torch installation is present (looked up, never imported), its bundled runtime is loaded first and this library's
-    dependency on libamdhip64.so.7 resolves to it; whichever of torch / this package comes first then works.
-    TG_HIP_RUNTIME=system keeps the system runtime (then import torch and touch torch.cuda BEFORE creating engines)."""
-    if os.environ.get("TG_HIP_RUNTIME", "auto") == "system":
+    ("No HIP GPUs are available") — and zero-copy hand-over (`DeviceArray`) needs both sides in one runtime anyway.
+
+    The engine is built and tested against the SYSTEM runtime, so that is the default and nothing is preloaded.  The bundled
+    runtime is taken only
+      * when torch has ALREADY been imported by this process (`"torch" in sys.modules`: its runtime is loaded anyway, the
+        dynamic linker resolves our libamdhip64.so.N to it if the sonames match — preloading just makes that explicit), or
+      * on request: TG_HIP_RUNTIME=torch (engine first, torch later in the same process).
+    Either way only a bundled library whose SONAME equals the one this engine links against is accepted (two different
+    runtimes in one process is the failure this exists to avoid); TG_HIP_RUNTIME=system never preloads.  The choice is
+    recorded in `_native.HIP_RUNTIME` (and printed with TG_VERBOSE=1)."""
+    global HIP_RUNTIME
+    import sys
+
+    mode = os.environ.get("TG_HIP_RUNTIME", "auto")
+    if mode == "system" or (mode != "torch" and "torch" not in sys.modules):
         return
     try:
         import importlib.util
@@ -119,10 +132,58 @@ def _share_torch_hip_runtime():
         if spec is None or not spec.submodule_search_locations:
             return
         cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if os.path.exists(cand):
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        if not os.path.exists(cand):
+            return
+        want, have = _needed_hip_soname(LIB_PATH), _soname(cand)
+        if want and have and want != have:
+            if os.environ.get("TG_VERBOSE"):
+                print(f"tetris_gymnasium_amd: torch bundles {have}, the engine links {want}: keeping the system runtime",
+                      file=sys.stderr)
+            return
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        HIP_RUNTIME = cand
     except Exception:  # a broken / non-ROCm torch installation must not keep the engine from loading
         pass
+
+
+def _elf_strings(path, tag):
+    """DT_SONAME (14) / DT_NEEDED (1) strings of an ELF64 shared object, read without loading it."""
+    import struct
+
+    with open(path, "rb") as f:
+        d = f.read()
+    if d[:4] != b"\x7fELF" or d[4] != 2:
+        return []
+    shoff, shentsize, shnum = struct.unpack_from("<Q", d, 0x28)[0], *struct.unpack_from("<HH", d, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", d, shoff + i * shentsize) for i in range(shnum)]
+    out = []
+    for s in secs:
+        if s[1] != 6:  # SHT_DYNAMIC
+            continue
+        strtab = secs[s[6]]
+        for o in range(s[4], s[4] + s[5], 16):
+            t, v = struct.unpack_from("<qQ", d, o)
+            if t == 0:
+                break
+            if t == tag:
+                e = d.index(b"\0", strtab[4] + v)
+                out.append(d[strtab[4] + v:e].decode())
+    return out
+
+
+def _soname(path):
+    try:
+        r = _elf_strings(os.path.realpath(path), 14)
+        return r[0] if r else None
+    except Exception:
+        return None
+
+
+def _needed_hip_soname(path):
+    try:
+        return next((n for n in _elf_strings(path, 1) if n.startswith("libamdhip64")), None)
+    except Exception:
+        return None
 
 
 def load() -> C.CDLL:
@@ -146,6 +207,10 @@ def load() -> C.CDLL:
     if lib.tg_abi_version() != ABI_VERSION:
         raise NativeLibraryError("libtetris_gym_hip.so ABI version mismatch")
     _lib = lib
+    if os.environ.get("TG_VERBOSE"):
+        import sys
+
+        print(f"tetris_gymnasium_amd: HIP runtime = {HIP_RUNTIME}", file=sys.stderr)
     return lib
 
 

@@ -472,6 +472,7 @@ struct tg_handle {
   unsigned launch_no = 0;
   int fuse_max = tg::kMaxFuse; // TG_FUSE: transitions per launch in tg_step_k (1..16)
   int ring_fill = tg::kRing - 1;  // TG_RING_FILL (tests): fewer look-ahead permutations → the consumer's in-line shuffle runs
+  int fn_lazy = 0;             // TG_FN_LAZY (tests): KParams.fn_lazy
   bool dict_in_kernel = false; // TG_OBS_DICT packed by the bits step kernel itself (no observe launch after a transition)
   // TG_STREAMS=n (default 1) spreads the step launches of one transition over n streams (contiguous env shards).
   // Kept as a tested knob, off by default — measured on MI355X: every launch costs ≈2.8-3.4 µs of
@@ -634,6 +635,7 @@ tg::KParams step_params(tg_handle* h) {
   p.act_stride = (uint32_t)h->B;
   p.dict_in_kernel = h->dict_in_kernel ? 1 : 0;
   p.ring_fill = h->ring_fill;
+  p.fn_lazy = h->fn_lazy;
   return p;
 }
 
@@ -932,6 +934,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     if (cfg->fuse > 0) h->fuse_max = cfg->fuse > tg::kMaxFuse ? tg::kMaxFuse : cfg->fuse;
     if (const char* e = getenv("TG_RING_FILL")) { const int v = atoi(e); h->ring_fill = v < 0 ? 0 : (v > tg::kRing - 1 ? tg::kRing - 1 : v); }
     if (const char* e = getenv("TG_RNG_EVERY")) { const int v = atoi(e); h->rng_every = v < 1 ? 1 : (v > 3 ? 3 : v); }
+    if (const char* e = getenv("TG_FN_LAZY")) { const int v = atoi(e); h->fn_lazy = v < 0 ? 0 : (v > 2 ? 2 : v); }
     if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > tg::kMaxFuse ? tg::kMaxFuse : v); }
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
     int want = 1;

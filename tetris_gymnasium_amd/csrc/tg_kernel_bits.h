@@ -297,6 +297,7 @@ __device__ __forceinline__ uint32_t ring_get(const uint64_t w0, const uint64_t w
 //   n mod 4 lives in tg_env_rec.reserved (device-private), the key c_n in tg_rng_rec.key as the reference holds it.
 // bits_prepare_kernel builds all of it from the key after tg_reset / tg_set_state.
 // PARITY UNPINNED like every jax-dependent piece of this rule-set; engine == oracle is what tests check.
+constexpr uint32_t kFnNone = 0x1FFFFFu;  // a 21-bit bag field that has not been sorted (no permutation of 0..6 holds a 7)
 __device__ __forceinline__ uint32_t fn_pack21(const uint64_t bag) {  // 7 bytes → seven 3-bit fields
   uint32_t p = 0;
 #pragma unroll
@@ -395,6 +396,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t st_window(void* base, const ui
 }
 __device__ __forceinline__ void st_state_if(const __amdgpu_buffer_rsrc_t win, const uint32_t off, const u32x4 v, const bool on) {
   __builtin_amdgcn_raw_buffer_store_b128(v, win, on ? off : 0x80000000u, 0, TG_STATE_ST == 1 ? 2 : 0);  // (aux 2 = nontemporal)
+}
+// ... and the 8-byte form (plain): the sparse per-lane stores of the functional look-ahead
+__device__ __forceinline__ void st_b64_if(const __amdgpu_buffer_rsrc_t win, const uint32_t off, const u32x2 v, const bool on) {
+  __builtin_amdgcn_raw_buffer_store_b64(v, win, on ? off : 0x80000000u, 0, 0);
 }
 #endif
 #ifdef TG_COLS_NT
@@ -1557,6 +1562,10 @@ void step_kernel_bits(
   };
   // FUNCTIONAL: what this transition consumed of the key-chain look-ahead (made good behind the publish, fn_book below)
   bool fn_lock = false, fn_reset = false, fn_dirty = false;
+  // ... and whether the stack reaches rows 0-5 after the lock: only then can the NEXT lock end the game (every piece spawns
+  // in rows 0-1 and a piece that comes to rest on a stack below row 5 has no cell above row 2), i.e. only then is the bag a
+  // reset behind that lock deals (S2) worth a sort now.  Otherwise the field is left kFnNone and sorted if ever needed.
+  bool fn_hi = false;
 
   bool cols_dirty_any = false;
   for (int step = 0; step < nsteps; ++step) {
@@ -1898,6 +1907,12 @@ void step_kernel_bits(
       }
     }
     s.flags &= place ? ~TG_F_FULLROW : ~0;
+    if (RULESET == TG_RULESET_FUNCTIONAL) {  // (see fn_hi; p.fn_lazy: 0 = as described, 1 = never sort ahead, 2 = always: tests)
+      T orc = 0;
+#pragma unroll
+      for (int c = 0; c < W; ++c) orc |= v[c];
+      fn_hi = place & ((((orc & T(0x3F)) != 0) & (p.fn_lazy != 1)) | (p.fn_lazy == 2));
+    }
     // collision of the new piece at its spawn position (rows 0..3 of the columns it spans; static columns)
     bool sc;
     {
@@ -1968,7 +1983,20 @@ void step_kernel_bits(
       }
       // the reset deals permutation(split(key)[0]) and continues with split(key)[1] (owed until after the publish): S1 at
       // the env's position, S2 behind a lock of this transition
-      const uint64_t nb = fn_expand21((uint32_t)(fnw >> (fn_lock ? 21 : 0)) & 0x1FFFFFu);
+      uint32_t f21 = (uint32_t)(fnw >> (fn_lock ? 21 : 0)) & 0x1FFFFFu;
+      const bool unsorted = do_reset & (f21 == kFnNone);
+      if (__any(unsorted)) {
+        // The bag was not sorted ahead (fn_hi: the stack was low when the look-ahead was made good).  By the argument there
+        // this does not happen in play; it does after the test knob p.fn_lazy = 1 and would after a rule change — sort now,
+        // from R_{n+1} (a reset alone) or R_{n+2} (behind a lock) of the env's look-ahead block.  The block may have been
+        // written by an earlier transition of this launch: those stores are made visible first.
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        const uint2* rsl = reinterpret_cast<const uint2*>(bp.ahead) + (size_t)env * 16 + 4;
+        const uint2 rk = rsl[((int)(s.reserved & 3u) + (fn_lock ? 2 : 1)) & 3];
+        const uint32_t srt = fn_sort7(rk.x, rk.y);
+        f21 = unsorted ? srt : f21;
+      }
+      const uint64_t nb = fn_expand21(f21);
       s.bag = do_reset ? nb : s.bag; s.queue = do_reset ? 0 : s.queue; s.piece = do_reset ? (int)(nb & 0xFF) : s.piece;
       s.bidx = do_reset ? 1 : s.bidx;
       fn_reset = fn_reset | do_reset;
@@ -2068,97 +2096,50 @@ void step_kernel_bits(
 #endif
     TG_FN_STAMP(3);
     if (!__any(ev)) return;
-    uint2* cs = reinterpret_cast<uint2*>(bp.ahead) + (size_t)env * 16;  // c[4] | r[4] | (unused)
-    uint2* rs = cs + 4;
     const int n = (int)(s.reserved & 3u);
     const bool lk = fn_lock && !fn_reset;           // stays on its chain: position n + 1
     const bool needq = lk && s.bidx >= 7;           // ... whose lock will refill the bag
     // loads (event lanes): the key the lane continues from, the chain's last key, R_{n+1}
     uint2 ka = make_uint2(pf_c3.x, pf_c3.y), kb = make_uint2(pf_r1.x, pf_r1.y), knew = make_uint2(pf_c1.x, pf_c1.y);
     if (fn_reset) { knew = kb; ka = kb; }  // R_{n+1} behind a lock of this transition (SAME_STEP), R_n otherwise
-    // -DTG_FN_DENSE (off): the threefry blocks of the levels as a task list in LDS — only the event lanes (one in seven of the
-    // wave, one in sixty for a reset) have keys to advance, but a block costs the wave the same ~110 instructions however few
-    // lanes want it; the event lanes post {key, counter}, lane t runs task t, the owners read the results back: one block per
-    // level instead of two or three.  Measured: 8.07 -> 7.96 us per launch at 65 536 envs (within the engine-to-engine
-    // spread), but 4.13 -> 4.22 per fused transition and 5.80 -> 5.91 at 4 096 envs — the three LDS exchanges are latency on
-    // the logic wave's chain where that chain is what the launch waits for (profiles/r03/ab_functional_dense.log).
-    const uint64_t m1 = __ballot(ev);
-    const int n1 = __popcll(m1);
-    const int q1 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-#ifdef TG_FN_DENSE
-    uint4* tq = reinterpret_cast<uint4*>(lds + BG::OFF_FNT);
-    uint2* tr = reinterpret_cast<uint2*>(lds + BG::OFF_FNT + 192 * 16);
-    auto run_tasks = [&](const int ntask) {  // (ntask is wave-uniform)
-      wave_sync();
-      for (int t0 = 0; t0 < ntask; t0 += 64) {
-        const int t = t0 + lane;
-        const uint4 tk = tq[t < ntask ? t : 0];
-        uint32_t o0, o1;
-        threefry2x32(tk.x, tk.y, 0u, tk.z, o0, o1);
-        if (t < ntask) tr[t] = make_uint2(o0, o1);
-      }
-      wave_sync();
-    };
-#endif
+    // (The threefry blocks of the levels as a dense task list through LDS — one block per level instead of two or three — were
+    // built in round 3, bit-identical, and not kept: 8.07 -> 7.96 us per launch at 65 536 envs but +2 % per fused transition and
+    // at 4 096 envs, where the LDS exchanges are latency on the chain the launch waits for.  profiles/r03/ab_functional_dense.log)
     // level 1
     uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0, z0 = 0, z1 = 0;
-#ifndef TG_FN_DENSE
     threefry2x32(ka.x, ka.y, 0u, 0u, a0, a1);
     threefry2x32(ka.x, ka.y, 0u, 1u, b0, b1);
     if (__any(needq)) threefry2x32(kb.x, kb.y, 0u, 1u, z0, z1);
-#else
-    {
-      const uint64_t mq = __ballot(needq);
-      const int qq = 2 * n1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mq >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mq, 0u));
-      if (ev) { tq[2 * q1] = make_uint4(ka.x, ka.y, 0u, 0u); tq[2 * q1 + 1] = make_uint4(ka.x, ka.y, 1u, 0u); }
-      if (needq) tq[qq] = make_uint4(kb.x, kb.y, 1u, 0u);
-      run_tasks(2 * n1 + __popcll(mq));
-      const uint2 ra = tr[ev ? 2 * q1 : 0], rb = tr[ev ? 2 * q1 + 1 : 0], rz = tr[needq ? qq : 0];
-      a0 = ra.x; a1 = ra.y; b0 = rb.x; b1 = rb.y; z0 = rz.x; z1 = rz.y;
-    }
-#endif
-    uint32_t t1x = b0, t1y = b1, t2x = z0, t2y = z1;  // sort keys: lock lanes S2' = sort7(R_{n+3}), Q0' = sort7(f1(R_{n+1}))
 #ifdef TG_FINE_FN
     asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(z0), "+v"(z1));
 #endif
     TG_FN_STAMP(4);
-    uint2 c1 = make_uint2(a0, a1), r0 = make_uint2(b0, b1), c2 = c1, c3 = c1, r1 = r0, r2 = r0;
+    u32x2 c1 = u32x2{a0, a1}, r0 = u32x2{b0, b1}, c2 = c1, c3 = c1, r1 = r0, r2 = r0;
     if (__any(fn_reset) && !((TG_FN_ABL & 1) && p.batch >= 0)) {  // levels 2 and 3 of a fresh chain: c2, R1, then c3, R2
       uint32_t e0, e1, f0_, f1_, g0, g1, h0, h1;
-#ifndef TG_FN_DENSE
       threefry2x32(a0, a1, 0u, 0u, e0, e1);
       threefry2x32(a0, a1, 0u, 1u, f0_, f1_);
       threefry2x32(e0, e1, 0u, 0u, g0, g1);
       threefry2x32(e0, e1, 0u, 1u, h0, h1);
-#else
-      const uint64_t mr = __ballot(fn_reset);
-      const int nr = __popcll(mr);
-      const int qr = 2 * (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mr, 0u));
-      if (fn_reset) { tq[qr] = make_uint4(a0, a1, 0u, 0u); tq[qr + 1] = make_uint4(a0, a1, 1u, 0u); }
-      run_tasks(2 * nr);
-      const uint2 re = tr[fn_reset ? qr : 0], rf = tr[fn_reset ? qr + 1 : 0];
-      e0 = re.x; e1 = re.y; f0_ = rf.x; f1_ = rf.y;
-      if (fn_reset) { tq[qr] = make_uint4(e0, e1, 0u, 0u); tq[qr + 1] = make_uint4(e0, e1, 1u, 0u); }
-      run_tasks(2 * nr);
-      const uint2 rg = tr[fn_reset ? qr : 0], rh = tr[fn_reset ? qr + 1 : 0];
-      g0 = rg.x; g1 = rg.y; h0 = rh.x; h1 = rh.y;
-#endif
-      c2 = make_uint2(e0, e1); r1 = make_uint2(f0_, f1_); c3 = make_uint2(g0, g1); r2 = make_uint2(h0, h1);
-      if (fn_reset) { t1x = f0_; t1y = f1_; t2x = h0; t2y = h1; }  // S1 = sort7(R_1), S2 = sort7(R_2)
+      c2 = u32x2{e0, e1}; r1 = u32x2{f0_, f1_}; c3 = u32x2{g0, g1}; r2 = u32x2{h0, h1};
     }
-#ifdef TG_FINE_FN
-    asm volatile("" : "+v"(t1x), "+v"(t1y), "+v"(t2x), "+v"(t2y));
-#endif
     TG_FN_STAMP(5);
-    // the sorts, seven lanes each: task list = first sort of every event lane, then the second sorts
-    const bool two = needq || fn_reset;
-    const uint64_t m2 = __ballot(two);
-    const int nt = n1 + __popcll(m2);
-    const int q2 = n1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+    // The sorts, seven lanes each.  Round 4: only the bags the NEXT transition can deal are sorted now — S2' = sort7(R_{n+3}) of a
+    // lock that leaves the stack within reach of the spawn rows (fn_hi), Q0' = sort7(f1(R_{n+1})) when the next lock refills;
+    // a reset sorts nothing (its board is empty: S1 / S2 of the new chain stay kFnNone until a lock with a tall stack makes
+    // them).  Round 3 sorted S2' for every lock and S1, S2 for every reset: ~15 sorts per wave and transition, two trips'
+    // worth of threefry streams; now ~6 under the random policy, one stream.
+    const bool needs2 = lk && fn_hi;
+    const uint64_t mA = __ballot(needs2), mB = __ballot(needq);
+    const int nA = __popcll(mA), nt = nA + __popcll(mB);
+    const int qA = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u));
+    const int qB = nA + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u));
+    uint64_t p1 = kFnNone, p2 = 0;
+    if (nt > 0 && !((TG_FN_ABL & 2) && p.batch >= 0)) {
     uint2* xk = reinterpret_cast<uint2*>(lds + BG::OFF_FNX);
     uint32_t* xo = reinterpret_cast<uint32_t*>(lds + BG::OFF_FNX + 128 * 8);
-    if (ev) xk[q1] = make_uint2(t1x, t1y);
-    if (two) xk[q2] = make_uint2(t2x, t2y);
+    if (needs2) xk[qA] = make_uint2(b0, b1);
+    if (needq) xk[qB] = make_uint2(z0, z1);
     wave_sync();
     const int j = lane & 7;
     // stable rank of element j among the 7 of its 8-lane group (jax sort_key_val on 32 random bits; ties by index) → the
@@ -2169,14 +2150,6 @@ void step_kernel_bits(
     auto group_perm = [&](const uint32_t bits_in) -> uint32_t {
       const uint32_t bits = j < 7 ? bits_in : 0xFFFFFFFFu;
       int rank = 0;
-#ifdef TG_FN_BPERM  // (the LDS-crossbar form, for A/B)
-#pragma unroll
-      for (int rr = 1; rr < 7; ++rr) {
-        const int oj = j + rr >= 7 ? j + rr - 7 : j + rr;
-        const uint32_t ob = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & ~7) | oj) << 2, (int)bits);
-        rank += (ob < bits || (ob == bits && oj < j)) ? 1 : 0;
-      }
-#else
 #define TG_ROR(r) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0x120 + (r), 0xF, 0xF, true)  // row_ror:r
 #define TG_OTHER(r)                                                                    \
       {                                                                                \
@@ -2189,51 +2162,60 @@ void step_kernel_bits(
       TG_OTHER(1) TG_OTHER(2) TG_OTHER(3) TG_OTHER(4) TG_OTHER(5) TG_OTHER(6) TG_OTHER(7)
 #undef TG_OTHER
 #undef TG_ROR
-#endif
       uint32_t pm = j < 7 ? (uint32_t)j << (3 * rank) : 0u;
       pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
       pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
       pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x141, 0xF, 0xF, true);  // row_half_mirror: the other quad of the 8
       return pm;
     };
-    for (int t0 = 0; t0 < (((TG_FN_ABL & 2) && p.batch >= 0) ? 0 : nt); t0 += 16) {  // 16 sorts per trip: two independent threefry streams per lane
+    for (int t0 = 0; t0 < nt; t0 += 16) {  // 16 sorts per trip: two independent threefry streams per lane
       const int ta = t0 + (lane >> 3), tb = ta + 8;
       const uint2 xa = xk[ta < nt ? ta : 0], xb = xk[tb < nt ? tb : 0];
       uint32_t u0, u1, v0 = 0, v1 = 0;
       threefry2x32(xa.x, xa.y, 0u, (uint32_t)j, u0, u1);
       const uint32_t pa = group_perm(u0 ^ u1);
       if (j == 0 && ta < nt) xo[ta] = pa;
-#ifndef TG_FN_BOTH_STREAMS
       if (nt - t0 <= 8) break;  // (eight sorts or fewer left: the second stream would be ~130 instructions for nobody)
-#endif
       threefry2x32(xb.x, xb.y, 0u, (uint32_t)j, v0, v1);
       const uint32_t pb = group_perm(v0 ^ v1);
       if (j == 0 && tb < nt) xo[tb] = pb;
     }
     wave_sync();
-    uint64_t p1 = xo[ev ? q1 : 0], p2 = xo[two ? q2 : 0];
+    const uint32_t s1 = xo[needs2 ? qA : 0], s2 = xo[needq ? qB : 0];
+    p1 = needs2 ? s1 : kFnNone; p2 = s2;
     wave_sync();
+    }
 #ifdef TG_FINE_FN
     asm volatile("" : "+v"(p1), "+v"(p2));
 #endif
     TG_FN_STAMP(6);
-    if (lk) {
-      cs[n & 3] = c1;            // c_{n+4}
-      rs[(n + 3) & 3] = r0;      // R_{n+3}
+    if (lk) {  // S2 -> S1, the new S2 (or none), the refill bag
       fnw = ((fnw >> 21) & 0x1FFFFFULL) | (p1 << 21) | (needq ? p2 << 42 : 0ULL);
       s.reserved = (s.reserved & ~3u) | (uint32_t)((n + 1) & 3);
     }
-    if (fn_reset) {  // a fresh chain, renumbered from position 0
-      cs[1] = c1; cs[2] = c2; cs[3] = c3;
-      rs[0] = r0; rs[1] = r1; rs[2] = r2;
-      fnw = p1 | (p2 << 21);
+    if (fn_reset) {  // a fresh chain, renumbered from position 0; nothing sorted
+      fnw = (uint64_t)kFnNone | ((uint64_t)kFnNone << 21);
       s.reserved &= ~3u;
     }
-    if (ev && live) {
-      reinterpret_cast<uint2*>(p.rng + env)[5] = knew;  // State.rng_key
-      fn_dirty = true;
+    // The stores (look-ahead block: c[4] | r[4], 8 bytes each; State.rng_key) as raw-buffer stores with the predicate in the
+    // offset: no exec-mask region around any of them (st_state_if).  A lock stores c_{n+4} → c[n & 3], R_{n+3} → r[(n + 3) & 3];
+    // a reset c_1..c_3 → c[1..3], R_0..R_2 → r[0..2]: the level-1 results of both kinds leave by the same two instructions.
+    {
+      const __amdgpu_buffer_rsrc_t wla = st_window(bp.ahead, (uint32_t)hot_batch * 128u);
+      const uint32_t eo = env * 128u;
+      const bool evl = ev && live;
+      const bool rsl = fn_reset && live;
+      st_b64_if(wla, eo + 8u * (uint32_t)(fn_reset ? 1 : (n & 3)), c1, evl);
+      st_b64_if(wla, eo + 32u + 8u * (uint32_t)(fn_reset ? 0 : ((n + 3) & 3)), r0, evl);
+      st_b64_if(wla, eo + 16u, c2, rsl);
+      st_b64_if(wla, eo + 24u, c3, rsl);
+      st_b64_if(wla, eo + 40u, r1, rsl);
+      st_b64_if(wla, eo + 48u, r2, rsl);
+      st_b64_if(st_window(p.rng, (uint32_t)hot_batch * (uint32_t)sizeof(tg_rng_rec)), env * (uint32_t)sizeof(tg_rng_rec) + 40u,
+                u32x2{knew.x, knew.y}, evl);  // State.rng_key
+      fn_dirty = fn_dirty | evl;
     }
-    fn_lock = false; fn_reset = false;
+    fn_lock = false; fn_reset = false; fn_hi = false;
     TG_FN_STAMP(7);
   };
   const bool book_first = RULESET == TG_RULESET_NUMPY && early_book;
