@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 2 /* 2: tg_config launch knobs, tg_dev_copy, tg_get_state_dev / tg_set_state_dev */
+#define TG_ABI_VERSION 3 /* 2: tg_config launch knobs, tg_dev_copy, tg_get_state_dev / tg_set_state_dev
+                          * 3: TG_BUF_HOST_PACK, tg_host_pack_layout, tg_fetch_many, tg_step_fetch_many, tg_shape_mask */
 
 /* ---- rule-sets (the reference contains two different Tetris rule-sets) ---- */
 #define TG_RULESET_NUMPY 0      /* envs/tetris.py (the graded oracle) */
@@ -152,7 +153,15 @@ typedef struct tg_rng_rec { /* 48 bytes */
 #define TG_BUF_EPISODE 8    /* tg_episode_rec [B] (TG_FLAG_EPISODE_STATS) */
 #define TG_BUF_PLACEMENT_FEATS 9 /* u8 [B][4W][W+3] (TG_FLAG_FEATURES): per-placement feature vectors, see tg_features */
 #define TG_BUF_FEATS 10     /* u8 [B][W+3] (TG_FLAG_FEATURES): FeatureVectorObservation of the current observation */
-#define TG_BUF_COUNT 11
+#define TG_BUF_HOST_PACK 11 /* what a gymnasium-contract step() returns beside the observation, in the dtypes and the array-
+                             * per-field layout the host hands out (tg_host_pack_layout): rewards f64[B] | episode return f64[B]
+                             * | lines_cleared i32[B] | episode length i32[B] | terminated u8[B] — the episode fields hold the
+                             * finished episode's statistics where `terminated`, zero elsewhere (the RecordEpisodeStatistics
+                             * convention of examples/train_ppo.py:246-260), the invalid-action reward of the grouped action set
+                             * is the double -0.1.  Packed on demand from TG_BUF_STEP_OUT / TG_BUF_EPISODE by a small kernel
+                             * when the buffer is fetched (tg_fetch / tg_fetch_many / tg_step_fetch_many / tg_device_ptr); it sits
+                             * directly behind TG_BUF_OBS in device memory so that both leave in ONE device-to-host copy. */
+#define TG_BUF_COUNT 12
 
 typedef struct tg_step_out { /* 8 bytes, written by the step kernel with one store per env */
   float reward;        /* NUMPY rewards are integer-valued (envs/tetris.py:468-474); grouped illegal = -0.1f */
@@ -215,6 +224,25 @@ int tg_device_ptr(tg_handle* h, int which, void** ptr, size_t* bytes);
 /* Synchronous copy of an engine-owned buffer to host memory (waits for the stream). */
 int tg_fetch(tg_handle* h, int which, void* host_dst, size_t bytes);
 
+/* Byte offsets of the five arrays of TG_BUF_HOST_PACK for a config, in the order listed there, and the buffer's size in
+ * offsets[5] (every array starts 16-byte aligned). */
+int tg_host_pack_layout(const tg_config* cfg, size_t offsets[6]);
+
+/* m buffers in one call and ONE wait: all copies are enqueued, then the stream is synchronised once (tg_fetch costs a
+ * synchronisation per buffer: three per step of a gymnasium-style step()).  Requests that are neighbours in device memory
+ * AND in host memory at the same distance (TG_BUF_OBS followed by TG_BUF_HOST_PACK into one page-locked slab laid out like
+ * the device side: host_dst[1] - host_dst[0] == their device distance) are merged into a single copy. */
+int tg_fetch_many(tg_handle* h, int m, const int* which, void* const* host_dst, const size_t* bytes);
+
+/* One transition on n handles (one per GPU, or several shards of one GPU) and the fetches that follow it, from ONE host
+ * thread and with one wait per handle: phase 1 enqueues, handle by handle, the action upload, the step launch and the m
+ * device-to-host copies (nothing in it blocks when the destinations are page-locked); phase 2 waits for every stream.
+ * actions[k]: i32[batch of handle k] in host or device memory (kind), or actions == NULL to fetch only.  which[m] is
+ * the same for every handle; host_dst and bytes are [n][m] row-major.  What gymnasium.vector.SyncVectorEnv.step does
+ * with a Python loop over envs (examples/train_ppo.py:240-248), for all GPUs of a node in one call. */
+int tg_step_fetch_many(int n, tg_handle* const* hs, const void* const* actions, int kind, int m, const int* which,
+                       void* const* host_dst, const size_t* bytes);
+
 /* Full state snapshot / restore (host buffers; any pointer may be NULL to skip).
  * board u8[B][H][W], rec tg_env_rec[B], rng tg_rng_rec[B].  (envs/tetris.py:681-708) */
 int tg_get_state(tg_handle* h, uint8_t* board, tg_env_rec* rec, tg_rng_rec* rng);
@@ -269,6 +297,11 @@ int tg_step_kernel_name(tg_handle* h, int transitions_per_launch, int trajectory
 
 /* Host utility: numpy SeedSequence(seed) → PCG64 initial state, as tg_rng_rec (pinned by tests). */
 int tg_seed_pcg64(uint64_t seed, tg_rng_rec* out);
+
+/* Host utility: the 16-bit cell mask (bit 4*row + col of the 4x4 box) of tetromino `piece` (0..6: I O T S Z J L) after `rot`
+ * np.rot90(k=+1) rotations — the table every kernel uses (tests compare it with the reference's matrices,
+ * envs/tetris.py:47-75).  Negative on bad arguments. */
+int tg_shape_mask(int piece, int rot);
 
 /* Sizes derived from a config (bytes per env of the observation buffer, number of actions). */
 int tg_obs_bytes_per_env(const tg_config* cfg);

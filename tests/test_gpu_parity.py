@@ -541,15 +541,18 @@ def test_functional_large_batches_one_transition_per_launch(B, autoreset):
     e.close()
 
 
-@pytest.mark.parametrize("lazy", [0, 1, 2])
+@pytest.mark.parametrize("lazy", [0, 1, 2, 4, 5])
 @pytest.mark.parametrize("autoreset", [N.AUTORESET_SAME_STEP, N.AUTORESET_NEXT_STEP])
 @pytest.mark.parametrize("fuse", [1, 16])
 def test_functional_reset_bags_sorted_ahead_or_in_line(lazy, autoreset, fuse, monkeypatch):
     """FUNCTIONAL rule-set (envs/tetris_fn.py:318-367, functional/queue.py:20-35): the bag a reset deals is sorted AHEAD only by
     a lock that leaves the stack within reach of the spawn rows (rows 0-5: tg_kernel_bits.h fn_hi); TG_FN_LAZY=1 never sorts
-    ahead, so every episode end takes the in-line sort, TG_FN_LAZY=2 always sorts ahead (round 3).  All three against the
-    oracle — outputs of every transition, observation, state and jax keys — from fresh resets and from uploaded tall
-    boards (tg_set_state rebuilds the whole look-ahead), hard-drop-heavy so that episodes end all the time."""
+    ahead, so every episode end takes the in-line sort, TG_FN_LAZY=2 always sorts ahead (round 3).  The key-chain look-ahead
+    behind a reset is one key deep and catches up over the idle transitions that follow; TG_FN_LAZY bit 2 (4, 5) never
+    catches up, so every lock, refill and reset runs its depth-1 form.  All of them against the oracle — outputs of every
+    transition, observation, state and jax keys — from fresh resets, from uploaded tall boards (tg_set_state rebuilds the
+    whole look-ahead) and from uploaded game-over states (a reset that no lock of the transition precedes), hard-drop-heavy
+    so that episodes end all the time."""
     monkeypatch.setenv("TG_FN_LAZY", str(lazy))
     monkeypatch.setenv("TG_FUSE", str(fuse))
     B, W, H = 1500, 10, 20
@@ -566,6 +569,10 @@ def test_functional_reset_bags_sorted_ahead_or_in_line(lazy, autoreset, fuse, mo
                 top = 3 + 2 * (i % 3)
                 b[i, top:, :] = 2 + (i % 7)
                 b[i, top:, i % W] = 0
+            o.set_state(board=b, rec=r, rng=g); e.set_state(board=b, rec=r, rng=g)
+        if phase == 2:  # every fifth env is handed over already game over
+            b, r, g = o.get_state()
+            r["flags"][::5] |= N.F_GAME_OVER
             o.set_state(board=b, rec=r, rng=g); e.set_state(board=b, rec=r, rng=g)
         for K in (1, 7, 16, 40):
             acts = rng.integers(0, 7, (K, B)).astype(np.int8)

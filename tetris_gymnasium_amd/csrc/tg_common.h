@@ -66,8 +66,9 @@ struct KParams {
   int8_t* act_traj;         // optional: the drawn actions, rows act_stride apart
   int ring_fill;            // bits kernel only: ring entries the RNG role maintains (TG_RING_FILL, default all)
   int dict_in_kernel;       // bits kernel only: TG_OBS_DICT is packed by the step kernel's two waves (sizes with (H+4)(W+8) % 16 == 0)
-  int fn_lazy;              // bits kernel, FUNCTIONAL (TG_FN_LAZY, tests): 0 = a lock sorts the reset bag ahead only when the stack is within
-                            // reach of the spawn rows, 1 = never (every terminal lock takes the in-line sort), 2 = always (round 3)
+  int fn_lazy;              // bits kernel, FUNCTIONAL (TG_FN_LAZY, tests): bits 0-1: 0 = a lock sorts the reset bag ahead only when the stack is
+                            // within reach of the spawn rows, 1 = never (every episode end takes the in-line sort), 2 = always (round 3);
+                            // bit 2: the look-ahead never catches up behind a reset (the chain stays one key deep)
 };
 
 struct ResetParams {

@@ -434,6 +434,50 @@ Launchers rtc_launchers(const RtcSize* r) {
   return L;
 }
 
+// TG_BUF_HOST_PACK: rewards f64 | episode returns f64 | lines i32 | episode lengths i32 | terminated u8, each 16-byte aligned
+size_t host_pack_layout(size_t B, size_t* off) {
+  auto up = [](size_t v) { return (v + 15) / 16 * 16; };
+  size_t o[6];
+  o[0] = 0;
+  o[1] = up(o[0] + 8 * B);
+  o[2] = up(o[1] + 8 * B);
+  o[3] = up(o[2] + 4 * B);
+  o[4] = up(o[3] + 4 * B);
+  o[5] = up(o[4] + B);
+  if (off) for (int i = 0; i < 6; ++i) off[i] = o[i];
+  return o[5];
+}
+
+struct PackParams {
+  const uint2* out;             // tg_step_out [B]
+  const tg_episode_rec* ep;     // or null
+  uint8_t* pack;
+  size_t off[5];
+  int batch;
+};
+
+__global__ __launch_bounds__(256) void host_pack_kernel(const PackParams p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.batch) return;
+  const uint2 o = p.out[i];
+  const float r = __uint_as_float(o.x);
+  const uint32_t term = o.y & 0xFFu, lines = (o.y >> 8) & 0xFFu;
+  double er = 0.0;
+  int el = 0;
+  if (p.ep && term) {
+    const tg_episode_rec e = p.ep[i];
+    er = (double)e.last_ret;
+    el = (int)e.last_len;
+  }
+  // (the only negative reward is rewards.invalid_action of the grouped action set, mappings/rewards.py: the host hands out
+  // the Python float -0.1, not float32(-0.1))
+  reinterpret_cast<double*>(p.pack + p.off[0])[i] = r < 0.0f ? -0.1 : (double)r;
+  reinterpret_cast<double*>(p.pack + p.off[1])[i] = er;
+  reinterpret_cast<int32_t*>(p.pack + p.off[2])[i] = (int32_t)lines;
+  reinterpret_cast<int32_t*>(p.pack + p.off[3])[i] = el;
+  (p.pack + p.off[4])[i] = (uint8_t)(term ? 1 : 0);
+}
+
 std::string built_sizes() {
   std::string s;
 #define X(w, h) s += std::string(s.empty() ? "" : ", ") + #w "x" #h;
@@ -743,11 +787,64 @@ int launch_materialize_rng(tg_handle* h) {
   return TG_OK;
 }
 
+// TG_BUF_HOST_PACK is packed when somebody asks for it (the step path never pays for it)
+int launch_host_pack(tg_handle* h) {
+  PackParams q{};
+  q.out = (const uint2*)h->buf[TG_BUF_STEP_OUT];
+  q.ep = (const tg_episode_rec*)h->buf[TG_BUF_EPISODE];
+  q.pack = (uint8_t*)h->buf[TG_BUF_HOST_PACK];
+  size_t off[6];
+  host_pack_layout((size_t)h->B, off);
+  for (int i = 0; i < 5; ++i) q.off[i] = off[i];
+  q.batch = h->B;
+  hipLaunchKernelGGL(host_pack_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, q);
+  HIPCHK(h, hipGetLastError());
+  return TG_OK;
+}
+
+// the enqueue half of tg_fetch_many (no wait)
+int enqueue_fetches(tg_handle* h, int m, const int* which, void* const* host_dst, const size_t* bytes) {
+  for (int i = 0; i < m; ++i) {
+    if (which[i] < 0 || which[i] >= TG_BUF_COUNT || (!host_dst[i] && bytes[i])) return fail(h, TG_EINVAL, "tg_fetch_many: bad request %d", i);
+    if (bytes[i] > h->bytes[which[i]])
+      return fail(h, TG_EINVAL, "tg_fetch_many: %zu bytes requested, buffer %d holds %zu", bytes[i], which[i], h->bytes[which[i]]);
+  }
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
+  for (int i = 0; i < m; ++i) {
+    if (which[i] == TG_BUF_RNG) { int rc = launch_materialize_rng(h); if (rc != TG_OK) return rc; }
+    if (which[i] == TG_BUF_HOST_PACK) { int rc = launch_host_pack(h); if (rc != TG_OK) return rc; }
+  }
+  for (int i = 0; i < m;) {
+    // neighbours in device memory and, at the same distance, in host memory leave as one copy (the gap between two pieces of
+    // the arena is its tail padding: a few KiB)
+    const char* d0 = (const char*)h->buf[which[i]];
+    char* h0 = (char*)host_dst[i];
+    size_t len = bytes[i];
+    int j = i + 1;
+    while (j < m && bytes[j] && len) {
+      const char* dj = (const char*)h->buf[which[j]];
+      const ptrdiff_t dd = dj - d0, hd = (char*)host_dst[j] - h0;
+      if (dd != hd || dd < (ptrdiff_t)len || dd - (ptrdiff_t)len > 16384) break;
+      len = (size_t)dd + bytes[j];
+      ++j;
+    }
+    if (len) HIPCHK(h, hipMemcpyAsync(h0, d0, len, hipMemcpyDeviceToHost, h->stream));
+    i = j;
+  }
+  return TG_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
 int tg_abi_version(void) { return TG_ABI_VERSION; }
+
+int tg_host_pack_layout(const tg_config* cfg, size_t offsets[6]) {
+  if (!cfg || !offsets || cfg->batch <= 0) return TG_EINVAL;
+  host_pack_layout((size_t)cfg->batch, offsets);
+  return TG_OK;
+}
 
 int tg_device_count(void) {
   int n = 0;
@@ -885,7 +982,8 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
       /*FINAL_OBS*/ want_final ? B * h->cells : 0,
       /*EPISODE*/ (cfg->flags & TG_FLAG_EPISODE_STATS) ? B * sizeof(tg_episode_rec) : 0,
       /*PLACEMENT_FEATS*/ (cfg->flags & TG_FLAG_FEATURES) ? B * 4 * (size_t)cfg->width * (size_t)(cfg->width + 3) : 0,
-      /*FEATS*/ (cfg->flags & TG_FLAG_FEATURES) ? B * (size_t)(cfg->width + 3) : 0};
+      /*FEATS*/ (cfg->flags & TG_FLAG_FEATURES) ? B * (size_t)(cfg->width + 3) : 0,
+      /*HOST_PACK*/ host_pack_layout(B, nullptr)};
   {
     h->arena_skew = 0;
     if (const char* e = getenv("TG_ALLOC_SKEW")) h->arena_skew = (size_t)(atol(e) > 0 ? atol(e) : 0);
@@ -898,9 +996,16 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     h->arena_size = total;
     CRCHK(hipMemsetAsync(h->arena, 0, total, h->stream));
   }
-  for (int i = 0; i < TG_BUF_COUNT; ++i) {
-    int rc = alloc_buf(h, i, sizes[i]);
-    if (rc != TG_OK) return bail(rc);
+  {  // (fixed order; TG_BUF_HOST_PACK directly behind TG_BUF_OBS: a step's host-bound results are one device range)
+    int order[TG_BUF_COUNT], k = 0;
+    order[k++] = TG_BUF_OBS;
+    order[k++] = TG_BUF_HOST_PACK;
+    for (int i = 0; i < TG_BUF_COUNT; ++i)
+      if (i != TG_BUF_OBS && i != TG_BUF_HOST_PACK) order[k++] = i;
+    for (int i = 0; i < TG_BUF_COUNT; ++i) {
+      int rc = alloc_buf(h, order[i], sizes[order[i]]);
+      if (rc != TG_OK) return bail(rc);
+    }
   }
   CRCHK(arena_take(h, (void**)&h->d_new_rng, B * sizeof(tg_rng_rec)));
   CRCHK(arena_take(h, (void**)&h->d_reseed, B));
@@ -934,7 +1039,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     if (cfg->fuse > 0) h->fuse_max = cfg->fuse > tg::kMaxFuse ? tg::kMaxFuse : cfg->fuse;
     if (const char* e = getenv("TG_RING_FILL")) { const int v = atoi(e); h->ring_fill = v < 0 ? 0 : (v > tg::kRing - 1 ? tg::kRing - 1 : v); }
     if (const char* e = getenv("TG_RNG_EVERY")) { const int v = atoi(e); h->rng_every = v < 1 ? 1 : (v > 3 ? 3 : v); }
-    if (const char* e = getenv("TG_FN_LAZY")) { const int v = atoi(e); h->fn_lazy = v < 0 ? 0 : (v > 2 ? 2 : v); }
+    if (const char* e = getenv("TG_FN_LAZY")) { const int v = atoi(e); h->fn_lazy = v < 0 ? 0 : (v & 7); }
     if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > tg::kMaxFuse ? tg::kMaxFuse : v); }
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
     int want = 1;
@@ -1177,6 +1282,12 @@ int tg_device_ptr(tg_handle* h, int which, void** ptr, size_t* bytes) {
     if (rcj == TG_OK) rcj = launch_materialize_rng(h);
     if (rcj != TG_OK) return rcj;
   }
+  if (which == TG_BUF_HOST_PACK) {
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rcj = join_shards(h);
+    if (rcj == TG_OK) rcj = launch_host_pack(h);
+    if (rcj != TG_OK) return rcj;
+  }
   if (ptr) *ptr = h->buf[which];
   if (bytes) *bytes = h->bytes[which];
   return TG_OK;
@@ -1188,8 +1299,40 @@ int tg_fetch(tg_handle* h, int which, void* host_dst, size_t bytes) {
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   if (which == TG_BUF_RNG) { int rcm = launch_materialize_rng(h); if (rcm != TG_OK) return rcm; }
+  if (which == TG_BUF_HOST_PACK) { int rcm = launch_host_pack(h); if (rcm != TG_OK) return rcm; }
   if (bytes) HIPCHK(h, hipMemcpyAsync(host_dst, h->buf[which], bytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  return TG_OK;
+}
+
+int tg_fetch_many(tg_handle* h, int m, const int* which, void* const* host_dst, const size_t* bytes) {
+  if (!h || m < 0 || (m && (!which || !host_dst || !bytes))) return h ? fail(h, TG_EINVAL, "tg_fetch_many: bad arguments") : TG_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rc = enqueue_fetches(h, m, which, host_dst, bytes); if (rc != TG_OK) return rc; }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return TG_OK;
+}
+
+int tg_step_fetch_many(int n, tg_handle* const* hs, const void* const* actions, int kind, int m, const int* which,
+                       void* const* host_dst, const size_t* bytes) {
+  if (n <= 0 || !hs || m < 0 || (m && (!which || !host_dst || !bytes))) return TG_EINVAL;
+  for (int k = 0; k < n; ++k)
+    if (!hs[k]) return TG_EINVAL;
+  for (int k = 0; k < n; ++k) {  // phase 1: enqueue everything, handle by handle
+    tg_handle* h = hs[k];
+    if (actions) {
+      const int rc = tg_step(h, (const int32_t*)actions[k], kind);
+      if (rc != TG_OK) return rc;
+    } else {
+      HIPCHK(h, hipSetDevice(h->cfg.device));
+    }
+    if (m) { const int rc = enqueue_fetches(h, m, which, host_dst + (size_t)k * m, bytes + (size_t)k * m); if (rc != TG_OK) return rc; }
+  }
+  for (int k = 0; k < n; ++k) {  // phase 2: one wait per handle
+    tg_handle* h = hs[k];
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (m) HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
   return TG_OK;
 }
 

@@ -1586,13 +1586,15 @@ void step_kernel_bits(
 #else
   constexpr bool fn_prefetch_late = false;
 #endif
-  u32x2 pf_c1 = u32x2{0u, 0u}, pf_c3 = pf_c1, pf_r1 = pf_c1;  // (native vectors: HIP's uint2 struct went to scratch memory)
-  const int fn_n0 = (int)(s.reserved & 3u);
+  u32x2 pf_c1 = u32x2{0u, 0u}, pf_cf = pf_c1, pf_r1 = pf_c1;  // (native vectors: HIP's uint2 struct went to scratch memory)
+  // position n on the key chain (mod 4) and how far the look-ahead reaches (1..3 keys; tg_env_rec.reserved holds 3 - depth in
+  // bits 2-3, so a zeroed field = position 0 at full depth: what bits_prepare_kernel builds)
+  const int fn_n0 = (int)(s.reserved & 3u), fn_d0 = 3 - (int)((s.reserved >> 2) & 3u);
   // (an env that only resets in this transition — NEXT_STEP autoreset, the step after its end — continues with R_n)
   const bool fn_pend0 = p.autoreset == TG_AUTORESET_NEXT_STEP && (s.flags & TG_F_PENDING_RESET);
-  if (RULESET == TG_RULESET_FUNCTIONAL && !fn_prefetch_late) {
+  if (RULESET == TG_RULESET_FUNCTIONAL && !fn_prefetch_late) {  // c_{n+1}, the frontier key c_{n+depth}, R_{n+1} (R_n)
     const u32x2* cs = reinterpret_cast<const u32x2*>(bp.ahead) + (size_t)env * 16;
-    pf_c1 = cs[(fn_n0 + 1) & 3]; pf_c3 = cs[(fn_n0 + 3) & 3]; pf_r1 = cs[4 + ((fn_pend0 ? fn_n0 : fn_n0 + 1) & 3)];
+    pf_c1 = cs[(fn_n0 + 1) & 3]; pf_cf = cs[(fn_n0 + fn_d0) & 3]; pf_r1 = cs[4 + ((fn_pend0 ? fn_n0 : fn_n0 + 1) & 3)];
   }
   int action_in = hot_act_i8 ? (int)(int8_t)(((kMaxFuse > 8 && step >= 8) ? apack1 : apack) >> (8 * (step & 7))) : action0;
   if (RULESET == TG_RULESET_NUMPY && sample_mode) {
@@ -1907,11 +1909,11 @@ void step_kernel_bits(
       }
     }
     s.flags &= place ? ~TG_F_FULLROW : ~0;
-    if (RULESET == TG_RULESET_FUNCTIONAL) {  // (see fn_hi; p.fn_lazy: 0 = as described, 1 = never sort ahead, 2 = always: tests)
+    if (RULESET == TG_RULESET_FUNCTIONAL) {  // (see fn_hi; p.fn_lazy & 3: 0 = as described, 1 = never sort ahead, 2 = always: tests)
       T orc = 0;
 #pragma unroll
       for (int c = 0; c < W; ++c) orc |= v[c];
-      fn_hi = place & ((((orc & T(0x3F)) != 0) & (p.fn_lazy != 1)) | (p.fn_lazy == 2));
+      fn_hi = place & ((((orc & T(0x3F)) != 0) & ((p.fn_lazy & 3) != 1)) | ((p.fn_lazy & 3) == 2));
     }
     // collision of the new piece at its spawn position (rows 0..3 of the columns it spans; static columns)
     bool sc;
@@ -1987,13 +1989,17 @@ void step_kernel_bits(
       const bool unsorted = do_reset & (f21 == kFnNone);
       if (__any(unsorted)) {
         // The bag was not sorted ahead (fn_hi: the stack was low when the look-ahead was made good).  By the argument there
-        // this does not happen in play; it does after the test knob p.fn_lazy = 1 and would after a rule change — sort now,
-        // from R_{n+1} (a reset alone) or R_{n+2} (behind a lock) of the env's look-ahead block.  The block may have been
+        // this does not happen in play; it does after the test knob p.fn_lazy = 1 and would after a rule change — sort now:
+        // R_{n+1} (a reset alone) or R_{n+2} (behind a lock), derived from the env's current key (the look-ahead block may
+        // not reach that far: its depth grows back over the idle transitions behind a reset).  The key may have been
         // written by an earlier transition of this launch: those stores are made visible first.
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-        const uint2* rsl = reinterpret_cast<const uint2*>(bp.ahead) + (size_t)env * 16 + 4;
-        const uint2 rk = rsl[((int)(s.reserved & 3u) + (fn_lock ? 2 : 1)) & 3];
-        const uint32_t srt = fn_sort7(rk.x, rk.y);
+        const uint2 ck = reinterpret_cast<const uint2*>(p.rng + env)[5];  // c_n = State.rng_key (fn_book keeps it current)
+        uint32_t x0, x1, y0, y1, r0_, r1_;
+        threefry2x32(ck.x, ck.y, 0u, 0u, x0, x1);                                   // c_{n+1}
+        threefry2x32(x0, x1, 0u, 0u, y0, y1);                                       // c_{n+2}
+        threefry2x32(fn_lock ? y0 : x0, fn_lock ? y1 : x1, 0u, 1u, r0_, r1_);       // R_{n+2} | R_{n+1}
+        const uint32_t srt = fn_sort7(r0_, r1_);
         f21 = unsorted ? srt : f21;
       }
       const uint64_t nb = fn_expand21(f21);
@@ -2081,55 +2087,75 @@ void step_kernel_bits(
     }
   };
   // FUNCTIONAL: make good what this transition consumed of the key-chain look-ahead (protocol at the top of this file),
-  // beside the stream wave's work.  Lanes with a lock: one threefry level (c_{n+4}, R_{n+3}, f1(R_{n+1}) when the next
-  // lock refills) + the sorts S2', Q0'.  Lanes with a reset: three levels from the new key + the sorts S1, S2.
+  // beside the stream wave's work.  ONE threefry level per lane and transition (round 4; round 3 ran three levels for a reset):
+  //   a lock at n        advances the frontier  c_{n+d} -> c_{n+d+1}, R_{n+d}          (position n + 1, depth d as before)
+  //   a reset            starts a chain          K -> c_1, R_0                           (position 0, depth 1)
+  //   neither, d < 3     catches up              c_{n+d} -> c_{n+d+1}, R_{n+d}           (depth d + 1)
+  // — the levels a fresh chain lacks are made in the idle transitions behind the reset, by lanes that would sit out the
+  // wave's pass anyway (a pass costs the wave the same however few lanes want it, and some lane locks in practically every
+  // transition).  Nothing needs them earlier: the next lock takes c_{n+1}; the bag a refill deals (Q0', six locks away)
+  // needs R_{n+1}, which a depth-1 lock makes in this very pass; the bag a reset behind the next lock deals (S2') is
+  // sorted ahead only at full depth — a tall stack within two transitions of a reset does not occur, and the in-line sort
+  // where the bag is dealt covers whatever does.
   auto fn_book = [&]() {
     const bool ev = fn_lock || fn_reset;
-#ifndef TG_FN_ABL  // timing ablations (results wrong): 1 no reset levels, 2 no sorts, 4 nothing, 8 no level 1
+    const bool cu = !ev && fn_d0 < 3 && !(p.fn_lazy & 4);  // (test knob: bit 2 = never catch up — the chain stays one key deep)
+#ifndef TG_FN_ABL  // timing ablations (results wrong): 2 no sorts, 4 nothing
 #define TG_FN_ABL 0
 #endif
     if ((TG_FN_ABL & 4) && p.batch >= 0) return;
-#ifdef TG_FINE_FN  // (stamps: 3 = fn_book entered, 4 = level 1 done, 5 = reset levels done, 6 = sorts done, 7 = fn_book left)
+#ifdef TG_FINE_FN  // (stamps: 3 = fn_book entered, 4 = level done, 6 = sorts done, 7 = fn_book left)
 #define TG_FN_STAMP(i) TG_BITS_STAMP(i)
 #else
 #define TG_FN_STAMP(i) do {} while (0)
 #endif
     TG_FN_STAMP(3);
-    if (!__any(ev)) return;
-    const int n = (int)(s.reserved & 3u);
+    if (!__any(ev | cu)) return;
+    const int n = fn_n0, d = fn_d0;
     const bool lk = fn_lock && !fn_reset;           // stays on its chain: position n + 1
     const bool needq = lk && s.bidx >= 7;           // ... whose lock will refill the bag
-    // loads (event lanes): the key the lane continues from, the chain's last key, R_{n+1}
-    uint2 ka = make_uint2(pf_c3.x, pf_c3.y), kb = make_uint2(pf_r1.x, pf_r1.y), knew = make_uint2(pf_c1.x, pf_c1.y);
-    if (fn_reset) { knew = kb; ka = kb; }  // R_{n+1} behind a lock of this transition (SAME_STEP), R_n otherwise
-    // (The threefry blocks of the levels as a dense task list through LDS — one block per level instead of two or three — were
+    u32x2 kb = pf_r1;
+    // The key a reset continues with: R_n — or R_{n+1} behind a lock of this transition (SAME_STEP).  The prefetch took R_n for
+    // an env that was waiting for its reset (NEXT_STEP) and R_{n+1} otherwise; the two cases it cannot serve are rare and
+    // wave-uniform branches: a reset without a lock of an env that was not waiting (a game-over state uploaded under SAME_STEP:
+    // R_n is fetched now) and a reset behind a lock at depth 1 (R_{n+1} = f1(c_{n+1}) is not in the block yet).
+    {
+      const bool want_rn = fn_reset && !fn_lock && !fn_pend0;
+      if (__any(want_rn)) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        const u32x2 rn = (reinterpret_cast<const u32x2*>(bp.ahead) + (size_t)env * 16)[4 + (n & 3)];
+        kb = want_rn ? rn : kb;
+      }
+      const bool deep = fn_reset && fn_lock && d < 2;
+      if (__any(deep)) {
+        uint32_t q0, q1;
+        threefry2x32(pf_c1.x, pf_c1.y, 0u, 1u, q0, q1);
+        kb = deep ? u32x2{q0, q1} : kb;
+      }
+    }
+    const u32x2 ka = fn_reset ? kb : pf_cf, knew = fn_reset ? kb : pf_c1;
+    // (The threefry blocks as a dense task list through LDS — one block for the wave's ~27 tasks instead of two or three — were
     // built in round 3, bit-identical, and not kept: 8.07 -> 7.96 us per launch at 65 536 envs but +2 % per fused transition and
     // at 4 096 envs, where the LDS exchanges are latency on the chain the launch waits for.  profiles/r03/ab_functional_dense.log)
-    // level 1
     uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0, z0 = 0, z1 = 0;
     threefry2x32(ka.x, ka.y, 0u, 0u, a0, a1);
     threefry2x32(ka.x, ka.y, 0u, 1u, b0, b1);
-    if (__any(needq)) threefry2x32(kb.x, kb.y, 0u, 1u, z0, z1);
+    if (__any(needq)) {  // Q0' = sort7(f1(R_{n+1})); at depth 1 R_{n+1} is what this pass has just made
+      const bool shallow = d < 2;
+      threefry2x32(shallow ? b0 : kb.x, shallow ? b1 : kb.y, 0u, 1u, z0, z1);
+    }
 #ifdef TG_FINE_FN
     asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(z0), "+v"(z1));
 #endif
     TG_FN_STAMP(4);
-    u32x2 c1 = u32x2{a0, a1}, r0 = u32x2{b0, b1}, c2 = c1, c3 = c1, r1 = r0, r2 = r0;
-    if (__any(fn_reset) && !((TG_FN_ABL & 1) && p.batch >= 0)) {  // levels 2 and 3 of a fresh chain: c2, R1, then c3, R2
-      uint32_t e0, e1, f0_, f1_, g0, g1, h0, h1;
-      threefry2x32(a0, a1, 0u, 0u, e0, e1);
-      threefry2x32(a0, a1, 0u, 1u, f0_, f1_);
-      threefry2x32(e0, e1, 0u, 0u, g0, g1);
-      threefry2x32(e0, e1, 0u, 1u, h0, h1);
-      c2 = u32x2{e0, e1}; r1 = u32x2{f0_, f1_}; c3 = u32x2{g0, g1}; r2 = u32x2{h0, h1};
-    }
+    const u32x2 c1 = u32x2{a0, a1}, r0 = u32x2{b0, b1};
     TG_FN_STAMP(5);
     // The sorts, seven lanes each.  Round 4: only the bags the NEXT transition can deal are sorted now — S2' = sort7(R_{n+3}) of a
     // lock that leaves the stack within reach of the spawn rows (fn_hi), Q0' = sort7(f1(R_{n+1})) when the next lock refills;
     // a reset sorts nothing (its board is empty: S1 / S2 of the new chain stay kFnNone until a lock with a tall stack makes
     // them).  Round 3 sorted S2' for every lock and S1, S2 for every reset: ~15 sorts per wave and transition, two trips'
     // worth of threefry streams; now ~6 under the random policy, one stream.
-    const bool needs2 = lk && fn_hi;
+    const bool needs2 = lk && fn_hi && d == 3;  // (b = R_{n+3} only at full depth)
     const uint64_t mA = __ballot(needs2), mB = __ballot(needq);
     const int nA = __popcll(mA), nt = nA + __popcll(mB);
     const int qA = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u));
@@ -2193,26 +2219,22 @@ void step_kernel_bits(
       fnw = ((fnw >> 21) & 0x1FFFFFULL) | (p1 << 21) | (needq ? p2 << 42 : 0ULL);
       s.reserved = (s.reserved & ~3u) | (uint32_t)((n + 1) & 3);
     }
-    if (fn_reset) {  // a fresh chain, renumbered from position 0; nothing sorted
+    if (fn_reset) {  // a fresh chain, renumbered from position 0, one key deep; nothing sorted
       fnw = (uint64_t)kFnNone | ((uint64_t)kFnNone << 21);
-      s.reserved &= ~3u;
+      s.reserved = (s.reserved & ~15u) | (2u << 2);
     }
+    if (cu) s.reserved = (s.reserved & ~(3u << 2)) | ((uint32_t)(3 - (d + 1)) << 2);
     // The stores (look-ahead block: c[4] | r[4], 8 bytes each; State.rng_key) as raw-buffer stores with the predicate in the
-    // offset: no exec-mask region around any of them (st_state_if).  A lock stores c_{n+4} → c[n & 3], R_{n+3} → r[(n + 3) & 3];
-    // a reset c_1..c_3 → c[1..3], R_0..R_2 → r[0..2]: the level-1 results of both kinds leave by the same two instructions.
+    // offset: no exec-mask region around any of them (st_state_if).  c_{n+d+1} → c[(n + d + 1) & 3], R_{n+d} → r[(n + d) & 3];
+    // a reset's c_1 → c[1], R_0 → r[0]: the same two instructions.
     {
       const __amdgpu_buffer_rsrc_t wla = st_window(bp.ahead, (uint32_t)hot_batch * 128u);
       const uint32_t eo = env * 128u;
-      const bool evl = ev && live;
-      const bool rsl = fn_reset && live;
-      st_b64_if(wla, eo + 8u * (uint32_t)(fn_reset ? 1 : (n & 3)), c1, evl);
-      st_b64_if(wla, eo + 32u + 8u * (uint32_t)(fn_reset ? 0 : ((n + 3) & 3)), r0, evl);
-      st_b64_if(wla, eo + 16u, c2, rsl);
-      st_b64_if(wla, eo + 24u, c3, rsl);
-      st_b64_if(wla, eo + 40u, r1, rsl);
-      st_b64_if(wla, eo + 48u, r2, rsl);
+      const bool anyl = (ev || cu) && live, evl = ev && live;
+      st_b64_if(wla, eo + 8u * (uint32_t)(fn_reset ? 1 : ((n + d + 1) & 3)), c1, anyl);
+      st_b64_if(wla, eo + 32u + 8u * (uint32_t)(fn_reset ? 0 : ((n + d) & 3)), r0, anyl);
       st_b64_if(st_window(p.rng, (uint32_t)hot_batch * (uint32_t)sizeof(tg_rng_rec)), env * (uint32_t)sizeof(tg_rng_rec) + 40u,
-                u32x2{knew.x, knew.y}, evl);  // State.rng_key
+                knew, evl);  // State.rng_key
       fn_dirty = fn_dirty | evl;
     }
     fn_lock = false; fn_reset = false; fn_hi = false;
@@ -2236,11 +2258,11 @@ void step_kernel_bits(
   }
   // (every load result the rest of the transition uses is claimed HERE, in front of the first store behind the publish: on
   // gfx9 a wait for a load with stores pending is a wait for the stores — vmcnt counts both, and they complete out of order)
-  if (fn_prefetch_late && (fn_lock | fn_reset)) {
+  if (fn_prefetch_late && (fn_lock | fn_reset | (fn_d0 < 3))) {
     const u32x2* cs = reinterpret_cast<const u32x2*>(bp.ahead) + (size_t)env * 16;
-    pf_c1 = cs[(fn_n0 + 1) & 3]; pf_c3 = cs[(fn_n0 + 3) & 3]; pf_r1 = cs[4 + ((fn_pend0 ? fn_n0 : fn_n0 + 1) & 3)];
+    pf_c1 = cs[(fn_n0 + 1) & 3]; pf_cf = cs[(fn_n0 + fn_d0) & 3]; pf_r1 = cs[4 + ((fn_pend0 ? fn_n0 : fn_n0 + 1) & 3)];
   }
-  if (RULESET == TG_RULESET_FUNCTIONAL) asm volatile("" : "+v"(pf_c1), "+v"(pf_c3), "+v"(pf_r1));
+  if (RULESET == TG_RULESET_FUNCTIONAL) asm volatile("" : "+v"(pf_c1), "+v"(pf_cf), "+v"(pf_r1));
 #ifndef TG_NO_EP_CLAIM
   asm volatile("" : "+v"(ep.ret), "+v"(ep.len), "+v"(ep.last_ret), "+v"(ep.last_len));
 #endif
