@@ -365,15 +365,17 @@ def vector_env_block(local, *, B=65536, steps=64, warmup=8):
     rng = np.random.default_rng(0)
     acts = rng.integers(0, 8, (warmup + steps, B)).astype(np.int32)
     for kind in ("board", "dict"):
-        v = TetrisVectorEnv(B, observation=kind, autoreset_mode="same_step", devices=(local,))
-        v.reset(seed=1)
         res = {}
-        e0 = v.engines[0]
-        d_acts = e0.dev_alloc(acts.nbytes)  # the third form: the policy's actions are on the device already (int32 [T][B])
-        e0.dev_upload(d_acts, acts)
         for form in ("host", "host_pinned", "device", "device_actions"):
-            if form == "host_pinned":  # (gymnasium's copy=False: views of rotating page-locked buffers)
-                e0.use_pinned_observations(2)
+            if form in ("host", "host_pinned"):  # (host_pinned = gymnasium's copy=False: views of rotating page-locked slabs)
+                if form == "host_pinned":
+                    e0.dev_free(d_acts)
+                    v.close()
+                v = TetrisVectorEnv(B, observation=kind, autoreset_mode="same_step", devices=(local,), copy=(form == "host"))
+                v.reset(seed=1)
+                e0 = v.engines[0]
+                d_acts = e0.dev_alloc(acts.nbytes)  # the last form: the policy's actions are on the device already (int32 [T][B])
+                e0.dev_upload(d_acts, acts)
             act = (lambda t: d_acts + t * B * 4) if form == "device_actions" else (lambda t: acts[t])
             for t in range(warmup):
                 v.step(act(t), to_host=form.startswith("host"))
@@ -386,7 +388,7 @@ def vector_env_block(local, *, B=65536, steps=64, warmup=8):
             res[form] = {"value": B * steps / dt, "unit": "env steps/s", "us_per_step": dt / steps * 1e6}
         e0.dev_free(d_acts)
         obs_bytes = 200 if kind == "board" else 944
-        res["host"]["pcie_bytes_per_env_step"] = res["host_pinned"]["pcie_bytes_per_env_step"] = obs_bytes + 8 + 4
+        res["host"]["pcie_bytes_per_env_step"] = res["host_pinned"]["pcie_bytes_per_env_step"] = obs_bytes + 25 + 4  # (+ TG_BUF_HOST_PACK + actions)
         res["device"]["pcie_bytes_per_env_step"] = 4  # the host actions
         res["device_actions"]["pcie_bytes_per_env_step"] = 0
         out[kind] = res
@@ -395,6 +397,88 @@ def vector_env_block(local, *, B=65536, steps=64, warmup=8):
                    "(gymnasium contract; `host_pinned`: copy=False, views of page-locked buffers), `device` returns DeviceArray views (__cuda_array_interface__ / DLPack) and copies "
                    "nothing back, `device_actions` additionally takes the actions from a device pointer; Python overhead "
                    "included")
+    return out
+
+
+def single_env_block(local, *, steps=4000, warmup=200):
+    """BASELINE config 1 through the drop-in class: `Tetris()` (reference envs/tetris.py:203-307) — one 10x20 env, random
+    policy, `reset()` on done — steps/s of a plain `step` loop (one call into the C ABI per step, results copied to host
+    NumPy), beside the oracle's single-env rate on this host (the reference's own ~3.4k steps/s was measured in the survey
+    container: the Python reference cannot travel).  Also: the same loop when every step reads an attribute (`env.board`:
+    one tg_get_state per step, and an upload before the next one since the array is mutable)."""
+    from oracle import pyoracle as po
+    from tetris_gymnasium_amd.envs.tetris import Tetris
+
+    acts = np.random.default_rng(0).integers(0, 8, warmup + steps)
+    out = {}
+    for form in ("plain_loop", "reads_board_every_step"):
+        env = Tetris(device=local)
+        env.reset(seed=1)
+        n = steps if form == "plain_loop" else steps // 8
+        t0 = None
+        for t in range(warmup + n):
+            if t == warmup:
+                t0 = time.perf_counter()
+            _, _, term, _, _ = env.step(int(acts[t]))
+            if form != "plain_loop":
+                env.board  # noqa: B018 - the read is the point
+            if term:
+                env.reset()
+        dt = time.perf_counter() - t0
+        out[form] = {"value": n / dt, "unit": "env steps/s", "us_per_step": dt / n * 1e6, "steps": n}
+        env.close()
+    o = po.OracleBatch(1, 10, 20, po.RULESET_NUMPY, True, 4, nthreads=1)
+    o.reset(np.array([1], np.uint64))
+    t0 = time.perf_counter()
+    for t in range(steps):
+        _, term, _ = o.step(acts[t:t + 1].astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+        o.observe(po.OBS_DICT)
+    dt = time.perf_counter() - t0
+    out["cpu_port_single_env"] = {"value": steps / dt, "unit": "env steps/s", "cores": 1, "kind": "port",
+                                  "sample": f"{steps} steps of ONE env through the C oracle's Python binding (step + dict observation)"}
+    out["reference_python_single_env"] = "~3.4k steps/s (NumPy Tetris.step on one 2.6 GHz Xeon core, survey container; BASELINE.md §2)"
+    out["note"] = ("one env per launch is all launch boundary + PCIe latency: this is the drop-in / debugging surface of config 1; "
+                   "throughput is the batched engine's job")
+    return out
+
+
+def shards_block(local, *, per_shard=8192, steps=256, warmup=32):
+    """TetrisVectorEnv(devices=(d,) * k): microseconds per step against the number of shards driven from ONE Python process
+    (VERDICT r03 weak #7), device-resident results, actions a device pointer per shard.  All k shards share one GPU here
+    (a 1-GPU box): what is measured is the host-side cost per shard — one call into the C ABI for all of them."""
+    from tetris_gymnasium_amd.vector import TetrisVectorEnv
+
+    out = {}
+    for k in (1, 2, 4, 8):
+        B = per_shard * k
+        v = TetrisVectorEnv(B, observation="board", autoreset_mode="same_step", devices=(local,) * k)
+        v.reset(seed=1)
+        acts = np.random.default_rng(k).integers(0, 8, (warmup + steps, per_shard)).astype(np.int32)
+        ptrs = []
+        for e in v.engines:
+            d = e.dev_alloc(acts.nbytes)
+            e.dev_upload(d, acts)
+            ptrs.append(d)
+        for t in range(warmup):
+            v.step([p + t * per_shard * 4 for p in ptrs], to_host=False)
+        for e in v.engines:
+            e.sync()
+        t0 = time.perf_counter()
+        for t in range(warmup, warmup + steps):
+            v.step([p + t * per_shard * 4 for p in ptrs], to_host=False)
+        t_enq = time.perf_counter() - t0
+        for e in v.engines:
+            e.sync()
+        dt = time.perf_counter() - t0
+        out[f"k{k}"] = {"shards": k, "envs": B, "us_per_step": dt / steps * 1e6, "host_us_per_step": t_enq / steps * 1e6,
+                        "value": B * steps / dt, "unit": "env steps/s"}
+        for e, d in zip(v.engines, ptrs):
+            e.dev_free(d)
+        v.close()
+    out["note"] = (f"{per_shard} envs per shard, `step(actions, to_host=False)` with per-shard device action pointers; "
+                   "host_us_per_step = time to enqueue (Python + one tg_step_fetch_many call for all shards), us_per_step "
+                   "includes the final wait; k shards on ONE GPU serialise their kernels, so us_per_step grows with k by the "
+                   "kernel time — the host column is the cost the adapter adds per shard")
     return out
 
 
@@ -470,10 +554,11 @@ def rank_main(args) -> int:
         blocks["functional"] = run_block(D, "functional", steps=ks, warmup=kw, want_cpu=want_cpu, cpu_budget=3.0, **fcommon)
         blocks["functional_fused"] = run_block(D, "functional_fused16", fuse=16, steps=(ks + 15) // 16 * 16, warmup=64,
                                                want_cpu=False, **fcommon)
-        try:
-            blocks["vector_env"] = vector_env_block(local)
-        except Exception as ex:  # pragma: no cover - adapter problems must not lose the headline line
-            blocks["vector_env"] = {"error": repr(ex)}
+        for name, fn in (("vector_env", vector_env_block), ("single_env", single_env_block), ("vector_env_shards", shards_block)):
+            try:
+                blocks[name] = fn(local)
+            except Exception as ex:  # pragma: no cover - adapter problems must not lose the headline line
+                blocks[name] = {"error": repr(ex)}
     elif D.world > 1 and not args.no_blocks and std_head:
         pass  # the further configs are single-GPU cases (BASELINE.json configs[1], [4]); config 4 IS this run at N = 8
     if D.rank == 0:

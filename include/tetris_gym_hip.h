@@ -93,8 +93,8 @@ typedef struct tg_config {
   /* launch knobs of the step kernel (0 = default; the environment variables TG_FUSE / TG_RNG_EVERY / TG_RING_FILL override
    * them — test hooks).  Results never depend on them. */
   int32_t fuse;         /* transitions per launch of tg_step_k / tg_rollout / tg_grouped_rollout: 1..16, default 16 */
-  int32_t rng_every;    /* NUMPY rules: one-transition launches carry the bag-shuffle look-ahead workgroups every n-th time
-                           (1..3, default 3) */
+  int32_t rng_every;    /* NUMPY rules: one-transition launches carry the bag-shuffle look-ahead workgroups for the whole batch
+                           every n-th time (1..3, default 3); 4 = for one third of the batch in every launch, in rotation */
   int32_t ring_fill_p1; /* NUMPY rules: 1 + look-ahead bag permutations kept per env (1..4, default 4 = 3 permutations);
                            smaller values exercise the in-line shuffle of the step kernel */
   int32_t reserved2;
@@ -231,17 +231,19 @@ int tg_host_pack_layout(const tg_config* cfg, size_t offsets[6]);
 /* m buffers in one call and ONE wait: all copies are enqueued, then the stream is synchronised once (tg_fetch costs a
  * synchronisation per buffer: three per step of a gymnasium-style step()).  Requests that are neighbours in device memory
  * AND in host memory at the same distance (TG_BUF_OBS followed by TG_BUF_HOST_PACK into one page-locked slab laid out like
- * the device side: host_dst[1] - host_dst[0] == their device distance) are merged into a single copy. */
-int tg_fetch_many(tg_handle* h, int m, const int* which, void* const* host_dst, const size_t* bytes);
+ * the device side: host_dst[1] - host_dst[0] == their device distance) are merged into a single copy.  src_off (or NULL):
+ * byte offset into each buffer — a range of a buffer, e.g. one array of the dict observation of one shard straight into its
+ * slice of the adapter's whole-batch array. */
+int tg_fetch_many(tg_handle* h, int m, const int* which, void* const* host_dst, const size_t* bytes, const size_t* src_off);
 
 /* One transition on n handles (one per GPU, or several shards of one GPU) and the fetches that follow it, from ONE host
  * thread and with one wait per handle: phase 1 enqueues, handle by handle, the action upload, the step launch and the m
  * device-to-host copies (nothing in it blocks when the destinations are page-locked); phase 2 waits for every stream.
  * actions[k]: i32[batch of handle k] in host or device memory (kind), or actions == NULL to fetch only.  which[m] is
- * the same for every handle; host_dst and bytes are [n][m] row-major.  What gymnasium.vector.SyncVectorEnv.step does
+ * the same for every handle; host_dst, bytes and src_off (or NULL) are [n][m] row-major.  What gymnasium.vector.SyncVectorEnv.step does
  * with a Python loop over envs (examples/train_ppo.py:240-248), for all GPUs of a node in one call. */
 int tg_step_fetch_many(int n, tg_handle* const* hs, const void* const* actions, int kind, int m, const int* which,
-                       void* const* host_dst, const size_t* bytes);
+                       void* const* host_dst, const size_t* bytes, const size_t* src_off);
 
 /* Full state snapshot / restore (host buffers; any pointer may be NULL to skip).
  * board u8[B][H][W], rec tg_env_rec[B], rng tg_rng_rec[B].  (envs/tetris.py:681-708) */
@@ -314,7 +316,7 @@ int tg_dev_free(tg_handle* h, void* ptr);
  * copy through the runtime's bounce buffers — what the host-NumPy observation path of the gymnasium.vector adapter uses
  * (TetrisVectorEnv(copy=False); replaces the per-step `np.stack` of SyncVectorEnv, gymnasium/vector/sync_vector_env.py). */
 int tg_host_alloc(tg_handle* h, size_t bytes, void** ptr);
-int tg_host_free(tg_handle* h, void* ptr);
+int tg_host_free(tg_handle* h, void* ptr); /* h may be NULL (memory that outlived its engine: nothing to wait for) */
 int tg_dev_upload(tg_handle* h, void* dst_dev, const void* src_host, size_t bytes);
 int tg_dev_download(tg_handle* h, void* dst_host, const void* src_dev, size_t bytes);
 /* device → device, asynchronous on the handle's stream (e.g. keep a copy of TG_BUF_OBS before the next transition overwrites it) */

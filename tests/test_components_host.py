@@ -1,0 +1,105 @@
+"""The importable component classes (tetris_gymnasium_amd/components/tetromino_{randomizer,queue,holder}.py) and the remaining
+host-side functional callables (update_state, place_active_tetromino, get_tetromino_color): the properties the reference's
+own tests check (tests/test_components/*: determinism, bag coverage, FIFO order, hold semantics), the exact BagRandomizer
+stream against the numpy-generated fixture that also pins the engine's device-side generator, and update_state against the
+oracle's functional step.  CPU only."""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import replay
+from tetris_gymnasium_amd.components import BagRandomizer, TetrominoHolder, TetrominoQueue, TrueRandomizer
+from tetris_gymnasium_amd.components.tetromino import make_tetromino
+from tetris_gymnasium_amd.envs import tetris_fn
+from tetris_gymnasium_amd.functional import TETROMINOES, EnvConfig, State, get_tetromino_color, prng
+
+
+def test_bag_randomizer_stream_matches_the_fixture(golden_dir):
+    """stream = successive in-place shuffles of arange(7) (components/tetromino_randomizer.py:65-91); pcg64_streams.npz was
+    generated with numpy's own Generator and is what the device-side generator is tested against, too."""
+    fx = replay.load(golden_dir, "pcg64_streams")
+    for k, seed in enumerate(fx["seeds"]):
+        r = BagRandomizer(7)
+        r.reset(int(seed))
+        got = [int(r.get_next_tetromino()) for _ in range(70)]
+        assert got == [int(v) for v in fx["streams"][k]], f"seed {seed}"
+
+
+def test_bag_randomizer_properties():  # reference tests/test_components/test_tetromino_randomizer.py:7-34
+    r = BagRandomizer(7)
+    r.reset(seed=3)
+    for _ in range(5):
+        assert sorted(int(r.get_next_tetromino()) for _ in range(7)) == list(range(7))
+    a, b = BagRandomizer(7), BagRandomizer(7)
+    a.reset(seed=9); b.reset(seed=9)
+    assert [a.get_next_tetromino() for _ in range(30)] == [b.get_next_tetromino() for _ in range(30)]
+    c = copy.copy(a)  # the copy continues exactly like the original, and independently of it
+    assert [a.get_next_tetromino() for _ in range(20)] == [c.get_next_tetromino() for _ in range(20)]
+    r.reset()  # no seed: the running generator continues (reference :40: `if seed and seed > 0`)
+    r.reset(seed=0)
+    t = TrueRandomizer(7)
+    t.reset(seed=5)
+    assert all(0 <= t.get_next_tetromino() < 7 for _ in range(50))
+
+
+def test_queue_and_holder_semantics():  # reference test_tetromino_queue.py:5-56, test_tetromino_holder.py
+    q = TetrominoQueue(BagRandomizer(7), size=4)
+    q.reset(seed=42)
+    assert len(q.get_queue()) == 4
+    head = q.get_queue()[0]
+    assert q.get_next_tetromino() == head and len(q.get_queue()) == 4
+    q2 = TetrominoQueue(BagRandomizer(7), size=4)
+    q2.reset(seed=42)
+    q2.get_next_tetromino()
+    assert [q.get_next_tetromino() for _ in range(12)] == [q2.get_next_tetromino() for _ in range(12)]
+    twin = q.copy(copy.copy(q.randomizer))
+    assert [q.get_next_tetromino() for _ in range(12)] == [twin.get_next_tetromino() for _ in range(12)]
+    # the stream a queue hands out is the randomizer's stream: active piece = stream[0], visible queue = stream[1..4]
+    r = BagRandomizer(7); r.reset(seed=42)
+    stream = [int(r.get_next_tetromino()) for _ in range(10)]
+    q3 = TetrominoQueue(BagRandomizer(7), size=4); q3.reset(seed=42)
+    assert [int(q3.get_next_tetromino()) for _ in range(6)] == stream[:6]
+    h = TetrominoHolder()
+    a, b = make_tetromino(0), make_tetromino(3)
+    assert h.swap(a) is None and h.get_tetrominoes() == [a]
+    assert h.swap(b) is a and h.get_tetrominoes() == [b]
+    hc = copy.copy(h)
+    h.reset()
+    assert h.get_tetrominoes() == [] and hc.get_tetrominoes() == [b]
+
+
+def test_get_tetromino_color():
+    assert list(get_tetromino_color(TETROMINOES, 0)) == [0, 240, 240] and list(get_tetromino_color(TETROMINOES, 6)) == [240, 160, 0]
+
+
+@pytest.mark.parametrize("gravity", [True, False])
+def test_update_state_matches_the_oracle_step(gravity):
+    """update_state / place_active_tetromino (reference envs/tetris_fn.py:161-270, 370-413) on the host, one env, against the
+    oracle's functional step along random trajectories incl. clamped action ids: every State field, lines and the score."""
+    cfg = EnvConfig(10, 20, 4, 7, gravity)
+    rng = np.random.default_rng(4 + gravity)
+    for ep in range(6):
+        key = prng.PRNGKey(100 + ep)
+        o = po.OracleBatch(1, 10, 20, po.RULESET_FUNCTIONAL, gravity)
+        o.reset(np.array([(int(key[0]) << 32) | int(key[1])], np.uint64))
+        b, rec, g = o.get_state()
+        board = np.ones((24, 18), np.int8); board[:20, 4:14] = b[0]
+        st = State(rng_key=g["key"][0].copy(), board=board, active_tetromino=np.int32(rec["piece"][0]), rotation=np.int32(0),
+                   x=np.int32(rec["x"][0]), y=np.int32(rec["y"][0]), queue=rec["bag"][0].astype(np.int32),
+                   queue_index=np.int32(rec["bag_index"][0]), game_over=np.bool_(False), score=np.float32(0))
+        for t in range(250):
+            a = int(rng.integers(-1, 9)) if t % 9 == 0 else int(rng.integers(0, 7))
+            st, lines = tetris_fn.update_state(a, cfg, st, tetrominoes=TETROMINOES)
+            _, term, lo = o.step(np.array([a], np.int32))
+            b, rec, g = o.get_state()
+            r = rec[0]
+            assert int(lines) == int(lo[0]), f"lines t={t}"
+            np.testing.assert_array_equal(st.board[:20, 4:14].astype(np.uint8), b[0], err_msg=f"board t={t}")
+            assert (int(st.active_tetromino), int(st.rotation), int(st.x), int(st.y)) == (int(r["piece"]), int(r["rot"]), int(r["x"]), int(r["y"])), f"t={t}"
+            assert list(st.queue) == list(r["bag"]) and int(st.queue_index) == int(r["bag_index"]) and float(st.score) == float(r["score"])
+            np.testing.assert_array_equal(st.rng_key, g["key"][0])
+            assert bool(st.game_over) == bool(term[0])
+            if term[0]:
+                break

@@ -270,3 +270,34 @@ def test_vector_env_copy_false_returns_pinned_views_with_the_same_content(kind):
         seen_ptrs.add(first(ob).__array_interface__["data"][0])
     assert len(seen_ptrs) == 2  # two slots, rotating
     a.close(); b.close()
+
+
+def test_lifetimes_after_close_and_unconsumed_dlpack_capsules():
+    """(round 3 advisor findings) Page-locked observation arrays outlive `close()` (they own their block, like gymnasium's
+    copy=False arrays own theirs); a DLPack capsule that nobody consumes releases what it pinned; a DeviceArray / pooled
+    DeviceBuffer of a closed engine fails loudly instead of pointing into freed device memory."""
+    import gc
+
+    from tetris_gymnasium_amd import engine as E
+
+    env = TetrisVectorEnv(512, observation="board", autoreset_mode="same_step", copy=False)
+    env.reset(seed=2)
+    obs, rew, term, _, _ = env.step(np.zeros(512, np.int32))
+    keep, ref = obs, obs.copy()
+    e = env.engines[0]
+    view = e.device_array(N.BUF_OBS)
+    n_live = len(E._dl_live)
+    cap = view.__dlpack__()
+    assert len(E._dl_live) == n_live + 1
+    del cap
+    gc.collect()
+    assert len(E._dl_live) == n_live  # the capsule's destructor ran the deleter
+    snap = e.get_state_device()  # pooled device buffers still referenced at close
+    env.close()
+    gc.collect()
+    np.testing.assert_array_equal(keep, ref)  # still readable: the block is freed when `keep` dies
+    assert all(b.ptr == 0 for b in snap)
+    with pytest.raises(E.EngineError):
+        view.__cuda_array_interface__
+    del keep
+    gc.collect()

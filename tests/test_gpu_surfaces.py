@@ -280,6 +280,52 @@ def test_vector_env_sharding_is_transparent():
     one.close(); two.close()
 
 
+@pytest.mark.parametrize("obs", ["board", "dict", "rgb", "functional"])
+def test_vector_env_host_step_is_one_call_for_every_layout(obs):
+    """TetrisVectorEnv.step with host results goes through tg_step_fetch_many: one shard (observation + TG_BUF_HOST_PACK as
+    ONE copy into a slab; fresh pageable arrays or, copy=False, two rotating page-locked slabs) and several shards (every
+    array of a shard straight into its slice of the whole-batch array) must return the same values, dtypes and shapes —
+    rewards float64, terminations bool, lines int32, infos["episode"] r / l / t with the finished episodes' statistics."""
+    B = 300
+    kw = dict(observation=obs, autoreset_mode="same_step", ruleset="functional" if obs == "functional" else "numpy")
+    envs = [TetrisVectorEnv(B, devices=(0,), **kw), TetrisVectorEnv(B, devices=(0,), copy=False, **kw),
+            TetrisVectorEnv(B, devices=(0, 0, 0), copy=False, **kw), TetrisVectorEnv(B, devices=(0, 0), **kw)]
+    first = [e.reset(seed=21)[0] for e in envs]
+    na = envs[0].single_action_space.n
+    rng = np.random.default_rng(8)
+    n_eps = 0
+    held = None
+    for t in range(150):
+        a = rng.integers(0, na, B)
+        res = [e.step(a) for e in envs]
+        o0, r0, t0, tr0, i0 = res[0]
+        assert r0.dtype == np.float64 and t0.dtype == np.bool_ and i0["lines_cleared"].dtype == np.int32 and not tr0.any()
+        for o, r, te, tr, info in res[1:]:
+            for k in (o0 if isinstance(o0, dict) else [None]):
+                x, y = (o0[k], o[k]) if k else (o0, o)
+                assert x.dtype == y.dtype and x.shape == y.shape
+                np.testing.assert_array_equal(x, y, err_msg=f"{k} t={t}")
+            np.testing.assert_array_equal(r, r0); np.testing.assert_array_equal(te, t0)
+            np.testing.assert_array_equal(info["lines_cleared"], i0["lines_cleared"])
+            assert ("episode" in info) == ("episode" in i0)
+            if "episode" in i0:
+                for f in ("r", "l", "t"):
+                    np.testing.assert_array_equal(info["episode"][f], i0["episode"][f])
+                np.testing.assert_array_equal(info["_episode"], i0["_episode"])
+        if "episode" in i0:
+            assert i0["episode"]["r"].dtype == np.float64 and i0["episode"]["l"].dtype == np.int32
+            assert (i0["episode"]["l"][~t0] == 0).all() and (i0["episode"]["l"][t0] > 0).all()
+            n_eps += int(t0.sum())
+        # copy=True hands out fresh arrays: what step t returned is untouched by step t + 1
+        if held is not None:
+            np.testing.assert_array_equal(held[0], held[1])
+        ob = o0["board"] if isinstance(o0, dict) else o0
+        held = (ob, ob.copy())
+    assert n_eps > 0
+    for e in envs:
+        e.close()
+
+
 def test_vector_env_grouped_placement_features():
     """The reference's train_lin_grouped.py loop: obs = [4W, 13] features per env, infos["action_mask"], infos["board"]."""
     B = 64

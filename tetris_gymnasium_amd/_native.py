@@ -13,14 +13,14 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TG_LIB") or os.path.join(_PKG, "libtetris_gym_hip.so")  # TG_LIB: the test-only legacy build
 
-ABI_VERSION = 2  # include/tetris_gym_hip.h TG_ABI_VERSION
+ABI_VERSION = 3  # include/tetris_gym_hip.h TG_ABI_VERSION
 RULESET_NUMPY, RULESET_FUNCTIONAL = 0, 1
 OBS_NONE, OBS_BOARD, OBS_DICT, OBS_FN, OBS_RGB = 0, 1, 2, 3, 4
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = 0, 1, 2
 ACTIONS_BASE, ACTIONS_GROUPED = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 (BUF_OBS, BUF_STEP_OUT, BUF_ACTIONS, BUF_BOARD, BUF_REC, BUF_RNG, BUF_LEGAL_MASK, BUF_FINAL_OBS,
- BUF_EPISODE, BUF_PLACEMENT_FEATS, BUF_FEATS) = range(11)
+ BUF_EPISODE, BUF_PLACEMENT_FEATS, BUF_FEATS, BUF_HOST_PACK) = range(12)
 FLAG_EPISODE_STATS, FLAG_FINAL_OBS, FLAG_FEATURES = 1, 2, 4
 NONE = 0xFF
 F_GAME_OVER, F_HAS_SWAPPED, F_PENDING_RESET = 1, 2, 4
@@ -70,6 +70,10 @@ SYMBOLS = {
     "tg_grouped_rollout": (_i, [_vp, C.c_uint32, C.c_uint32, _i, _vp, _vp, _vp]),
     "tg_device_ptr": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_sz)]),
     "tg_fetch": (_i, [_vp, _i, _vp, _sz]),
+    "tg_host_pack_layout": (_i, [C.POINTER(TgConfig), C.POINTER(_sz)]),
+    "tg_fetch_many": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_sz)]),
+    "tg_step_fetch_many": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _i, _i, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_sz),
+                                C.POINTER(_sz)]),
     "tg_get_state": (_i, [_vp, _vp, _vp, _vp]),
     "tg_set_state": (_i, [_vp, _vp, _vp, _vp]),
     "tg_get_state_dev": (_i, [_vp, _vp, _vp, _vp]),

@@ -74,6 +74,23 @@ int g_simds = 1024;  // SIMDs of the device (4 per CU), set by tg_create
 int g_split = 1;     // TG_SPLIT=0: never pick the instantiations with two stream waves per workgroup (kFeatSplit)
 int g_wide = 1;      // TG_WIDE=0: never pick the instantiations compiled for fewer waves per SIMD (kFeatWide)
 
+// RNG-role workgroups of a launch (128 envs each): the whole batch, or — `thirds` — the third this launch serves
+int rng_blocks(const tg::KParams& p, const int RS) {
+  if (RS != TG_RULESET_NUMPY || !p.rng_role) return 0;
+  if (p.thirds && p.rng_third < 3) {
+    const long B3 = ((((long)p.batch + 2) / 3) + 127) & ~127L, lo = (long)p.rng_third * B3;
+    const long n = lo < p.batch ? (p.batch - lo < B3 ? p.batch - lo : B3) : 0;
+    return (int)((n + 127) / 128);
+  }
+  return (p.batch + 127) / 128;
+}
+// the packed scalar argument of step_kernel_bits (layout: there)
+uint32_t bits_hot_misc(const tg::KParams& p, const int RS, const int n_step_wgs) {
+  const bool thirds = RS == TG_RULESET_NUMPY && p.thirds;
+  return (uint32_t)n_step_wgs | (thirds ? ((uint32_t)(p.ring_par & 7) << 19) | ((uint32_t)(p.rng_third & 3) << 22) | (1u << 31) : (3u << 22)) |
+         ((p.act_i8 ? 1u : 0u) << 24) | ((uint32_t)(p.nsteps > 0 ? p.nsteps : 0) << 25);
+}
+
 // which instantiation of the bits kernel a launch with these parameters uses (FEAT flags, tg_kernel_bits.h)
 int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw);
 int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw, const bool split_ok) {
@@ -86,7 +103,7 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
       !(base == 0 || base == M || base == (M | T) || base == tg::kFeatDict || base == (M | T | tg::kFeatDict))) return feat;
   const int per_simd = tg::bits_waves_per_simd(RS, feat);
   const long cap = (long)(g_simds / 4) * (4 * per_simd / 3);
-  const long wgs = (p.batch + epw - 1) / epw + ((RS == TG_RULESET_NUMPY && p.rng_role) ? (p.batch + 127) / 128 : 0);
+  const long wgs = (p.batch + epw - 1) / epw + rng_blocks(p, RS);
   return wgs <= cap ? (feat | tg::kFeatSplit) : feat;
 }
 int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw) {
@@ -125,7 +142,8 @@ template <int W, int H, int RS>
 void launch_step(const tg::KParams& p, hipStream_t s) {
   if (p.cols) {  // "bits": the handle carries the column masks / look-ahead permutations
     using BG = tg::BitsGeo<W, H>;
-    const int nrb = (RS == TG_RULESET_NUMPY && p.rng_role) ? (p.batch + 127) / 128 : 0;  // RNG-role workgroups (tg_kernel_bits.h)
+    const int nrb = rng_blocks(p, RS);  // RNG-role workgroups (tg_kernel_bits.h)
+    const bool thirds = RS == TG_RULESET_NUMPY && p.thirds;
     const uint4* const ring4 = reinterpret_cast<const uint4*>(p.ring);
     // (FUNCTIONAL: hbuf is the look-ahead word array fnw [B] u64 — private to each env's logic wave, no parities)
     const size_t hrd = RS == TG_RULESET_NUMPY ? (size_t)p.hbuf_cur * p.ring_stride : 0, hwr = RS == TG_RULESET_NUMPY ? (size_t)(1 - p.hbuf_cur) * p.ring_stride : 0;
@@ -140,8 +158,8 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
                        : ((feat & D) ? ((feat & tg::kFeatSplit) ? BG::BYTES_DICT_SPLIT : BG::BYTES_DICT)
                                      : ((feat & R) ? BG::BYTES_RGB : ((feat & F) ? BG::BYTES_FIN : BG::BYTES)));
 #define TG_LAUNCH_BITS(FT)                                                                                                  \
-  hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(64 * (1 + tg::bits_stream_waves<W, H>(FT))), lds, s, p.board, p.rec, p.cols, bp.ring_rd, bp.hbuf_rd, \
-                     p.actions, p.batch, (uint32_t)n_step_wgs | ((p.act_i8 ? 1u : 0u) << 24) | ((uint32_t)(p.nsteps > 0 ? p.nsteps : 0) << 25), \
+  hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(64 * (1 + tg::bits_stream_waves<W, H>(FT))), lds, s, p.board, p.rec, p.cols, (thirds ? ring4 : bp.ring_rd), bp.hbuf_rd, \
+                     p.actions, p.batch, bits_hot_misc(p, RS, n_step_wgs), \
                      p, bp)
     if (feat == F) { TG_LAUNCH_BITS(F); return; }
     if (feat == (M | T | F)) { TG_LAUNCH_BITS(M | T | F); return; }
@@ -399,7 +417,7 @@ Launchers rtc_launchers(const RtcSize* r) {
   L.dict_ok = dict_ok; L.rgb_ok = rgb_ok;
   L.step = [=](const tg::KParams& p, hipStream_t s) {
     constexpr int D = tg::kFeatDict, F = tg::kFeatFinal, R = tg::kFeatRgb;
-    const int nrb = (RS == TG_RULESET_NUMPY && p.rng_role) ? (p.batch + 127) / 128 : 0;
+    const int nrb = rng_blocks(p, RS);
     const uint4* const ring4 = reinterpret_cast<const uint4*>(p.ring);
     const size_t hrd = RS == TG_RULESET_NUMPY ? (size_t)p.hbuf_cur * p.ring_stride : 0, hwr = RS == TG_RULESET_NUMPY ? (size_t)(1 - p.hbuf_cur) * p.ring_stride : 0;
     tg::BitsParams bp{p.cols, p.ahead, ring4 + (size_t)p.ring_cur * p.ring_stride, const_cast<uint4*>(ring4) + (size_t)(1 - p.ring_cur) * p.ring_stride,
@@ -412,9 +430,9 @@ Launchers rtc_launchers(const RtcSize* r) {
                                      : ((feat & R) ? r->geo[3] : ((feat & F) ? r->geo[4] : r->geo[1])));
     auto it = r->step.find(feat);
     if (it == r->step.end()) return;
-    uint8_t* a0 = p.board; uint32_t* a1 = p.rec; void* a2 = p.cols; const uint4* a3 = bp.ring_rd; const uint32_t* a4 = bp.hbuf_rd;
+    uint8_t* a0 = p.board; uint32_t* a1 = p.rec; void* a2 = p.cols; const uint4* a3 = (RS == TG_RULESET_NUMPY && p.thirds) ? ring4 : bp.ring_rd; const uint32_t* a4 = bp.hbuf_rd;
     const void* a5 = p.actions; int a6 = p.batch;
-    uint32_t a7 = (uint32_t)n_step_wgs | ((p.act_i8 ? 1u : 0u) << 24) | ((uint32_t)(p.nsteps > 0 ? p.nsteps : 0) << 25);
+    uint32_t a7 = bits_hot_misc(p, RS, n_step_wgs);
     tg::KParams kp = p;
     void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &kp, &bp};
     // (threads per workgroup: tg::bits_stream_waves of this size and instantiation)
@@ -509,7 +527,12 @@ struct tg_handle {
   uint64_t* d_ring = nullptr;  // bits kernel: permutation rings, double-buffered by launch parity [2][B]
   uint32_t* d_hbuf = nullptr;  // bits kernel: consumed counters + state location (+ FUNCTIONAL: bag index, chain epoch) [2][B]
   uint4* d_inl = nullptr;      // bits kernel: generator states after in-line shuffles [2 buffers][B][2]
-  int ring_cur = 0;            // ring parity the next step launch reads
+  int ring_par = 0;            // ring parity the next step launch reads, one bit per third of the batch (all equal without `thirds`)
+  bool thirds = false;         // NUMPY: the RNG role serves one third of the batch per one-transition launch, in rotation (TG_RNG_EVERY=0
+                               // / tg_config.rng_every = 4).  Built and measured in round 4 (every launch at 65 536 envs then fits
+                               // the two-stream-wave build): the same at 65 536 envs (6.29 vs 6.28 us), 3 % slower at 32 768, 10 %
+                               // at 131 072 — RNG workgroups in every launch cost more than the whole batch's in every third.
+                               // Default: the whole batch every rng_every-th launch.  profiles/r04/ab_rng_thirds.log
   int hbuf_cur = 0;            // consumed-counter parity the next step launch reads
   int rng_every = 3;           // TG_RNG_EVERY: one-transition launches carry the RNG-role workgroups every n-th time (the ring
                                // looks 3 entries ahead and the consumer shuffles in line when it runs dry): 7.5 -> 7.3 us per launch
@@ -670,7 +693,10 @@ tg::KParams step_params(tg_handle* h) {
   p.ring = h->d_ring;
   p.hbuf = h->d_hbuf;
   p.inl = h->d_inl;
-  p.ring_cur = h->ring_cur;
+  p.ring_cur = h->ring_par & 1;
+  p.ring_par = h->ring_par;
+  p.thirds = h->thirds ? 1 : 0;
+  p.rng_third = 3;
   p.hbuf_cur = h->hbuf_cur;
   p.rng_role = 1;
   p.ring_stride = (uint32_t)h->B;
@@ -761,7 +787,9 @@ int launch_prepare_bits(tg_handle* h, const uint8_t* d_mask, int force) {
   q.ahead = h->d_ahead;
   q.ring = h->d_ring;
   q.hbuf = h->d_hbuf;
-  q.cur = h->ring_cur;
+  q.cur = h->ring_par & 1;
+  q.thirds = (h->thirds && h->cfg.ruleset == TG_RULESET_NUMPY) ? 1 : 0;
+  q.ring_par = h->ring_par;
   q.hcur = h->hbuf_cur;
   q.mask = d_mask;
   q.batch = h->B;
@@ -787,6 +815,22 @@ int launch_materialize_rng(tg_handle* h) {
   return TG_OK;
 }
 
+// Which envs the RNG role of the next launch serves (p.nsteps is set): launches of several transitions consume several ring
+// entries per env and refill everybody; one-transition launches serve one third of the batch in rotation — or, with the
+// every-n-th cadence (TG_RNG_EVERY), everybody every n-th time.
+void next_rng_role(tg_handle* h, tg::KParams& p) {
+  p.rng_third = 3;
+  if (p.nsteps > 1) { p.rng_role = 1; return; }
+  const unsigned no = h->launch_no++;
+  if (h->thirds) { p.rng_role = 1; p.rng_third = (int)(no % 3u); return; }
+  p.rng_role = (no % (unsigned)h->rng_every) == 0;
+}
+// ... and what flips afterwards: the ring parity of every third that was served, the consumed-counter parity
+void after_launch(tg_handle* h, const tg::KParams& p) {
+  if (p.rng_role) h->ring_par ^= (h->thirds && p.rng_third < 3) ? (1 << p.rng_third) : 7;
+  h->hbuf_cur ^= 1;
+}
+
 // TG_BUF_HOST_PACK is packed when somebody asks for it (the step path never pays for it)
 int launch_host_pack(tg_handle* h) {
   PackParams q{};
@@ -803,11 +847,12 @@ int launch_host_pack(tg_handle* h) {
 }
 
 // the enqueue half of tg_fetch_many (no wait)
-int enqueue_fetches(tg_handle* h, int m, const int* which, void* const* host_dst, const size_t* bytes) {
+int enqueue_fetches(tg_handle* h, int m, const int* which, void* const* host_dst, const size_t* bytes, const size_t* src_off) {
   for (int i = 0; i < m; ++i) {
     if (which[i] < 0 || which[i] >= TG_BUF_COUNT || (!host_dst[i] && bytes[i])) return fail(h, TG_EINVAL, "tg_fetch_many: bad request %d", i);
-    if (bytes[i] > h->bytes[which[i]])
-      return fail(h, TG_EINVAL, "tg_fetch_many: %zu bytes requested, buffer %d holds %zu", bytes[i], which[i], h->bytes[which[i]]);
+    const size_t so = src_off ? src_off[i] : 0;
+    if (so > h->bytes[which[i]] || bytes[i] > h->bytes[which[i]] - so)
+      return fail(h, TG_EINVAL, "tg_fetch_many: %zu bytes at offset %zu requested, buffer %d holds %zu", bytes[i], so, which[i], h->bytes[which[i]]);
   }
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   for (int i = 0; i < m; ++i) {
@@ -817,12 +862,12 @@ int enqueue_fetches(tg_handle* h, int m, const int* which, void* const* host_dst
   for (int i = 0; i < m;) {
     // neighbours in device memory and, at the same distance, in host memory leave as one copy (the gap between two pieces of
     // the arena is its tail padding: a few KiB)
-    const char* d0 = (const char*)h->buf[which[i]];
+    const char* d0 = (const char*)h->buf[which[i]] + (src_off ? src_off[i] : 0);
     char* h0 = (char*)host_dst[i];
     size_t len = bytes[i];
     int j = i + 1;
     while (j < m && bytes[j] && len) {
-      const char* dj = (const char*)h->buf[which[j]];
+      const char* dj = (const char*)h->buf[which[j]] + (src_off ? src_off[j] : 0);
       const ptrdiff_t dd = dj - d0, hd = (char*)host_dst[j] - h0;
       if (dd != hd || dd < (ptrdiff_t)len || dd - (ptrdiff_t)len > 16384) break;
       len = (size_t)dd + bytes[j];
@@ -1035,10 +1080,14 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
                          (cfg->obs_mode == TG_OBS_RGB && L.rgb_ok && cfg->queue_size == 4));  // (the in-kernel RGB image is laid out for four queue pieces)
     // launch knobs: tg_config (0 = default), overridden by the environment (test hooks)
     if (cfg->ring_fill_p1 > 0) h->ring_fill = cfg->ring_fill_p1 - 1 > tg::kRing - 1 ? tg::kRing - 1 : cfg->ring_fill_p1 - 1;
-    if (cfg->rng_every > 0) h->rng_every = cfg->rng_every > 3 ? 3 : cfg->rng_every;
+    if (cfg->rng_every > 0) { h->rng_every = cfg->rng_every > 3 ? 3 : cfg->rng_every; h->thirds = cfg->rng_every == 4; }
     if (cfg->fuse > 0) h->fuse_max = cfg->fuse > tg::kMaxFuse ? tg::kMaxFuse : cfg->fuse;
     if (const char* e = getenv("TG_RING_FILL")) { const int v = atoi(e); h->ring_fill = v < 0 ? 0 : (v > tg::kRing - 1 ? tg::kRing - 1 : v); }
-    if (const char* e = getenv("TG_RNG_EVERY")) { const int v = atoi(e); h->rng_every = v < 1 ? 1 : (v > 3 ? 3 : v); }
+    if (const char* e = getenv("TG_RNG_EVERY")) {  // (0 or 4 = rotating thirds)
+      const int v = atoi(e);
+      h->thirds = v <= 0 || v == 4;
+      if (v > 0) h->rng_every = v > 3 ? 3 : v;
+    }
     if (const char* e = getenv("TG_FN_LAZY")) { const int v = atoi(e); h->fn_lazy = v < 0 ? 0 : (v & 7); }
     if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > tg::kMaxFuse ? tg::kMaxFuse : v); }
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
@@ -1047,6 +1096,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     if (!h->d_cols || cfg->obs_mode == TG_OBS_DICT || cfg->obs_mode == TG_OBS_RGB || (cfg->flags & TG_FLAG_FINAL_OBS)) want = 1;
     while (want > 1 && (B + want - 1) / want < 8192) --want;  // small shards only add launches
     if (want > 1) {
+      h->thirds = false;  // (stream shards launch sub-ranges of the batch: the whole-batch cadence keeps one ring parity)
       const int chunk = (int)(((B + want - 1) / want + 127) / 128 * 128);  // RNG workgroups own 128-env ranges
       for (int o = 0; o < (int)B; o += chunk) {
         h->sh_off.push_back(o);
@@ -1164,13 +1214,12 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind) {
   } else {
     return fail(h, TG_EINVAL, "tg_step: unknown memory kind %d", kind);
   }
-  p.rng_role = (h->launch_no++ % (unsigned)h->rng_every) == 0;
+  next_rng_role(h, p);
   {
     int rc = launch_step_all(h, p);
     if (rc != TG_OK) return rc;
   }
-  if (p.rng_role) h->ring_cur ^= 1;
-  h->hbuf_cur ^= 1;
+  after_launch(h, p);
   HIPCHK(h, hipGetLastError());
   if ((h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) && !h->dict_in_kernel) return launch_observe_dict(h);
   return TG_OK;
@@ -1241,9 +1290,10 @@ static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, u
         p.actions = actions_dev + (size_t)k * h->B;
       }
       p.nsteps = K - k < fuse ? K - k : fuse;
-      p.ring_cur = h->ring_cur;
+      p.ring_cur = h->ring_par & 1;
+      p.ring_par = h->ring_par;
       p.hbuf_cur = h->hbuf_cur;
-      p.rng_role = p.nsteps > 1 || (h->launch_no++ % (unsigned)h->rng_every) == 0;
+      next_rng_role(h, p);
       if (in_kernel) {
         p.obs_traj = obs_traj_dev ? obs_traj_dev + (size_t)k * obs_stride : nullptr;
         p.out_traj = out_traj_dev ? (uint2*)out_traj_dev + (size_t)k * h->B : nullptr;
@@ -1251,8 +1301,7 @@ static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, u
       }
       int rc = launch_step_all(h, p);
       if (rc != TG_OK) return rc;
-      if (p.rng_role) h->ring_cur ^= 1;
-      h->hbuf_cur ^= 1;
+      after_launch(h, p);
       if (post_kernel) {  // packed by its own kernel after every transition
         rc = launch_observe_dict(h);
         if (rc != TG_OK) return rc;
@@ -1305,16 +1354,16 @@ int tg_fetch(tg_handle* h, int which, void* host_dst, size_t bytes) {
   return TG_OK;
 }
 
-int tg_fetch_many(tg_handle* h, int m, const int* which, void* const* host_dst, const size_t* bytes) {
+int tg_fetch_many(tg_handle* h, int m, const int* which, void* const* host_dst, const size_t* bytes, const size_t* src_off) {
   if (!h || m < 0 || (m && (!which || !host_dst || !bytes))) return h ? fail(h, TG_EINVAL, "tg_fetch_many: bad arguments") : TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
-  { int rc = enqueue_fetches(h, m, which, host_dst, bytes); if (rc != TG_OK) return rc; }
+  { int rc = enqueue_fetches(h, m, which, host_dst, bytes, src_off); if (rc != TG_OK) return rc; }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return TG_OK;
 }
 
 int tg_step_fetch_many(int n, tg_handle* const* hs, const void* const* actions, int kind, int m, const int* which,
-                       void* const* host_dst, const size_t* bytes) {
+                       void* const* host_dst, const size_t* bytes, const size_t* src_off) {
   if (n <= 0 || !hs || m < 0 || (m && (!which || !host_dst || !bytes))) return TG_EINVAL;
   for (int k = 0; k < n; ++k)
     if (!hs[k]) return TG_EINVAL;
@@ -1326,7 +1375,7 @@ int tg_step_fetch_many(int n, tg_handle* const* hs, const void* const* actions, 
     } else {
       HIPCHK(h, hipSetDevice(h->cfg.device));
     }
-    if (m) { const int rc = enqueue_fetches(h, m, which, host_dst + (size_t)k * m, bytes + (size_t)k * m); if (rc != TG_OK) return rc; }
+    if (m) { const int rc = enqueue_fetches(h, m, which, host_dst + (size_t)k * m, bytes + (size_t)k * m, src_off ? src_off + (size_t)k * m : nullptr); if (rc != TG_OK) return rc; }
   }
   for (int k = 0; k < n; ++k) {  // phase 2: one wait per handle
     tg_handle* h = hs[k];
@@ -1530,6 +1579,7 @@ int tg_step_kernel_name(tg_handle* h, int transitions_per_launch, int trajectory
   tg::KParams p = step_params(h);
   p.nsteps = transitions_per_launch > 1 ? transitions_per_launch : 1;
   p.sample_mode = sampled ? 1 : 0;
+  if (h->thirds && p.nsteps == 1) p.rng_third = 0;  // (a one-transition launch serves one third: what the instantiation is picked by)
   if (trajectory) p.out_traj = (uint2*)h->buf[TG_BUF_STEP_OUT];  // (only its non-nullness selects the instantiation)
   h->L.step_name(p, buf, n);
   return TG_OK;
@@ -1573,7 +1623,7 @@ int tg_host_alloc(tg_handle* h, size_t bytes, void** ptr) {
 }
 
 int tg_host_free(tg_handle* h, void* ptr) {
-  if (!h) return TG_EINVAL;
+  if (!h) return hipHostFree(ptr) == hipSuccess ? TG_OK : TG_EHIP;  // (a block that outlived its engine: nothing to wait for)
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   HIPCHK(h, hipStreamSynchronize(h->stream));

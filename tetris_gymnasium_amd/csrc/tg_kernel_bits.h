@@ -795,9 +795,14 @@ void step_kernel_bits(
     // segment are preloaded into SGPRs by the dispatcher (-mllvm -amdgpu-kernarg-preload-count=16, 14 user SGPRs are free;
     // struct arguments are not eligible), so the slab / record / ring loads leave without waiting for a scalar load of
     // the argument block (a memory round trip at the start of every workgroup).  The structs arrive in their shadow.
-    uint8_t* const hot_board, uint32_t* const hot_rec, void* const hot_cols, const uint4* const hot_ring_rd,
+    uint8_t* const hot_board, uint32_t* const hot_rec, void* const hot_cols,
+    // the permutation rings: the parity this launch reads — or, with `thirds` (hot_misc bit 31), the base of both parities
+    // [2][batch]: which one an env reads is then a bit per third of the batch (see the RNG role)
+    const uint4* const hot_ring_rd,
     const uint32_t* const hot_hbuf_rd, const void* const hot_actions, const int hot_batch,
-    const uint32_t hot_misc,  // step workgroups (bits 0-23) | act_i8 << 24 | nsteps << 25
+    // step workgroups (bits 0-18) | ring parity of thirds 0..2 (19-21) | the third the RNG role serves, 3 = all (22-23) |
+    // act_i8 (24) | nsteps (25-29) | thirds (31)
+    const uint32_t hot_misc,
     const KParams p, const BitsParams bp) {
   constexpr bool MULTI = (FEAT & kFeatMulti) != 0, TRAJ = (FEAT & kFeatTraj) != 0, DICTK = (FEAT & kFeatDict) != 0,
                  SAMPLE = (FEAT & kFeatSample) != 0, FINAL = (FEAT & kFeatFinal) != 0, RGBK = (FEAT & kFeatRgb) != 0;
@@ -817,6 +822,19 @@ void step_kernel_bits(
   const int wave = rfl((int)(threadIdx.x >> 6));
 
   const uint32_t B = (uint32_t)hot_batch;
+  // `thirds` (round 4; TG_RNG_EVERY=0, NOT the default): the RNG role serves ONE THIRD of the batch per one-transition launch, in
+  // rotation, instead of the whole batch every third launch — every launch then carries a third of the RNG workgroups and, at
+  // 65 536 envs, every launch fits the build with two stream waves (kFeatSplit), where two of three do.  Measured: the same at
+  // 65 536 envs, 3-10 % slower at 32 768 / 131 072 (profiles/r04/ab_rng_thirds.log) — RNG workgroups in every launch cost more
+  // than three times as many in every third.  Kept, tested, off.  The ring's double buffer flips per third: thirds are
+  // contiguous env ranges of B3 envs (a multiple of 128, so that a step workgroup and an RNG workgroup lie inside one), and
+  // which parity a third reads is a bit of hot_misc — scalar arithmetic on preloaded arguments in front of the first loads.
+  const bool thirds = (hot_misc >> 31) != 0u;
+  const uint32_t B3 = thirds ? ((((B + 2u) / 3u) + 127u) & ~127u) : 0xFFFFFFFFu;
+  auto ring_par_of = [&](const uint32_t e0) -> uint32_t {  // (wave-uniform argument)
+    const uint32_t t = (e0 >= B3 ? 1u : 0u) + ((e0 >> 1) >= B3 ? 1u : 0u);
+    return (hot_misc >> (19u + t)) & 1u;
+  };
   // role split by blockIdx: the RNG workgroups lead (placing them last measured the same)
 #ifdef TG_RNG_FIRST
   const bool rng_role = (int)blockIdx.x < bp.nrb;
@@ -824,7 +842,7 @@ void step_kernel_bits(
 #else
   // the step workgroups are dispatched first (a grid of this size starts first → last within 0.3-0.7 us, and the step
   // workgroups are the longer pole since the RNG role produces one entry per launch)
-  const uint32_t n_step = hot_misc & 0xFFFFFFu;
+  const uint32_t n_step = hot_misc & 0x7FFFFu;
   const bool rng_role = blockIdx.x >= n_step;
   const uint32_t step_block = blockIdx.x, rng_block = blockIdx.x - n_step;
 #endif
@@ -851,7 +869,7 @@ void step_kernel_bits(
   // p.nsteps consecutive transitions in this launch (tg_step_k): records / masks / slabs stay in registers and LDS in
   // between, only actions come in and observations go out per transition; one s_barrier per transition, and the
   // stream wave packs transition k while the logic wave already decides transition k + 1
-  const int hot_nsteps = (int)(hot_misc >> 25);
+  const int hot_nsteps = (int)((hot_misc >> 25) & 31u);
   const bool hot_act_i8 = ((hot_misc >> 24) & 1u) != 0;
   const int nsteps = MULTI ? (hot_nsteps > 1 ? hot_nsteps : 1) : 1;
   const bool sample_mode = SAMPLE && p.sample_mode;  // (device-side action sampling: the kernels that carry it wait here)
@@ -891,10 +909,17 @@ void step_kernel_bits(
     const unsigned long long rng_t0 = TG_NOW();
 #endif
     if (bits_stream_waves<W, H>(FEAT) > 1 && threadIdx.x >= 128) TG_ROLE_END();  // (a third wave of the workgroup has no RNG range)
-    const uint32_t e = rng_block * 128u + threadIdx.x;
-    const bool on = e < B;
-    const uint32_t ee = on ? e : B - 1u;
-    const uint4 rw = hot_ring_rd[ee];
+    // the env range this launch's RNG role serves: third `rt` (or the whole batch: launches of several transitions, the
+    // every-n-th-launch cadence of TG_RNG_EVERY)
+    const uint32_t rt = (hot_misc >> 22) & 3u;
+    const uint32_t r_lo = (thirds && rt < 3u) ? rt * B3 : 0u;
+    const uint32_t r_hi = (thirds && rt < 3u) ? (r_lo + B3 < B ? r_lo + B3 : B) : B;
+    const uint32_t e = r_lo + rng_block * 128u + threadIdx.x;
+    const bool on = e < r_hi;
+    const uint32_t ee = on ? e : r_hi - 1u;
+    const uint32_t rpar = thirds ? ring_par_of(rfl(r_lo + rng_block * 128u)) : 0u;
+    const uint4* const ring_rd_r = hot_ring_rd + (size_t)(thirds ? rpar * B : 0u);
+    const uint4 rw = ring_rd_r[ee];
     uint64_t w0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32), w1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
     const int Hraw = hot_hbuf_rd[ee];
     const int Hn = Hraw & 0xFF;
@@ -949,7 +974,8 @@ void step_kernel_bits(
       }
     }
     if (on) {
-      u32x4* rdst = reinterpret_cast<u32x4*>(bp.ring_wr) + e;
+      u32x4* rdst = (thirds ? reinterpret_cast<u32x4*>(const_cast<uint4*>(hot_ring_rd)) + (size_t)((1u - rpar) * B)
+                            : reinterpret_cast<u32x4*>(bp.ring_wr)) + e;
       const u32x4 rv = u32x4{(uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32)};
 #ifdef TG_RING_PLAIN
       *rdst = rv;
@@ -1451,7 +1477,7 @@ void step_kernel_bits(
   int Hc = 0;
   uint64_t fnw = 0;  // FUNCTIONAL: the bags this transition may deal (S1 | S2 << 21 | Q0 << 42), see the look-ahead above
   if (RULESET == TG_RULESET_NUMPY) {
-    const uint4 rw = hot_ring_rd[env];
+    const uint4 rw = (hot_ring_rd + (size_t)(thirds ? ring_par_of(base_env) * B : 0u))[env];
     ring0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32);
     ring1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
     Hc = hot_hbuf_rd[env];  // H | loc << 8, split below
@@ -2476,7 +2502,8 @@ struct PrepareParams {
   int batch;
   int ruleset;
   int force;            // refill every ring
-  int cur;              // ring parity the next launch reads
+  int cur;              // ring parity the next launch reads ...
+  int thirds, ring_par; // ... or, with `thirds`, one bit per third of the batch (see step_kernel_bits)
   int hcur;             // consumed-counter parity the next launch reads
 };
 
@@ -2498,7 +2525,13 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
   uint4* ring4 = reinterpret_cast<uint4*>(p.ring);
   if (!moved) {  // ring untouched: make both parities agree with the one the next launch reads
     if (p.ruleset != TG_RULESET_NUMPY) return;  // (FUNCTIONAL: the look-ahead has no parities)
-    ring4[(size_t)(1 - p.cur) * B + env] = ring4[(size_t)p.cur * B + env];
+    int cur = p.cur;
+    if (p.thirds) {
+      const uint32_t B3 = ((((uint32_t)p.batch + 2u) / 3u) + 127u) & ~127u;
+      const uint32_t t = ((uint32_t)env >= B3 ? 1u : 0u) + (((uint32_t)env >> 1) >= B3 ? 1u : 0u);
+      cur = (p.ring_par >> t) & 1;
+    }
+    ring4[(size_t)(1 - cur) * B + env] = ring4[(size_t)cur * B + env];
     p.hbuf[(size_t)(1 - p.hcur) * B + env] = p.hbuf[(size_t)p.hcur * B + env];
     return;
   }

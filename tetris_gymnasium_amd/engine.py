@@ -41,9 +41,26 @@ def _dl_deleter(mt):
     _dl_live.pop(C.addressof(mt.contents), None)
 
 
+_PyCapsule_Destructor = C.CFUNCTYPE(None, C.c_void_p)
 _PyCapsule_New = C.pythonapi.PyCapsule_New
 _PyCapsule_New.restype = C.py_object
-_PyCapsule_New.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+_PyCapsule_New.argtypes = [C.c_void_p, C.c_char_p, _PyCapsule_Destructor]
+_PyCapsule_IsValid = C.pythonapi.PyCapsule_IsValid
+_PyCapsule_IsValid.restype = C.c_int
+_PyCapsule_IsValid.argtypes = [C.c_void_p, C.c_char_p]
+_PyCapsule_GetPointer = C.pythonapi.PyCapsule_GetPointer
+_PyCapsule_GetPointer.restype = C.c_void_p
+_PyCapsule_GetPointer.argtypes = [C.c_void_p, C.c_char_p]
+
+
+@_PyCapsule_Destructor
+def _dl_capsule_destructor(capsule):
+    """DLPack protocol: a capsule that dies still named "dltensor" was never consumed (the consumer renames it to
+    "used_dltensor" when it takes ownership) — the producer's deleter must then run, or the view, its pooled device
+    buffer and the engine reference it pins stay alive for ever."""
+    if _PyCapsule_IsValid(capsule, b"dltensor"):
+        _dl_live.pop(_PyCapsule_GetPointer(capsule, b"dltensor"), None)
+
 
 
 class DeviceArray:
@@ -67,6 +84,8 @@ class DeviceArray:
         return len(self.shape)
 
     def _ready(self):
+        if not getattr(self.engine, "h", None) or (self._owner is not None and not self._owner.ptr):
+            raise EngineError("this DeviceArray's engine has been closed: its device memory is gone")
         if self._sync:
             self.engine.sync()
 
@@ -80,6 +99,8 @@ class DeviceArray:
         return (_KDLROCM, int(self.engine.cfg.device))
 
     def __dlpack__(self, stream=None, **_):
+        # (`stream`: the consumer's stream.  Export waits for the engine's stream on the host first — `sync=True` views — so
+        # the data is complete whatever stream reads it; a view created with sync=False leaves ordering to the caller.)
         self._ready()
         nd = len(self.shape)
         shape = (C.c_int64 * nd)(*self.shape)
@@ -93,7 +114,7 @@ class DeviceArray:
         mt.manager_ctx = None
         mt.deleter = _dl_deleter
         _dl_live[C.addressof(mt)] = (mt, shape, strides, self)  # the view (and its owner) lives as long as the consumer's tensor
-        return _PyCapsule_New(C.addressof(mt), b"dltensor", None)
+        return _PyCapsule_New(C.addressof(mt), b"dltensor", _dl_capsule_destructor)
 
     def numpy(self):
         """Download (waits for the engine's stream)."""
@@ -123,13 +144,37 @@ class DeviceBuffer:
         self.engine, self.nbytes = engine, int(nbytes)
         free = engine._pool.setdefault(self.nbytes, [])
         self.ptr = free.pop() if free else engine.dev_alloc(self.nbytes)
+        engine._live_bufs.add(self)  # (weakly: Engine.close frees what is still out and zeroes `ptr`, so late users fail loudly)
 
     def __del__(self):
         try:
-            if self.engine.h:
+            if self.engine.h and self.ptr:
                 self.engine._pool.setdefault(self.nbytes, []).append(self.ptr)
         except Exception:
             pass
+
+
+class _PinnedBlock:
+    """A page-locked host allocation (tg_host_alloc) that lives as long as any NumPy view of it: arrays made from it keep the
+    block as their base object, and the block's finalizer returns the memory (tg_host_free with a NULL handle needs no
+    engine).  Engine.close() therefore never pulls memory from under an array the caller still holds — gymnasium's
+    `copy=False` arrays stay valid after `envs.close()`, so do these."""
+
+    def __init__(self, lib, handle, nbytes):
+        import weakref
+
+        self.nbytes = max(int(nbytes), 1)
+        p = C.c_void_p()
+        rc = lib.tg_host_alloc(handle, self.nbytes, C.byref(p))
+        if rc != 0:
+            raise EngineError(f"tg_host_alloc failed ({rc}): {lib.tg_last_error(handle).decode()}")
+        self.ptr = p.value
+        self.__array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+        weakref.finalize(self, lib.tg_host_free, None, C.c_void_p(self.ptr))
+
+    def array(self, nbytes=None):
+        a = np.asarray(self)  # (base = this block)
+        return a if nbytes is None else a[:nbytes]
 
 
 class Engine:
@@ -145,9 +190,12 @@ class Engine:
                  ring_fill=None):
         """fuse / rng_every / ring_fill: launch knobs of the step kernel (tg_config; 0 / None = the defaults 16 / 3 / 3).
         Results never depend on them."""
+        import weakref
+
         self.lib = N.load()
         self._pool = {}      # free device buffers by size (DeviceBuffer)
-        self._pinned, self._pinned_ptrs, self._pin_slots = {}, [], 0  # page-locked host buffers (use_pinned_observations)
+        self._live_bufs = weakref.WeakSet()  # DeviceBuffers handed out and not yet returned
+        self._pinned, self._pin_slots = {}, 0  # page-locked host buffers (use_pinned_observations): views of _PinnedBlocks
         if queue_size is None:
             queue_size = 4 if ruleset == N.RULESET_NUMPY else 7
         if obs_mode is None:
@@ -181,10 +229,11 @@ class Engine:
                 for p in ptrs:
                     self.lib.tg_dev_free(self.h, C.c_void_p(p))
             self._pool = {}
-            self._pinned = {}
-            for p in self._pinned_ptrs:
-                self.lib.tg_host_free(self.h, C.c_void_p(p))
-            self._pinned_ptrs = []
+            for b in list(self._live_bufs):  # buffers still referenced by States / DeviceArrays: freed now, marked dead
+                if b.ptr:
+                    self.lib.tg_dev_free(self.h, C.c_void_p(b.ptr))
+                    b.ptr = 0
+            self._pinned = {}  # (the page-locked blocks free themselves when the last array viewing them dies)
             self.lib.tg_destroy(self.h)
             self.h = None
 
@@ -284,6 +333,10 @@ class Engine:
         overwritten `slots` calls later (gymnasium's `copy=False`); the buffers live until close()."""
         self._pin_slots = max(2, int(slots))
 
+    def pinned_bytes(self, nbytes):
+        """uint8[nbytes] in page-locked host memory that frees itself when the last view of it dies (_PinnedBlock)"""
+        return _PinnedBlock(self.lib, self.h, nbytes).array(nbytes)
+
     def _host_array(self, shape, dtype, tag):
         """a host array for a fetch: fresh (default) or the next page-locked slot of its kind"""
         if not getattr(self, "_pin_slots", 0):
@@ -291,10 +344,7 @@ class Engine:
         ring = self._pinned.setdefault((tag, tuple(shape), np.dtype(dtype).str), [])
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         if len(ring) < self._pin_slots:
-            p = C.c_void_p()
-            self._chk(self.lib.tg_host_alloc(self.h, nbytes, C.byref(p)), "tg_host_alloc")
-            self._pinned_ptrs.append(p.value)
-            ring.append(np.ctypeslib.as_array((C.c_uint8 * max(nbytes, 1)).from_address(p.value))[:nbytes].view(dtype).reshape(shape))
+            ring.append(self.pinned_bytes(nbytes).view(dtype).reshape(shape))
             return ring[-1]
         ring.append(ring.pop(0))
         return ring[-1]

@@ -3,10 +3,14 @@ the HIP engine (rule-set NUMPY, one env).  Same constructor kwargs, `reset`/`ste
 dict, rewards, and the attributes the reference's wrappers and tests reach into (`board, x, y,
 active_tetromino, queue, holder, randomizer, has_swapped, game_over, padding, width_padded, ...`).
 
-The attributes are plain host values: `step()` pushes them to the device (so poking `env.x`, `env.board`
-or `env.active_tetromino` between steps works like in the reference's tests), runs ONE engine transition,
-and pulls the new state back.  This is the drop-in / debugging surface; throughput comes from
-`TetrisVectorEnv` / `Engine`, where state never leaves the GPU.
+The state lives on the device.  The attributes are host-side views of it that are filled in LAZILY: the first
+read after a transition downloads the state once (`tg_get_state`), a write (or a read of a mutable object —
+`env.board[...] = ...`, `env.queue.queue`, `env.active_tetromino`) marks the host copy as possibly changed and
+the next `step()` uploads it first (`tg_set_state`), so poking `env.x`, `env.board` or `env.active_tetromino`
+between steps works like in the reference's tests.  A plain `reset(); while ...: step(a)` loop touches none of
+them: a step is then ONE call into the C ABI (tg_step_fetch_many: action upload, kernel launch, the copies of
+TG_BUF_OBS and TG_BUF_STEP_OUT, one wait) — round 3 made six synchronous round trips per step.  This is the
+drop-in / debugging surface; throughput comes from `TetrisVectorEnv` / `Engine`.
 """
 from __future__ import annotations
 
@@ -20,41 +24,33 @@ import numpy as np
 from .. import _native as N
 from .._gym_compat import EnvBase, spaces
 from ..components.tetromino import COLORS, Pixel, Tetromino, identify, make_tetromino
+from ..components.tetromino_holder import TetrominoHolder
+from ..components.tetromino_queue import TetrominoQueue
+from ..components.tetromino_randomizer import BagRandomizer
 from ..engine import Engine
 from ..mappings.actions import ActionsMapping
 from ..mappings.rewards import RewardsMapping
 
 
-class _QueueView:
-    """Read view of the device-side TetrominoQueue (reference components/tetromino_queue.py)."""
+class _QueueView(TetrominoQueue):
+    """`Tetris.queue`: a TetrominoQueue (reference components/tetromino_queue.py) whose content mirrors the device-side queue
+    of the env — the randomizer behind it runs on the device."""
 
     def __init__(self, size):
-        self.size = size
-        self.queue = deque(maxlen=size)
-
-    def get_queue(self):
-        return list(self.queue)
+        super().__init__(None, size)
 
 
-class _HolderView:
-    """Read view of the device-side TetrominoHolder (reference components/tetromino_holder.py)."""
-
-    def __init__(self, size=1):
-        self.size = size
-        self.queue = deque(maxlen=size)
-
-    def get_tetrominoes(self):
-        return list(self.queue)
+class _HolderView(TetrominoHolder):
+    """`Tetris.holder`: a TetrominoHolder (reference components/tetromino_holder.py) mirroring the device-side hold slot."""
 
 
-class _RandomizerView:
-    """Read view of the device-side BagRandomizer (reference components/tetromino_randomizer.py:49-102)."""
+class _RandomizerView(BagRandomizer):
+    """`Tetris.randomizer`: a BagRandomizer (reference components/tetromino_randomizer.py:49-102) whose bag / index mirror the
+    device-side generator of the env; `pcg64_state` is that generator as a tg_rng_rec NumPy record."""
 
     def __init__(self, size=7):
-        self.size = size
-        self.bag = np.arange(size, dtype=np.int8)
-        self.index = 0
-        self.pcg64_state = None  # tg_rng_rec as a NumPy record
+        super().__init__(size)
+        self.pcg64_state = None
 
 
 @dataclass
@@ -64,8 +60,34 @@ class TetrisState:
     rng: np.ndarray
 
 
+def _state_attr(name, mutable):
+    """a Tetris attribute backed by the lazily downloaded device state (see the module docstring)"""
+
+    def get(self):
+        self._sync_host()
+        if mutable:  # the caller may change the object in place: upload before the next transition
+            self._dirty = True
+        return self._hs[name]
+
+    def set(self, value):
+        self._sync_host()
+        self._hs[name] = value
+        self._dirty = True
+
+    return property(get, set)
+
+
 class Tetris(EnvBase):
     metadata = {"render_modes": ["rgb_array", "ansi"], "render_fps": 1}
+    board = _state_attr("board", True)
+    x = _state_attr("x", False)
+    y = _state_attr("y", False)
+    active_tetromino = _state_attr("active_tetromino", True)
+    has_swapped = _state_attr("has_swapped", False)
+    game_over = _state_attr("game_over", False)
+    queue = _state_attr("queue", True)
+    holder = _state_attr("holder", True)
+    randomizer = _state_attr("randomizer", True)
 
     BASE_PIXELS = [Pixel(0, [0, 0, 0]), Pixel(1, [128, 128, 128])]
     TETROMINOES = [Tetromino(i, list(COLORS[i]), make_tetromino(i, 0, 1).matrix) for i in range(7)]
@@ -78,6 +100,7 @@ class Tetris(EnvBase):
                                       "HIP engine (they are also broken in the reference: envs/tetris.py:114-144)")
         if actions_mapping != ActionsMapping() or rewards_mapping != RewardsMapping():
             raise NotImplementedError("the HIP engine implements the stock ActionsMapping / RewardsMapping")
+        self._hs, self._stale, self._dirty, self._engine = {}, False, False, None
         self.game_over = False
         self.height, self.width = int(height), int(width)
         self.base_pixels = copy.deepcopy(self.BASE_PIXELS)
@@ -97,7 +120,9 @@ class Tetris(EnvBase):
         self.board = self.create_board()
         self._engine = Engine(1, self.width, self.height, ruleset=N.RULESET_NUMPY, gravity=gravity,
                               queue_size=queue_size, obs_mode=N.OBS_DICT, device=device)
-        self._rng_rec = None
+        self._rec = None
+        self._init_fast_step()
+        self._stale, self._dirty = True, False  # (whatever the placeholders above were: the device state is the truth)
         hi = len(self.pixels)
         self.observation_space = spaces.Dict({
             "board": spaces.Box(low=0, high=hi, shape=(self.height_padded, self.width_padded), dtype=np.uint8),
@@ -113,59 +138,95 @@ class Tetris(EnvBase):
         self.render_scaling_factor = render_upscale
 
     # ---- host <-> device state ----------------------------------------------------------------
+    def _sync_host(self):
+        """fill the host-side attributes from the device state if a transition has run since the last download"""
+        if self._stale:
+            self._stale = False
+            self._pull()
+
+    def _ro(self, name):
+        """read an attribute without marking the host copy as changed (the helpers below only look)"""
+        self._sync_host()
+        return self._hs[name]
+
     def _push(self):
-        e = self._engine
-        _, rec, rng = e.get_state()
-        idx, rot, val = identify(self.active_tetromino)
+        """upload the host-side attributes (they are current: every write path went through _sync_host first)"""
+        e, hs = self._engine, self._hs
+        rec, rng = self._rec, hs["randomizer"].pcg64_state
+        idx, rot, val = identify(hs["active_tetromino"])
         rec["piece"], rec["rot"], rec["val"] = idx, rot, val
-        rec["x"], rec["y"] = self.x, self.y
-        rec["flags"] = (N.F_GAME_OVER if self.game_over else 0) | (N.F_HAS_SWAPPED if self.has_swapped else 0)
-        held = self.holder.get_tetrominoes()
+        rec["x"], rec["y"] = hs["x"], hs["y"]
+        rec["flags"] = (N.F_GAME_OVER if hs["game_over"] else 0) | (N.F_HAS_SWAPPED if hs["has_swapped"] else 0)
+        held = hs["holder"].get_tetrominoes()
         if held:
             hi_, hr, hv = identify(held[0])
             rec["holder_piece"], rec["holder_rot"], rec["holder_val"] = hi_, hr, hv
         else:
             rec["holder_piece"] = N.NONE
-        q = list(self.queue.queue)
+        q = list(hs["queue"].queue)
         rec["queue"][0, : len(q)] = q
-        rec["bag"][0] = self.randomizer.bag
-        rec["bag_index"] = self.randomizer.index
+        rec["bag"][0] = hs["randomizer"].bag
+        rec["bag_index"] = hs["randomizer"].index
         p = self.padding
-        board = np.ascontiguousarray(self.board[: self.height, p: p + self.width], np.uint8)[None]
-        e.set_state(board=board, rec=rec, rng=self.randomizer.pcg64_state)  # (tg_set_state re-packs TG_BUF_OBS itself)
+        board = np.ascontiguousarray(hs["board"][: self.height, p: p + self.width], np.uint8)[None]
+        e.set_state(board=board, rec=rec, rng=rng)  # (tg_set_state re-packs TG_BUF_OBS itself)
+        self._dirty = False
 
     def _pull(self):
         board, rec, rng = self._engine.get_state()
-        r = rec[0]
-        self.board = self.create_board()
+        r, hs = rec[0], self._hs
+        self._rec = rec
+        hs["board"] = self.create_board()
         p = self.padding
-        self.board[: self.height, p: p + self.width] = board[0]
-        self.active_tetromino = make_tetromino(int(r["piece"]), int(r["rot"]), int(r["val"]))
-        self.x, self.y = int(r["x"]), int(r["y"])
-        self.game_over = bool(r["flags"] & N.F_GAME_OVER)
-        self.has_swapped = bool(r["flags"] & N.F_HAS_SWAPPED)
-        self.queue.queue = deque((np.int8(v) for v in r["queue"][: self.queue.size]), maxlen=self.queue.size)
-        self.holder.queue = deque(maxlen=1)
+        hs["board"][: self.height, p: p + self.width] = board[0]
+        hs["active_tetromino"] = make_tetromino(int(r["piece"]), int(r["rot"]), int(r["val"]))
+        hs["x"], hs["y"] = int(r["x"]), int(r["y"])
+        hs["game_over"] = bool(r["flags"] & N.F_GAME_OVER)
+        hs["has_swapped"] = bool(r["flags"] & N.F_HAS_SWAPPED)
+        hs["queue"].queue = deque((np.int8(v) for v in r["queue"][: hs["queue"].size]), maxlen=hs["queue"].size)
+        hs["holder"].queue = deque(maxlen=1)
         if r["holder_piece"] != N.NONE:
-            self.holder.queue.append(make_tetromino(int(r["holder_piece"]), int(r["holder_rot"]), int(r["holder_val"])))
-        self.randomizer.bag = r["bag"].astype(np.int8)
-        self.randomizer.index = int(r["bag_index"])
-        self.randomizer.pcg64_state = rng.copy()
+            hs["holder"].queue.append(make_tetromino(int(r["holder_piece"]), int(r["holder_rot"]), int(r["holder_val"])))
+        hs["randomizer"].bag = r["bag"].astype(np.int8)
+        hs["randomizer"].index = int(r["bag_index"])
+        hs["randomizer"].pcg64_state = rng.copy()
 
     def _obs(self) -> "dict[str, Any]":
         # TG_BUF_OBS is what the step kernel wrote (after a transition) or what tg_reset / tg_set_state re-packed
         o = self._engine.observation()
         return {k: v[0].copy() for k, v in o.items()}
 
+    def _init_fast_step(self):
+        """ctypes arguments of the one-call step: [TG_BUF_OBS, TG_BUF_STEP_OUT] of the one-env engine into two host arrays"""
+        import ctypes as C
+
+        e = self._engine
+        cells, pp = self.height_padded * self.width_padded, self.padding * self.padding
+        self._obs_flat = np.empty(2 * cells + pp + pp * e.Q, np.uint8)
+        self._out1 = np.empty(1, N.STEP_OUT)
+        self._act1 = np.zeros(1, np.int32)
+        self._fs = ((C.c_void_p * 1)(e.h.value), (C.c_void_p * 1)(self._act1.ctypes.data), (C.c_int * 2)(N.BUF_OBS, N.BUF_STEP_OUT),
+                    (C.c_void_p * 2)(self._obs_flat.ctypes.data, self._out1.ctypes.data),
+                    (C.c_size_t * 2)(self._obs_flat.nbytes, self._out1.nbytes))
+        hp, wp, p = self.height_padded, self.width_padded, self.padding
+        f = self._obs_flat
+        self._obs_views = {"board": f[:cells].reshape(hp, wp), "active_tetromino_mask": f[cells:2 * cells].reshape(hp, wp),
+                           "holder": f[2 * cells:2 * cells + pp].reshape(p, p), "queue": f[2 * cells + pp:].reshape(p, p * e.Q)}
+
     # ---- gymnasium API --------------------------------------------------------------------------
     def step(self, action):
         """reference envs/tetris.py:203-272"""
         assert self.action_space.contains(action), f"{action!r} ({type(action)}) invalid"
-        self._push()
-        rew, term, lines = self._engine.step(np.array([int(action)], np.int32))
-        self._pull()
-        reward = int(rew[0]) if float(rew[0]).is_integer() else float(rew[0])
-        return self._obs(), reward, bool(term[0]), False, {"lines_cleared": int(lines[0])}
+        if self._dirty:
+            self._push()
+        e = self._engine
+        hs, acts, which, dst, nbytes = self._fs
+        self._act1[0] = int(action)
+        e._chk(e.lib.tg_step_fetch_many(1, hs, acts, N.MEM_HOST, 2, which, dst, nbytes, None), "tg_step_fetch_many")
+        self._stale = True
+        rew, term, lines = float(self._out1["reward"][0]), bool(self._out1["terminated"][0]), int(self._out1["lines"][0])
+        reward = int(rew) if rew.is_integer() else rew
+        return {k: v.copy() for k, v in self._obs_views.items()}, reward, term, False, {"lines_cleared": lines}
 
     def reset(self, *, seed: "int | None" = None, options: "dict[str, Any] | None" = None):
         """reference envs/tetris.py:274-307 (seed=None or 0 keeps the running generator)"""
@@ -174,7 +235,7 @@ class Tetris(EnvBase):
         except TypeError:
             pass
         self._engine.reset(None if not seed else np.array([int(seed)], np.uint64))
-        self._pull()
+        self._stale, self._dirty = True, False
         return self._obs(), {"lines_cleared": 0}
 
     # ---- helpers the reference's wrappers / tests call ------------------------------------------
@@ -187,7 +248,7 @@ class Tetris(EnvBase):
         return (slice(y, y + h), slice(x, x + w))
 
     def collision(self, tetromino, x, y) -> bool:
-        sub = self.board[self.get_tetromino_slices(tetromino, x, y)]
+        sub = self._ro("board")[self.get_tetromino_slices(tetromino, x, y)]
         return bool(np.any(sub[tetromino.matrix > 0] > 0))
 
     def rotate(self, tetromino, clockwise=True):
@@ -197,10 +258,10 @@ class Tetris(EnvBase):
         return matrix[0: -self.padding, self.padding: -self.padding]
 
     def project_tetromino(self, tetromino=None, x=None, y=None):
-        tetromino = self.active_tetromino if tetromino is None else tetromino
-        x = self.x if x is None else x
-        y = self.y if y is None else y
-        proj = self.board.copy()
+        tetromino = self._ro("active_tetromino") if tetromino is None else tetromino
+        x = self._ro("x") if x is None else x
+        y = self._ro("y") if y is None else y
+        proj = self._ro("board").copy()
         if self.collision(tetromino, x, y):
             return proj
         proj[self.get_tetromino_slices(tetromino, x, y)] += tetromino.matrix
@@ -211,13 +272,14 @@ class Tetris(EnvBase):
 
     def get_state(self) -> TetrisState:
         """Clone the full state incl. the PCG64 generator (reference envs/tetris.py:694-708)."""
-        self._push()
+        if self._dirty:
+            self._push()
         b, r, g = self._engine.get_state()
         return TetrisState(b.copy(), r.copy(), g.copy())
 
     def set_state(self, state: TetrisState) -> None:
         self._engine.set_state(board=state.board, rec=state.rec, rng=state.rng)
-        self._pull()
+        self._stale, self._dirty = True, False
 
     def render(self):
         if self.render_mode == "ansi":

@@ -344,3 +344,57 @@ def get_observation(board, x, y, active_tetromino, rotation, game_over, tetromin
         b[int(y): int(y) + 4, int(x): int(x) + 4] -= m[: b.shape[0] - int(y), : b.shape[1] - int(x)]
     p = config.padding
     return b[0:-p, p:-p]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The two remaining functions of reference envs/tetris_fn.py as host-side NumPy for ONE state (arguments and returns as in
+# the reference; `queue_fn` may be any callable with the reference's signature — this is plain host code).  The engine runs
+# the same rules inside its step kernel; these exist for callers and tests that use the pieces on their own.
+def place_active_tetromino(config, tetrominoes, state: State, queue_fn=bag_queue_get_next_element):
+    """→ (state, reward, lines_cleared): lock the active piece, clear rows, spawn the next piece of the queue, detect game
+    over, advance the key (reference envs/tetris_fn.py:370-413)."""
+    from ..functional import core as fc
+
+    board, reward, lines = fc.lock_active_tetromino(config, tetrominoes, state.board, state.active_tetromino, state.rotation,
+                                                    state.x, state.y)
+    piece, queue, queue_index, _ = queue_fn(config, state.queue, state.queue_index, state.rng_key)
+    x, y = fc.get_initial_x_y(config, tetrominoes, piece)
+    over = fc.check_game_over(tetrominoes, board, piece, 0, x, y)
+    new = State(rng_key=split(np.asarray(state.rng_key, np.uint32))[0], board=board, active_tetromino=np.int32(piece),
+                rotation=np.int32(0), x=np.int32(x), y=np.int32(y), queue=np.asarray(queue, np.int32),
+                queue_index=np.int32(queue_index), game_over=np.bool_(over), score=state.score)
+    return new, np.int32(reward), np.int32(lines)
+
+
+def update_state(action, config, state: State, queue_fn=bag_queue_get_next_element, tetrominoes=TETROMINOES):
+    """→ (state, lines_cleared): one action applied to a state that is not game over (reference envs/tetris_fn.py:161-270):
+    move / rotate if the target is free (ids outside 0..6 are clamped the way lax.switch clamps its index), soft drop scores
+    a row, hard drop two per row and always locks, gravity pulls one row and locks the piece when it cannot fall."""
+    from ..functional import core as fc
+
+    a = min(max(int(action), 0), 6)
+    x, y, rot = int(state.x), int(state.y), int(state.rotation)
+    board, piece = state.board, int(state.active_tetromino)
+    mat = tetrominoes.matrices[piece, rot & 3]
+    drop_reward = 0
+    if a == 0 and not fc.collision(board, mat, x - 1, y):
+        x -= 1
+    elif a == 1 and not fc.collision(board, mat, x + 1, y):
+        x += 1
+    elif a == 2 and not fc.collision(board, mat, x, y + 1):
+        y, drop_reward = y + 1, 1
+    elif a in (3, 4):
+        nrot = (rot + (1 if a == 4 else -1)) % 4
+        if not fc.collision(board, tetrominoes.matrices[piece, nrot], x, y):
+            rot, mat = nrot, tetrominoes.matrices[piece, nrot]
+    elif a == 6:
+        y, drop_reward = fc.hard_drop(board, mat, x, y)
+    y_gravity = fc.graviy_step(tetrominoes, board, piece, rot, x, y) if config.gravity_enabled else y
+    should_lock = (y_gravity == y) and bool(config.gravity_enabled)
+    mid = State(rng_key=state.rng_key, board=board, active_tetromino=state.active_tetromino, rotation=np.int32(rot),
+                x=np.int32(x), y=np.int32(y_gravity), queue=state.queue, queue_index=state.queue_index,
+                game_over=np.bool_(False), score=state.score)
+    new, lock_reward, lines = (place_active_tetromino(config, tetrominoes, mid, queue_fn)
+                               if (should_lock or int(action) == 6) else (mid, np.int32(0), np.int32(0)))
+    new = new.replace(score=np.float32(np.float32(new.score) + np.float32(int(drop_reward)) + np.float32(int(lock_reward))))
+    return new, lines

@@ -37,3 +37,8 @@ TETROMINOES = _build()
 
 def get_tetromino_matrix(tetrominoes: Tetrominoes, tetromino_id: int, rotation: int) -> np.ndarray:
     return tetrominoes.matrices[tetromino_id, rotation]
+
+
+def get_tetromino_color(tetrominoes: Tetrominoes, tetromino_id: int) -> np.ndarray:
+    """RGB colour of tetromino `tetromino_id` (reference functional/tetrominoes.py:169-180)."""
+    return tetrominoes.colors[int(tetromino_id)]

@@ -23,6 +23,23 @@ _OBS = {"dict": N.OBS_DICT, "board": N.OBS_BOARD, "functional": N.OBS_FN, "place
 _AUTORESET = {"next_step": N.AUTORESET_NEXT_STEP, "same_step": N.AUTORESET_SAME_STEP, "disabled": N.AUTORESET_NONE}
 
 
+def _gym_autoreset_mode(name: str):
+    """metadata["autoreset_mode"] the way the installed gymnasium wants it: gymnasium >= 1.1 (the reference pins 1.1.1,
+    poetry.lock:743-744) defines gymnasium.vector.AutoresetMode and its vector wrappers compare / assert against that enum
+    (e.g. wrappers.vector.RecordEpisodeStatistics); older versions and the duck-typed fallback take the plain string.
+    UNVERIFIED against a live gymnasium — neither image of this project has one (tests/test_gymnasium_conformance.py runs
+    wherever `import gymnasium` works)."""
+    if HAVE_GYMNASIUM:  # pragma: no cover - depends on the environment
+        try:
+            from gymnasium.vector import AutoresetMode
+
+            return {"next_step": AutoresetMode.NEXT_STEP, "same_step": AutoresetMode.SAME_STEP,
+                    "disabled": AutoresetMode.DISABLED}[name]
+        except Exception:
+            pass
+    return name
+
+
 def shard_ranges(num_envs: int, n_shards: int):
     """Contiguous, balanced env ranges: shard k owns [lo_k, hi_k).  (SURVEY §8e: env i → GPU i // (B/G))"""
     base, extra = divmod(num_envs, n_shards)
@@ -39,6 +56,154 @@ def default_seeds(lo: int, hi: int, seed=None) -> np.ndarray:
     the number of devices.  seed=None → 1 + i."""
     base = 1 if seed is None else int(seed)
     return np.arange(base + lo, base + hi, dtype=np.uint64)
+
+
+class _HostStep:
+    """One gymnasium-contract step of all shards in ONE call into the C ABI (tg_step_fetch_many): action upload, step launch,
+    the device-side pack of rewards / terminations / lines / episode statistics in their final dtypes (TG_BUF_HOST_PACK) and
+    the device-to-host copies are enqueued for every shard, then every stream is waited for once.  The observation lands
+    where the caller reads it — with one shard the observation and the pack leave as a single copy into one slab laid out
+    like the device side; with several shards every array of a shard goes straight into its slice of the whole-batch array —
+    and everything `step` returns is a view of that memory: no per-step astype / zeros / concatenate of observation-sized
+    arrays.  pinned=True (copy=False): the slab is one of `slots` rotating page-locked buffers (a returned array is valid until
+    the next-but-one call); otherwise fresh pageable arrays per call.
+    Replaces the per-env Python loop + np.stack of gymnasium.vector.SyncVectorEnv.step (examples/train_ppo.py:240-248)."""
+
+    def __init__(self, venv, pinned, slots=2):
+        import ctypes as C
+
+        self.C, self.v, self.pinned = C, venv, bool(pinned)
+        self.lib = venv.engines[0].lib
+        es = venv.engines
+        self.n = len(es)
+        self.hs = (C.c_void_p * self.n)(*[e.h.value for e in es])
+        e0 = es[0]
+        # observation arrays: (name, per-env shape, dtype); bytes per env of each
+        if e0.obs_mode == N.OBS_DICT:
+            self.fields = [("board", (e0.Hp, e0.Wp), np.uint8), ("active_tetromino_mask", (e0.Hp, e0.Wp), np.uint8),
+                           ("holder", (e0.P, e0.P), np.uint8), ("queue", (e0.P, e0.P * e0.Q), np.uint8)]
+        elif e0.obs_mode == N.OBS_RGB:
+            self.fields = [("", (e0.Hp, e0.Wp + e0.P * max(1, e0.Q), 3), np.uint8)]
+        else:
+            self.fields = [("", (e0.H, e0.W), np.int8 if e0.obs_mode == N.OBS_FN else np.uint8)]
+        self.fbytes = [int(np.prod(sh)) * np.dtype(dt).itemsize for _, sh, dt in self.fields]
+        self.pack_off = []
+        for e in es:
+            off = (C.c_size_t * 6)()
+            self.lib.tg_host_pack_layout(C.byref(e.cfg), off)
+            self.pack_off.append([int(x) for x in off])
+        self.single = self.n == 1
+        if self.single:  # [TG_BUF_OBS | gap | TG_BUF_HOST_PACK] as on the device: one copy
+            po, _ = e0.device_ptr(N.BUF_OBS)
+            pp, _ = e0.device_ptr(N.BUF_HOST_PACK)
+            self.gap = pp - po
+            self.obs_bytes = e0.B * sum(self.fbytes)
+            self.m = 2
+            self.which = (C.c_int * 2)(N.BUF_OBS, N.BUF_HOST_PACK)
+            self.nbytes = (C.c_size_t * 2)(self.obs_bytes, self.pack_off[0][5])
+            self.src_off = None
+            self.slab_bytes = self.gap + self.pack_off[0][5]
+            if not (0 < self.gap - self.obs_bytes <= 16384):  # (not neighbours after all: two copies, still one wait)
+                self.gap = (self.obs_bytes + 63) // 64 * 64
+                self.slab_bytes = self.gap + self.pack_off[0][5]
+        else:  # per shard: every observation array into its slice of the whole-batch array + the shard's pack
+            self.m = len(self.fields) + 1
+            self.which = (C.c_int * self.m)(*([N.BUF_OBS] * len(self.fields) + [N.BUF_HOST_PACK]))
+            nb, so = [], []
+            for e, offs in zip(es, self.pack_off):
+                o = 0
+                for fb in self.fbytes:
+                    nb.append(e.B * fb); so.append(o); o += e.B * fb
+                nb.append(offs[5]); so.append(0)
+            self.nbytes = (C.c_size_t * (self.n * self.m))(*nb)
+            self.src_off = (C.c_size_t * (self.n * self.m))(*so)
+        self.slots, self.cur = [], 0
+        self.n_slots = max(2, int(slots)) if self.pinned else 0
+        self.act_ptrs = (C.c_void_p * self.n)()
+
+    # -- destination memory ---------------------------------------------------------------------------------------------
+    def _raw(self, nbytes):
+        """uint8[nbytes]: page-locked or a fresh pageable array"""
+        if not self.pinned:
+            return np.empty(nbytes, np.uint8)
+        return self.v.engines[0].pinned_bytes(nbytes)  # (frees itself when the last view dies: valid beyond close())
+
+    def _make_slot(self):
+        C, v = self.C, self.v
+        B = v.num_envs
+        slot = {}
+        dst = (C.c_void_p * (self.n * self.m))()
+        if self.single:
+            raw = self._raw(self.slab_bytes)
+            base = raw.ctypes.data
+            dst[0], dst[1] = base, base + self.gap
+            obs, o = {}, 0
+            for (name, sh, dt), fb in zip(self.fields, self.fbytes):
+                obs[name] = raw[o:o + B * fb].view(dt).reshape((B,) + sh)
+                o += B * fb
+            packs = [raw[self.gap:self.gap + self.pack_off[0][5]]]
+            slot["keep"] = raw
+        else:
+            obs, keep = {}, []
+            for (name, sh, dt), fb in zip(self.fields, self.fbytes):
+                raw = self._raw(B * fb)
+                keep.append(raw)
+                obs[name] = raw.view(dt).reshape((B,) + sh)
+            packs = []
+            for k, ((lo, hi), offs) in enumerate(zip(v.ranges, self.pack_off)):
+                for f, fb in enumerate(self.fbytes):
+                    dst[k * self.m + f] = keep[f].ctypes.data + lo * fb
+                pk = self._raw(offs[5])
+                packs.append(pk)
+                dst[k * self.m + self.m - 1] = pk.ctypes.data
+            slot["keep"] = keep
+        slot["dst"] = dst
+        slot["obs"] = obs[""] if "" in obs else obs
+        # the five arrays of every shard's pack, as views
+        parts = []
+        for pk, offs, (lo, hi) in zip(packs, self.pack_off, v.ranges):
+            b = hi - lo
+            # (rewards, terminations, lines, episode returns, episode lengths) — tg_host_pack_layout's offsets 0, 4, 2, 1, 3
+            parts.append((pk[offs[0]:offs[0] + 8 * b].view(np.float64), pk[offs[4]:offs[4] + b].view(np.bool_),
+                          pk[offs[2]:offs[2] + 4 * b].view(np.int32), pk[offs[1]:offs[1] + 8 * b].view(np.float64),
+                          pk[offs[3]:offs[3] + 4 * b].view(np.int32)))
+        slot["parts"] = parts
+        return slot
+
+    def _next_slot(self):
+        if not self.pinned:
+            return self._make_slot()
+        if len(self.slots) < self.n_slots:
+            self.slots.append(self._make_slot())
+            self.cur = len(self.slots) - 1
+            return self.slots[-1]
+        self.cur = (self.cur + 1) % self.n_slots
+        return self.slots[self.cur]
+
+    # -- the call ---------------------------------------------------------------------------------------------------------
+    def step(self, actions):
+        """actions: contiguous int32[num_envs] (host) or None (fetch only).  Returns (obs, rewards f64, terminations bool,
+        lines i32, episode returns f64, episode lengths i32) — whole-batch arrays."""
+        v, C = self.v, self.C
+        slot = self._next_slot()
+        acts = None
+        if actions is not None:
+            base = actions.ctypes.data
+            for k, (lo, _) in enumerate(v.ranges):
+                self.act_ptrs[k] = base + 4 * lo
+            acts = self.act_ptrs
+        rc = self.lib.tg_step_fetch_many(self.n, self.hs, acts, N.MEM_HOST, self.m, self.which, slot["dst"], self.nbytes,
+                                         self.src_off)
+        if rc != 0:
+            for e in v.engines:  # (the failing handle carries the message)
+                msg = self.lib.tg_last_error(e.h).decode()
+                if msg:
+                    raise RuntimeError(f"tg_step_fetch_many failed ({rc}): {msg}")
+            raise RuntimeError(f"tg_step_fetch_many failed ({rc})")
+        parts = slot["parts"]
+        if len(parts) == 1:
+            return (slot["obs"],) + parts[0]
+        return (slot["obs"],) + tuple(np.concatenate([p[i] for p in parts]) for i in range(5))  # (25 bytes per env)
 
 
 class TetrisVectorEnv(VectorEnvBase):
@@ -62,7 +227,7 @@ class TetrisVectorEnv(VectorEnvBase):
         self.ruleset = N.RULESET_NUMPY if ruleset == "numpy" else N.RULESET_FUNCTIONAL
         self.obs_kind = observation
         self.autoreset_mode = autoreset_mode
-        self.metadata = dict(self.metadata, autoreset_mode=autoreset_mode)
+        self.metadata = dict(self.metadata, autoreset_mode=_gym_autoreset_mode(autoreset_mode))
         if queue_size is None:
             queue_size = 4 if self.ruleset == N.RULESET_NUMPY else 7
         self.queue_size = queue_size
@@ -121,6 +286,9 @@ class TetrisVectorEnv(VectorEnvBase):
         # matter — every entry point sets its device itself.
         self._pool = ThreadPoolExecutor(len(self.engines), thread_name_prefix="tg-shard") if len(self.engines) > 1 else None
         self._dev_views = {}  # shard -> (observation view(s), outputs views) of step_device
+        self._copy, self._host, self._sd = bool(copy), None, None
+        self._ones, self._falses = np.ones(self.num_envs, bool), np.zeros(self.num_envs, bool)
+        self._zeros_t = np.zeros(self.num_envs, np.float64)  # infos["episode"]["t"] (elapsed time: not tracked)
         if not copy:
             for e in self.engines:
                 e.use_pinned_observations(2)
@@ -197,28 +365,52 @@ class TetrisVectorEnv(VectorEnvBase):
         dev_actions = isinstance(actions, (list, tuple)) and len(actions) == len(self.engines) and \
             all(isinstance(a, (DeviceArray, int)) for a in actions)
         if not dev_actions:
-            actions = np.asarray(actions, np.int32).reshape(self.num_envs)
+            actions = np.ascontiguousarray(actions, np.int32).reshape(self.num_envs)
 
-        def one(k, e, lo, hi):
-            if dev_actions:
-                a = actions[k]
-                e.step_device(a.ptr if isinstance(a, DeviceArray) else a)
-            else:
-                e.step_async(actions[lo:hi])
+        # every shard's launch from ONE call into the C ABI (tg_step_fetch_many with nothing to fetch): one handle after the
+        # other on this thread — a launch is an asynchronous ~10 us enqueue, a hand-off to a worker thread per shard under the
+        # GIL costs more than that (round 3 used the thread pool here: 6.8 us per step with one shard, but growing with k)
+        import ctypes as C
+
+        if self._sd is None:
+            self._sd = ((C.c_void_p * len(self.engines))(*[e.h.value for e in self.engines]), (C.c_void_p * len(self.engines))())
+        hs, ptrs = self._sd
+        if dev_actions:
+            for k, a in enumerate(actions):
+                ptrs[k] = a.ptr if isinstance(a, DeviceArray) else a
+        else:
+            base = actions.ctypes.data
+            for k, (lo, _) in enumerate(self.ranges):
+                ptrs[k] = base + 4 * lo
+        lib = self.engines[0].lib
+        rc = lib.tg_step_fetch_many(len(self.engines), hs, ptrs, N.MEM_DEVICE if dev_actions else N.MEM_HOST, 0, None, None, None, None)
+        if rc != 0:
+            msgs = [lib.tg_last_error(e.h).decode() for e in self.engines]
+            raise RuntimeError(f"tg_step_fetch_many failed ({rc}): {next((m for m in msgs if m), '')}")
+        parts = []
+        for k, e in enumerate(self.engines):
             views = self._dev_views.get(k)  # (the engine's buffers never move: the views are built once per shard)
             if views is None:
                 views = self._dev_views[k] = (e.device_array(N.BUF_OBS) if e.obs_mode != N.OBS_NONE else None,
                                               e.device_array(N.BUF_STEP_OUT))
-            return views
-
-        jobs = [(k, e, lo, hi) for k, (e, (lo, hi)) in enumerate(zip(self.engines, self.ranges))]
-        parts = [one(*j) for j in jobs] if self._pool is None else list(self._pool.map(lambda j: one(*j), jobs))
+            parts.append(views)
         return parts[0] if len(parts) == 1 else parts
 
     def step(self, actions, to_host: bool = True):
         if not to_host:
             return self.step_device(actions)
-        actions = np.asarray(actions, np.int32).reshape(self.num_envs)
+        actions = np.ascontiguousarray(actions, np.int32).reshape(self.num_envs)
+        if self.obs_kind in ("board", "functional", "dict", "rgb") and not self.grouped and not self.final_obs:
+            # the whole step — upload, launch, pack, copies, one wait per device — is one call into the C ABI
+            if self._host is None:
+                self._host = _HostStep(self, pinned=not self._copy)
+            obs, rewards, terminations, lines, ep_r, ep_l = self._host.step(actions)
+            fresh = (lambda a: a.copy()) if self._copy else (lambda a: a)  # (copy=False: the constant arrays are shared, too)
+            infos = {"lines_cleared": lines, "_lines_cleared": fresh(self._ones)}
+            if self.episode_stats and terminations.any():
+                infos["episode"] = {"r": ep_r, "l": ep_l, "t": fresh(self._zeros_t)}
+                infos["_episode"] = fresh(terminations)
+            return obs, rewards, terminations, fresh(self._falses), infos
 
         def one(e, lo, hi):  # launch, then collect everything this shard returns, on the shard's own thread
             e.step_async(actions[lo:hi])
@@ -278,11 +470,32 @@ class TetrisVectorEnv(VectorEnvBase):
                 np.concatenate([p[2] for p in parts], axis=1).astype(bool),
                 np.concatenate([p[3] for p in parts], axis=1).astype(np.int32))
 
+    # ---- gymnasium.vector.VectorEnv odds and ends (call / get_attr / set_attr of the sub-environments) ----------------
+    def get_attr(self, name: str):
+        """Per-env values of an attribute, as gymnasium.vector.VectorEnv.get_attr returns them (a tuple of num_envs entries).
+        The sub-environments are rows of the device batch, not Python objects: the attributes that exist are the
+        configuration (`width`, `height`, `queue_size`, `gravity_enabled`, `padding`, `render_mode`, `metadata`, `spec`)."""
+        const = {"width": self.width, "height": self.height, "queue_size": self.queue_size, "padding": 4,
+                 "gravity_enabled": bool(self.engines[0].cfg.gravity) if self.engines else True, "render_mode": None,
+                 "metadata": {"render_modes": []}, "spec": None}
+        if name not in const:
+            raise AttributeError(f"the sub-environments of TetrisVectorEnv have no attribute {name!r} (they live on the GPU)")
+        return tuple(const[name] for _ in range(self.num_envs))
+
+    def set_attr(self, name: str, values):
+        raise AttributeError(f"cannot set {name!r}: the sub-environments of TetrisVectorEnv are rows of a device batch; "
+                             "create a new TetrisVectorEnv with the configuration you want")
+
+    def call(self, name: str, *args, **kwargs):
+        """gymnasium.vector.VectorEnv.call: attributes come from get_attr; methods of a sub-environment do not exist here."""
+        return self.get_attr(name)
+
     def close(self, **kwargs):
         if self._pool is not None:
             self._pool.shutdown(wait=True)
             self._pool = None
         self._dev_views = {}
+        self._host = None
         for e in self.engines:
             e.close()
         self.engines = []

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX: the round's profile set → gpurun_out/<tag>/ (copy the summaries + latest.json into profiles/<round>/).
 #   per block (config3 = headline, config2, config5, dict, fused16, rgb, functional, functional_fused16, config2_fused16): rocprofv3
 #   --kernel-trace --stats of the bench block's command
-#   config3 / dict / config5 / rgb / functional: HBM traffic (FETCH_SIZE, WRITE_SIZE in separate --pmc passes, calibrated on the stream-copy kernel)
+#   every block: HBM traffic (FETCH_SIZE, WRITE_SIZE in separate --pmc passes, calibrated on the stream-copy kernel)
 #   config3: two SQ_* counter passes
 # usage: tools/gpu_profile.sh <tag> [blocks...]
 TAG=${1:-prof}; shift; BLOCKS=${@:-config3 config2 config5 dict fused16 rgb functional functional_fused16 config2_fused16}
@@ -15,7 +15,7 @@ for b in $BLOCKS; do
   echo "== $b"; grep -h "step_kernel\|observe_kernel" $OUT/${b}_kt_summary.md | head -3 | cut -c1-140
 done
 for b in $BLOCKS; do
-  case $b in config3|dict|config5|rgb|functional)
+  case $b in config3|config2|dict|config5|rgb|fused16|functional|functional_fused16|config2_fused16)
     rocprofv3 --pmc FETCH_SIZE -d $OUT/${b}_f -o f -- python3 bench.py $COMMON --steps 32 --warmup 8 ${ARGS[$b]} > $OUT/${b}_f.log 2>&1
     rocprofv3 --pmc WRITE_SIZE -d $OUT/${b}_w -o w -- python3 bench.py $COMMON --steps 32 --warmup 8 ${ARGS[$b]} > $OUT/${b}_w.log 2>&1
   ;; esac
