@@ -459,6 +459,67 @@ def test_rng_role_every_nth_launch(every, W, H, Q, B, grouped, monkeypatch):
     e.close()
 
 
+@pytest.mark.parametrize("fuse", [1, 16])
+@pytest.mark.parametrize("W,H,Q,B,grouped", [(10, 20, 4, 1000, False), (20, 40, 7, 300, True), (6, 12, 2, 100, False), (12, 24, 4, 77 * 4, False)])
+def test_packed_board_handles(fuse, W, H, Q, B, grouped, monkeypatch):
+    """TG_PACKED=1: the handle keeps its board as nibbles (tg_kernel_bits.h kFeatPacked — what large working sets pick by
+    themselves) and the uint8 TG_BUF_BOARD is brought up to date on demand.  Single steps, rollouts, trajectories, masked
+    resets, state round trips (host and device), board fetches and ragged last workgroups against the oracle; cell values
+    the nibbles cannot hold are refused by tg_set_state."""
+    monkeypatch.setenv("TG_PACKED", "1")
+    monkeypatch.setenv("TG_FUSE", str(fuse))
+    na = 4 * W if grouped else 8
+    e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP, grouped=grouped)
+    assert int(e.step_kernel_name().rstrip(">").split(",")[-1]) & 256
+    o = po.OracleBatch(B, W, H, N.RULESET_NUMPY, True, Q)
+    seeds = np.arange(5, 5 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(fuse * 10 + W)
+
+    def ostep(a):
+        return o.grouped_step(a.astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)[:3] if grouped \
+            else o.step(a.astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+
+    for rnd in range(6):
+        for _ in range(1 + rnd):
+            a = rng.integers(0, na, B).astype(np.int8)
+            if not grouped:
+                a[rng.random(B) < 0.3] = 5
+            got = e.step(a)
+            ro, to, lo = ostep(a)
+            np.testing.assert_array_equal(got[0], ro); np.testing.assert_array_equal(got[1], to)
+            np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_BOARD))
+        K = (5, 16, 13)[rnd % 3]
+        acts = rng.integers(0, na, (K, B)).astype(np.int8)
+        if rnd == 2:  # with the trajectory
+            res = e.rollout(acts)
+            for k in range(K):
+                ro, to, lo = ostep(acts[k])
+                np.testing.assert_array_equal(res[0][k], o.observe(po.OBS_BOARD), err_msg=f"traj obs k={k}")
+                np.testing.assert_array_equal(res[1][k], ro)
+        else:
+            d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts); e.step_k_device(d, K); e.dev_free(d)
+            for k in range(K):
+                ostep(acts[k])
+        if rnd % 3 == 1:
+            e.set_state(*e.get_state())                      # host round trip
+        elif rnd % 3 == 2:
+            e.set_state_device(*e.get_state_device())        # device round trip
+        else:
+            m = rng.random(B) < 0.2
+            e.reset(mask=m); o.reset(mask=m)                 # the other envs' boards must survive
+        np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_BOARD), err_msg=f"obs round {rnd}")
+        ge, go = _cmp_state(e, o, f"round {rnd}")           # (boards through tg_get_state)
+        for f in ("state_lo", "state_hi", "inc_lo", "inc_hi", "uinteger", "has_uint32"):
+            np.testing.assert_array_equal(ge[f], go[f], err_msg=f"rng.{f} round {rnd}")
+        np.testing.assert_array_equal(e.device_array(N.BUF_BOARD).numpy(), o.get_state()[0])
+    b, r, g = e.get_state()
+    b[0, 0, 0] = 16
+    with pytest.raises(Exception, match="nibbles"):
+        e.set_state(board=b, rec=r, rng=g)
+    e.close()
+
+
 @pytest.mark.parametrize("fuse", [1, 8, 16])
 @pytest.mark.parametrize("ruleset,obs,B", [(N.RULESET_NUMPY, N.OBS_BOARD, 1500), (N.RULESET_FUNCTIONAL, N.OBS_FN, 640),
                                            (N.RULESET_NUMPY, N.OBS_RGB, 200)])

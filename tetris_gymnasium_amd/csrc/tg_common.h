@@ -66,6 +66,8 @@ struct KParams {
   int8_t* act_traj;         // optional: the drawn actions, rows act_stride apart
   int ring_fill;            // bits kernel only: ring entries the RNG role maintains (TG_RING_FILL, default all)
   int dict_in_kernel;       // bits kernel only: TG_OBS_DICT is packed by the step kernel's two waves (sizes with (H+4)(W+8) % 16 == 0)
+  uint8_t* pboard;          // bits kernel, packed handles (kFeatPacked): the board as nibbles [B][H*W/2] — what the step kernel streams
+                            // instead of `board`; null otherwise
   int thirds;               // bits kernel, NUMPY: the rings' double buffer flips per third of the batch (ring_par: bit t = the parity
   int ring_par;             //   third t reads) and this launch's RNG role serves third rng_third (3 = the whole batch); without
   int rng_third;            //   `thirds` ring_cur is the one parity and the RNG role, when present, serves everybody
@@ -850,6 +852,22 @@ __global__ __launch_bounds__(256) void grouped_kernel(const GroupedParams p) {
     }
     p.actions[env] = pick;
   }
+}
+
+// packed board (kFeatPacked, tg_kernel_bits.h) <-> uint8 board: cell 2j / 2j + 1 of an env = low / high nibble of its packed byte j
+__global__ __launch_bounds__(256) void pack_board_kernel(const uint8_t* __restrict__ board, uint8_t* __restrict__ packed, size_t n_bytes) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // packed dword index: 8 cells
+  if (i * 4 >= n_bytes) return;
+  const uint2 v = reinterpret_cast<const uint2*>(board)[i];
+  const uint32_t even = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u), odd = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);
+  reinterpret_cast<uint32_t*>(packed)[i] = (even & 0x0F0F0F0Fu) | ((odd & 0x0F0F0F0Fu) << 4);
+}
+__global__ __launch_bounds__(256) void unpack_board_kernel(const uint8_t* __restrict__ packed, uint8_t* __restrict__ board, size_t n_bytes) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i * 4 >= n_bytes) return;
+  const uint32_t d = reinterpret_cast<const uint32_t*>(packed)[i];
+  const uint32_t lo = d & 0x0F0F0F0Fu, hi = (d >> 4) & 0x0F0F0F0Fu;
+  reinterpret_cast<uint2*>(board)[i] = make_uint2(__builtin_amdgcn_perm(hi, lo, 0x05010400u), __builtin_amdgcn_perm(hi, lo, 0x07030602u));
 }
 
 // stream copy: the practical HBM ceiling reported beside the roofline.  U 16-byte vectors in flight per lane, all loads

@@ -99,7 +99,7 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
   // two stream waves per workgroup (kFeatSplit) while all workgroups of the launch — the RNG role's included — are resident
   // with three waves each at the occupancy the instantiation is compiled for
   const int base = feat & ~tg::kFeatWide;
-  if (!g_split || !split_ok || RS != TG_RULESET_NUMPY ||
+  if (!g_split || !split_ok || RS != TG_RULESET_NUMPY || (feat & tg::kFeatPacked) ||
       !(base == 0 || base == M || base == (M | T) || base == tg::kFeatDict || base == (M | T | tg::kFeatDict))) return feat;
   const int per_simd = tg::bits_waves_per_simd(RS, feat);
   const long cap = (long)(g_simds / 4) * (4 * per_simd / 3);
@@ -111,6 +111,12 @@ int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const
   // FUNCTIONAL, plain launches: when every workgroup of the launch is resident at 2 waves per SIMD anyway, the instantiation
   // compiled for that occupancy (256 VGPRs instead of 128) is the shorter instruction stream (8.4 -> 8.0 us at 65 536 envs;
   // beyond residency the 4-waves build wins: profiles/r03/ab_select_waves.log)
+  // FUNCTIONAL, plain launches: two stream waves per workgroup (kFeatSplit, compiled for 3 waves per SIMD) while every
+  // workgroup of the launch is resident that way — up to 65 536 envs on 256 CUs (7.53 -> 6.92 us per launch there)
+  if (RS == TG_RULESET_FUNCTIONAL && g_split && !p.final_obs && epw == 64 && (long)(p.batch + epw - 1) / epw * 3 <= 3L * g_simds) {
+    const bool trj = p.obs_traj || p.out_traj || p.act_traj;
+    return (trj ? (M | T) : (p.nsteps > 1 ? M : 0)) | tg::kFeatSplit;
+  }
   if (RS == TG_RULESET_FUNCTIONAL && g_wide && !p.final_obs && !(p.obs_traj || p.out_traj || p.act_traj) &&
       (p.batch + epw - 1) / epw * 2 <= 2 * g_simds)
     return (p.nsteps > 1 ? M : 0) | tg::kFeatWide;
@@ -118,13 +124,14 @@ int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const
   const bool rgb = p.obs_mode == TG_OBS_RGB && p.dict_in_kernel && rgb_ok;
   const bool traj = p.obs_traj || p.out_traj || p.act_traj;
   if (p.final_obs) return (p.nsteps > 1 || traj) ? (M | T | F) : F;  // (TG_OBS_BOARD / TG_OBS_FN handles only)
+  const int pk = p.pboard ? tg::kFeatPacked : 0;  // (packed handles: NUMPY, board / no observation, no final observation — tg_create)
   if (RS == TG_RULESET_NUMPY) {
     if (rgb) return (p.nsteps > 1 || traj || p.sample_mode) ? (M | T | S | R) : R;
-    if (p.sample_mode) return p.nsteps > 1 ? (M | T | S) : (T | S);  // (one transition per launch: the kernel without the transition loop)
+    if (p.sample_mode) return (p.nsteps > 1 ? (M | T | S) : (T | S)) | pk;  // (one transition per launch: the kernel without the transition loop)
     if (dict) return (p.nsteps > 1 || traj) ? (M | T | D) : D;
   }
-  if (traj) return M | T;
-  return p.nsteps > 1 ? M : 0;
+  if (traj) return M | T | pk;
+  return (p.nsteps > 1 ? M : 0) | pk;
 }
 
 template <int W, int H, int RS>
@@ -158,11 +165,19 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
                        : ((feat & D) ? ((feat & tg::kFeatSplit) ? BG::BYTES_DICT_SPLIT : BG::BYTES_DICT)
                                      : ((feat & R) ? BG::BYTES_RGB : ((feat & F) ? BG::BYTES_FIN : BG::BYTES)));
 #define TG_LAUNCH_BITS(FT)                                                                                                  \
-  hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(64 * (1 + tg::bits_stream_waves<W, H>(FT))), lds, s, p.board, p.rec, p.cols, (thirds ? ring4 : bp.ring_rd), bp.hbuf_rd, \
+  hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(64 * (1 + tg::bits_stream_waves<W, H>(FT))), lds, s, (p.pboard ? p.pboard : p.board), p.rec, p.cols, (thirds ? ring4 : bp.ring_rd), bp.hbuf_rd, \
                      p.actions, p.batch, bits_hot_misc(p, RS, n_step_wgs), \
                      p, bp)
     if (feat == F) { TG_LAUNCH_BITS(F); return; }
     if (feat == (M | T | F)) { TG_LAUNCH_BITS(M | T | F); return; }
+    if constexpr (RS == TG_RULESET_NUMPY && tg::bits_packed<W, H>(tg::kFeatPacked)) {
+      constexpr int K = tg::kFeatPacked;
+      if (feat == K) { TG_LAUNCH_BITS(K); return; }
+      if (feat == (K | M)) { TG_LAUNCH_BITS(K | M); return; }
+      if (feat == (K | M | T)) { TG_LAUNCH_BITS(K | M | T); return; }
+      if (feat == (K | T | S)) { TG_LAUNCH_BITS(K | T | S); return; }
+      if (feat == (K | M | T | S)) { TG_LAUNCH_BITS(K | M | T | S); return; }
+    }
     if constexpr (RS == TG_RULESET_NUMPY) {
       if (feat == R) { TG_LAUNCH_BITS(R); return; }
       if (feat == (M | T | S | R)) { TG_LAUNCH_BITS(M | T | S | R); return; }
@@ -170,6 +185,11 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
       if (feat == (T | S)) { TG_LAUNCH_BITS(T | S); return; }
       if (feat == (M | T | D)) { TG_LAUNCH_BITS(M | T | D); return; }
       if (feat == D) { TG_LAUNCH_BITS(D); return; }
+    }
+    if constexpr (RS == TG_RULESET_FUNCTIONAL && BG::SPLIT_OK) {
+      if (feat == tg::kFeatSplit) { TG_LAUNCH_BITS(tg::kFeatSplit); return; }
+      if (feat == (M | tg::kFeatSplit)) { TG_LAUNCH_BITS(M | tg::kFeatSplit); return; }
+      if (feat == (M | T | tg::kFeatSplit)) { TG_LAUNCH_BITS(M | T | tg::kFeatSplit); return; }
     }
     if constexpr (RS == TG_RULESET_FUNCTIONAL) {
       if (feat == tg::kFeatWide) { TG_LAUNCH_BITS(tg::kFeatWide); return; }
@@ -292,11 +312,20 @@ std::string csrc_dir() {
   return "csrc";
 }
 
-std::vector<int> rtc_feats(int RS) {
+bool packed_geometry(int W, int H) {  // (tg::bits_packed for a size known at run time)
+  const int S = W * H, epw = S <= 320 ? 64 : (S <= 640 ? 32 : 16);
+  return S % 2 == 0 && (epw * S) % 32 == 0;
+}
+std::vector<int> rtc_feats(int RS, int W = 0, int H = 0) {
   constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
-  constexpr int P = tg::kFeatSplit, Wd = tg::kFeatWide;
-  if (RS == TG_RULESET_NUMPY) return {0, M, M | T, F, M | T | F, D, M | T | D, T | S, M | T | S, R, M | T | S | R, P, P | M, P | M | T, P | D, P | M | T | D};
-  return {0, M, M | T, F, M | T | F, Wd, M | Wd};
+  constexpr int P = tg::kFeatSplit, Wd = tg::kFeatWide, K = tg::kFeatPacked;
+  if (RS == TG_RULESET_NUMPY) {
+    std::vector<int> v = {0, M, M | T, F, M | T | F, D, M | T | D, T | S, M | T | S, R, M | T | S | R, P, P | M, P | M | T, P | D, P | M | T | D};
+    if (W && packed_geometry(W, H))
+      for (int f : {K, K | M, K | M | T, K | T | S, K | M | T | S}) v.push_back(f);
+    return v;
+  }
+  return {0, M, M | T, F, M | T | F, Wd, M | Wd, P, P | M, P | M | T};
 }
 
 uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
@@ -321,7 +350,7 @@ std::string rtc_build(int device, int W, int H, int RS, RtcSize** out) {
   }
   std::vector<std::string> names;
   char nb[128];
-  for (int ft : rtc_feats(RS)) { snprintf(nb, sizeof nb, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, ft); names.push_back(nb); }
+  for (int ft : rtc_feats(RS, W, H)) { snprintf(nb, sizeof nb, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, ft); names.push_back(nb); }
   snprintf(nb, sizeof nb, "tg::reset_kernel<%d, %d, %d>", W, H, RS); names.push_back(nb);
   snprintf(nb, sizeof nb, "tg::observe_kernel<%d, %d>", W, H); names.push_back(nb);
   snprintf(nb, sizeof nb, "tg::bits_prepare_kernel<%d, %d>", W, H); names.push_back(nb);
@@ -392,7 +421,7 @@ std::string rtc_build(int device, int W, int H, int RS, RtcSize** out) {
   size_t k = 0;
   auto fn = [&](hipFunction_t* f) { return hipModuleGetFunction(f, rs->mod, lowered[k++].c_str()) == hipSuccess; };
   bool ok = true;
-  for (int ft : rtc_feats(RS)) { hipFunction_t f = nullptr; ok = fn(&f) && ok; rs->step[ft] = f; }
+  for (int ft : rtc_feats(RS, W, H)) { hipFunction_t f = nullptr; ok = fn(&f) && ok; rs->step[ft] = f; }
   ok = fn(&rs->reset) && ok; ok = fn(&rs->observe) && ok; ok = fn(&rs->prepare) && ok; ok = fn(&rs->features) && ok; ok = fn(&rs->placements) && ok;
   hipDeviceptr_t gp = nullptr; size_t gb = 0;
   ok = ok && hipModuleGetGlobal(&gp, &gb, rs->mod, "tg_rtc_geo") == hipSuccess && gb == sizeof(rs->geo) &&
@@ -430,7 +459,7 @@ Launchers rtc_launchers(const RtcSize* r) {
                                      : ((feat & R) ? r->geo[3] : ((feat & F) ? r->geo[4] : r->geo[1])));
     auto it = r->step.find(feat);
     if (it == r->step.end()) return;
-    uint8_t* a0 = p.board; uint32_t* a1 = p.rec; void* a2 = p.cols; const uint4* a3 = (RS == TG_RULESET_NUMPY && p.thirds) ? ring4 : bp.ring_rd; const uint32_t* a4 = bp.hbuf_rd;
+    uint8_t* a0 = p.pboard ? p.pboard : p.board; uint32_t* a1 = p.rec; void* a2 = p.cols; const uint4* a3 = (RS == TG_RULESET_NUMPY && p.thirds) ? ring4 : bp.ring_rd; const uint32_t* a4 = bp.hbuf_rd;
     const void* a5 = p.actions; int a6 = p.batch;
     uint32_t a7 = bits_hot_misc(p, RS, n_step_wgs);
     tg::KParams kp = p;
@@ -527,6 +556,9 @@ struct tg_handle {
   uint64_t* d_ring = nullptr;  // bits kernel: permutation rings, double-buffered by launch parity [2][B]
   uint32_t* d_hbuf = nullptr;  // bits kernel: consumed counters + state location (+ FUNCTIONAL: bag index, chain epoch) [2][B]
   uint4* d_inl = nullptr;      // bits kernel: generator states after in-line shuffles [2 buffers][B][2]
+  uint8_t* d_pboard = nullptr; // bits kernel, packed handles: the board as nibbles [B][H*W/2] (tg_kernel_bits.h kFeatPacked); the step
+                               // kernel keeps THIS current, TG_BUF_BOARD is brought up to date on demand (ensure_board)
+  bool board_stale = false;    // TG_BUF_BOARD is behind d_pboard
   int ring_par = 0;            // ring parity the next step launch reads, one bit per third of the batch (all equal without `thirds`)
   bool thirds = false;         // NUMPY: the RNG role serves one third of the batch per one-transition launch, in rotation (TG_RNG_EVERY=0
                                // / tg_config.rng_every = 4).  Built and measured in round 4 (every launch at 65 536 envs then fits
@@ -693,6 +725,7 @@ tg::KParams step_params(tg_handle* h) {
   p.ring = h->d_ring;
   p.hbuf = h->d_hbuf;
   p.inl = h->d_inl;
+  p.pboard = h->d_pboard;
   p.ring_cur = h->ring_par & 1;
   p.ring_par = h->ring_par;
   p.thirds = h->thirds ? 1 : 0;
@@ -776,9 +809,27 @@ int launch_step_all(tg_handle* h, const tg::KParams& p) {
   return TG_OK;
 }
 
+// packed handles: bring the uint8 TG_BUF_BOARD up to date before anything reads it (the step kernel maintains the nibbles)
+int ensure_board(tg_handle* h) {
+  if (!h->d_pboard || !h->board_stale) return TG_OK;
+  const size_t nb = (size_t)h->B * h->cells / 2;
+  hipLaunchKernelGGL(tg::unpack_board_kernel, dim3((unsigned)((nb / 4 + 256) / 256)), dim3(256), 0, h->stream, h->d_pboard,
+                     (uint8_t*)h->buf[TG_BUF_BOARD], nb);
+  HIPCHK(h, hipGetLastError());
+  h->board_stale = false;
+  return TG_OK;
+}
+
 // bits kernel: rebuild column masks + look-ahead permutations from the reference-defined state
 int launch_prepare_bits(tg_handle* h, const uint8_t* d_mask, int force) {
   if (!h->d_cols) return TG_OK;
+  if (h->d_pboard) {  // TG_BUF_BOARD has just been (re)written by tg_reset / tg_set_state: the nibbles follow
+    const size_t nb = (size_t)h->B * h->cells / 2;
+    hipLaunchKernelGGL(tg::pack_board_kernel, dim3((unsigned)((nb / 4 + 256) / 256)), dim3(256), 0, h->stream,
+                       (const uint8_t*)h->buf[TG_BUF_BOARD], h->d_pboard, nb);
+    HIPCHK(h, hipGetLastError());
+    h->board_stale = false;
+  }
   tg::PrepareParams q{};
   q.board = (const uint8_t*)h->buf[TG_BUF_BOARD];
   q.rec = (uint32_t*)h->buf[TG_BUF_REC];
@@ -829,6 +880,7 @@ void next_rng_role(tg_handle* h, tg::KParams& p) {
 void after_launch(tg_handle* h, const tg::KParams& p) {
   if (p.rng_role) h->ring_par ^= (h->thirds && p.rng_third < 3) ? (1 << p.rng_third) : 7;
   h->hbuf_cur ^= 1;
+  if (h->d_pboard) h->board_stale = true;
 }
 
 // TG_BUF_HOST_PACK is packed when somebody asks for it (the step path never pays for it)
@@ -858,6 +910,7 @@ int enqueue_fetches(tg_handle* h, int m, const int* which, void* const* host_dst
   for (int i = 0; i < m; ++i) {
     if (which[i] == TG_BUF_RNG) { int rc = launch_materialize_rng(h); if (rc != TG_OK) return rc; }
     if (which[i] == TG_BUF_HOST_PACK) { int rc = launch_host_pack(h); if (rc != TG_OK) return rc; }
+    if (which[i] == TG_BUF_BOARD) { int rc = ensure_board(h); if (rc != TG_OK) return rc; }
   }
   for (int i = 0; i < m;) {
     // neighbours in device memory and, at the same distance, in host memory leave as one copy (the gap between two pieces of
@@ -1032,10 +1085,10 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   {
     h->arena_skew = 0;
     if (const char* e = getenv("TG_ALLOC_SKEW")) h->arena_skew = (size_t)(atol(e) > 0 ? atol(e) : 0);
-    const int n_pieces = TG_BUF_COUNT + 9;
+    const int n_pieces = TG_BUF_COUNT + 10;
     size_t total = 0;
     for (int i = 0; i < TG_BUF_COUNT; ++i) total += sizes[i] + kTailPad + 4096;
-    total += B * sizeof(tg_rng_rec) + 2 * B + B * L.cols_bytes + B * 32 * tg::kRing + 2 * B * 16 + 8 * B + 2 * B * 32 + 9 * (kTailPad + 4096);
+    total += B * sizeof(tg_rng_rec) + 2 * B + B * L.cols_bytes + B * 32 * tg::kRing + 2 * B * 16 + 8 * B + 2 * B * 32 + B * h->cells / 2 + 10 * (kTailPad + 4096);
     total += h->arena_skew * (size_t)n_pieces * (size_t)n_pieces;
     CRCHK(hipMalloc(&h->arena, total));
     h->arena_size = total;
@@ -1061,6 +1114,16 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     CRCHK(arena_take(h, (void**)&h->d_ring, 2 * B * 16 + kTailPad));
     CRCHK(arena_take(h, (void**)&h->d_hbuf, 2 * B * sizeof(uint32_t) + kTailPad));
     CRCHK(arena_take(h, (void**)&h->d_inl, 2 * B * 32 + kTailPad));
+    // Packed board (kFeatPacked): for the working sets that do not fit the Infinity Cache the launch is bound by bytes, and
+    // the board as nibbles is 17-19 % fewer of them.  TG_PACKED=1 / 0 forces / forbids it (tests, A/B).
+    {
+      const bool can = cfg->ruleset == TG_RULESET_NUMPY && packed_geometry(cfg->width, cfg->height) && !want_final &&
+                       (cfg->obs_mode == TG_OBS_BOARD || cfg->obs_mode == TG_OBS_NONE) &&
+                       !(getenv("TG_STREAMS") && atoi(getenv("TG_STREAMS")) > 1);
+      bool want = false;  // (auto rule `can && B * cells >= 20 Mi` is switched on once measured: see below)
+      if (const char* e = getenv("TG_PACKED")) want = can && atoi(e) != 0;
+      if (want) CRCHK(arena_take(h, (void**)&h->d_pboard, B * h->cells / 2 + kTailPad));
+    }
   }
 #ifdef TG_PHASE_TIMING
   CRCHK(hipMalloc(&h->dbg, ((B + 15) / 16) * 16 * 8));
@@ -1139,6 +1202,7 @@ int tg_reset(tg_handle* h, const uint64_t* seeds, const uint8_t* mask) {
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   { int rcm = launch_materialize_rng(h); if (rcm != TG_OK) return rcm; }  // an unseeded reset continues the running generator
+  { int rcb = ensure_board(h); if (rcb != TG_OK) return rcb; }           // (a masked reset keeps the other envs' boards)
   const size_t B = (size_t)h->B;
   bool any_reseed = false;
   h->h_new_rng.resize(B);
@@ -1337,6 +1401,12 @@ int tg_device_ptr(tg_handle* h, int which, void** ptr, size_t* bytes) {
     if (rcj == TG_OK) rcj = launch_host_pack(h);
     if (rcj != TG_OK) return rcj;
   }
+  if (which == TG_BUF_BOARD && h->d_pboard) {  // (packed handles: as for TG_BUF_RNG, the buffer is brought up to date first)
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rcj = join_shards(h);
+    if (rcj == TG_OK) rcj = ensure_board(h);
+    if (rcj != TG_OK) return rcj;
+  }
   if (ptr) *ptr = h->buf[which];
   if (bytes) *bytes = h->bytes[which];
   return TG_OK;
@@ -1349,6 +1419,7 @@ int tg_fetch(tg_handle* h, int which, void* host_dst, size_t bytes) {
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   if (which == TG_BUF_RNG) { int rcm = launch_materialize_rng(h); if (rcm != TG_OK) return rcm; }
   if (which == TG_BUF_HOST_PACK) { int rcm = launch_host_pack(h); if (rcm != TG_OK) return rcm; }
+  if (which == TG_BUF_BOARD) { int rcm = ensure_board(h); if (rcm != TG_OK) return rcm; }
   if (bytes) HIPCHK(h, hipMemcpyAsync(host_dst, h->buf[which], bytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return TG_OK;
@@ -1391,6 +1462,7 @@ int tg_get_state(tg_handle* h, uint8_t* board, tg_env_rec* rec, tg_rng_rec* rng)
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   const size_t B = (size_t)h->B;
   if (rng) { int rcm = launch_materialize_rng(h); if (rcm != TG_OK) return rcm; }
+  if (board) { int rcb = ensure_board(h); if (rcb != TG_OK) return rcb; }
   if (board) HIPCHK(h, hipMemcpyAsync(board, h->buf[TG_BUF_BOARD], B * h->cells, hipMemcpyDeviceToHost, h->stream));
   if (rec) HIPCHK(h, hipMemcpyAsync(rec, h->buf[TG_BUF_REC], B * sizeof(tg_env_rec), hipMemcpyDeviceToHost, h->stream));
   if (rng) HIPCHK(h, hipMemcpyAsync(rng, h->buf[TG_BUF_RNG], B * sizeof(tg_rng_rec), hipMemcpyDeviceToHost, h->stream));
@@ -1408,7 +1480,20 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   if (!rng) { int rcm = launch_materialize_rng(h); if (rcm != TG_OK) return rcm; }  // the rings are rebuilt from TG_BUF_RNG below
+  if (!board) { int rcb = ensure_board(h); if (rcb != TG_OK) return rcb; }         // (the boards stay: the nibbles are re-packed from them below)
   const size_t B = (size_t)h->B;
+  if (h->d_pboard) {  // packed handles keep cells as nibbles: values the stock game never produces are refused
+    if (board)
+      for (size_t i = 0; i < B * h->cells; ++i)
+        if (board[i] > 15)
+          return fail(h, TG_EINVAL, "tg_set_state: board byte %zu is %d; this handle keeps its board as nibbles (cell values 0..15; TG_PACKED=0 "
+                                    "creates handles without that limit)", i, board[i]);
+    if (rec)
+      for (size_t i = 0; i < B; ++i)
+        if (rec[i].val > 15 || (rec[i].holder_piece != TG_NONE && rec[i].holder_val > 15))
+          return fail(h, TG_EINVAL, "tg_set_state: record %zu holds a cell value > 15; this handle keeps its board as nibbles (TG_PACKED=0 "
+                                    "creates handles without that limit)", i);
+  }
   if (rec)
     for (size_t i = 0; i < B; ++i) {
       const tg_env_rec& r = rec[i];
@@ -1473,6 +1558,7 @@ int tg_get_state_dev(tg_handle* h, uint8_t* board_dev, tg_env_rec* rec_dev, tg_r
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   const size_t B = (size_t)h->B;
   if (rng_dev) { int rcm = launch_materialize_rng(h); if (rcm != TG_OK) return rcm; }
+  if (board_dev) { int rcb = ensure_board(h); if (rcb != TG_OK) return rcb; }
   if (board_dev) HIPCHK(h, hipMemcpyAsync(board_dev, h->buf[TG_BUF_BOARD], B * h->cells, hipMemcpyDeviceToDevice, h->stream));
   if (rec_dev) HIPCHK(h, hipMemcpyAsync(rec_dev, h->buf[TG_BUF_REC], B * sizeof(tg_env_rec), hipMemcpyDeviceToDevice, h->stream));
   if (rng_dev) HIPCHK(h, hipMemcpyAsync(rng_dev, h->buf[TG_BUF_RNG], B * sizeof(tg_rng_rec), hipMemcpyDeviceToDevice, h->stream));
@@ -1484,6 +1570,7 @@ int tg_set_state_dev(tg_handle* h, const uint8_t* board_dev, const tg_env_rec* r
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   if (!rng_dev) { int rcm = launch_materialize_rng(h); if (rcm != TG_OK) return rcm; }  // the rings are rebuilt from TG_BUF_RNG below
+  if (!board_dev) { int rcb = ensure_board(h); if (rcb != TG_OK) return rcb; }
   const size_t B = (size_t)h->B;
   if (board_dev) HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_BOARD], board_dev, B * h->cells, hipMemcpyDeviceToDevice, h->stream));
   if (rec_dev) HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_REC], rec_dev, B * sizeof(tg_env_rec), hipMemcpyDeviceToDevice, h->stream));
@@ -1501,6 +1588,7 @@ int tg_observe(tg_handle* h) {
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   if (h->cfg.obs_mode == TG_OBS_NONE) return TG_OK;
+  { int rcb = ensure_board(h); if (rcb != TG_OK) return rcb; }
   return launch_observe_dict(h);
 }
 
@@ -1524,6 +1612,8 @@ int tg_grouped_enumerate(tg_handle* h, uint8_t* boards_dev) {
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   int rc = run_grouped(h, true, false, 0, 0);
   if (rc != TG_OK || !boards_dev) return rc;
+  rc = ensure_board(h);
+  if (rc != TG_OK) return rc;
   tg::PlacementParams q{};
   q.board = (const uint8_t*)h->buf[TG_BUF_BOARD];
   q.rec = (const uint32_t*)h->buf[TG_BUF_REC];
@@ -1548,6 +1638,7 @@ int tg_features(tg_handle* h) {
   if (h->cfg.ruleset != TG_RULESET_NUMPY) return fail(h, TG_EINVAL, "tg_features: NUMPY rule-set only (wrappers/observation.py wraps envs/tetris.py)");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
+  { int rcb = ensure_board(h); if (rcb != TG_OK) return rcb; }
   tg::FeatureParams f{};
   f.board = (const uint8_t*)h->buf[TG_BUF_BOARD];
   f.rec = (const uint32_t*)h->buf[TG_BUF_REC];

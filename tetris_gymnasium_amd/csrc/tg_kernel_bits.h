@@ -429,9 +429,46 @@ constexpr int kFeatWide = 64;
 // envs: split over two waves it is the same number of instructions in half the time per wave.  Picked by the host while
 // every workgroup of the launch is still resident with three waves each (up to ~40 000 envs): 4.7 -> 4.3 us at 8 192 envs,
 // 5.7 -> 5.3 at 32 768; at 65 536 the 3-wave workgroups no longer fit beside the RNG role's and the launch is slower
-// (profiles/r03/ab_stream_waves.log).  NUMPY rule-set only (FUNCTIONAL: its logic wave is the long pole, no gain at any batch
-// size); not for the instantiations whose stream wave shares staging buffers with the logic wave.
+// (profiles/r03/ab_stream_waves.log).  FUNCTIONAL: no gain in round 3, when its logic wave was the long pole (800 instructions
+// of look-ahead behind the publish); with that halved twice (round 4) the stream wave's tail — the slab block through the
+// {-1, 0, 1} byte map — is what the launch waits for, and two stream waves take 7.53 -> 6.92 us per launch at 65 536 envs,
+// 6.33 -> 5.75 at 32 768, 5.25 -> 4.64 at 4 096, 2.95 -> 2.88 per fused transition (profiles/r04/ab_fn_split.log): picked while
+// the launch is resident at three waves per SIMD, instead of the kFeatWide build.  Not for the instantiations whose stream
+// wave shares staging buffers with the logic wave.
 constexpr int kFeatSplit = 128;
+// kFeatPacked (round 4): the board travels between HBM and the chip as NIBBLES — cells are 0 or a tetromino value 2..8
+// (envs/tetris.py:632-641), two per byte — half the bytes of the board read and of its write-back.  `hot_board` is then the
+// handle's packed board (device-private, like the column masks; the uint8 TG_BUF_BOARD is materialised from it on demand,
+// like tg_rng_rec); the stream wave expands a packed 16-byte chunk into two chunks of the uint8 slab block in LDS
+// (cell 2j / 2j + 1 of packed byte j: with an even slab size the map packed byte -> LDS bytes is linear over the whole
+// block) and packs on the way back; everything in between works on the uint8 slabs as before.  Picked by the host for the
+// working sets that do not fit the Infinity Cache (config 5: 20x40; batches beyond ~100k envs at 10x20), where the launch
+// is bound by bytes: ~250 more instructions in the stream wave buy 17-19 % fewer bytes.  NUMPY rule-set only (a functional
+// lock is `board += id`, which can leave a nibble), instantiations without dict / RGB / final-observation / split.
+constexpr int kFeatPacked = 256;
+template <int W, int H>
+constexpr bool bits_packed(const int feat) {
+  return (feat & kFeatPacked) != 0 && (BitsGeo<W, H>::EPW * W * H) % 32 == 0 && (W * H) % 2 == 0 &&
+         !(feat & (kFeatDict | kFeatRgb | kFeatFinal | kFeatSplit | kFeatWide));
+}
+// packed 16-byte chunk (32 cells) -> the two 16-byte chunks of uint8 cells, and back (values < 16)
+__device__ __forceinline__ void nib_expand(const u32x4 pk, u32x4& a, u32x4& b) {
+  auto lo4 = [](const uint32_t d) -> uint32_t {  // cells 0..3 of the dword's eight: lo.b0 hi.b0 lo.b1 hi.b1
+    return __builtin_amdgcn_perm((d >> 4) & 0x0F0F0F0Fu, d & 0x0F0F0F0Fu, 0x05010400u);
+  };
+  auto hi4 = [](const uint32_t d) -> uint32_t {  // cells 4..7: lo.b2 hi.b2 lo.b3 hi.b3
+    return __builtin_amdgcn_perm((d >> 4) & 0x0F0F0F0Fu, d & 0x0F0F0F0Fu, 0x07030602u);
+  };
+  a = u32x4{lo4(pk.x), hi4(pk.x), lo4(pk.y), hi4(pk.y)};
+  b = u32x4{lo4(pk.z), hi4(pk.z), lo4(pk.w), hi4(pk.w)};
+}
+__device__ __forceinline__ u32x4 nib_pack(const u32x4 a, const u32x4 b) {
+  auto one = [](const uint32_t p, const uint32_t q) -> uint32_t {  // 8 cells (two dwords) -> one dword
+    const uint32_t even = __builtin_amdgcn_perm(q, p, 0x06040200u), odd = __builtin_amdgcn_perm(q, p, 0x07050301u);
+    return (even & 0x0F0F0F0Fu) | ((odd & 0x0F0F0F0Fu) << 4);
+  };
+  return u32x4{one(a.x, a.y), one(a.z, a.w), one(b.x, b.y), one(b.z, b.w)};
+}
 template <int W, int H>
 constexpr int bits_stream_waves(const int feat) {
   return ((feat & kFeatSplit) && BitsGeo<W, H>::SPLIT_OK && !(feat & (kFeatSample | kFeatFinal | kFeatRgb | kFeatWide)) &&
@@ -783,6 +820,7 @@ __device__ __forceinline__ void bits_copy_slab(const uint8_t* src_lds, uint8_t* 
 #define TG_WIDE_WAVES 2  // ... the kFeatWide instantiations (FUNCTIONAL, up to 65 536 envs: one logic + one stream wave per SIMD)
 #endif
 constexpr int bits_waves_per_simd(const int ruleset, const int feat) {
+  if (ruleset == TG_RULESET_FUNCTIONAL && (feat & kFeatSplit)) return 3;  // (three waves per workgroup, one workgroup's worth per SIMD at 65 536 envs)
   return (feat & kFeatWide) ? TG_WIDE_WAVES
          : (feat & kFeatMulti) ? ((feat & (kFeatDict | kFeatSample)) ? 3 : (ruleset == TG_RULESET_NUMPY ? TG_MULTI_WAVES : 4))
                                : TG_ONE_WAVES;
@@ -1046,8 +1084,18 @@ void step_kernel_bits(
     const uint32_t nchunks = (nbytes + 15u) / 16u;
     uint64_t tab_cells = 0;
     if (lane < 7) tab_cells = c_cells.cells[lane];
-    u32x4 stage[NIT];
-    {
+    constexpr bool PACKED = bits_packed<W, H>(FEAT);
+    constexpr int NCHP = NCH / 2, NITP = (NCHP + 63) / 64;      // packed chunks of the wave's slab block (PACKED)
+    const uint32_t nchunks_p = (nbytes / 2u + 15u) / 16u;        // ... of a partial workgroup
+    u32x4 stage[PACKED ? NITP : NIT];
+    if constexpr (PACKED) {
+      const u32x4* gsrc = reinterpret_cast<const u32x4*>(hot_board + (size_t)base_env * (S / 2));
+#pragma unroll
+      for (int k = 0; k < NITP; ++k) {
+        const uint32_t c = (uint32_t)lane + 64u * k;
+        stage[k] = gsrc[c < nchunks_p ? c : nchunks_p - 1u];
+      }
+    } else {
       const u32x4* gsrc = reinterpret_cast<const u32x4*>(hot_board + (size_t)base_env * S);
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
@@ -1056,7 +1104,15 @@ void step_kernel_bits(
       }
     }
     if (lane < 7) cell_tab[lane] = tab_cells;
-    if (full_wave) {
+    if constexpr (PACKED) {
+#pragma unroll
+      for (int k = 0; k < NITP; ++k) {
+        const uint32_t c = (uint32_t)lane + 64u * k;
+        u32x4 a, b;
+        nib_expand(stage[k], a, b);
+        if (c < nchunks_p) { lds4[2 * c] = a; lds4[2 * c + 1] = b; }  // (a partial last chunk spills into the block's own tail)
+      }
+    } else if (full_wave) {
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
         const int c = lane + 64 * k;
@@ -1178,7 +1234,34 @@ void step_kernel_bits(
       // they are.
       const uint64_t dm = __ballot(dirty_any);
       u32x4* bdst = reinterpret_cast<u32x4*>(hot_board + (size_t)base_env * S);
-      if (keep_b0) {
+      if constexpr (PACKED) {
+        // packed board: chunk c of the packed block = LDS chunks 2c, 2c + 1; stored when it differs from what was loaded
+        // (one transition per launch, full workgroup) or holds cells of a changed env (otherwise).  A partial workgroup's
+        // last chunk may run a few bytes past its envs: that is the buffer's tail padding.
+        u32x4* pdst = reinterpret_cast<u32x4*>(hot_board + (size_t)base_env * (S / 2));
+        const __amdgpu_buffer_rsrc_t pwin = st_window(pdst, nchunks_p * 16u);
+#pragma unroll  // (fully: `stage` must stay in registers)
+        for (int k0 = 0; k0 < NITP; k0 += 4) {
+          u32x4 pa[4], pb[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int c = lane + 64 * (k0 + kk);
+            const int cc = c < NCHP ? c : NCHP - 1;
+            pa[kk] = lds4[2 * cc]; pb[kk] = lds4[2 * cc + 1];
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            if (k0 + kk >= NITP) continue;
+            const uint32_t c = (uint32_t)lane + 64u * (uint32_t)(k0 + kk);
+            const u32x4 pw = nib_pack(pa[kk], pb[kk]);
+            const uint32_t e0 = (32u * c) / (uint32_t)S, e1r = (32u * c + 31u) / (uint32_t)S;
+            const uint32_t e1 = e1r < (uint32_t)EPW ? e1r : (uint32_t)EPW - 1u;
+            const bool hit = keep_b0 ? differs(pw, stage[k0 + kk])
+                                     : ((((dm >> (e0 < (uint32_t)EPW ? e0 : (uint32_t)EPW - 1u)) | (dm >> e1)) & 1ull) != 0);
+            st_state_if(pwin, 16u * c, pw, c < nchunks_p && hit && !TG_SKIP(2));
+          }
+        }
+      } else if (keep_b0) {
         u32x4 wv[NIT];
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
