@@ -339,9 +339,22 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
                          "alg_bytes_per_env_step": bytes_alg,
                          "resident": "Infinity Cache" if bytes_alg * B < 200e6 else "HBM",
                          "note": "achieved = algorithmic bytes x envs / median HIP-event launch time over "
-                                 f"{len(rep_us)} repetitions of the timed region; at this batch the working set fits the "
-                                 "256 MB Infinity Cache, so the HBM-peak fraction is nominal (launch floor + latency bound)"},
+                                 f"{len(rep_us)} repetitions of the timed region ({steps} launches each: with the driver's "
+                                 "--steps 20 a repetition is ~0.13 ms and the median reads 0.2-0.4 us per launch above a "
+                                 "1 024-launch region); " +
+                                 ("at this batch the working set fits the 256 MB Infinity Cache, so the HBM-peak fraction is "
+                                  "nominal (launch floor + latency bound)" if bytes_alg * B < 200e6 else
+                                  "the working set exceeds the 256 MB Infinity Cache: bytes are the bound")},
         }
+        try:  # packed handles (kFeatPacked, FEAT bit 256): the board crosses HBM as nibbles
+            feat_bits = int(sym.rstrip(">").split(",")[-1])
+        except ValueError:
+            feat_bits = 0
+        if feat_bits & 256 and fuse == 1:
+            packed_bytes = 2 * H * W + 76  # H*W/2 read + H*W observation + H*W/2 write-back (p_lock = 1.0) + 76
+            out["roofline"]["board_format"] = "nibbles in HBM (kFeatPacked): half the board bytes of SURVEY 8(d)'s uint8 formula"
+            out["roofline"]["alg_bytes_per_env_step_packed"] = packed_bytes
+            out["roofline"]["frac_packed_bytes"] = packed_bytes * B / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBPS
         if copy_gbps is not None:
             out["hbm_copy_gbps"] = copy_gbps
         if want_cpu and obs in ("board", "dict", "rgb", "fn"):  # (rank 0 only, whatever the number of ranks)

@@ -93,8 +93,8 @@ typedef struct tg_config {
   /* launch knobs of the step kernel (0 = default; the environment variables TG_FUSE / TG_RNG_EVERY / TG_RING_FILL override
    * them — test hooks).  Results never depend on them. */
   int32_t fuse;         /* transitions per launch of tg_step_k / tg_rollout / tg_grouped_rollout: 1..16, default 16 */
-  int32_t rng_every;    /* NUMPY rules: one-transition launches carry the bag-shuffle look-ahead workgroups for the whole batch
-                           every n-th time (1..3, default 3); 4 = for one third of the batch in every launch, in rotation */
+  int32_t rng_every;    /* NUMPY rules: one-transition launches carry the bag-shuffle look-ahead workgroups every n-th time
+                           (1..3, default 3) */
   int32_t ring_fill_p1; /* NUMPY rules: 1 + look-ahead bag permutations kept per env (1..4, default 4 = 3 permutations);
                            smaller values exercise the in-line shuffle of the step kernel */
   int32_t reserved2;

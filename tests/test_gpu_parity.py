@@ -414,15 +414,13 @@ def test_fused_rollout_equals_single_transitions(fuse, ring_fill, ruleset, W, H,
     e.close()
 
 
-@pytest.mark.parametrize("every", [0, 1, 2, 3])
+@pytest.mark.parametrize("every", [1, 2, 3])
 @pytest.mark.parametrize("W,H,Q,B,grouped", [(10, 20, 4, 1000, False), (10, 20, 7, 600, True), (6, 12, 2, 500, True),
                                              (10, 20, 4, 132, False), (10, 20, 4, 64, False)])
 def test_rng_role_every_nth_launch(every, W, H, Q, B, grouped, monkeypatch):
-    """TG_RNG_EVERY = 0: the RNG role of a one-transition launch serves ONE THIRD of the batch, in rotation, and the
-    ring parity flips per third (thirds of 384 / 384 / 232 envs at 1 000; 128 / 4 / none at 132; one at 64).  1..3 (3 = the default): the whole
-    batch every n-th launch (the ring parity then flips less often than the consumed-counter parity).  Whatever the cadence —
-    and with single steps, rollouts (which serve everybody), state round trips and masked resets in between — pieces and
-    generator must equal the oracle's."""
+    """One-transition launches carry the RNG-role workgroups only every TG_RNG_EVERY-th time (the ring parity then flips
+    less often than the consumed-counter parity); whatever the cadence — and with single steps, rollouts, state
+    round trips and masked resets in between, batches of 1 000 / 132 / 64 envs — pieces and generator must equal the oracle's."""
     monkeypatch.setenv("TG_RNG_EVERY", str(every))
     monkeypatch.setenv("TG_FUSE", "1")
     na = 4 * W if grouped else 8

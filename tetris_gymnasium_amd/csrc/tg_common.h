@@ -68,9 +68,9 @@ struct KParams {
   int dict_in_kernel;       // bits kernel only: TG_OBS_DICT is packed by the step kernel's two waves (sizes with (H+4)(W+8) % 16 == 0)
   uint8_t* pboard;          // bits kernel, packed handles (kFeatPacked): the board as nibbles [B][H*W/2] — what the step kernel streams
                             // instead of `board`; null otherwise
-  int thirds;               // bits kernel, NUMPY: the rings' double buffer flips per third of the batch (ring_par: bit t = the parity
-  int ring_par;             //   third t reads) and this launch's RNG role serves third rng_third (3 = the whole batch); without
-  int rng_third;            //   `thirds` ring_cur is the one parity and the RNG role, when present, serves everybody
+#ifdef TG_KPAD  // (A/B knob: the struct's layout decides how the compiler groups its scalar loads)
+  int kpad[TG_KPAD];
+#endif
   int fn_lazy;              // bits kernel, FUNCTIONAL (TG_FN_LAZY, tests): bits 0-1: 0 = a lock sorts the reset bag ahead only when the stack is
                             // within reach of the spawn rows, 1 = never (every episode end takes the in-line sort), 2 = always (round 3);
                             // bit 2: the look-ahead never catches up behind a reset (the chain stays one key deep)

@@ -9,6 +9,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -16,10 +18,12 @@
 #include <fstream>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "tg_kernel_bits.h"
@@ -74,21 +78,12 @@ int g_simds = 1024;  // SIMDs of the device (4 per CU), set by tg_create
 int g_split = 1;     // TG_SPLIT=0: never pick the instantiations with two stream waves per workgroup (kFeatSplit)
 int g_wide = 1;      // TG_WIDE=0: never pick the instantiations compiled for fewer waves per SIMD (kFeatWide)
 
-// RNG-role workgroups of a launch (128 envs each): the whole batch, or — `thirds` — the third this launch serves
-int rng_blocks(const tg::KParams& p, const int RS) {
-  if (RS != TG_RULESET_NUMPY || !p.rng_role) return 0;
-  if (p.thirds && p.rng_third < 3) {
-    const long B3 = ((((long)p.batch + 2) / 3) + 127) & ~127L, lo = (long)p.rng_third * B3;
-    const long n = lo < p.batch ? (p.batch - lo < B3 ? p.batch - lo : B3) : 0;
-    return (int)((n + 127) / 128);
-  }
-  return (p.batch + 127) / 128;
-}
+// RNG-role workgroups of a launch (128 envs each)
+int rng_blocks(const tg::KParams& p, const int RS) { return (RS == TG_RULESET_NUMPY && p.rng_role) ? (p.batch + 127) / 128 : 0; }
 // the packed scalar argument of step_kernel_bits (layout: there)
 uint32_t bits_hot_misc(const tg::KParams& p, const int RS, const int n_step_wgs) {
-  const bool thirds = RS == TG_RULESET_NUMPY && p.thirds;
-  return (uint32_t)n_step_wgs | (thirds ? ((uint32_t)(p.ring_par & 7) << 19) | ((uint32_t)(p.rng_third & 3) << 22) | (1u << 31) : (3u << 22)) |
-         ((p.act_i8 ? 1u : 0u) << 24) | ((uint32_t)(p.nsteps > 0 ? p.nsteps : 0) << 25);
+  (void)RS;
+  return (uint32_t)n_step_wgs | ((p.act_i8 ? 1u : 0u) << 24) | ((uint32_t)(p.nsteps > 0 ? p.nsteps : 0) << 25);
 }
 
 // which instantiation of the bits kernel a launch with these parameters uses (FEAT flags, tg_kernel_bits.h)
@@ -113,7 +108,10 @@ int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const
   // beyond residency the 4-waves build wins: profiles/r03/ab_select_waves.log)
   // FUNCTIONAL, plain launches: two stream waves per workgroup (kFeatSplit, compiled for 3 waves per SIMD) while every
   // workgroup of the launch is resident that way — up to 65 536 envs on 256 CUs (7.53 -> 6.92 us per launch there)
-  if (RS == TG_RULESET_FUNCTIONAL && g_split && !p.final_obs && epw == 64 && (long)(p.batch + epw - 1) / epw * 3 <= 3L * g_simds) {
+#ifndef TG_FN_SPLIT_CAP  // (A/B knob: workgroups up to which FUNCTIONAL launches take the two-stream-wave build; default = residency)
+#define TG_FN_SPLIT_CAP g_simds
+#endif
+  if (RS == TG_RULESET_FUNCTIONAL && g_split && !p.final_obs && epw == 64 && (long)(p.batch + epw - 1) / epw <= (long)(TG_FN_SPLIT_CAP)) {
     const bool trj = p.obs_traj || p.out_traj || p.act_traj;
     return (trj ? (M | T) : (p.nsteps > 1 ? M : 0)) | tg::kFeatSplit;
   }
@@ -150,7 +148,6 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
   if (p.cols) {  // "bits": the handle carries the column masks / look-ahead permutations
     using BG = tg::BitsGeo<W, H>;
     const int nrb = rng_blocks(p, RS);  // RNG-role workgroups (tg_kernel_bits.h)
-    const bool thirds = RS == TG_RULESET_NUMPY && p.thirds;
     const uint4* const ring4 = reinterpret_cast<const uint4*>(p.ring);
     // (FUNCTIONAL: hbuf is the look-ahead word array fnw [B] u64 — private to each env's logic wave, no parities)
     const size_t hrd = RS == TG_RULESET_NUMPY ? (size_t)p.hbuf_cur * p.ring_stride : 0, hwr = RS == TG_RULESET_NUMPY ? (size_t)(1 - p.hbuf_cur) * p.ring_stride : 0;
@@ -165,7 +162,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
                        : ((feat & D) ? ((feat & tg::kFeatSplit) ? BG::BYTES_DICT_SPLIT : BG::BYTES_DICT)
                                      : ((feat & R) ? BG::BYTES_RGB : ((feat & F) ? BG::BYTES_FIN : BG::BYTES)));
 #define TG_LAUNCH_BITS(FT)                                                                                                  \
-  hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(64 * (1 + tg::bits_stream_waves<W, H>(FT))), lds, s, (p.pboard ? p.pboard : p.board), p.rec, p.cols, (thirds ? ring4 : bp.ring_rd), bp.hbuf_rd, \
+  hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(64 * (1 + tg::bits_stream_waves<W, H>(FT))), lds, s, (p.pboard ? p.pboard : p.board), p.rec, p.cols, bp.ring_rd, bp.hbuf_rd, \
                      p.actions, p.batch, bits_hot_misc(p, RS, n_step_wgs), \
                      p, bp)
     if (feat == F) { TG_LAUNCH_BITS(F); return; }
@@ -369,22 +366,45 @@ std::string rtc_build(int device, int W, int H, int RS, RtcSize** out) {
   std::string keytext = all + src;
   for (auto& o : optv) keytext += o;
   for (auto& n : names) keytext += n;
+  {  // what a cached code object depends on besides the sources: the compiler, the runtime, the device
+    int maj = 0, min = 0, rt = 0;
+    (void)hiprtcVersion(&maj, &min);
+    (void)hipRuntimeGetVersion(&rt);
+    hipDeviceProp_t prop;
+    const bool okp = hipGetDeviceProperties(&prop, device) == hipSuccess;
+    keytext += "|hiprtc " + std::to_string(maj) + "." + std::to_string(min) + "|runtime " + std::to_string(rt) + "|" +
+               (okp ? prop.gcnArchName : "?");
+  }
   char hashb[32];
   snprintf(hashb, sizeof hashb, "%016llx", (unsigned long long)fnv1a(keytext));
-  std::string cdir = getenv("TG_CACHE_DIR") ? getenv("TG_CACHE_DIR") : (std::string(getenv("HOME") ? getenv("HOME") : "/tmp") + "/.cache/tetris_gym_hip");
-  const std::string cfile = cdir + "/" + std::to_string(W) + "x" + std::to_string(H) + "_" + std::to_string(RS) + "_" + hashb + ".bin";
-  std::string code;
-  std::vector<std::string> lowered;
-  {  // cache: lowered names (one per line) | blank line | code object
-    std::ifstream in(cfile, std::ios::binary);
-    if (in) {
-      std::string line;
-      while (std::getline(in, line) && !line.empty()) lowered.push_back(line);
-      std::stringstream ss; ss << in.rdbuf(); code = ss.str();
-      if (lowered.size() != names.size() || code.empty()) { lowered.clear(); code.clear(); }
-    }
+  // The cache directory must be ours alone: what sits there goes straight to hipModuleLoadData.  TG_CACHE_DIR, else
+  // ~/.cache/tetris_gym_hip, else (no HOME) /tmp/tetris_gym_hip-<uid>; created 0700; a directory that is not owned by this
+  // user or is writable by others is not used (every process then compiles for itself).
+  std::string cdir;
+  if (const char* e = getenv("TG_CACHE_DIR")) cdir = e;
+  else if (const char* hm = getenv("HOME")) { mkdir((std::string(hm) + "/.cache").c_str(), 0755); cdir = std::string(hm) + "/.cache/tetris_gym_hip"; }
+  else cdir = "/tmp/tetris_gym_hip-" + std::to_string((long)geteuid());
+  bool cache_ok = false;
+  {
+    mkdir(cdir.c_str(), 0700);
+    struct stat st;
+    cache_ok = stat(cdir.c_str(), &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & 022) == 0;
   }
-  if (code.empty()) {
+  const std::string cfile = cdir + "/" + std::to_string(W) + "x" + std::to_string(H) + "_" + std::to_string(RS) + "_" + hashb + ".bin";
+  // cache file: lowered names (one per line) | blank line | checksum of the code object (16 hex digits) | code object
+  auto from_cache = [&](std::vector<std::string>& lowered, std::string& code) -> bool {
+    if (!cache_ok) return false;
+    std::ifstream in(cfile, std::ios::binary);
+    if (!in) return false;
+    std::string line, sum;
+    while (std::getline(in, line) && !line.empty()) lowered.push_back(line);
+    if (!std::getline(in, sum)) return false;
+    std::stringstream ss; ss << in.rdbuf(); code = ss.str();
+    char want[32];
+    snprintf(want, sizeof want, "%016llx", (unsigned long long)fnv1a(code));
+    return lowered.size() == names.size() && !code.empty() && sum == want;
+  };
+  auto compile = [&](std::vector<std::string>& lowered, std::string& code) -> std::string {
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "tg_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return "hiprtcCreateProgram failed";
     for (auto& n : names) hiprtcAddNameExpression(prog, n.c_str());
@@ -403,30 +423,50 @@ std::string rtc_build(int device, int W, int H, int RS, RtcSize** out) {
     code.resize(cs);
     hiprtcGetCode(prog, &code[0]);
     hiprtcDestroyProgram(&prog);
-    mkdir((std::string(getenv("HOME") ? getenv("HOME") : "/tmp") + "/.cache").c_str(), 0755);
-    mkdir(cdir.c_str(), 0755);
-    const std::string tmp = cfile + ".tmp" + std::to_string((long)getpid());
-    std::ofstream o(tmp, std::ios::binary);
-    if (o) {
-      for (auto& l : lowered) o << l << "\n";
-      o << "\n";
-      o.write(code.data(), (std::streamsize)code.size());
-      o.close();
-      rename(tmp.c_str(), cfile.c_str());
+    if (cache_ok) {
+      const std::string tmp = cfile + ".tmp" + std::to_string((long)getpid());
+      std::ofstream o(tmp, std::ios::binary);
+      if (o) {
+        char sum[32];
+        snprintf(sum, sizeof sum, "%016llx", (unsigned long long)fnv1a(code));
+        for (auto& l : lowered) o << l << "\n";
+        o << "\n" << sum << "\n";
+        o.write(code.data(), (std::streamsize)code.size());
+        o.close();
+        rename(tmp.c_str(), cfile.c_str());
+      }
     }
-  }
+    return "";
+  };
+  // load a code object and look every kernel up; false (nothing kept) when anything is missing
+  auto load = [&](const std::vector<std::string>& lowered, const std::string& code, RtcSize* rs) -> bool {
+    if (hipModuleLoadData(&rs->mod, code.data()) != hipSuccess) return false;
+    size_t k = 0;
+    auto fn = [&](hipFunction_t* f) { return hipModuleGetFunction(f, rs->mod, lowered[k++].c_str()) == hipSuccess; };
+    bool ok = true;
+    for (int ft : rtc_feats(RS, W, H)) { hipFunction_t f = nullptr; ok = fn(&f) && ok; rs->step[ft] = f; }
+    ok = fn(&rs->reset) && ok; ok = fn(&rs->observe) && ok; ok = fn(&rs->prepare) && ok; ok = fn(&rs->features) && ok; ok = fn(&rs->placements) && ok;
+    hipDeviceptr_t gp = nullptr; size_t gb = 0;
+    ok = ok && hipModuleGetGlobal(&gp, &gb, rs->mod, "tg_rtc_geo") == hipSuccess && gb == sizeof(rs->geo) &&
+         hipMemcpy(rs->geo, gp, sizeof(rs->geo), hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) { (void)hipModuleUnload(rs->mod); rs->mod = nullptr; rs->step.clear(); }
+    return ok;
+  };
   RtcSize* rs = new RtcSize();
   rs->W = W; rs->H = H; rs->RS = RS;
-  if (hipModuleLoadData(&rs->mod, code.data()) != hipSuccess) { delete rs; return "hipModuleLoadData failed for the compiled kernels"; }
-  size_t k = 0;
-  auto fn = [&](hipFunction_t* f) { return hipModuleGetFunction(f, rs->mod, lowered[k++].c_str()) == hipSuccess; };
-  bool ok = true;
-  for (int ft : rtc_feats(RS, W, H)) { hipFunction_t f = nullptr; ok = fn(&f) && ok; rs->step[ft] = f; }
-  ok = fn(&rs->reset) && ok; ok = fn(&rs->observe) && ok; ok = fn(&rs->prepare) && ok; ok = fn(&rs->features) && ok; ok = fn(&rs->placements) && ok;
-  hipDeviceptr_t gp = nullptr; size_t gb = 0;
-  ok = ok && hipModuleGetGlobal(&gp, &gb, rs->mod, "tg_rtc_geo") == hipSuccess && gb == sizeof(rs->geo) &&
-       hipMemcpy(rs->geo, gp, sizeof(rs->geo), hipMemcpyDeviceToHost) == hipSuccess;
-  if (!ok) { delete rs; return "the compiled module lacks an expected kernel"; }
+  bool loaded = false;
+  {
+    std::vector<std::string> lowered;
+    std::string code;
+    if (from_cache(lowered, code)) loaded = load(lowered, code, rs);  // (a stale or damaged file falls through to a compile)
+  }
+  if (!loaded) {
+    std::vector<std::string> lowered;
+    std::string code;
+    const std::string err = compile(lowered, code);
+    if (!err.empty()) { delete rs; return err; }
+    if (!load(lowered, code, rs)) { delete rs; return "the compiled module lacks an expected kernel"; }
+  }
   g_rtc[keyb] = rs;
   *out = rs;
   return "";
@@ -459,7 +499,7 @@ Launchers rtc_launchers(const RtcSize* r) {
                                      : ((feat & R) ? r->geo[3] : ((feat & F) ? r->geo[4] : r->geo[1])));
     auto it = r->step.find(feat);
     if (it == r->step.end()) return;
-    uint8_t* a0 = p.pboard ? p.pboard : p.board; uint32_t* a1 = p.rec; void* a2 = p.cols; const uint4* a3 = (RS == TG_RULESET_NUMPY && p.thirds) ? ring4 : bp.ring_rd; const uint32_t* a4 = bp.hbuf_rd;
+    uint8_t* a0 = p.pboard ? p.pboard : p.board; uint32_t* a1 = p.rec; void* a2 = p.cols; const uint4* a3 = bp.ring_rd; const uint32_t* a4 = bp.hbuf_rd;
     const void* a5 = p.actions; int a6 = p.batch;
     uint32_t a7 = bits_hot_misc(p, RS, n_step_wgs);
     tg::KParams kp = p;
@@ -559,12 +599,7 @@ struct tg_handle {
   uint8_t* d_pboard = nullptr; // bits kernel, packed handles: the board as nibbles [B][H*W/2] (tg_kernel_bits.h kFeatPacked); the step
                                // kernel keeps THIS current, TG_BUF_BOARD is brought up to date on demand (ensure_board)
   bool board_stale = false;    // TG_BUF_BOARD is behind d_pboard
-  int ring_par = 0;            // ring parity the next step launch reads, one bit per third of the batch (all equal without `thirds`)
-  bool thirds = false;         // NUMPY: the RNG role serves one third of the batch per one-transition launch, in rotation (TG_RNG_EVERY=0
-                               // / tg_config.rng_every = 4).  Built and measured in round 4 (every launch at 65 536 envs then fits
-                               // the two-stream-wave build): the same at 65 536 envs (6.29 vs 6.28 us), 3 % slower at 32 768, 10 %
-                               // at 131 072 — RNG workgroups in every launch cost more than the whole batch's in every third.
-                               // Default: the whole batch every rng_every-th launch.  profiles/r04/ab_rng_thirds.log
+  int ring_cur = 0;            // ring parity the next step launch reads
   int hbuf_cur = 0;            // consumed-counter parity the next step launch reads
   int rng_every = 3;           // TG_RNG_EVERY: one-transition launches carry the RNG-role workgroups every n-th time (the ring
                                // looks 3 entries ahead and the consumer shuffles in line when it runs dry): 7.5 -> 7.3 us per launch
@@ -726,10 +761,7 @@ tg::KParams step_params(tg_handle* h) {
   p.hbuf = h->d_hbuf;
   p.inl = h->d_inl;
   p.pboard = h->d_pboard;
-  p.ring_cur = h->ring_par & 1;
-  p.ring_par = h->ring_par;
-  p.thirds = h->thirds ? 1 : 0;
-  p.rng_third = 3;
+  p.ring_cur = h->ring_cur;
   p.hbuf_cur = h->hbuf_cur;
   p.rng_role = 1;
   p.ring_stride = (uint32_t)h->B;
@@ -838,9 +870,7 @@ int launch_prepare_bits(tg_handle* h, const uint8_t* d_mask, int force) {
   q.ahead = h->d_ahead;
   q.ring = h->d_ring;
   q.hbuf = h->d_hbuf;
-  q.cur = h->ring_par & 1;
-  q.thirds = (h->thirds && h->cfg.ruleset == TG_RULESET_NUMPY) ? 1 : 0;
-  q.ring_par = h->ring_par;
+  q.cur = h->ring_cur;
   q.hcur = h->hbuf_cur;
   q.mask = d_mask;
   q.batch = h->B;
@@ -866,19 +896,14 @@ int launch_materialize_rng(tg_handle* h) {
   return TG_OK;
 }
 
-// Which envs the RNG role of the next launch serves (p.nsteps is set): launches of several transitions consume several ring
-// entries per env and refill everybody; one-transition launches serve one third of the batch in rotation — or, with the
-// every-n-th cadence (TG_RNG_EVERY), everybody every n-th time.
+// Whether the next launch carries the RNG-role workgroups (p.nsteps is set): launches of several transitions consume several
+// ring entries per env and always do; one-transition launches every rng_every-th time (TG_RNG_EVERY).
 void next_rng_role(tg_handle* h, tg::KParams& p) {
-  p.rng_third = 3;
-  if (p.nsteps > 1) { p.rng_role = 1; return; }
-  const unsigned no = h->launch_no++;
-  if (h->thirds) { p.rng_role = 1; p.rng_third = (int)(no % 3u); return; }
-  p.rng_role = (no % (unsigned)h->rng_every) == 0;
+  p.rng_role = p.nsteps > 1 || (h->launch_no++ % (unsigned)h->rng_every) == 0;
 }
-// ... and what flips afterwards: the ring parity of every third that was served, the consumed-counter parity
+// ... and what flips afterwards: the ring parity when the role ran, the consumed-counter parity always
 void after_launch(tg_handle* h, const tg::KParams& p) {
-  if (p.rng_role) h->ring_par ^= (h->thirds && p.rng_third < 3) ? (1 << p.rng_third) : 7;
+  if (p.rng_role) h->ring_cur ^= 1;
   h->hbuf_cur ^= 1;
   if (h->d_pboard) h->board_stale = true;
 }
@@ -931,6 +956,79 @@ int enqueue_fetches(tg_handle* h, int m, const int* which, void* const* host_dst
   }
   return TG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Enqueue pool of tg_step_fetch_many: one persistent worker per additional handle, so that the launches of n devices are
+// issued side by side instead of one after the other (a launch is ~3 us of host time; eight in a row are 27 us, measured
+// with eight shards of one GPU: bench.py `vector_env_shards`).  A worker spins for its next job for a short while after it
+// finished one (a stepping loop hands it the next within microseconds) and blocks on a condition variable otherwise, so
+// an idle process burns nothing.  TG_STEP_THREADS=0 keeps everything on the calling thread.
+// ---------------------------------------------------------------------------------------------------------------------
+class EnqueuePool {
+ public:
+  static EnqueuePool& get() { static EnqueuePool p; return p; }
+  // run job(k) for k = 0 .. n - 1 (k = 0 on the calling thread); returns the first non-zero result
+  int run(int n, const std::function<int(int)>& job) {
+    static const bool enabled = !(getenv("TG_STEP_THREADS") && atoi(getenv("TG_STEP_THREADS")) == 0);
+    if (n <= 1 || !enabled) {
+      for (int k = 0; k < n; ++k) { const int rc = job(k); if (rc != TG_OK) return rc; }
+      return TG_OK;
+    }
+    std::lock_guard<std::mutex> serial(call_mu_);  // (one tg_step_fetch_many at a time uses the workers)
+    while ((int)workers_.size() < n - 1) workers_.emplace_back(new Worker());
+    job_ = &job;
+    for (int k = 1; k < n; ++k) workers_[k - 1]->post(this, k);
+    int rc = job(0);
+    for (int k = 1; k < n; ++k) { const int r = workers_[k - 1]->wait(); if (rc == TG_OK) rc = r; }
+    return rc;
+  }
+
+ private:
+  struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<int> state{0};  // 0 idle, 1 job posted, 2 done, 3 exit
+    EnqueuePool* pool = nullptr;
+    int k = 0, rc = 0;
+    Worker() { th = std::thread([this] { loop(); }); }
+    ~Worker() {
+      { std::lock_guard<std::mutex> l(m); state.store(3, std::memory_order_release); }
+      cv.notify_one();
+      if (th.joinable()) th.join();
+    }
+    void post(EnqueuePool* p, int kk) {
+      pool = p; k = kk;
+      { std::lock_guard<std::mutex> l(m); state.store(1, std::memory_order_release); }
+      cv.notify_one();
+    }
+    int wait() {
+      while (state.load(std::memory_order_acquire) != 2) { /* the job is a handful of asynchronous HIP calls: microseconds */ }
+      state.store(0, std::memory_order_release);
+      return rc;
+    }
+    void loop() {
+      for (;;) {
+        int st = 0;
+        for (int spin = 0; spin < 200000; ++spin) {  // (~100 us of polling before going to sleep)
+          st = state.load(std::memory_order_acquire);
+          if (st == 1 || st == 3) break;
+        }
+        if (st != 1 && st != 3) {
+          std::unique_lock<std::mutex> l(m);
+          cv.wait(l, [&] { const int v = state.load(std::memory_order_acquire); return v == 1 || v == 3; });
+          st = state.load(std::memory_order_acquire);
+        }
+        if (st == 3) return;
+        rc = (*pool->job_)(k);
+        state.store(2, std::memory_order_release);
+      }
+    }
+  };
+  std::vector<std::unique_ptr<Worker>> workers_;
+  const std::function<int(int)>* job_ = nullptr;
+  std::mutex call_mu_;
+};
 
 }  // namespace
 
@@ -1120,7 +1218,9 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
       const bool can = cfg->ruleset == TG_RULESET_NUMPY && packed_geometry(cfg->width, cfg->height) && !want_final &&
                        (cfg->obs_mode == TG_OBS_BOARD || cfg->obs_mode == TG_OBS_NONE) &&
                        !(getenv("TG_STREAMS") && atoi(getenv("TG_STREAMS")) > 1);
-      bool want = false;  // (auto rule `can && B * cells >= 20 Mi` is switched on once measured: see below)
+      // (measured, profiles/r04/ab_packed_board.log: config 5 24.3 -> 21.7 us, 524 288 envs at 10x20 46.7 -> 41.7, 131 072
+      // 11.7 -> 11.1; at 65 536 x 10x20 — Infinity-Cache resident, bound by instruction issue — 6.30 -> 6.87: hence the size rule)
+      bool want = can && B * h->cells >= ((size_t)20 << 20);
       if (const char* e = getenv("TG_PACKED")) want = can && atoi(e) != 0;
       if (want) CRCHK(arena_take(h, (void**)&h->d_pboard, B * h->cells / 2 + kTailPad));
     }
@@ -1143,14 +1243,10 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
                          (cfg->obs_mode == TG_OBS_RGB && L.rgb_ok && cfg->queue_size == 4));  // (the in-kernel RGB image is laid out for four queue pieces)
     // launch knobs: tg_config (0 = default), overridden by the environment (test hooks)
     if (cfg->ring_fill_p1 > 0) h->ring_fill = cfg->ring_fill_p1 - 1 > tg::kRing - 1 ? tg::kRing - 1 : cfg->ring_fill_p1 - 1;
-    if (cfg->rng_every > 0) { h->rng_every = cfg->rng_every > 3 ? 3 : cfg->rng_every; h->thirds = cfg->rng_every == 4; }
+    if (cfg->rng_every > 0) h->rng_every = cfg->rng_every > 3 ? 3 : cfg->rng_every;
     if (cfg->fuse > 0) h->fuse_max = cfg->fuse > tg::kMaxFuse ? tg::kMaxFuse : cfg->fuse;
     if (const char* e = getenv("TG_RING_FILL")) { const int v = atoi(e); h->ring_fill = v < 0 ? 0 : (v > tg::kRing - 1 ? tg::kRing - 1 : v); }
-    if (const char* e = getenv("TG_RNG_EVERY")) {  // (0 or 4 = rotating thirds)
-      const int v = atoi(e);
-      h->thirds = v <= 0 || v == 4;
-      if (v > 0) h->rng_every = v > 3 ? 3 : v;
-    }
+    if (const char* e = getenv("TG_RNG_EVERY")) { const int v = atoi(e); h->rng_every = v < 1 ? 1 : (v > 3 ? 3 : v); }
     if (const char* e = getenv("TG_FN_LAZY")) { const int v = atoi(e); h->fn_lazy = v < 0 ? 0 : (v & 7); }
     if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > tg::kMaxFuse ? tg::kMaxFuse : v); }
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
@@ -1159,7 +1255,6 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     if (!h->d_cols || cfg->obs_mode == TG_OBS_DICT || cfg->obs_mode == TG_OBS_RGB || (cfg->flags & TG_FLAG_FINAL_OBS)) want = 1;
     while (want > 1 && (B + want - 1) / want < 8192) --want;  // small shards only add launches
     if (want > 1) {
-      h->thirds = false;  // (stream shards launch sub-ranges of the batch: the whole-batch cadence keeps one ring parity)
       const int chunk = (int)(((B + want - 1) / want + 127) / 128 * 128);  // RNG workgroups own 128-env ranges
       for (int o = 0; o < (int)B; o += chunk) {
         h->sh_off.push_back(o);
@@ -1354,8 +1449,7 @@ static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, u
         p.actions = actions_dev + (size_t)k * h->B;
       }
       p.nsteps = K - k < fuse ? K - k : fuse;
-      p.ring_cur = h->ring_par & 1;
-      p.ring_par = h->ring_par;
+      p.ring_cur = h->ring_cur;
       p.hbuf_cur = h->hbuf_cur;
       next_rng_role(h, p);
       if (in_kernel) {
@@ -1438,7 +1532,8 @@ int tg_step_fetch_many(int n, tg_handle* const* hs, const void* const* actions, 
   if (n <= 0 || !hs || m < 0 || (m && (!which || !host_dst || !bytes))) return TG_EINVAL;
   for (int k = 0; k < n; ++k)
     if (!hs[k]) return TG_EINVAL;
-  for (int k = 0; k < n; ++k) {  // phase 1: enqueue everything, handle by handle
+  // phase 1: enqueue everything — handle 0 on this thread, the others on the pool's workers, side by side
+  const std::function<int(int)> enqueue = [&](int k) -> int {
     tg_handle* h = hs[k];
     if (actions) {
       const int rc = tg_step(h, (const int32_t*)actions[k], kind);
@@ -1446,8 +1541,10 @@ int tg_step_fetch_many(int n, tg_handle* const* hs, const void* const* actions, 
     } else {
       HIPCHK(h, hipSetDevice(h->cfg.device));
     }
-    if (m) { const int rc = enqueue_fetches(h, m, which, host_dst + (size_t)k * m, bytes + (size_t)k * m, src_off ? src_off + (size_t)k * m : nullptr); if (rc != TG_OK) return rc; }
-  }
+    if (m) return enqueue_fetches(h, m, which, host_dst + (size_t)k * m, bytes + (size_t)k * m, src_off ? src_off + (size_t)k * m : nullptr);
+    return TG_OK;
+  };
+  { const int rc = EnqueuePool::get().run(n, enqueue); if (rc != TG_OK) return rc; }
   for (int k = 0; k < n; ++k) {  // phase 2: one wait per handle
     tg_handle* h = hs[k];
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1670,7 +1767,6 @@ int tg_step_kernel_name(tg_handle* h, int transitions_per_launch, int trajectory
   tg::KParams p = step_params(h);
   p.nsteps = transitions_per_launch > 1 ? transitions_per_launch : 1;
   p.sample_mode = sampled ? 1 : 0;
-  if (h->thirds && p.nsteps == 1) p.rng_third = 0;  // (a one-transition launch serves one third: what the instantiation is picked by)
   if (trajectory) p.out_traj = (uint2*)h->buf[TG_BUF_STEP_OUT];  // (only its non-nullness selects the instantiation)
   h->L.step_name(p, buf, n);
   return TG_OK;

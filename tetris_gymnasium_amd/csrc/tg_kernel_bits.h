@@ -833,14 +833,9 @@ void step_kernel_bits(
     // segment are preloaded into SGPRs by the dispatcher (-mllvm -amdgpu-kernarg-preload-count=16, 14 user SGPRs are free;
     // struct arguments are not eligible), so the slab / record / ring loads leave without waiting for a scalar load of
     // the argument block (a memory round trip at the start of every workgroup).  The structs arrive in their shadow.
-    uint8_t* const hot_board, uint32_t* const hot_rec, void* const hot_cols,
-    // the permutation rings: the parity this launch reads — or, with `thirds` (hot_misc bit 31), the base of both parities
-    // [2][batch]: which one an env reads is then a bit per third of the batch (see the RNG role)
-    const uint4* const hot_ring_rd,
+    uint8_t* const hot_board, uint32_t* const hot_rec, void* const hot_cols, const uint4* const hot_ring_rd,
     const uint32_t* const hot_hbuf_rd, const void* const hot_actions, const int hot_batch,
-    // step workgroups (bits 0-18) | ring parity of thirds 0..2 (19-21) | the third the RNG role serves, 3 = all (22-23) |
-    // act_i8 (24) | nsteps (25-29) | thirds (31)
-    const uint32_t hot_misc,
+    const uint32_t hot_misc,  // step workgroups (bits 0-23) | act_i8 << 24 | nsteps << 25
     const KParams p, const BitsParams bp) {
   constexpr bool MULTI = (FEAT & kFeatMulti) != 0, TRAJ = (FEAT & kFeatTraj) != 0, DICTK = (FEAT & kFeatDict) != 0,
                  SAMPLE = (FEAT & kFeatSample) != 0, FINAL = (FEAT & kFeatFinal) != 0, RGBK = (FEAT & kFeatRgb) != 0;
@@ -860,19 +855,10 @@ void step_kernel_bits(
   const int wave = rfl((int)(threadIdx.x >> 6));
 
   const uint32_t B = (uint32_t)hot_batch;
-  // `thirds` (round 4; TG_RNG_EVERY=0, NOT the default): the RNG role serves ONE THIRD of the batch per one-transition launch, in
-  // rotation, instead of the whole batch every third launch — every launch then carries a third of the RNG workgroups and, at
-  // 65 536 envs, every launch fits the build with two stream waves (kFeatSplit), where two of three do.  Measured: the same at
-  // 65 536 envs, 3-10 % slower at 32 768 / 131 072 (profiles/r04/ab_rng_thirds.log) — RNG workgroups in every launch cost more
-  // than three times as many in every third.  Kept, tested, off.  The ring's double buffer flips per third: thirds are
-  // contiguous env ranges of B3 envs (a multiple of 128, so that a step workgroup and an RNG workgroup lie inside one), and
-  // which parity a third reads is a bit of hot_misc — scalar arithmetic on preloaded arguments in front of the first loads.
-  const bool thirds = (hot_misc >> 31) != 0u;
-  const uint32_t B3 = thirds ? ((((B + 2u) / 3u) + 127u) & ~127u) : 0xFFFFFFFFu;
-  auto ring_par_of = [&](const uint32_t e0) -> uint32_t {  // (wave-uniform argument)
-    const uint32_t t = (e0 >= B3 ? 1u : 0u) + ((e0 >> 1) >= B3 ? 1u : 0u);
-    return (hot_misc >> (19u + t)) & 1u;
-  };
+  // (Round 4 built the RNG role on rotating THIRDS of the batch — every one-transition launch serves one third, the ring's double
+  // buffer flips per third, every launch at 65 536 envs fits the two-stream-wave build — parity-green, and measured no gain at
+  // 65 536 envs, 3-10 % loss at 32 768 / 131 072; even switched off, its scalar arithmetic in front of the first loads cost the
+  // headline launch 0.07 us.  Removed again: commit c0175b2 has it, profiles/r04/ab_rng_thirds.log the numbers.)
   // role split by blockIdx: the RNG workgroups lead (placing them last measured the same)
 #ifdef TG_RNG_FIRST
   const bool rng_role = (int)blockIdx.x < bp.nrb;
@@ -880,8 +866,10 @@ void step_kernel_bits(
 #else
   // the step workgroups are dispatched first (a grid of this size starts first → last within 0.3-0.7 us, and the step
   // workgroups are the longer pole since the RNG role produces one entry per launch)
-  const uint32_t n_step = hot_misc & 0x7FFFFu;
-  const bool rng_role = blockIdx.x >= n_step;
+  const uint32_t n_step = hot_misc & 0xFFFFFFu;
+  // (FUNCTIONAL launches have no RNG-role workgroups: compiled out there — the role's code also kept its argument words alive in
+  // the scalar loads at the top of the kernel, see TG_LATE_ARGS)
+  const bool rng_role = RULESET == TG_RULESET_NUMPY && blockIdx.x >= n_step;
   const uint32_t step_block = blockIdx.x, rng_block = blockIdx.x - n_step;
 #endif
   const uint32_t base_env = step_block * (uint32_t)EPW;  // (meaningless in the RNG role)
@@ -891,14 +879,26 @@ void step_kernel_bits(
   const uint32_t env = base_env + (uint32_t)slot;
   // What depends on the argument structs (they arrive by scalar loads) is derived in each wave BEHIND its first global
   // loads: the first use of any struct word is where the wave waits for all of them.
+  // (Round 4 tried to make this robust by keeping every word of both structs "used" until that point — a 16-byte scalar load
+  // of which an instantiation needs one word has dead registers, the allocator reuses them at once, and overwriting a register
+  // that a load in flight will write costs an `s_waitcnt lgkmcnt(0)` for the whole argument block at the head of the logic
+  // wave.  Pinning removes that wait and loses more than it wins — NUMPY 6.31 -> 6.54 us, functional fused 2.90 -> 3.21 —
+  // because every word is then fetched: profiles/r04/ab_pin_kernargs_rejected.log.)
 #define TG_LATE_ARGS()                                                                                            \
   const bool need_slab = p.obs_mode == TG_OBS_BOARD || p.obs_mode == TG_OBS_FN;                                   \
-  const bool dict = DICTK && BG::DICT_OK && p.obs_mode == TG_OBS_DICT && p.dict_in_kernel;                        \
-  const bool rgb = RGBK && BG::RGB_OK && p.obs_mode == TG_OBS_RGB && p.dict_in_kernel;                            \
+  /* (the host picks the dict / RGB instantiations exactly when the handle's observation is packed in the kernel: no run- */ \
+  /* time test — the argument words it read were fetched, waited for and copied at the very head of the logic wave)        */ \
+  constexpr bool dict = DICTK && BG::DICT_OK;                                                                     \
+  constexpr bool rgb = RGBK && BG::RGB_OK;                                                                        \
   uint8_t* const obs_traj = TRAJ ? p.obs_traj : nullptr;                                                          \
   uint2* const out_traj = TRAJ ? p.out_traj : nullptr;                                                            \
   int8_t* const act_traj = TRAJ ? p.act_traj : nullptr;                                                           \
   uint8_t* const final_obs = FINAL ? p.final_obs : nullptr;                                                       \
+  /* (p.queue_size shares a 16-byte scalar load with gravity / autoreset / obs_mode; FUNCTIONAL never reads it, the allocator */ \
+  /* handed its register to the first scalar value of the prologue, and overwriting a register that a load in flight will    */ \
+  /* write costs `s_waitcnt lgkmcnt(0)` — a wait for the argument block at the very top of every wave: 6.93 vs 7.24 us.      */ \
+  /* Kept "used" until here, the word's register is not free that early.)                                                     */ \
+  asm volatile("" ::"s"(p.queue_size));                                                                           \
   (void)need_slab; (void)dict; (void)rgb; (void)obs_traj; (void)out_traj; (void)act_traj; (void)final_obs
   uint4* post2 = reinterpret_cast<uint4*>(lds + BG::OFF_RGB);                      // (RGB instantiations only)
   const uint32_t* lut_l = reinterpret_cast<const uint32_t*>(lds + BG::OFF_TAB + 256);  // colour table (RGB)
@@ -947,17 +947,10 @@ void step_kernel_bits(
     const unsigned long long rng_t0 = TG_NOW();
 #endif
     if (bits_stream_waves<W, H>(FEAT) > 1 && threadIdx.x >= 128) TG_ROLE_END();  // (a third wave of the workgroup has no RNG range)
-    // the env range this launch's RNG role serves: third `rt` (or the whole batch: launches of several transitions, the
-    // every-n-th-launch cadence of TG_RNG_EVERY)
-    const uint32_t rt = (hot_misc >> 22) & 3u;
-    const uint32_t r_lo = (thirds && rt < 3u) ? rt * B3 : 0u;
-    const uint32_t r_hi = (thirds && rt < 3u) ? (r_lo + B3 < B ? r_lo + B3 : B) : B;
-    const uint32_t e = r_lo + rng_block * 128u + threadIdx.x;
-    const bool on = e < r_hi;
-    const uint32_t ee = on ? e : r_hi - 1u;
-    const uint32_t rpar = thirds ? ring_par_of(rfl(r_lo + rng_block * 128u)) : 0u;
-    const uint4* const ring_rd_r = hot_ring_rd + (size_t)(thirds ? rpar * B : 0u);
-    const uint4 rw = ring_rd_r[ee];
+    const uint32_t e = rng_block * 128u + threadIdx.x;
+    const bool on = e < B;
+    const uint32_t ee = on ? e : B - 1u;
+    const uint4 rw = hot_ring_rd[ee];
     uint64_t w0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32), w1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
     const int Hraw = hot_hbuf_rd[ee];
     const int Hn = Hraw & 0xFF;
@@ -1012,8 +1005,7 @@ void step_kernel_bits(
       }
     }
     if (on) {
-      u32x4* rdst = (thirds ? reinterpret_cast<u32x4*>(const_cast<uint4*>(hot_ring_rd)) + (size_t)((1u - rpar) * B)
-                            : reinterpret_cast<u32x4*>(bp.ring_wr)) + e;
+      u32x4* rdst = reinterpret_cast<u32x4*>(bp.ring_wr) + e;
       const u32x4 rv = u32x4{(uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32)};
 #ifdef TG_RING_PLAIN
       *rdst = rv;
@@ -1560,7 +1552,7 @@ void step_kernel_bits(
   int Hc = 0;
   uint64_t fnw = 0;  // FUNCTIONAL: the bags this transition may deal (S1 | S2 << 21 | Q0 << 42), see the look-ahead above
   if (RULESET == TG_RULESET_NUMPY) {
-    const uint4 rw = (hot_ring_rd + (size_t)(thirds ? ring_par_of(base_env) * B : 0u))[env];
+    const uint4 rw = hot_ring_rd[env];
     ring0 = (uint64_t)rw.x | ((uint64_t)rw.y << 32);
     ring1 = (uint64_t)rw.z | ((uint64_t)rw.w << 32);
     Hc = hot_hbuf_rd[env];  // H | loc << 8, split below
@@ -2349,6 +2341,19 @@ void step_kernel_bits(
     fn_lock = false; fn_reset = false; fn_hi = false;
     TG_FN_STAMP(7);
   };
+  // obs["active_tetromino_mask"] of the workgroup's envs, GD at a time (dict_mask_group), into TG_BUF_OBS / the trajectory slot
+  auto dict_masks = [&]() {
+    const size_t Bt = p.act_stride;  // the handle's batch
+    uint8_t* d0 = obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs;
+    uint8_t* d1 = (step == nsteps - 1 && obs_traj) ? p.obs : nullptr;
+    constexpr int GD = BG::GD;
+    uint8_t* grpm = lds + BG::OFF_DICT + GD * BG::PC;  // all zero between groups (zeroed at launch start, un-stamped by every group)
+    for (int g0 = 0; g0 < EPW; g0 += GD) {
+      const uint32_t nlg = nlive > (uint32_t)g0 ? nlive - (uint32_t)g0 : 0u;
+      dict_mask_group<W, H, GD>(grpm, post + (step & 1) * EPW + g0, nlg, lane, d0 + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC,
+                                d1 ? d1 + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC : nullptr);
+    }
+  };
   const bool book_first = RULESET == TG_RULESET_NUMPY && early_book;
   if constexpr (MULTI) {
     // (the kernels with the transition loop are at their register budget: one publish site, two passes)
@@ -2362,6 +2367,9 @@ void step_kernel_bits(
     }
   } else {
     if (!book_first) publish();
+    // (the dict observation's mask array depends on nothing behind the publish — but stored HERE, in front of the bookkeeping, the
+    // launch takes 23.5 instead of 17.3 us: the bookkeeping's loads then wait behind 28 store instructions per lane, vmcnt counts
+    // both.  profiles/r04/ab_dict_mask_early_rejected.log)
     if (RULESET == TG_RULESET_NUMPY && !TG_SKIP(512)) bookkeeping();
     if (book_first) publish();
   }
@@ -2417,22 +2425,9 @@ void step_kernel_bits(
     const size_t Bt = p.act_stride;  // the handle's batch
     uint8_t* dsts[2] = {obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs,
                         (step == nsteps - 1 && obs_traj) ? p.obs : nullptr};
-    constexpr int GD = BG::GD;
-    uint8_t* grpm = lds + BG::OFF_DICT + GD * BG::PC;  // all zero between groups (zeroed at launch start, un-stamped by every group)
-    uint32_t* oldpw = reinterpret_cast<uint32_t*>(lds + BG::OFF_OLDPW);
-    for (int g0 = 0; g0 < EPW; g0 += GD) {
-      const uint32_t nlg = nlive > (uint32_t)g0 ? nlive - (uint32_t)g0 : 0u;
-#ifdef TG_DICT_INCR_MASK  // (measured and rejected, see dict_mask_group_incr: sparse 16-byte stores cost more than the full stream)
-      // a trajectory slot is fresh memory and gets the whole array; TG_BUF_OBS only what changed
-      if (obs_traj) dict_mask_group<W, H, GD>(grpm, post + (step & 1) * EPW + g0, nlg, lane, dsts[0] + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC, nullptr);
-      if (!obs_traj || step == nsteps - 1)
-        dict_mask_group_incr<W, H, GD>(grpm, post + (step & 1) * EPW + g0, oldpw + g0, nlg, lane, p.obs + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC);
-#else
-      dict_mask_group<W, H, GD>(grpm, post + (step & 1) * EPW + g0, nlg, lane,
-                                dsts[0] + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC,
-                                dsts[1] ? dsts[1] + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC : nullptr);
-#endif
-    }
+    // (storing only the chunks the old / the new bounding box covers — dict_mask_group_incr, TG_BUF_OBS keeps its content — was
+    // measured in round 3 and rejected: 18.0 vs 17.1 us, profiles/r03/ab_dict_incremental_mask.log)
+    dict_masks();
     // holder and queue strips change only with a hold, a spawn or a reset: TG_BUF_OBS keeps the strips of the previous
     // transition (tg_reset / tg_observe / tg_set_state re-pack it completely), so only those envs store them; a
     // trajectory slot is fresh memory and gets every env's strips
@@ -2585,8 +2580,7 @@ struct PrepareParams {
   int batch;
   int ruleset;
   int force;            // refill every ring
-  int cur;              // ring parity the next launch reads ...
-  int thirds, ring_par; // ... or, with `thirds`, one bit per third of the batch (see step_kernel_bits)
+  int cur;              // ring parity the next launch reads
   int hcur;             // consumed-counter parity the next launch reads
 };
 
@@ -2608,13 +2602,7 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
   uint4* ring4 = reinterpret_cast<uint4*>(p.ring);
   if (!moved) {  // ring untouched: make both parities agree with the one the next launch reads
     if (p.ruleset != TG_RULESET_NUMPY) return;  // (FUNCTIONAL: the look-ahead has no parities)
-    int cur = p.cur;
-    if (p.thirds) {
-      const uint32_t B3 = ((((uint32_t)p.batch + 2u) / 3u) + 127u) & ~127u;
-      const uint32_t t = ((uint32_t)env >= B3 ? 1u : 0u) + (((uint32_t)env >> 1) >= B3 ? 1u : 0u);
-      cur = (p.ring_par >> t) & 1;
-    }
-    ring4[(size_t)(1 - cur) * B + env] = ring4[(size_t)cur * B + env];
+    ring4[(size_t)(1 - p.cur) * B + env] = ring4[(size_t)p.cur * B + env];
     p.hbuf[(size_t)(1 - p.hcur) * B + env] = p.hbuf[(size_t)p.hcur * B + env];
     return;
   }

@@ -417,10 +417,22 @@ class Engine:
                 DeviceBuffer(self, self.B * N.RNG_REC.itemsize))
         self._chk(self.lib.tg_get_state_dev(self.h, C.c_void_p(bufs[0].ptr), C.c_void_p(bufs[1].ptr), C.c_void_p(bufs[2].ptr)),
                   "tg_get_state_dev")
+        for b in bufs:
+            b._state_of = (self.B, self.W, self.H, self.ruleset)  # (what set_state_device accepts without `unchecked`)
         return bufs
 
-    def set_state_device(self, board=None, rec=None, rng=None):
-        """Restore from device buffers (DeviceBuffer or raw pointers) — the counterpart of get_state_device."""
+    def set_state_device(self, board=None, rec=None, rng=None, unchecked=False):
+        """Restore from device buffers — the counterpart of get_state_device.  tg_set_state_dev cannot range-check what is on
+        the device (tg_set_state does: piece / rotation / position / bag entries, cell values), and an out-of-range record
+        would index the kernels' tables and LDS slabs out of bounds: by default only snapshots that get_state_device of an
+        engine of the same shape produced are accepted.  unchecked=True takes raw device pointers / foreign buffers — the
+        caller then vouches for their contents."""
+        for b in (board, rec, rng):
+            if b is None or unchecked:
+                continue
+            if not isinstance(b, DeviceBuffer) or getattr(b, "_state_of", None) != (self.B, self.W, self.H, self.ruleset):
+                raise EngineError("set_state_device takes the DeviceBuffers get_state_device returned for an engine of this shape "
+                                  "(device records are not validated); pass unchecked=True for anything else")
         p = [None if b is None else C.c_void_p(b.ptr if isinstance(b, DeviceBuffer) else int(b)) for b in (board, rec, rng)]
         self._chk(self.lib.tg_set_state_dev(self.h, *p), "tg_set_state_dev")
 
