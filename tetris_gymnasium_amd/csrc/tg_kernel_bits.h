@@ -2398,7 +2398,7 @@ void step_kernel_bits(
   if (RULESET == TG_RULESET_FUNCTIONAL) {
     // (behind everything that waits for a load of the launch's start — the episode record above: a wait for it behind
     // fn_book's stores is a wait for those stores, a round trip through a memory system busy with the stream waves' tail)
-#ifndef TG_FN_NO_SWAP
+#if !defined(TG_FN_NO_SWAP) && !defined(TG_FN_KEEP_PRIO)
     if (!MULTI) __builtin_amdgcn_s_setprio(0);  // the look-ahead is nobody's critical path: the stream wave's tail goes first
 #endif
     fn_book();
