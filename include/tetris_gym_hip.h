@@ -233,7 +233,8 @@ int tg_host_pack_layout(const tg_config* cfg, size_t offsets[6]);
  * AND in host memory at the same distance (TG_BUF_OBS followed by TG_BUF_HOST_PACK into one page-locked slab laid out like
  * the device side: host_dst[1] - host_dst[0] == their device distance) are merged into a single copy.  src_off (or NULL):
  * byte offset into each buffer — a range of a buffer, e.g. one array of the dict observation of one shard straight into its
- * slice of the adapter's whole-batch array. */
+ * slice of the adapter's whole-batch array.  TG_BUF_RNG, TG_BUF_HOST_PACK, TG_BUF_BOARD and (grouped action set) TG_BUF_LEGAL_MASK
+ * are brought up to date for the state as it stands before they are copied. */
 int tg_fetch_many(tg_handle* h, int m, const int* which, void* const* host_dst, const size_t* bytes, const size_t* src_off);
 
 /* One transition on n handles (one per GPU, or several shards of one GPU) and the fetches that follow it, from ONE host

@@ -326,6 +326,35 @@ def test_vector_env_host_step_is_one_call_for_every_layout(obs):
         e.close()
 
 
+@pytest.mark.parametrize("devices,copy", [((0,), True), ((0,), False), ((0, 0, 0), False)])
+def test_vector_env_grouped_actions_with_board_observation(devices, copy):
+    """The grouped action set (wrappers/grouped.py:209-269) with a plain board observation through the one-call host step:
+    infos["action_mask"] is the mask of the NEW state (recomputed on the device when it is fetched), the invalid-action reward
+    is the Python float -0.1, illegal actions terminate — all against the oracle's grouped step."""
+    B = 240
+    env = TetrisVectorEnv(B, observation="board", grouped=True, autoreset_mode="same_step", devices=devices, copy=copy)
+    obs, info = env.reset(seed=9)
+    o = po.OracleBatch(B)
+    o.reset(np.arange(9, 9 + B, dtype=np.uint64))
+    rng = np.random.default_rng(2)
+    n_illegal = n_done = 0
+    for t in range(120):
+        mask = info["action_mask"]
+        np.testing.assert_array_equal(mask, o.grouped_enumerate(), err_msg=f"mask t={t}")
+        a = np.array([rng.choice(np.flatnonzero(m)) for m in mask])
+        bad = rng.random(B) < 0.05
+        a[bad] = rng.integers(0, 40, int(bad.sum()))
+        obs, rew, term, trunc, info = env.step(a)
+        ro, to, lo, ill = o.grouped_step(a.astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+        np.testing.assert_array_equal(term, to.astype(bool)); np.testing.assert_array_equal(info["lines_cleared"], lo)
+        exp = ro.astype(np.float64); exp[ro < 0] = -0.1
+        np.testing.assert_array_equal(rew, exp)
+        np.testing.assert_array_equal(obs, o.observe(po.OBS_BOARD), err_msg=f"obs t={t}")
+        n_illegal += int((ro < 0).sum()); n_done += int(to.sum())
+    assert n_illegal > 0 and n_done > 0
+    env.close()
+
+
 def test_vector_env_grouped_placement_features():
     """The reference's train_lin_grouped.py loop: obs = [4W, 13] features per env, infos["action_mask"], infos["board"]."""
     B = 64

@@ -908,6 +908,8 @@ void after_launch(tg_handle* h, const tg::KParams& p) {
   if (h->d_pboard) h->board_stale = true;
 }
 
+int run_grouped_mask(tg_handle* h);  // (defined with the grouped entry points below)
+
 // TG_BUF_HOST_PACK is packed when somebody asks for it (the step path never pays for it)
 int launch_host_pack(tg_handle* h) {
   PackParams q{};
@@ -936,6 +938,10 @@ int enqueue_fetches(tg_handle* h, int m, const int* which, void* const* host_dst
     if (which[i] == TG_BUF_RNG) { int rc = launch_materialize_rng(h); if (rc != TG_OK) return rc; }
     if (which[i] == TG_BUF_HOST_PACK) { int rc = launch_host_pack(h); if (rc != TG_OK) return rc; }
     if (which[i] == TG_BUF_BOARD) { int rc = ensure_board(h); if (rc != TG_OK) return rc; }
+    if (which[i] == TG_BUF_LEGAL_MASK && h->cfg.action_set == TG_ACTIONS_GROUPED) {  // the mask of the state as it stands now
+      int rc = run_grouped_mask(h);
+      if (rc != TG_OK) return rc;
+    }
   }
   for (int i = 0; i < m;) {
     // neighbours in device memory and, at the same distance, in host memory leave as one copy (the gap between two pieces of
@@ -1701,6 +1707,10 @@ static int run_grouped(tg_handle* h, bool mask, bool sample, uint32_t seed, uint
   HIPCHK(h, hipGetLastError());
   return TG_OK;
 }
+
+}  // extern "C"
+namespace { int run_grouped_mask(tg_handle* h) { return run_grouped(h, true, false, 0, 0); } }
+extern "C" {
 
 int tg_grouped_enumerate(tg_handle* h, uint8_t* boards_dev) {
   if (!h) return TG_EINVAL;

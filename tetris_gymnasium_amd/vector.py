@@ -87,6 +87,14 @@ class _HostStep:
         else:
             self.fields = [("", (e0.H, e0.W), np.int8 if e0.obs_mode == N.OBS_FN else np.uint8)]
         self.fbytes = [int(np.prod(sh)) * np.dtype(dt).itemsize for _, sh, dt in self.fields]
+        # further whole buffers per shard: the legal-action mask of the grouped action set (recomputed on the device for the new
+        # state when it is fetched), the terminal observation of same-step autoreset
+        self.extras = []
+        if venv.grouped:
+            self.extras.append(("action_mask", N.BUF_LEGAL_MASK, (4 * e0.W,), np.uint8))
+        if venv.final_obs:
+            self.extras.append(("final_observation", N.BUF_FINAL_OBS, (e0.H, e0.W), np.int8 if e0.obs_mode == N.OBS_FN else np.uint8))
+        self.xbytes = [int(np.prod(sh)) * np.dtype(dt).itemsize for _, _, sh, dt in self.extras]
         self.pack_off = []
         for e in es:
             off = (C.c_size_t * 6)()
@@ -98,23 +106,25 @@ class _HostStep:
             pp, _ = e0.device_ptr(N.BUF_HOST_PACK)
             self.gap = pp - po
             self.obs_bytes = e0.B * sum(self.fbytes)
-            self.m = 2
-            self.which = (C.c_int * 2)(N.BUF_OBS, N.BUF_HOST_PACK)
-            self.nbytes = (C.c_size_t * 2)(self.obs_bytes, self.pack_off[0][5])
+            self.m = 2 + len(self.extras)
+            self.which = (C.c_int * self.m)(N.BUF_OBS, N.BUF_HOST_PACK, *[x[1] for x in self.extras])
+            self.nbytes = (C.c_size_t * self.m)(self.obs_bytes, self.pack_off[0][5], *[e0.B * xb for xb in self.xbytes])
             self.src_off = None
             self.slab_bytes = self.gap + self.pack_off[0][5]
             if not (0 < self.gap - self.obs_bytes <= 16384):  # (not neighbours after all: two copies, still one wait)
                 self.gap = (self.obs_bytes + 63) // 64 * 64
                 self.slab_bytes = self.gap + self.pack_off[0][5]
         else:  # per shard: every observation array into its slice of the whole-batch array + the shard's pack
-            self.m = len(self.fields) + 1
-            self.which = (C.c_int * self.m)(*([N.BUF_OBS] * len(self.fields) + [N.BUF_HOST_PACK]))
+            self.m = len(self.fields) + 1 + len(self.extras)
+            self.which = (C.c_int * self.m)(*([N.BUF_OBS] * len(self.fields) + [N.BUF_HOST_PACK] + [x[1] for x in self.extras]))
             nb, so = [], []
             for e, offs in zip(es, self.pack_off):
                 o = 0
                 for fb in self.fbytes:
                     nb.append(e.B * fb); so.append(o); o += e.B * fb
                 nb.append(offs[5]); so.append(0)
+                for xb in self.xbytes:
+                    nb.append(e.B * xb); so.append(0)
             self.nbytes = (C.c_size_t * (self.n * self.m))(*nb)
             self.src_off = (C.c_size_t * (self.n * self.m))(*so)
         self.slots, self.cur = [], 0
@@ -142,6 +152,11 @@ class _HostStep:
                 obs[name] = raw[o:o + B * fb].view(dt).reshape((B,) + sh)
                 o += B * fb
             packs = [raw[self.gap:self.gap + self.pack_off[0][5]]]
+            xs = {}
+            for i, ((name, _, sh, dt), xb) in enumerate(zip(self.extras, self.xbytes)):
+                xr = self._raw(B * xb)
+                dst[2 + i] = xr.ctypes.data
+                xs[name] = xr.view(dt).reshape((B,) + sh)
             slot["keep"] = raw
         else:
             obs, keep = {}, []
@@ -155,9 +170,17 @@ class _HostStep:
                     dst[k * self.m + f] = keep[f].ctypes.data + lo * fb
                 pk = self._raw(offs[5])
                 packs.append(pk)
-                dst[k * self.m + self.m - 1] = pk.ctypes.data
+                dst[k * self.m + len(self.fbytes)] = pk.ctypes.data
+            xs = {}
+            for i, ((name, _, sh, dt), xb) in enumerate(zip(self.extras, self.xbytes)):
+                xr = self._raw(B * xb)
+                keep.append(xr)
+                xs[name] = xr.view(dt).reshape((B,) + sh)
+                for k, (lo, hi) in enumerate(v.ranges):
+                    dst[k * self.m + len(self.fbytes) + 1 + i] = xr.ctypes.data + lo * xb
             slot["keep"] = keep
         slot["dst"] = dst
+        slot["extras"] = xs
         slot["obs"] = obs[""] if "" in obs else obs
         # the five arrays of every shard's pack, as views
         parts = []
@@ -183,7 +206,7 @@ class _HostStep:
     # -- the call ---------------------------------------------------------------------------------------------------------
     def step(self, actions):
         """actions: contiguous int32[num_envs] (host) or None (fetch only).  Returns (obs, rewards f64, terminations bool,
-        lines i32, episode returns f64, episode lengths i32) — whole-batch arrays."""
+        lines i32, episode returns f64, episode lengths i32, extras {"action_mask", "final_observation"}) — whole-batch arrays."""
         v, C = self.v, self.C
         slot = self._next_slot()
         acts = None
@@ -202,8 +225,8 @@ class _HostStep:
             raise RuntimeError(f"tg_step_fetch_many failed ({rc})")
         parts = slot["parts"]
         if len(parts) == 1:
-            return (slot["obs"],) + parts[0]
-        return (slot["obs"],) + tuple(np.concatenate([p[i] for p in parts]) for i in range(5))  # (25 bytes per env)
+            return (slot["obs"],) + parts[0] + (slot["extras"],)
+        return (slot["obs"],) + tuple(np.concatenate([p[i] for p in parts]) for i in range(5)) + (slot["extras"],)  # (25 bytes per env)
 
 
 class TetrisVectorEnv(VectorEnvBase):
@@ -400,16 +423,22 @@ class TetrisVectorEnv(VectorEnvBase):
         if not to_host:
             return self.step_device(actions)
         actions = np.ascontiguousarray(actions, np.int32).reshape(self.num_envs)
-        if self.obs_kind in ("board", "functional", "dict", "rgb") and not self.grouped and not self.final_obs:
+        if self.obs_kind in ("board", "functional", "dict", "rgb"):
             # the whole step — upload, launch, pack, copies, one wait per device — is one call into the C ABI
             if self._host is None:
                 self._host = _HostStep(self, pinned=not self._copy)
-            obs, rewards, terminations, lines, ep_r, ep_l = self._host.step(actions)
+            obs, rewards, terminations, lines, ep_r, ep_l, extras = self._host.step(actions)
             fresh = (lambda a: a.copy()) if self._copy else (lambda a: a)  # (copy=False: the constant arrays are shared, too)
             infos = {"lines_cleared": lines, "_lines_cleared": fresh(self._ones)}
-            if self.episode_stats and terminations.any():
+            any_done = terminations.any()
+            if self.episode_stats and any_done:
                 infos["episode"] = {"r": ep_r, "l": ep_l, "t": fresh(self._zeros_t)}
                 infos["_episode"] = fresh(terminations)
+            if self.grouped:  # the mask the NEXT action must be drawn from (wrappers/grouped.py:266-267)
+                infos["action_mask"] = extras["action_mask"]
+            if self.final_obs and any_done:  # (valid where `_final_observation`; the other rows are whatever they last held)
+                infos["final_observation"] = extras["final_observation"]
+                infos["_final_observation"] = fresh(terminations)
             return obs, rewards, terminations, fresh(self._falses), infos
 
         def one(e, lo, hi):  # launch, then collect everything this shard returns, on the shard's own thread
