@@ -255,18 +255,18 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
     e = Engine(B, W, H, ruleset=rs, queue_size=(Q if rs == N.RULESET_NUMPY else 7), obs_mode=obs_mode,
                autoreset=N.AUTORESET_SAME_STEP, device=local, env_offset=lo, grouped=grouped, fuse=fuse)  # (tg_config.fuse)
     e.reset(seeds)
-    copy_gbps = None
-    if copy_first:  # the practical ceiling, measured before the timed region (it also brings the clocks up)
-        try:
-            copy_gbps = e.stream_copy_gbps(1 << 30, 20)
-        except Exception:  # pragma: no cover
-            copy_gbps = None
     # pre-generated uniform random actions, uploaded once: [T][B] int8 resident in HBM
     T = min(max(warmup + steps, fuse), 512)
     T = (T + fuse - 1) // fuse * fuse
     acts = np.random.default_rng(D.rank).integers(0, n_act, (T, B)).astype(np.int8)
     d_acts = e.dev_alloc(acts.nbytes)
     e.dev_upload(d_acts, acts)
+    copy_gbps = None
+    if copy_first:  # the practical ceiling, measured right before the warm-up (it also brings the clocks up: with the host-side
+        try:        # action generation behind it the GPU idled for milliseconds before a short timed region)
+            copy_gbps = e.stream_copy_gbps(1 << 30, 20)
+        except Exception:  # pragma: no cover
+            copy_gbps = None
 
     def run(k0, k):
         if grouped:  # legal placements drawn on the device inside the step kernel (tg_grouped_rollout)

@@ -254,7 +254,11 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
 /* The same between DEVICE buffers of the caller (layouts as above; any pointer may be NULL), asynchronous on the handle's
  * stream: what a host program that keeps many states resident (a functional State per call, envs/tetris_fn.py:276-315; a
  * search that branches) needs instead of a round trip through host memory.  tg_set_state_dev rebuilds the engine's private
- * acceleration state exactly as tg_set_state does; records are not range-checked (they come from tg_get_state_dev). */
+ * acceleration state exactly as tg_set_state does.  The host cannot range-check device-resident state, so a kernel does, right
+ * behind the copies: whatever tg_set_state would refuse (piece / rotation / position / bag or queue entries out of range; for the
+ * functional rule-set board bytes >= 0x80; for handles that keep the board as nibbles cell values > 15) is CLAMPED — nothing
+ * then indexes out of range — and the next call on the handle that waits for the stream (tg_sync, tg_fetch*, tg_get_state,
+ * tg_step_fetch_many) returns TG_EINVAL once, with the reason in tg_last_error. */
 int tg_get_state_dev(tg_handle* h, uint8_t* board_dev, tg_env_rec* rec_dev, tg_rng_rec* rng_dev);
 int tg_set_state_dev(tg_handle* h, const uint8_t* board_dev, const tg_env_rec* rec_dev, const tg_rng_rec* rng_dev);
 

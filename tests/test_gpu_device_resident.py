@@ -301,3 +301,34 @@ def test_lifetimes_after_close_and_unconsumed_dlpack_capsules():
         view.__cuda_array_interface__
     del keep
     gc.collect()
+
+
+def test_set_state_device_is_range_checked_on_the_device():
+    """tg_set_state_dev cannot validate device-resident records on the host: a kernel clamps what tg_set_state would refuse (so
+    nothing indexes out of range) and the next synchronising call reports it once; valid uploads pass silently."""
+    from tetris_gymnasium_amd.engine import EngineError
+
+    B = 256
+    e = Engine(B, 10, 20, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP)
+    e.reset(np.arange(1, B + 1, dtype=np.uint64))
+    e.step(np.zeros(B, np.int32))
+    good = e.get_state_device()
+    e.set_state_device(*good)
+    e.sync()                                           # nothing to report
+    board, rec, rng = e.get_state()
+    bad = rec.copy()
+    bad["piece"][3] = 9; bad["x"][5] = 200; bad["bag"][7, 2] = 11
+    d = e.dev_alloc(bad.nbytes)
+    e.dev_upload(d, bad)
+    with pytest.raises(EngineError, match="DeviceBuffers"):
+        e.set_state_device(rec=d)                      # raw pointers need unchecked=True ...
+    e.set_state_device(rec=d, unchecked=True)          # ... and are then checked on the device
+    with pytest.raises(EngineError, match="tg_set_state_dev"):
+        e.sync()
+    e.sync()                                           # reported once
+    _, rec2, _ = e.get_state()
+    assert rec2["piece"][3] <= 6 and rec2["x"][5] <= 14 and rec2["bag"][7, 2] <= 6
+    for _ in range(20):                                # the engine keeps running on the clamped state
+        e.step(np.random.default_rng(0).integers(0, 8, B))
+    e.dev_free(d)
+    e.close()

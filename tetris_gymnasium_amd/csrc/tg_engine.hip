@@ -565,6 +565,55 @@ __global__ __launch_bounds__(256) void host_pack_kernel(const PackParams p) {
   (p.pack + p.off[4])[i] = (uint8_t)(term ? 1 : 0);
 }
 
+// tg_set_state_dev cannot range-check device-resident records on the host (tg_set_state does).  This pass does it on the device, right
+// behind the copies: what tg_set_state would refuse is CLAMPED to something harmless (an out-of-range piece / position would index the
+// kernels' tables and LDS slabs out of bounds) and flagged in *err; the next synchronising call on the handle reports it (TG_EINVAL).
+struct SanitizeParams {
+  uint32_t* rec;         // [B][8]
+  uint8_t* board;        // [B][H*W] or null (not uploaded)
+  int* err;              // flag word: bit 0 record field out of range, bit 1 board byte out of range
+  int batch, W, H, Q, ruleset, packed;
+};
+__global__ __launch_bounds__(256) void sanitize_state_kernel(const SanitizeParams p) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= p.batch) return;
+  uint32_t* r = p.rec + (size_t)env * 8;
+  uint32_t d0 = r[0], d1 = r[1], d2 = r[2], d3 = r[3], d4 = r[4], d5 = r[5];
+  int bad = 0;
+  auto fix = [&](uint32_t& w, const int shift, const uint32_t limit, const uint32_t safe) {  // byte field <= limit, else := safe
+    if (((w >> shift) & 0xFFu) > limit) { w = (w & ~(0xFFu << shift)) | (safe << shift); bad |= 1; }
+  };
+  fix(d0, 0, 6, 0);                                   // piece
+  fix(d0, 8, 3, 0);                                   // rot
+  fix(d0, 16, (uint32_t)p.W + 4u, 7);                 // x
+  fix(d0, 24, (uint32_t)p.H + 3u, 0);                 // y
+  if (((d1 >> 16) & 0xFFu) != TG_NONE) { fix(d1, 16, 6, TG_NONE); fix(d1, 24, 3, 0); }  // holder piece / rot
+  fix(d2, 8, 7, 7);                                   // bag index
+  fix(d2, 16, 6, 0); fix(d2, 24, 6, 0);               // bag[0..1]
+  fix(d3, 0, 6, 0); fix(d3, 8, 6, 0); fix(d3, 16, 6, 0); fix(d3, 24, 6, 0);  // bag[2..5]
+  fix(d4, 0, 6, 0);                                   // bag[6]
+  if (p.ruleset == TG_RULESET_NUMPY) {                // visible queue (first Q entries)
+    if (p.Q > 0) fix(d4, 8, 6, 0);
+    if (p.Q > 1) fix(d4, 16, 6, 0);
+    if (p.Q > 2) fix(d4, 24, 6, 0);
+    if (p.Q > 3) fix(d5, 0, 6, 0);
+    if (p.Q > 4) fix(d5, 8, 6, 0);
+    if (p.Q > 5) fix(d5, 16, 6, 0);
+    if (p.Q > 6) fix(d5, 24, 6, 0);
+  }
+  if (p.packed) { fix(d1, 0, 15, 2); if (((d1 >> 16) & 0xFFu) != TG_NONE) fix(d2, 0, 15, 2); }  // val / holder val as nibbles
+  if (bad) { r[0] = d0; r[1] = d1; r[2] = d2; r[3] = d3; r[4] = d4; r[5] = d5; }
+  if (p.board) {
+    const uint32_t lim = p.packed ? 15u : (p.ruleset == TG_RULESET_FUNCTIONAL ? 0x7Fu : 0xFFu);
+    if (lim < 0xFFu) {
+      uint8_t* b = p.board + (size_t)env * p.W * p.H;
+      for (int i = 0; i < p.W * p.H; ++i)
+        if (b[i] > lim) { b[i] = 2; bad |= 2; }
+    }
+  }
+  if (bad) atomicOr(p.err, bad);
+}
+
 std::string built_sizes() {
   std::string s;
 #define X(w, h) s += std::string(s.empty() ? "" : ", ") + #w "x" #h;
@@ -599,6 +648,8 @@ struct tg_handle {
   uint8_t* d_pboard = nullptr; // bits kernel, packed handles: the board as nibbles [B][H*W/2] (tg_kernel_bits.h kFeatPacked); the step
                                // kernel keeps THIS current, TG_BUF_BOARD is brought up to date on demand (ensure_board)
   bool board_stale = false;    // TG_BUF_BOARD is behind d_pboard
+  int* d_err = nullptr;        // flag word of sanitize_state_kernel (tg_set_state_dev)
+  bool dev_state_pending = false;  // a tg_set_state_dev has been enqueued whose flag word nobody has looked at yet
   int ring_cur = 0;            // ring parity the next step launch reads
   int hbuf_cur = 0;            // consumed-counter parity the next step launch reads
   int rng_every = 3;           // TG_RNG_EVERY: one-transition launches carry the RNG-role workgroups every n-th time (the ring
@@ -839,6 +890,19 @@ int launch_step_all(tg_handle* h, const tg::KParams& p) {
     h->L.step(q, h->sh_stream[i]);
   }
   return TG_OK;
+}
+
+// after a wait for the handle's stream: did a tg_set_state_dev since the last look upload something tg_set_state would have refused?
+int check_dev_state(tg_handle* h) {
+  if (!h->dev_state_pending) return TG_OK;
+  h->dev_state_pending = false;
+  int flags = 0;
+  HIPCHK(h, hipMemcpy(&flags, h->d_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (!flags) return TG_OK;
+  HIPCHK(h, hipMemsetAsync(h->d_err, 0, sizeof(int), h->stream));
+  return fail(h, TG_EINVAL, "tg_set_state_dev: the uploaded device state held values tg_set_state refuses (%s%s); they were clamped so that "
+                            "nothing indexes out of range — the engine's state is not what was uploaded",
+              (flags & 1) ? "record field out of range" : "", (flags & 2) ? ((flags & 1) ? ", board byte out of range" : "board byte out of range") : "");
 }
 
 // packed handles: bring the uint8 TG_BUF_BOARD up to date before anything reads it (the step kernel maintains the nibbles)
@@ -1189,10 +1253,10 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   {
     h->arena_skew = 0;
     if (const char* e = getenv("TG_ALLOC_SKEW")) h->arena_skew = (size_t)(atol(e) > 0 ? atol(e) : 0);
-    const int n_pieces = TG_BUF_COUNT + 10;
+    const int n_pieces = TG_BUF_COUNT + 11;
     size_t total = 0;
     for (int i = 0; i < TG_BUF_COUNT; ++i) total += sizes[i] + kTailPad + 4096;
-    total += B * sizeof(tg_rng_rec) + 2 * B + B * L.cols_bytes + B * 32 * tg::kRing + 2 * B * 16 + 8 * B + 2 * B * 32 + B * h->cells / 2 + 10 * (kTailPad + 4096);
+    total += B * sizeof(tg_rng_rec) + 2 * B + B * L.cols_bytes + B * 32 * tg::kRing + 2 * B * 16 + 8 * B + 2 * B * 32 + B * h->cells / 2 + 64 + 11 * (kTailPad + 4096);
     total += h->arena_skew * (size_t)n_pieces * (size_t)n_pieces;
     CRCHK(hipMalloc(&h->arena, total));
     h->arena_size = total;
@@ -1212,6 +1276,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   CRCHK(arena_take(h, (void**)&h->d_new_rng, B * sizeof(tg_rng_rec)));
   CRCHK(arena_take(h, (void**)&h->d_reseed, B));
   CRCHK(arena_take(h, (void**)&h->d_mask, B));
+  CRCHK(arena_take(h, (void**)&h->d_err, 64));
   if (g_kernel_lanes == 16) {
     CRCHK(arena_take(h, &h->d_cols, B * L.cols_bytes + kTailPad));
     CRCHK(arena_take(h, (void**)&h->d_ahead, B * 32 * tg::kRing + kTailPad));
@@ -1522,7 +1587,7 @@ int tg_fetch(tg_handle* h, int which, void* host_dst, size_t bytes) {
   if (which == TG_BUF_BOARD) { int rcm = ensure_board(h); if (rcm != TG_OK) return rcm; }
   if (bytes) HIPCHK(h, hipMemcpyAsync(host_dst, h->buf[which], bytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  return TG_OK;
+  return check_dev_state(h);
 }
 
 int tg_fetch_many(tg_handle* h, int m, const int* which, void* const* host_dst, const size_t* bytes, const size_t* src_off) {
@@ -1530,7 +1595,7 @@ int tg_fetch_many(tg_handle* h, int m, const int* which, void* const* host_dst, 
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rc = enqueue_fetches(h, m, which, host_dst, bytes, src_off); if (rc != TG_OK) return rc; }
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  return TG_OK;
+  return check_dev_state(h);
 }
 
 int tg_step_fetch_many(int n, tg_handle* const* hs, const void* const* actions, int kind, int m, const int* which,
@@ -1554,7 +1619,11 @@ int tg_step_fetch_many(int n, tg_handle* const* hs, const void* const* actions, 
   for (int k = 0; k < n; ++k) {  // phase 2: one wait per handle
     tg_handle* h = hs[k];
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    if (m) HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (m) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      const int rc = check_dev_state(h);
+      if (rc != TG_OK) return rc;
+    }
   }
   return TG_OK;
 }
@@ -1570,6 +1639,7 @@ int tg_get_state(tg_handle* h, uint8_t* board, tg_env_rec* rec, tg_rng_rec* rng)
   if (rec) HIPCHK(h, hipMemcpyAsync(rec, h->buf[TG_BUF_REC], B * sizeof(tg_env_rec), hipMemcpyDeviceToHost, h->stream));
   if (rng) HIPCHK(h, hipMemcpyAsync(rng, h->buf[TG_BUF_RNG], B * sizeof(tg_rng_rec), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  { const int rcc = check_dev_state(h); if (rcc != TG_OK) return rcc; }
   if (rec)
     for (size_t i = 0; i < B; ++i) {  // device-private: full-row hint, look-ahead permutation
       rec[i].flags &= (uint8_t)~TG_F_FULLROW;
@@ -1681,6 +1751,16 @@ int tg_set_state_dev(tg_handle* h, const uint8_t* board_dev, const tg_env_rec* r
     HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_RNG], rng_dev, B * sizeof(tg_rng_rec), hipMemcpyDeviceToDevice, h->stream));
     h->rng_valid.assign(B, 1);
   }
+  if (rec_dev || board_dev) {  // (range checks on the device: see sanitize_state_kernel)
+    SanitizeParams q{};
+    q.rec = (uint32_t*)h->buf[TG_BUF_REC];
+    q.board = board_dev ? (uint8_t*)h->buf[TG_BUF_BOARD] : nullptr;
+    q.err = h->d_err;
+    q.batch = h->B; q.W = h->W; q.H = h->H; q.Q = h->Q; q.ruleset = h->cfg.ruleset; q.packed = h->d_pboard ? 1 : 0;
+    hipLaunchKernelGGL(sanitize_state_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, q);
+    HIPCHK(h, hipGetLastError());
+    h->dev_state_pending = true;
+  }
   { int rc = launch_prepare_bits(h, nullptr, 1); if (rc != TG_OK) return rc; }
   if (h->cfg.obs_mode != TG_OBS_NONE) return launch_observe_dict(h);  // (the observation of the restored state)
   return TG_OK;
@@ -1765,11 +1845,11 @@ int tg_sync(tg_handle* h) {
   // several step launches); after ~200 us of polling fall back to the blocking wait
   for (int i = 0; i < 4000; ++i) {
     const hipError_t q = hipStreamQuery(h->stream);
-    if (q == hipSuccess) return TG_OK;
+    if (q == hipSuccess) return check_dev_state(h);
     if (q != hipErrorNotReady) return fail(h, TG_EHIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  return TG_OK;
+  return check_dev_state(h);
 }
 
 int tg_step_kernel_name(tg_handle* h, int transitions_per_launch, int trajectory, int sampled, char* buf, size_t n) {

@@ -422,11 +422,11 @@ class Engine:
         return bufs
 
     def set_state_device(self, board=None, rec=None, rng=None, unchecked=False):
-        """Restore from device buffers — the counterpart of get_state_device.  tg_set_state_dev cannot range-check what is on
-        the device (tg_set_state does: piece / rotation / position / bag entries, cell values), and an out-of-range record
-        would index the kernels' tables and LDS slabs out of bounds: by default only snapshots that get_state_device of an
-        engine of the same shape produced are accepted.  unchecked=True takes raw device pointers / foreign buffers — the
-        caller then vouches for their contents."""
+        """Restore from device buffers — the counterpart of get_state_device.  By default only snapshots that get_state_device of
+        an engine of the same shape produced are accepted; unchecked=True takes raw device pointers / foreign buffers.  Either
+        way tg_set_state_dev range-checks the records (and, where cell values are restricted, the boards) ON THE DEVICE: what
+        tg_set_state would refuse is clamped so that nothing indexes out of range, and the next call that waits for the engine
+        (sync / fetch / get_state / step with host results) raises EngineError once."""
         for b in (board, rec, rng):
             if b is None or unchecked:
                 continue
