@@ -149,13 +149,7 @@ struct BitsGeo {
   // FUNCTIONAL rule-set (never together with the dict / RGB staging): the logic wave's exchange area for the sorts of the
   // key-chain look-ahead — uint2 keys [128] | uint32 permutations [128] — behind the FINAL_OBS records
   static constexpr int OFF_FNX = BYTES_FIN;
-  // ... and behind them (-DTG_FN_DENSE only) the task list of the dense threefry levels: uint4 {key, counter word 1} [192] | uint2 results [192]
-  static constexpr int OFF_FNT = BYTES_FIN + 128 * 8 + 128 * 4;
-#ifdef TG_FN_DENSE
-  static constexpr int BYTES_FNX = OFF_FNT + 192 * 16 + 192 * 8;
-#else
-  static constexpr int BYTES_FNX = OFF_FNT;
-#endif
+  static constexpr int BYTES_FNX = BYTES_FIN + 128 * 8 + 128 * 4;
   static constexpr int WC = bits_cols_words<W, H>();  // column-mask words per env in HBM
   // two stream waves per workgroup (each owns half of the envs and their slabs: no exchange between them) when the halves
   // are whole 16-byte chunks
