@@ -393,12 +393,16 @@ def vector_env_block(local, *, B=65536, steps=64, warmup=8):
             for t in range(warmup):
                 v.step(act(t), to_host=form.startswith("host"))
             e0.sync()
-            t0 = time.perf_counter()
-            for t in range(warmup, warmup + steps):
-                v.step(act(t), to_host=form.startswith("host"))
-            e0.sync()
-            dt = time.perf_counter() - t0
-            res[form] = {"value": B * steps / dt, "unit": "env steps/s", "us_per_step": dt / steps * 1e6}
+            dts = []
+            for _ in range(3):  # (median of three regions: a 64-step region is 0.5-20 ms, one host hiccup shows)
+                t0 = time.perf_counter()
+                for t in range(warmup, warmup + steps):
+                    v.step(act(t), to_host=form.startswith("host"))
+                e0.sync()
+                dts.append(time.perf_counter() - t0)
+            dt = statistics.median(dts)
+            res[form] = {"value": B * steps / dt, "unit": "env steps/s", "us_per_step": dt / steps * 1e6,
+                         "us_per_step_regions": [round(x / steps * 1e6, 2) for x in dts]}
         e0.dev_free(d_acts)
         obs_bytes = 200 if kind == "board" else 944
         res["host"]["pcie_bytes_per_env_step"] = res["host_pinned"]["pcie_bytes_per_env_step"] = obs_bytes + 25 + 4  # (+ TG_BUF_HOST_PACK + actions)
@@ -406,7 +410,7 @@ def vector_env_block(local, *, B=65536, steps=64, warmup=8):
         res["device_actions"]["pcie_bytes_per_env_step"] = 0
         out[kind] = res
         v.close()
-    out["note"] = (f"TetrisVectorEnv.step at {B} envs on one GPU, {steps} steps after {warmup}: `host` returns NumPy observations "
+    out["note"] = (f"TetrisVectorEnv.step at {B} envs on one GPU, median of three regions of {steps} steps after {warmup}: `host` returns NumPy observations "
                    "(gymnasium contract; `host_pinned`: copy=False, views of page-locked buffers), `device` returns DeviceArray views (__cuda_array_interface__ / DLPack) and copies "
                    "nothing back, `device_actions` additionally takes the actions from a device pointer; Python overhead "
                    "included")
@@ -476,15 +480,19 @@ def shards_block(local, *, per_shard=8192, steps=256, warmup=32):
             v.step([p + t * per_shard * 4 for p in ptrs], to_host=False)
         for e in v.engines:
             e.sync()
-        t0 = time.perf_counter()
-        for t in range(warmup, warmup + steps):
-            v.step([p + t * per_shard * 4 for p in ptrs], to_host=False)
-        t_enq = time.perf_counter() - t0
-        for e in v.engines:
-            e.sync()
-        dt = time.perf_counter() - t0
+        regions = []
+        for _ in range(3):  # (median region by total time)
+            t0 = time.perf_counter()
+            for t in range(warmup, warmup + steps):
+                v.step([p + t * per_shard * 4 for p in ptrs], to_host=False)
+            t_enq = time.perf_counter() - t0
+            for e in v.engines:
+                e.sync()
+            regions.append((time.perf_counter() - t0, t_enq))
+        dt, t_enq = sorted(regions)[1]
         out[f"k{k}"] = {"shards": k, "envs": B, "us_per_step": dt / steps * 1e6, "host_us_per_step": t_enq / steps * 1e6,
-                        "value": B * steps / dt, "unit": "env steps/s"}
+                        "value": B * steps / dt, "unit": "env steps/s",
+                        "us_per_step_regions": [round(r[0] / steps * 1e6, 2) for r in regions]}
         for e, d in zip(v.engines, ptrs):
             e.dev_free(d)
         v.close()
