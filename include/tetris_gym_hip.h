@@ -247,7 +247,11 @@ int tg_step_fetch_many(int n, tg_handle* const* hs, const void* const* actions, 
                        void* const* host_dst, const size_t* bytes, const size_t* src_off);
 
 /* Full state snapshot / restore (host buffers; any pointer may be NULL to skip).
- * board u8[B][H][W], rec tg_env_rec[B], rng tg_rng_rec[B].  (envs/tetris.py:681-708) */
+ * board u8[B][H][W], rec tg_env_rec[B], rng tg_rng_rec[B].  (envs/tetris.py:681-708)
+ * Handles that keep their board as nibbles (boards above 20 Mi cells, or TG_PACKED=1) refuse cell values > 15.  Functional
+ * rule-set on such a handle: a lock is `board += id` (functional/core.py:103-121); should a piece uploaded on top of filled
+ * cells produce a sum > 15, the next call that waits for the stream returns TG_EINVAL (never in play; TG_PACKED=0 handles keep
+ * bytes and hold such sums like the reference's int8 board). */
 int tg_get_state(tg_handle* h, uint8_t* board, tg_env_rec* rec, tg_rng_rec* rng);
 int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, const tg_rng_rec* rng);
 

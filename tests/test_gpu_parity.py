@@ -518,6 +518,93 @@ def test_packed_board_handles(fuse, W, H, Q, B, grouped, monkeypatch):
     e.close()
 
 
+@pytest.mark.parametrize("fuse", [1, 16])
+@pytest.mark.parametrize("autoreset", [N.AUTORESET_SAME_STEP, N.AUTORESET_NEXT_STEP])
+@pytest.mark.parametrize("W,H,B", [(10, 20, 1000), (12, 24, 77 * 4), (6, 12, 100)])
+def test_packed_board_functional_handles(fuse, autoreset, W, H, B, monkeypatch):
+    """TG_PACKED=1 with the FUNCTIONAL rule-set (what its handles above ~50 Mi cells pick by themselves): single steps,
+    rollouts with and without the trajectory, masked resets, host and device state round trips, uploaded tall boards and
+    game-over states against the oracle, jax keys included.  A lock there is `board += id` (functional/core.py:103-121): in
+    play that stays a nibble; a piece uploaded INSIDE the stack makes the sum leave the range, which the step kernel notices
+    and the next wait reports (TG_EINVAL) instead of keeping a wrong board silently."""
+    monkeypatch.setenv("TG_PACKED", "1")
+    monkeypatch.setenv("TG_FUSE", str(fuse))
+    e = Engine(B, W, H, ruleset=N.RULESET_FUNCTIONAL, queue_size=7, obs_mode=N.OBS_FN, autoreset=autoreset)
+    assert int(e.step_kernel_name().rstrip(">").split(",")[-1]) & 256
+    o = po.OracleBatch(B, W, H, po.RULESET_FUNCTIONAL, True, 7)
+    seeds = np.arange(31, 31 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(fuse * 100 + W + autoreset)
+    n_done = 0
+
+    def check(msg):
+        np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_FN), err_msg="obs " + msg)
+        ge, go = _cmp_state(e, o, msg)  # (boards through tg_get_state: unpacked on demand)
+        np.testing.assert_array_equal(ge["key"], go["key"], err_msg="rng.key " + msg)
+        np.testing.assert_array_equal(e.device_array(N.BUF_BOARD).numpy(), o.get_state()[0], err_msg="TG_BUF_BOARD " + msg)
+
+    for rnd in range(6):
+        if rnd == 3:  # tall stacks (ids 2..8), one free column: locks, line clears (vacated rows = copies of old row 0) and game overs
+            b, r, g = o.get_state()
+            for i in range(B):
+                top = 3 + 2 * (i % 3)
+                b[i, top:, :] = 2 + (i % 7)
+                b[i, top:, i % W] = 0
+            r["y"][:] = 0; r["rot"][:] = 0; r["x"][:] = (W + 8) // 2 - 2  # (every piece back at its spawn cell, above the stacks)
+            o.set_state(board=b, rec=r, rng=g); e.set_state(board=b, rec=r, rng=g)
+        if rnd == 5:  # every fifth env is handed over already game over
+            b, r, g = o.get_state()
+            r["flags"][::5] |= N.F_GAME_OVER
+            o.set_state(board=b, rec=r, rng=g); e.set_state(board=b, rec=r, rng=g)
+        for _ in range(1 + rnd):
+            a = rng.integers(0, 7, B).astype(np.int8)
+            a[rng.random(B) < 0.4] = 6
+            got = e.step(a)
+            exp = o.step(a.astype(np.int32), autoreset=autoreset)
+            for g_, x, nm in zip(got, exp, ("reward", "terminated", "lines")):
+                np.testing.assert_array_equal(g_, x, err_msg=f"{nm} round {rnd}")
+            n_done += int(exp[1].sum())
+            np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_FN))
+        K = (5, 16, 13)[rnd % 3]
+        acts = rng.integers(0, 7, (K, B)).astype(np.int8)
+        acts[rng.random((K, B)) < 0.4] = 6
+        if rnd == 2:  # with the trajectory
+            res = e.rollout(acts)
+            for k in range(K):
+                ro, to, lo = o.step(acts[k].astype(np.int32), autoreset=autoreset)
+                n_done += int(to.sum())
+                np.testing.assert_array_equal(res[0][k], o.observe(po.OBS_FN), err_msg=f"traj obs k={k}")
+                np.testing.assert_array_equal(res[1][k], ro)
+        else:
+            d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts); e.step_k_device(d, K); e.dev_free(d)
+            for k in range(K):
+                n_done += int(o.step(acts[k].astype(np.int32), autoreset=autoreset)[1].sum())
+        if rnd % 3 == 1:
+            e.set_state(*e.get_state())                      # host round trip
+        elif rnd % 3 == 2:
+            e.set_state_device(*e.get_state_device())        # device round trip
+        else:
+            m = rng.random(B) < 0.2
+            ks = rng.integers(1, 1 << 40, B).astype(np.uint64)
+            e.reset(ks, mask=m); o.reset(ks, mask=m)         # the other envs' boards must survive
+        check(f"round {rnd}")
+    assert n_done > B
+    # cell values the nibbles cannot hold are refused outright ...
+    b, r, g = e.get_state()
+    b2 = b.copy(); b2[0, 0, 0] = 16
+    with pytest.raises(Exception, match="nibbles"):
+        e.set_state(board=b2, rec=r, rng=g)
+    # ... and a piece uploaded INSIDE a stack of 15s (its lock adds 2..8 onto them) is reported by the wait behind that lock
+    b[:, 4:, :] = 15
+    r["flags"][:] = 0
+    r["y"][:] = 6; r["x"][:] = 6; r["rot"][:] = 0
+    e.set_state(board=b, rec=r, rng=g)
+    with pytest.raises(Exception, match="nibble range"):
+        e.step(np.full(B, 6, np.int8))
+        e.sync()
+    e.close()
+
+
 @pytest.mark.parametrize("fuse", [1, 8, 16])
 @pytest.mark.parametrize("ruleset,obs,B", [(N.RULESET_NUMPY, N.OBS_BOARD, 1500), (N.RULESET_FUNCTIONAL, N.OBS_FN, 640),
                                            (N.RULESET_NUMPY, N.OBS_RGB, 200)])

@@ -74,6 +74,8 @@ struct KParams {
   int fn_lazy;              // bits kernel, FUNCTIONAL (TG_FN_LAZY, tests): bits 0-1: 0 = a lock sorts the reset bag ahead only when the stack is
                             // within reach of the spawn rows, 1 = never (every episode end takes the in-line sort), 2 = always (round 3);
                             // bit 2: the look-ahead never catches up behind a reset (the chain stays one key deep)
+  uint32_t* nib_over;       // bits kernel, packed FUNCTIONAL handles: host-visible flag word, set when a lock's `board += id` leaves the
+                            // nibble range (only a piece uploaded on top of filled cells does: functional/core.py:103-121 adds)
 };
 
 struct ResetParams {

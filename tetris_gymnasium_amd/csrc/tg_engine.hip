@@ -111,6 +111,10 @@ int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const
 #ifndef TG_FN_SPLIT_CAP  // (A/B knob: workgroups up to which FUNCTIONAL launches take the two-stream-wave build; default = residency)
 #define TG_FN_SPLIT_CAP g_simds
 #endif
+  if (RS == TG_RULESET_FUNCTIONAL && p.pboard) {  // packed handles (batches beyond residency): the plain builds
+    const bool trj = p.obs_traj || p.out_traj || p.act_traj;
+    return (trj ? (M | T) : (p.nsteps > 1 ? M : 0)) | tg::kFeatPacked;
+  }
   if (RS == TG_RULESET_FUNCTIONAL && g_split && !p.final_obs && epw == 64 && (long)(p.batch + epw - 1) / epw <= (long)(TG_FN_SPLIT_CAP)) {
     const bool trj = p.obs_traj || p.out_traj || p.act_traj;
     return (trj ? (M | T) : (p.nsteps > 1 ? M : 0)) | tg::kFeatSplit;
@@ -167,13 +171,15 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
                      p, bp)
     if (feat == F) { TG_LAUNCH_BITS(F); return; }
     if (feat == (M | T | F)) { TG_LAUNCH_BITS(M | T | F); return; }
-    if constexpr (RS == TG_RULESET_NUMPY && tg::bits_packed<W, H>(tg::kFeatPacked)) {
+    if constexpr (tg::bits_packed<W, H>(tg::kFeatPacked)) {
       constexpr int K = tg::kFeatPacked;
       if (feat == K) { TG_LAUNCH_BITS(K); return; }
       if (feat == (K | M)) { TG_LAUNCH_BITS(K | M); return; }
       if (feat == (K | M | T)) { TG_LAUNCH_BITS(K | M | T); return; }
-      if (feat == (K | T | S)) { TG_LAUNCH_BITS(K | T | S); return; }
-      if (feat == (K | M | T | S)) { TG_LAUNCH_BITS(K | M | T | S); return; }
+      if constexpr (RS == TG_RULESET_NUMPY) {
+        if (feat == (K | T | S)) { TG_LAUNCH_BITS(K | T | S); return; }
+        if (feat == (K | M | T | S)) { TG_LAUNCH_BITS(K | M | T | S); return; }
+      }
     }
     if constexpr (RS == TG_RULESET_NUMPY) {
       if (feat == R) { TG_LAUNCH_BITS(R); return; }
@@ -322,7 +328,10 @@ std::vector<int> rtc_feats(int RS, int W = 0, int H = 0) {
       for (int f : {K, K | M, K | M | T, K | T | S, K | M | T | S}) v.push_back(f);
     return v;
   }
-  return {0, M, M | T, F, M | T | F, Wd, M | Wd, P, P | M, P | M | T};
+  std::vector<int> v = {0, M, M | T, F, M | T | F, Wd, M | Wd, P, P | M, P | M | T};
+  if (W && packed_geometry(W, H))
+    for (int f : {K, K | M, K | M | T}) v.push_back(f);
+  return v;
 }
 
 uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
@@ -648,6 +657,7 @@ struct tg_handle {
   uint8_t* d_pboard = nullptr; // bits kernel, packed handles: the board as nibbles [B][H*W/2] (tg_kernel_bits.h kFeatPacked); the step
                                // kernel keeps THIS current, TG_BUF_BOARD is brought up to date on demand (ensure_board)
   bool board_stale = false;    // TG_BUF_BOARD is behind d_pboard
+  uint32_t* h_nib_over = nullptr;  // packed FUNCTIONAL handles: page-locked flag word the step kernel raises (KParams::nib_over)
   int* d_err = nullptr;        // flag word of sanitize_state_kernel (tg_set_state_dev)
   bool dev_state_pending = false;  // a tg_set_state_dev has been enqueued whose flag word nobody has looked at yet
   int ring_cur = 0;            // ring parity the next step launch reads
@@ -822,6 +832,7 @@ tg::KParams step_params(tg_handle* h) {
   p.dict_in_kernel = h->dict_in_kernel ? 1 : 0;
   p.ring_fill = h->ring_fill;
   p.fn_lazy = h->fn_lazy;
+  p.nib_over = h->h_nib_over;
   return p;
 }
 
@@ -894,6 +905,12 @@ int launch_step_all(tg_handle* h, const tg::KParams& p) {
 
 // after a wait for the handle's stream: did a tg_set_state_dev since the last look upload something tg_set_state would have refused?
 int check_dev_state(tg_handle* h) {
+  if (h->h_nib_over && *(volatile uint32_t*)h->h_nib_over) {  // (host memory the kernel writes: visible once the launch is complete)
+    *(volatile uint32_t*)h->h_nib_over = 0;
+    return fail(h, TG_EINVAL, "a locked piece added its id onto filled cells and the sum left the nibble range of this handle's packed board "
+                              "(only a state uploaded with the piece on top of filled cells does that): the boards are no longer what the "
+                              "reference would hold; TG_PACKED=0 creates handles that keep bytes");
+  }
   if (!h->dev_state_pending) return TG_OK;
   h->dev_state_pending = false;
   int flags = 0;
@@ -1286,14 +1303,20 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     // Packed board (kFeatPacked): for the working sets that do not fit the Infinity Cache the launch is bound by bytes, and
     // the board as nibbles is 17-19 % fewer of them.  TG_PACKED=1 / 0 forces / forbids it (tests, A/B).
     {
-      const bool can = cfg->ruleset == TG_RULESET_NUMPY && packed_geometry(cfg->width, cfg->height) && !want_final &&
-                       (cfg->obs_mode == TG_OBS_BOARD || cfg->obs_mode == TG_OBS_NONE) &&
+      const bool can = packed_geometry(cfg->width, cfg->height) && !want_final &&
+                       (cfg->obs_mode == TG_OBS_BOARD || cfg->obs_mode == TG_OBS_NONE ||
+                        (cfg->obs_mode == TG_OBS_FN && cfg->ruleset == TG_RULESET_FUNCTIONAL)) &&
                        !(getenv("TG_STREAMS") && atoi(getenv("TG_STREAMS")) > 1);
       // (measured, profiles/r04/ab_packed_board.log: config 5 24.3 -> 21.7 us, 524 288 envs at 10x20 46.7 -> 41.7, 131 072
-      // 11.7 -> 11.1; at 65 536 x 10x20 — Infinity-Cache resident, bound by instruction issue — 6.30 -> 6.87: hence the size rule)
+      // 11.7 -> 11.1; at 65 536 x 10x20 — Infinity-Cache resident, bound by instruction issue — 6.30 -> 6.87: hence the size rule;
+      // FUNCTIONAL, ab_fn_packed_board.log: 524 288 envs 49.8 -> 45.0, 262 144 26.2 -> 24.5, 131 072 14.7 -> 14.4)
       bool want = can && B * h->cells >= ((size_t)20 << 20);
       if (const char* e = getenv("TG_PACKED")) want = can && atoi(e) != 0;
       if (want) CRCHK(arena_take(h, (void**)&h->d_pboard, B * h->cells / 2 + kTailPad));
+      if (want && cfg->ruleset == TG_RULESET_FUNCTIONAL) {
+        CRCHK(hipHostMalloc((void**)&h->h_nib_over, 64, hipHostMallocDefault));
+        *h->h_nib_over = 0;
+      }
     }
   }
 #ifdef TG_PHASE_TIMING
@@ -1357,6 +1380,7 @@ void tg_destroy(tg_handle* h) {
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->arena) (void)hipFree(h->arena);
+  if (h->h_nib_over) (void)hipHostFree(h->h_nib_over);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -437,8 +437,10 @@ constexpr int kFeatSplit = 128;
 // (cell 2j / 2j + 1 of packed byte j: with an even slab size the map packed byte -> LDS bytes is linear over the whole
 // block) and packs on the way back; everything in between works on the uint8 slabs as before.  Picked by the host for the
 // working sets that do not fit the Infinity Cache (config 5: 20x40; batches beyond ~100k envs at 10x20), where the launch
-// is bound by bytes: ~250 more instructions in the stream wave buy 17-19 % fewer bytes.  NUMPY rule-set only (a functional
-// lock is `board += id`, which can leave a nibble), instantiations without dict / RGB / final-observation / split.
+// is bound by bytes: ~250 more instructions in the stream wave buy 17-19 % fewer bytes.  Instantiations without dict / RGB /
+// final-observation / split.  FUNCTIONAL: a lock is `board += id` (functional/core.py:103-121), which stays a nibble in play
+// (free cells + ids 2..8) but not for a piece uploaded on top of filled cells: the stamp notices the sum leaving the range and
+// raises KParams::nib_over, which the engine reports at its next wait.
 constexpr int kFeatPacked = 256;
 template <int W, int H>
 constexpr bool bits_packed(const int feat) {
@@ -1166,8 +1168,11 @@ void step_kernel_bits(
     const bool dirty = place || do_reset;
     dirty_any = dirty_any || dirty;
     if (__any(dirty) && !TG_SKIP(128)) {
-      bd.stamp(po.x & 0xFFFFu, (int)(po.y & 0xFFu), (int)((po.y >> 8) & 0xFFu), (po.x >> 16) & 0xFFu,
-               RULESET == TG_RULESET_FUNCTIONAL, place);
+      const bool nib_over = bd.template stamp<PACKED && RULESET == TG_RULESET_FUNCTIONAL>(
+          po.x & 0xFFFFu, (int)(po.y & 0xFFu), (int)((po.y >> 8) & 0xFFu), (po.x >> 16) & 0xFFu, RULESET == TG_RULESET_FUNCTIONAL, place);
+      if constexpr (PACKED && RULESET == TG_RULESET_FUNCTIONAL) {  // (never in play: the engine reports it at its next wait)
+        if (nib_over) *p.nib_over = 1u;
+      }
       wave_sync();
       uint64_t todo = __ballot(do_clear);
       while (todo) {  // cooperative row compaction of the uint8 slab, one env at a time (rare)

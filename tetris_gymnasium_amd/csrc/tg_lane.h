@@ -201,9 +201,12 @@ struct LaneBoard {
     }
     return yd;
   }
-  __device__ __forceinline__ void stamp(uint32_t cells, int x, int y, uint32_t val, bool add, bool on) const {
+  // (NIBBLE: returns whether a sum left the nibble range — the packed board of the FUNCTIONAL rule-set, whose lock ADDS)
+  template <bool NIBBLE = false>
+  __device__ __forceinline__ bool stamp(uint32_t cells, int x, int y, uint32_t val, bool add, bool on) const {
     constexpr int CPL = 4 / L;
     int addr[CPL];
+    bool over = false;
 #pragma unroll
     for (int jj = 0; jj < CPL; ++jj) {
       const int j = jj * L + sub;
@@ -215,13 +218,16 @@ struct LaneBoard {
 #pragma unroll
       for (int jj = 0; jj < CPL; ++jj) old[jj] = my[addr[jj] < 0 ? 0 : addr[jj]];
 #pragma unroll
-      for (int jj = 0; jj < CPL; ++jj)
+      for (int jj = 0; jj < CPL; ++jj) {
         if (on && addr[jj] >= 0) my[addr[jj]] = (uint8_t)(old[jj] + val);
+        if (NIBBLE) over |= on && addr[jj] >= 0 && (uint32_t)old[jj] + val > 15u;
+      }
     } else {
 #pragma unroll
       for (int jj = 0; jj < CPL; ++jj)
         if (on && addr[jj] >= 0) my[addr[jj]] = (uint8_t)val;
     }
+    return over;
   }
   // is playfield row `row` completely filled?  (16-bit reads when W is even, all issued before use)
   __device__ __forceinline__ bool row_full(int row) const {
