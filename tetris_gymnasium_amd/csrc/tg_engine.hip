@@ -75,6 +75,7 @@ int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = lane kernels' pipelined p
                             // the prefetched inputs spill), 1 = off
 
 int g_simds = 1024;  // SIMDs of the device (4 per CU), set by tg_create
+int g_mask_wave = 1; // TG_MASK_WAVE=0: dict instantiations without the third (mask) wave
 int g_split = 1;     // TG_SPLIT=0: never pick the instantiations with two stream waves per workgroup (kFeatSplit)
 int g_wide = 1;      // TG_WIDE=0: never pick the instantiations compiled for fewer waves per SIMD (kFeatWide)
 
@@ -94,6 +95,10 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
   // two stream waves per workgroup (kFeatSplit) while all workgroups of the launch — the RNG role's included — are resident
   // with three waves each at the occupancy the instantiation is compiled for
   const int base = feat & ~tg::kFeatWide;
+  // dict instantiations: a third wave for the mask array instead of a second stream wave (tg_kernel_bits.h kFeatMaskWave)
+  // (one transition per launch: 4 096 envs 8.50 -> 6.73 us, 32 768 10.2 -> 8.65, 65 536 17.1 -> 15.6, 131 072 30.7 -> 29.9; launches of 16
+  // transitions 13.7 -> 13.9 per transition, and two stream waves beside it only help at 4 096 envs: profiles/r04/ab_dict_mask_wave.log)
+  if (g_mask_wave && RS == TG_RULESET_NUMPY && base == tg::kFeatDict) return feat | tg::kFeatMaskWave;
   if (!g_split || !split_ok || RS != TG_RULESET_NUMPY || (feat & tg::kFeatPacked) ||
       !(base == 0 || base == M || base == (M | T) || base == tg::kFeatDict || base == (M | T | tg::kFeatDict))) return feat;
   const int per_simd = tg::bits_waves_per_simd(RS, feat);
@@ -166,7 +171,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
                        : ((feat & D) ? ((feat & tg::kFeatSplit) ? BG::BYTES_DICT_SPLIT : BG::BYTES_DICT)
                                      : ((feat & R) ? BG::BYTES_RGB : ((feat & F) ? BG::BYTES_FIN : BG::BYTES)));
 #define TG_LAUNCH_BITS(FT)                                                                                                  \
-  hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(64 * (1 + tg::bits_stream_waves<W, H>(FT))), lds, s, (p.pboard ? p.pboard : p.board), p.rec, p.cols, bp.ring_rd, bp.hbuf_rd, \
+  hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(64 * tg::bits_wg_waves<W, H>(FT)), lds, s, (p.pboard ? p.pboard : p.board), p.rec, p.cols, bp.ring_rd, bp.hbuf_rd, \
                      p.actions, p.batch, bits_hot_misc(p, RS, n_step_wgs), \
                      p, bp)
     if (feat == F) { TG_LAUNCH_BITS(F); return; }
@@ -188,6 +193,10 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
       if (feat == (T | S)) { TG_LAUNCH_BITS(T | S); return; }
       if (feat == (M | T | D)) { TG_LAUNCH_BITS(M | T | D); return; }
       if (feat == D) { TG_LAUNCH_BITS(D); return; }
+      if constexpr (BG::DICT_OK) {
+        constexpr int X = tg::kFeatMaskWave;
+        if (feat == (D | X)) { TG_LAUNCH_BITS(D | X); return; }
+      }
     }
     if constexpr (RS == TG_RULESET_FUNCTIONAL && BG::SPLIT_OK) {
       if (feat == tg::kFeatSplit) { TG_LAUNCH_BITS(tg::kFeatSplit); return; }
@@ -323,7 +332,8 @@ std::vector<int> rtc_feats(int RS, int W = 0, int H = 0) {
   constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
   constexpr int P = tg::kFeatSplit, Wd = tg::kFeatWide, K = tg::kFeatPacked;
   if (RS == TG_RULESET_NUMPY) {
-    std::vector<int> v = {0, M, M | T, F, M | T | F, D, M | T | D, T | S, M | T | S, R, M | T | S | R, P, P | M, P | M | T, P | D, P | M | T | D};
+    std::vector<int> v = {0, M, M | T, F, M | T | F, D, M | T | D, T | S, M | T | S, R, M | T | S | R, P, P | M, P | M | T, P | D, P | M | T | D,
+                          D | tg::kFeatMaskWave};
     if (W && packed_geometry(W, H))
       for (int f : {K, K | M, K | M | T, K | T | S, K | M | T | S}) v.push_back(f);
     return v;
@@ -514,7 +524,7 @@ Launchers rtc_launchers(const RtcSize* r) {
     tg::KParams kp = p;
     void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &kp, &bp};
     // (threads per workgroup: tg::bits_stream_waves of this size and instantiation)
-    (void)hipModuleLaunchKernel(it->second, (unsigned)(nrb + n_step_wgs), 1, 1, (feat & tg::kFeatSplit) ? 192 : 128, 1, 1, (unsigned)lds, s, args, nullptr);
+    (void)hipModuleLaunchKernel(it->second, (unsigned)(nrb + n_step_wgs), 1, 1, 128 + ((feat & tg::kFeatSplit) ? 64 : 0) + ((feat & tg::kFeatMaskWave) ? 64 : 0), 1, 1, (unsigned)lds, s, args, nullptr);
   };
   L.step_name = [=](const tg::KParams& p, char* buf, size_t n) {
     snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, EPW == 64 && (32 * W * H) % 16 == 0));
@@ -1251,6 +1261,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     g_simds = 4 * prop.multiProcessorCount;
     if (const char* w = getenv("TG_WIDE")) g_wide = atoi(w) != 0;
     if (const char* w = getenv("TG_SPLIT")) g_split = atoi(w) != 0;
+    if (const char* w = getenv("TG_MASK_WAVE")) g_mask_wave = atoi(w) != 0;
   }
   CRCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CRCHK(hipEventCreate(&h->ev0));

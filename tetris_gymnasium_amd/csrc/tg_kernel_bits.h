@@ -349,6 +349,17 @@ __device__ __forceinline__ void st_dict(V* dst, const V v) {
   __builtin_nontemporal_store(v, dst);
 #endif
 }
+// ... of which the mask array (28 MB, almost all zeros, the same lines every transition) leaves with PLAIN stores since round 4: with
+// the mask wave 15.5 -> 14.3 us per transition at 65 536 envs, 30.2 -> 26.1 at 131 072, 54.8 -> 48.5 at 262 144, 13.9 -> 10.1 per
+// transition of a 16-transition launch; the board array plain as well: 14.6 / 27.4 / 60.3 / 9.8 (profiles/r04/ab_dict_mask_wave.log)
+template <typename V>
+__device__ __forceinline__ void st_dict_mask(V* dst, const V v) {
+#if defined(TG_DICT_MASK_NT) && !defined(TG_DICT_PLAIN)
+  __builtin_nontemporal_store(v, dst);
+#else
+  *dst = v;
+#endif
+}
 
 // state that the NEXT launch reads again (board, records, rings).  TG_STATE_ST: 0 = plain stores (dirty in the XCD's L2
 // until the end-of-kernel write-back), 1 = nontemporal (default: measured -0.45 us per launch with the chunk-major
@@ -470,6 +481,17 @@ constexpr int bits_stream_waves(const int feat) {
   return ((feat & kFeatSplit) && BitsGeo<W, H>::SPLIT_OK && !(feat & (kFeatSample | kFeatFinal | kFeatRgb | kFeatWide)) &&
           (!(feat & kFeatDict) || (BitsGeo<W, H>::DICT_OK && (BitsGeo<W, H>::EPW / 2) % BitsGeo<W, H>::GD == 0))) ? 2 : 1;
 }
+// kFeatMaskWave (round 4, dict instantiations): a THIRD wave per workgroup that does nothing but obs["active_tetromino_mask"]
+// (28 of the 62 MB a dict transition stores at 65 536 envs).  The array needs only the post records — no slab, no lock stamp —
+// so it runs beside the stream wave's board pack from the publish on; in the logic wave, behind the bookkeeping, it was the
+// launch's tail (phase stamps: logic wave 26 000 cycles against the stream wave's 19 300; profiles/r04/ab_dict_mask_wave.log).
+constexpr int kFeatMaskWave = 512;
+template <int W, int H>
+constexpr bool bits_mask_wave(const int feat) {
+  return (feat & kFeatMaskWave) && (feat & kFeatDict) && BitsGeo<W, H>::DICT_OK && !(feat & kFeatSplit);
+}
+template <int W, int H>
+constexpr int bits_wg_waves(const int feat) { return 1 + bits_stream_waves<W, H>(feat) + (bits_mask_wave<W, H>(feat) ? 1 : 0); }
 
 // bytes: 0xFF (active) stays -1, other non-zero → 1  (the functional observation, envs/tetris_fn.py:137-158).  Board cells
 // are 0 or a tetromino value 2..8 (tg_set_state rejects bytes >= 0x80 for this rule-set), so the only byte with its top bit
@@ -688,8 +710,8 @@ __device__ __forceinline__ void dict_mask_group(uint8_t* buf, const uint4* post_
     if (nlive_g > 9999u)
 #endif
     if (c < NCHG && (uint32_t)c / (PC / 16) < nlive_g) {
-      st_dict(reinterpret_cast<u32x4*>(dst0 + 16 * (size_t)c), v[i]);
-      if (dst1) st_dict(reinterpret_cast<u32x4*>(dst1 + 16 * (size_t)c), v[i]);
+      st_dict_mask(reinterpret_cast<u32x4*>(dst0 + 16 * (size_t)c), v[i]);
+      if (dst1) st_dict_mask(reinterpret_cast<u32x4*>(dst1 + 16 * (size_t)c), v[i]);
     }
   }
   wave_sync();
@@ -822,7 +844,7 @@ constexpr int bits_waves_per_simd(const int ruleset, const int feat) {
                                : TG_ONE_WAVES;
 }
 template <int W, int H, int RULESET, int FEAT>
-__global__ __attribute__((amdgpu_flat_work_group_size(64 * (1 + bits_stream_waves<W, H>(FEAT)), 64 * (1 + bits_stream_waves<W, H>(FEAT))),
+__global__ __attribute__((amdgpu_flat_work_group_size(64 * bits_wg_waves<W, H>(FEAT), 64 * bits_wg_waves<W, H>(FEAT)),
                           amdgpu_waves_per_eu(bits_waves_per_simd(RULESET, FEAT), bits_waves_per_simd(RULESET, FEAT))))
 void step_kernel_bits(
     // The arguments every wave needs BEFORE its first global loads, as scalars: the first 14 dwords of the kernel-argument
@@ -942,7 +964,7 @@ void step_kernel_bits(
 #ifdef TG_PHASE_TIMING
     const unsigned long long rng_t0 = TG_NOW();
 #endif
-    if (bits_stream_waves<W, H>(FEAT) > 1 && threadIdx.x >= 128) TG_ROLE_END();  // (a third wave of the workgroup has no RNG range)
+    if (bits_wg_waves<W, H>(FEAT) > 2 && threadIdx.x >= 128) TG_ROLE_END();  // (a third wave of the workgroup has no RNG range)
     const uint32_t e = rng_block * 128u + threadIdx.x;
     const bool on = e < B;
     const uint32_t ee = on ? e : B - 1u;
@@ -1026,6 +1048,35 @@ void step_kernel_bits(
 #endif
   TG_BITS_STAMP(0);
 
+  if constexpr (bits_mask_wave<W, H>(FEAT)) {
+    if (wave == 1 + bits_stream_waves<W, H>(FEAT)) {
+      // =====================================================================================================
+      // MASK WAVE (kFeatMaskWave): obs["active_tetromino_mask"] of the workgroup's envs, GD at a time, from the post records
+      // the logic wave publishes — one barrier per transition, like the stream wave.
+      // =====================================================================================================
+#ifndef TG_MASK_PRIO
+#define TG_MASK_PRIO 1
+#endif
+      __builtin_amdgcn_s_setprio(TG_MASK_PRIO);
+      TG_LATE_ARGS();
+      const size_t Bt = p.act_stride;  // the handle's batch
+      constexpr int GD = BG::GD;
+      uint8_t* grpm = lds + BG::OFF_DICT + GD * BG::PC;  // (zeroed by the logic wave in front of its first publish)
+      for (int step = 0; step < nsteps; ++step) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        uint8_t* d0 = obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs;
+        uint8_t* d1 = (step == nsteps - 1 && obs_traj) ? p.obs : nullptr;
+        for (int g0 = 0; g0 < EPW; g0 += GD) {
+          const uint32_t nlg = nlive > (uint32_t)g0 ? nlive - (uint32_t)g0 : 0u;
+          dict_mask_group<W, H, GD>(grpm, post + (step & 1) * EPW + g0, nlg, lane, d0 + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC,
+                                    d1 ? d1 + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC : nullptr);
+        }
+      }
+      TG_ROLE_END();
+    }
+  }
   // (the stream block out of line: the logic wave's code comes first, straight behind the common prologue)
   if (__builtin_expect(wave >= 1, 0)) {
     // =====================================================================================================
@@ -2426,7 +2477,7 @@ void step_kernel_bits(
                         (step == nsteps - 1 && obs_traj) ? p.obs : nullptr};
     // (storing only the chunks the old / the new bounding box covers — dict_mask_group_incr, TG_BUF_OBS keeps its content — was
     // measured in round 3 and rejected: 18.0 vs 17.1 us, profiles/r03/ab_dict_incremental_mask.log)
-    dict_masks();
+    if constexpr (!bits_mask_wave<W, H>(FEAT)) dict_masks();
     // holder and queue strips change only with a hold, a spawn or a reset: TG_BUF_OBS keeps the strips of the previous
     // transition (tg_reset / tg_observe / tg_set_state re-pack it completely), so only those envs store them; a
     // trajectory slot is fresh memory and gets every env's strips
