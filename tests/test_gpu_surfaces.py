@@ -554,6 +554,20 @@ def test_dict_observation_engine_vs_oracle(W, H, Q, B, monkeypatch):
             o.step(acts[k].astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
         same(f"after fused K={K}")
         e.dev_free(d)
+    # ... and every transition of a rollout WITH the trajectory (the looped instantiation: the mask wave — tg_kernel_bits.h
+    # kFeatMaskWave — writes each transition's mask array into its trajectory slot, the last one also into TG_BUF_OBS)
+    cells, pp = (H + 4) * (W + 8), 16
+    for K in (3, 19):
+        acts = rng.integers(0, 8, (K, B)).astype(np.int8)
+        traj, rew, term, lines = e.rollout(acts)
+        for k in range(K):
+            ro, to, lo = o.step(acts[k].astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+            np.testing.assert_array_equal(rew[k], ro); np.testing.assert_array_equal(term[k], to)
+            ref, flat, off = o.observe(po.OBS_DICT), traj[k], 0
+            for name, n in (("board", cells), ("active_tetromino_mask", cells), ("holder", pp), ("queue", pp * Q)):
+                np.testing.assert_array_equal(flat[off:off + B * n].reshape(ref[name].shape), ref[name], err_msg=f"traj {name} k={k} K={K}")
+                off += B * n
+        same(f"after rollout K={K}")
     e.close()
 
 

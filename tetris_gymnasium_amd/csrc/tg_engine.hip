@@ -99,6 +99,10 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
   // (one transition per launch: 4 096 envs 8.50 -> 6.73 us, 32 768 10.2 -> 8.65, 65 536 17.1 -> 15.6, 131 072 30.7 -> 29.9; launches of 16
   // transitions 13.7 -> 13.9 per transition, and two stream waves beside it only help at 4 096 envs: profiles/r04/ab_dict_mask_wave.log)
   if (g_mask_wave && RS == TG_RULESET_NUMPY && base == tg::kFeatDict) return feat | tg::kFeatMaskWave;
+  // ... and in the instantiation with the transition loop while the launch is bound by its chain, not by bytes: per transition of a
+  // 16-transition launch 6.0 -> 3.7 us at 4 096 envs, 6.6 -> 4.2 at 32 768, 8.0 -> 7.2 at 49 152, but 10.1 -> 10.6 at 65 536
+  if (g_mask_wave && RS == TG_RULESET_NUMPY && base == (M | T | tg::kFeatDict) && (long)((p.batch + epw - 1) / epw) * 4 <= 3L * g_simds)
+    return feat | tg::kFeatMaskWave;
   if (!g_split || !split_ok || RS != TG_RULESET_NUMPY || (feat & tg::kFeatPacked) ||
       !(base == 0 || base == M || base == (M | T) || base == tg::kFeatDict || base == (M | T | tg::kFeatDict))) return feat;
   const int per_simd = tg::bits_waves_per_simd(RS, feat);
@@ -196,6 +200,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
       if constexpr (BG::DICT_OK) {
         constexpr int X = tg::kFeatMaskWave;
         if (feat == (D | X)) { TG_LAUNCH_BITS(D | X); return; }
+        if (feat == (M | T | D | X)) { TG_LAUNCH_BITS(M | T | D | X); return; }
       }
     }
     if constexpr (RS == TG_RULESET_FUNCTIONAL && BG::SPLIT_OK) {
@@ -333,7 +338,7 @@ std::vector<int> rtc_feats(int RS, int W = 0, int H = 0) {
   constexpr int P = tg::kFeatSplit, Wd = tg::kFeatWide, K = tg::kFeatPacked;
   if (RS == TG_RULESET_NUMPY) {
     std::vector<int> v = {0, M, M | T, F, M | T | F, D, M | T | D, T | S, M | T | S, R, M | T | S | R, P, P | M, P | M | T, P | D, P | M | T | D,
-                          D | tg::kFeatMaskWave};
+                          D | tg::kFeatMaskWave, M | T | D | tg::kFeatMaskWave};
     if (W && packed_geometry(W, H))
       for (int f : {K, K | M, K | M | T, K | T | S, K | M | T | S}) v.push_back(f);
     return v;

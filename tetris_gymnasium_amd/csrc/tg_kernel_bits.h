@@ -920,7 +920,10 @@ void step_kernel_bits(
   (void)need_slab; (void)dict; (void)rgb; (void)obs_traj; (void)out_traj; (void)act_traj; (void)final_obs
   uint4* post2 = reinterpret_cast<uint4*>(lds + BG::OFF_RGB);                      // (RGB instantiations only)
   const uint32_t* lut_l = reinterpret_cast<const uint32_t*>(lds + BG::OFF_TAB + 256);  // colour table (RGB)
-  constexpr int ELOG = EPW / 2;  // RGB: the logic wave packs the envs below, the stream wave those from ELOG on
+#ifndef TG_RGB_ELOG
+#define TG_RGB_ELOG (EPW / 2)
+#endif
+  constexpr int ELOG = TG_RGB_ELOG;  // RGB: the logic wave packs the envs below, the stream wave those from ELOG on
   constexpr int WP = W + 8, HP = H + 4, PC = BG::PC;
   // p.nsteps consecutive transitions in this launch (tg_step_k): records / masks / slabs stay in registers and LDS in
   // between, only actions come in and observations go out per transition; one s_barrier per transition, and the
