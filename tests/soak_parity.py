@@ -20,6 +20,9 @@ for W, H, Q, B, grouped, fuse, rs in CASES:
     from tetris_gymnasium_amd import Engine
     numpy_rules = rs == N.RULESET_NUMPY
     obs = N.OBS_BOARD if numpy_rules else N.OBS_FN
+    surf = os.environ.get("SOAK_OBS", "")  # SOAK_OBS=dict / rgb: the NUMPY cases with that observation packed in the step kernel
+    if numpy_rules and not grouped and surf in ("dict", "rgb"):
+        obs = N.OBS_DICT if surf == "dict" else N.OBS_RGB
     e = Engine(B, W, H, ruleset=rs, queue_size=Q, obs_mode=obs, autoreset=N.AUTORESET_SAME_STEP, grouped=grouped)
     o = po.OracleBatch(B, W, H, rs, True, Q)
     seeds = np.arange(11, 11 + B, dtype=np.uint64)
@@ -42,7 +45,12 @@ for W, H, Q, B, grouped, fuse, rs in CASES:
         if numpy_rules:
             for f in ("state_lo", "state_hi", "inc_lo", "inc_hi", "uinteger", "has_uint32"):
                 assert np.array_equal(ge[f], go[f]), f"rng.{f} differs after {done} steps"
-        po_obs = po.OBS_BOARD if numpy_rules else po.OBS_FN
-        assert np.array_equal(e.observation(), o.observe(po_obs)), f"observation differs after {done} steps"
-    print(f"ok  {W}x{H} Q={Q} B={B} grouped={grouped} fuse={fuse} ruleset={rs}: {STEPS} transitions per env")
+        po_obs = {N.OBS_BOARD: po.OBS_BOARD, N.OBS_FN: po.OBS_FN, N.OBS_DICT: po.OBS_DICT, N.OBS_RGB: po.OBS_RGB}[obs]
+        got, ref = e.observation(), o.observe(po_obs)
+        if isinstance(got, dict):
+            for kk in got:
+                assert np.array_equal(got[kk], ref[kk]), f"observation[{kk}] differs after {done} steps"
+        else:
+            assert np.array_equal(got, ref), f"observation differs after {done} steps"
+    print(f"ok  {W}x{H} Q={Q} B={B} grouped={grouped} fuse={fuse} ruleset={rs} obs={obs}: {STEPS} transitions per env  [{e.step_kernel_name(fuse, grouped)}]")
     e.close()

@@ -17,7 +17,7 @@ N.LIB_PATH = out
 from tetris_gymnasium_amd import Engine
 B = 65536
 fn = os.environ.get('TL_RULESET', 'numpy') == 'functional'  # TL_RULESET=functional: the functional rule-set's launch
-e = Engine(B, ruleset=(N.RULESET_FUNCTIONAL if fn else N.RULESET_NUMPY), obs_mode=(N.OBS_FN if fn else N.OBS_BOARD), autoreset=N.AUTORESET_SAME_STEP)
+e = Engine(B, ruleset=(N.RULESET_FUNCTIONAL if fn else N.RULESET_NUMPY), obs_mode=(N.OBS_FN if fn else {'board': N.OBS_BOARD, 'dict': N.OBS_DICT, 'rgb': N.OBS_RGB}[os.environ.get('TL_OBS', 'board')]), autoreset=N.AUTORESET_SAME_STEP)  # TL_OBS=dict / rgb
 e.reset(np.arange(1, B + 1, dtype=np.uint64))
 acts = np.random.default_rng(0).integers(0, 7 if fn else 8, (80, B)).astype(np.int8)
 d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts)
