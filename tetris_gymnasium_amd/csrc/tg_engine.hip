@@ -106,7 +106,10 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
   if (!g_split || !split_ok || RS != TG_RULESET_NUMPY || (feat & tg::kFeatPacked) ||
       !(base == 0 || base == M || base == (M | T) || base == tg::kFeatDict || base == (M | T | tg::kFeatDict))) return feat;
   const int per_simd = tg::bits_waves_per_simd(RS, feat);
-  const long cap = (long)(g_simds / 4) * (4 * per_simd / 3);
+#ifndef TG_SPLIT_CAP_EXTRA  // (A/B knob: workgroups beyond residency that still take the two-stream-wave build)
+#define TG_SPLIT_CAP_EXTRA 0
+#endif
+  const long cap = (long)(g_simds / 4) * (4 * per_simd / 3) + TG_SPLIT_CAP_EXTRA;
   const long wgs = (p.batch + epw - 1) / epw + rng_blocks(p, RS);
   return wgs <= cap ? (feat | tg::kFeatSplit) : feat;
 }
