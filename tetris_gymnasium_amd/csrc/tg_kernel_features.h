@@ -114,12 +114,17 @@ __global__ __launch_bounds__(kBlock) void features_kernel(const FeatureParams p)
   const M FLOOR = (M)(M(1) << H);
 
   const int n_half = s.piece == 0 ? 2 : 1;  // matrix.shape[1] // 2
-  for (int a0 = 0; a0 < NA; a0 += 64) {
+  // One pass over the lanes: lane a < 4W does placement a; the CURRENT observation (board + projected piece, rows 0 and 1
+  // wiped: the wrapper's uint8 mask with ones acts as integer row indices) rides along as lane 4W of the same instruction
+  // stream — as a pass of its own on one lane it cost the wave as much as all the placements together (round 4).
+  const bool want_cur = p.feats != nullptr;
+  for (int a0 = 0; a0 < NA + 1; a0 += 64) {
     const int a = a0 + lane;
-    if (a < NA) {
+    const bool is_cur = want_cur && a == NA;
+    if (a < NA || is_cur) {
       uint8_t* out = ft + a * NF;
-      const int colbase = a >> 2, nrot = (s.rot + (a & 3)) & 3;
-      const int x = colbase + 4 - n_half;
+      const int nrot = is_cur ? s.rot : (s.rot + (a & 3)) & 3;
+      const int x = is_cur ? s.x : (a >> 2) + 4 - n_half;
       const uint32_t cells = (uint32_t)(c_cells.cells[s.piece] >> (16 * nrot)) & 0xFFFFu;
       int kk[4], cc[4];
       bool legal = true;
@@ -129,45 +134,66 @@ __global__ __launch_bounds__(kBlock) void features_kernel(const FeatureParams p)
         cc[j] = x + (int)((cells >> (4 * j)) & 3) - 4;
         legal = legal && (unsigned)cc[j] < (unsigned)W;
       }
-      if (!legal) {  // np.ones_like(board_obs) → every column full below the wiped row 0
+      if (!is_cur && !legal) {  // np.ones_like(board_obs) → every column full below the wiped row 0
 #pragma unroll 1
         for (int c = 0; c < W; ++c) out[c] = (uint8_t)(H - 1);
         out[W] = (uint8_t)(H - 1);
         out[W + 1] = 0;
         out[W + 2] = 0;
       } else {
-        // hard drop from y = 0: first y' >= 1 where a cell is blocked (filled cell or floor), minus one
-        int yfirst = 1 << 20;
         M colm[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          colm[j] = cm[cc[j]];
-          const M m = (M)((colm[j] | FLOOR) >> (1 + kk[j]));  // rows >= 1 + k_j
-          const int yj = m_ctz(m) + 1;                        // y' at which cell j first hits
-          yfirst = yj < yfirst ? yj : yfirst;
-        }
-        const int y = yfirst - 1;
-        bool over = false;  // collides where it lands (only possible at y = 0): "game over placement" → zero board
+        for (int j = 0; j < 4; ++j) colm[j] = cm[(unsigned)cc[j] < (unsigned)W ? cc[j] : 0];
+        int y, wipe = 1;
+        bool draw = true, zero = false;
+        M F = 0;
+        if (is_cur) {
+          // the piece where it is; not drawn when it collides (out of the frame or on a filled cell)
+          y = s.y;
+          bool coll = !legal;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) over = over || ((colm[j] >> (y + kk[j])) & 1);
-        if (over) {
+          for (int j = 0; j < 4; ++j) {
+            const int r = y + kk[j];
+            coll = coll || r >= H || ((colm[j] >> (r < H ? r : 0)) & 1);
+          }
+          draw = !coll;
+          // bounding box of the native matrix clipped to the padded board: any cell inside ⇒ the mask holds a 1
+          const int n = s.piece == 0 ? 4 : (s.piece == 1 ? 2 : 3);
+          wipe = (s.y < H + 4 && s.x < W + 8 && n > 0) ? 2 : 1;
+        } else {
+          // hard drop from y = 0: first y' >= 1 where a cell is blocked (filled cell or floor), minus one
+          int yfirst = 1 << 20;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const M m = (M)((colm[j] | FLOOR) >> (1 + kk[j]));  // rows >= 1 + k_j
+            const int yj = m_ctz(m) + 1;                        // y' at which cell j first hits
+            yfirst = yj < yfirst ? yj : yfirst;
+          }
+          y = yfirst - 1;
+          // collides where it lands (only possible at y = 0): "game over placement" → zero board
+#pragma unroll
+          for (int j = 0; j < 4; ++j) zero = zero || ((colm[j] >> (y + kk[j])) & 1);
+          if (!zero) {  // completed rows among the rows the piece touches
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int rj = y + kk[j];
+              uint32_t add = 0;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) add |= (y + kk[i] == rj) ? (1u << cc[i]) : 0u;
+              if (((rm[rj] | add) & FULL) == FULL) F |= (M)(M(1) << rj);
+            }
+          }
+        }
+        if (zero) {
 #pragma unroll 1
           for (int c = 0; c < NF; ++c) out[c] = 0;
         } else {
-          // completed rows among the rows the piece touches
-          M F = 0;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int rj = y + kk[j];
-            uint32_t add = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) add |= (y + kk[i] == rj) ? (1u << cc[i]) : 0u;
-            if (((rm[rj] | add) & FULL) == FULL) F |= (M)(M(1) << rj);
-          }
           auto col = [&](int c) -> M {
             M m = cm[c];
+            if (draw) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) m |= (cc[j] == c) ? (M)(M(1) << (y + kk[j])) : (M)0;
+              for (int j = 0; j < 4; ++j) m |= (cc[j] == c) ? (M)(M(1) << (y + kk[j])) : (M)0;
+            }
             M f = F;
             while (f) {  // remove cleared rows top to bottom: rows above move down by one (envs/tetris.py:498-510)
               const int r = m_ctz(f);
@@ -177,42 +203,17 @@ __global__ __launch_bounds__(kBlock) void features_kernel(const FeatureParams p)
             }
             return m;
           };
-          column_features<W, H, M>(col, 1, out);
+          column_features<W, H, M>(col, wipe, out);
         }
       }
     }
   }
-  // current observation: board + projected piece, rows 0 and 1 wiped (uint8 mask with ones → integer row indices)
-  if (lane == 0 && p.feats) {
-    uint8_t* out = ft + NA * NF;
-    const uint32_t cells = (uint32_t)(c_cells.cells[s.piece] >> (16 * s.rot)) & 0xFFFFu;
-    int kk[4], cc[4];
-    bool coll = false;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      kk[j] = (cells >> (4 * j + 2)) & 3;
-      cc[j] = s.x + (int)((cells >> (4 * j)) & 3) - 4;
-      const int r = s.y + kk[j];
-      coll = coll || !((unsigned)cc[j] < (unsigned)W && r < H) || ((cm[(unsigned)cc[j] < (unsigned)W ? cc[j] : 0] >> r) & 1);
-    }
-    // bounding box of the native matrix clipped to the padded board: any cell inside ⇒ the mask holds a 1
-    const int n = s.piece == 0 ? 4 : (s.piece == 1 ? 2 : 3);
-    const bool mask_any = s.y < H + 4 && s.x < W + 8 && n > 0;
-    auto col = [&](int c) -> M {
-      M m = cm[c];
-      if (!coll) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) m |= (cc[j] == c) ? (M)(M(1) << (s.y + kk[j])) : (M)0;
-      }
-      return m;
-    };
-    column_features<W, H, M>(col, mask_any ? 2 : 1, out);
-  }
   wave_sync();
-  // staged features → HBM, coalesced
+  // staged features → HBM, coalesced dwords (4W (W + 3) bytes per env: a whole number of dwords, dword-aligned)
   if (p.placement_feats) {
-    uint8_t* dst = p.placement_feats + (size_t)env * NA * NF;
-    for (int i = lane; i < NA * NF; i += 64) dst[i] = ft[i];
+    uint32_t* dst = reinterpret_cast<uint32_t*>(p.placement_feats + (size_t)env * NA * NF);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(ft);
+    for (int i = lane; i < NA * NF / 4; i += 64) dst[i] = src[i];
   }
   if (p.feats && lane < NF) p.feats[(size_t)env * NF + lane] = ft[NA * NF + lane];
 }
