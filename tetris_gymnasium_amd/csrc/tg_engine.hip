@@ -88,10 +88,10 @@ uint32_t bits_hot_misc(const tg::KParams& p, const int RS, const int n_step_wgs)
 }
 
 // which instantiation of the bits kernel a launch with these parameters uses (FEAT flags, tg_kernel_bits.h)
-int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw);
+int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw, const bool split_ok);
 int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw, const bool split_ok) {
   constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj;
-  const int feat = bits_feat_base(p, RS, dict_ok, rgb_ok, epw);
+  const int feat = bits_feat_base(p, RS, dict_ok, rgb_ok, epw, split_ok);
   // two stream waves per workgroup (kFeatSplit) while all workgroups of the launch — the RNG role's included — are resident
   // with three waves each at the occupancy the instantiation is compiled for
   const int base = feat & ~tg::kFeatWide;
@@ -113,7 +113,7 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
   const long wgs = (p.batch + epw - 1) / epw + rng_blocks(p, RS);
   return wgs <= cap ? (feat | tg::kFeatSplit) : feat;
 }
-int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw) {
+int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw, const bool split_ok) {
   constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
   // FUNCTIONAL, plain launches: when every workgroup of the launch is resident at 2 waves per SIMD anyway, the instantiation
   // compiled for that occupancy (256 VGPRs instead of 128) is the shorter instruction stream (8.4 -> 8.0 us at 65 536 envs;
@@ -127,11 +127,11 @@ int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const
     const bool trj = p.obs_traj || p.out_traj || p.act_traj;
     return (trj ? (M | T) : (p.nsteps > 1 ? M : 0)) | tg::kFeatPacked;
   }
-  if (RS == TG_RULESET_FUNCTIONAL && g_split && !p.final_obs && epw == 64 && (long)(p.batch + epw - 1) / epw <= (long)(TG_FN_SPLIT_CAP)) {
+  if (RS == TG_RULESET_FUNCTIONAL && g_split && !p.final_obs && split_ok && (long)(p.batch + epw - 1) / epw <= (long)(TG_FN_SPLIT_CAP)) {
     const bool trj = p.obs_traj || p.out_traj || p.act_traj;
     return (trj ? (M | T) : (p.nsteps > 1 ? M : 0)) | tg::kFeatSplit;
   }
-  if (RS == TG_RULESET_FUNCTIONAL && g_wide && !p.final_obs && !(p.obs_traj || p.out_traj || p.act_traj) &&
+  if (RS == TG_RULESET_FUNCTIONAL && g_wide && !p.final_obs && !(p.obs_traj || p.out_traj || p.act_traj) && split_ok &&
       (p.batch + epw - 1) / epw * 2 <= 2 * g_simds)
     return (p.nsteps > 1 ? M : 0) | tg::kFeatWide;
   const bool dict = p.obs_mode == TG_OBS_DICT && p.dict_in_kernel && dict_ok;
@@ -316,7 +316,7 @@ struct RtcSize {
   std::map<int, hipFunction_t> step;  // by FEAT
   hipFunction_t reset = nullptr, observe = nullptr, prepare = nullptr, features = nullptr, placements = nullptr;
   int W = 0, H = 0, RS = 0;
-  int geo[12] = {};  // EPW, BYTES, BYTES_DICT, BYTES_RGB, BYTES_FIN, BYTES_FNX, DICT_OK, RGB_OK, cols_bytes, placements lds
+  int geo[12] = {};  // EPW, BYTES, BYTES_DICT, BYTES_RGB, BYTES_FIN, BYTES_FNX, DICT_OK, RGB_OK, cols_bytes, placements lds, NSW0, SPLIT_OK
 };
 std::mutex g_rtc_mu;
 std::map<std::string, RtcSize*> g_rtc;  // "dev:W:H:RS" → module (lives as long as the process)
@@ -333,7 +333,7 @@ std::string csrc_dir() {
 }
 
 bool packed_geometry(int W, int H) {  // (tg::bits_packed for a size known at run time)
-  const int S = W * H, epw = S <= 320 ? 64 : (S <= 640 ? 32 : 16);
+  const int S = W * H, epw = tg::bits_epw(W, H);
   return S % 2 == 0 && (epw * S) % 32 == 0;
 }
 std::vector<int> rtc_feats(int RS, int W = 0, int H = 0) {
@@ -386,7 +386,7 @@ std::string rtc_build(int device, int W, int H, int RS, RtcSize** out) {
            "typedef tg::BitsGeo<%d, %d> TgBG;\n"
            "extern \"C\" __constant__ int tg_rtc_geo[12] = {TgBG::EPW, TgBG::BYTES, TgBG::BYTES_DICT, TgBG::BYTES_RGB, TgBG::BYTES_FIN, "
            "TgBG::BYTES_FNX, TgBG::DICT_OK ? 1 : 0, TgBG::RGB_OK ? 1 : 0, (int)tg::bits_cols_bytes<%d, %d>(), "
-           "(int)tg::placements_lds_bytes<%d, %d>(), 0, 0};\n", W, H, W, H, W, H);
+           "(int)tg::placements_lds_bytes<%d, %d>(), TgBG::NSW0, TgBG::SPLIT_OK ? 1 : 0};\n", W, H, W, H, W, H);
   const std::string src = srcb;
   const std::vector<std::string> optv = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + dir, "-mllvm", "-amdgpu-kernarg-preload-count=16",
                                          "-mllvm", "-amdgpu-sched-strategy=max-ilp"};
@@ -519,7 +519,7 @@ Launchers rtc_launchers(const RtcSize* r) {
     tg::BitsParams bp{p.cols, p.ahead, ring4 + (size_t)p.ring_cur * p.ring_stride, const_cast<uint4*>(ring4) + (size_t)(1 - p.ring_cur) * p.ring_stride,
                       p.hbuf + hrd, p.hbuf + hwr, p.inl, nrb, p.ring_fill};
     const int n_step_wgs = (p.batch + EPW - 1) / EPW;
-    const bool split_ok = EPW == 64 && (32 * W * H) % 16 == 0;  // (BitsGeo::SPLIT_OK)
+    const bool split_ok = r->geo[11] != 0;  // (BitsGeo::SPLIT_OK)
     const int feat = bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, split_ok);
     const size_t lds = RS == TG_RULESET_FUNCTIONAL ? r->geo[5]
                        : ((feat & D) ? r->geo[2] + ((feat & tg::kFeatSplit) ? 16 * (W + 8) * (H + 4) : 0)  // (BYTES_DICT_SPLIT: + GD * PC)
@@ -532,10 +532,10 @@ Launchers rtc_launchers(const RtcSize* r) {
     tg::KParams kp = p;
     void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &kp, &bp};
     // (threads per workgroup: tg::bits_stream_waves of this size and instantiation)
-    (void)hipModuleLaunchKernel(it->second, (unsigned)(nrb + n_step_wgs), 1, 1, 128 + ((feat & tg::kFeatSplit) ? 64 : 0) + ((feat & tg::kFeatMaskWave) ? 64 : 0), 1, 1, (unsigned)lds, s, args, nullptr);
+    (void)hipModuleLaunchKernel(it->second, (unsigned)(nrb + n_step_wgs), 1, 1, 64 * (1 + r->geo[10] * ((feat & tg::kFeatSplit) ? 2 : 1) + ((feat & tg::kFeatMaskWave) ? 1 : 0)), 1, 1, (unsigned)lds, s, args, nullptr);
   };
   L.step_name = [=](const tg::KParams& p, char* buf, size_t n) {
-    snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, EPW == 64 && (32 * W * H) % 16 == 0));
+    snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, r->geo[11] != 0));
   };
   L.reset = [=](const tg::ResetParams& p, hipStream_t s) { rtc_launch(r->reset, dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p); };
   L.observe = [=](const tg::ObserveParams& p, hipStream_t s) {

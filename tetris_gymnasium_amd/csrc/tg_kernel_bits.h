@@ -108,13 +108,45 @@ constexpr int bits_cols_words() { return sizeof(ColT<H>) == 4 ? W + (W & 1) : W;
 template <int W, int H>
 constexpr size_t bits_cols_bytes() { return (size_t)bits_cols_words<W, H>() * sizeof(ColT<H>); }
 
-// dynamic LDS of one wave of step_kernel_bits.  EPW envs per wave (one per lane; on large boards fewer than 64 so that
-// the wave's slab block still fits the staging registers — the idle lanes only help streaming the slabs)
+// Envs per workgroup.  ONE STREAM WAVE carries at most EPS0 envs — its slab block has to fit the staging registers: 64 envs up
+// to 320 cells, 32 up to 640, 16 above — and by default a workgroup has one stream wave, so the LOGIC wave of a large board runs
+// with idle lanes.  A logic wave with idle lanes costs the SIMD as many issue slots as a full one: a 10x20 launch at the byte
+// volume of config 5 (52 Mi cells) takes 22.4 / 26.0 / 36.1 us with 64 / 32 / 16 envs per workgroup (-DTG_EPW_OVERRIDE).
+// -DTG_NSW0 (A/B, measured and NOT adopted) gives boards above 320 cells twice the envs per workgroup and TWO stream waves
+// (the two-stream-wave layout of kFeatSplit in every instantiation): config 5 21.9 -> 21.2 us only, and the dict / RGB staging
+// buffers no longer fit beside the slabs (those surfaces would go back to the observe kernel at 20x40).
+// profiles/r04/ab_envs_per_workgroup.log
+constexpr int bits_eps0(const int W, const int H) { return W * H <= 320 ? 64 : (W * H <= 640 ? 32 : 16); }
+constexpr int bits_lds_bytes_max(const int W, const int H, const int epw) {  // (BitsGeo::BYTES_FNX, the largest plain layout)
+  const int slabs = ((epw * W * H + 15) / 16) * 16, cst = (W + 2) | 1, tsz = (H + 6 <= 32) ? 4 : 8;
+  return ((slabs + 320 + 2 * epw * 16 + epw * cst * tsz + 15) / 16) * 16 + 2 * epw * 8 + 128 * 12;
+}
+constexpr int bits_epw(const int W, const int H) {
+#ifdef TG_EPW_OVERRIDE  // (A/B only: what fewer envs per workgroup — logic waves with idle lanes — cost at a given byte volume)
+  return TG_EPW_OVERRIDE;
+#else
+  const int e0 = bits_eps0(W, H);
+#ifdef TG_NSW0
+  return (e0 < 64 && bits_lds_bytes_max(W, H, 2 * e0) <= 65536) ? 2 * e0 : e0;
+#else
+  return e0;
+#endif
+#endif
+}
+constexpr int bits_nsw0(const int W, const int H) {  // stream waves a workgroup of this board size has at least
+#ifdef TG_EPW_OVERRIDE
+  return 1;
+#else
+  return bits_epw(W, H) / bits_eps0(W, H);
+#endif
+}
+// dynamic LDS of one workgroup of step_kernel_bits
 template <int W, int H>
 struct BitsGeo {
   using T = ColT<H>;
   static constexpr int S = W * H;
-  static constexpr int EPW = S <= 320 ? 64 : (S <= 640 ? 32 : 16);
+  static constexpr int EPW = bits_epw(W, H);
+  static constexpr int NSW0 = bits_nsw0(W, H);
   static constexpr int SLABS = ((EPW * S + 15) / 16) * 16;
   static constexpr int NCH = SLABS / 16;
   static constexpr int NIT = (NCH + 63) / 64;
@@ -132,7 +164,7 @@ struct BitsGeo {
   static constexpr int BYTES_DICT = OFF_OLDPW + EPW * 4;
   static constexpr int OFF_DICT2 = BYTES_DICT;             // (kFeatSplit: the second stream wave's board staging buffer)
   static constexpr int BYTES_DICT_SPLIT = BYTES_DICT + GD * PC;
-  static constexpr bool DICT_OK = PC % 16 == 0 && EPW % GD == 0 && H % 2 == 0 && W % 2 == 0;  // (row pairs as whole dwords)
+  static constexpr bool DICT_OK = NSW0 == 1 && PC % 16 == 0 && EPW % GD == 0 && H % 2 == 0 && W % 2 == 0;  // (row pairs as whole dwords)
   // TG_OBS_RGB packed in the kernel (queue_size 4): uint4 post2[EPW] {queue bytes | holder} published by the logic wave,
   // then one id-image staging buffer of GR envs per wave.  Image row = padded board row | 4 queue pieces x 4 columns.
   static constexpr int RS = W + 8 + 16;
@@ -141,7 +173,7 @@ struct BitsGeo {
   static constexpr int GR = 4;
   static constexpr int OFF_RGB = BYTES;
   static constexpr int BYTES_RGB = BYTES + EPW * 16 + 2 * GR * IDB;
-  static constexpr bool RGB_OK = NPX % 4 == 0 && H % 2 == 0 && W % 2 == 0 && (EPW / 2) % GR == 0;
+  static constexpr bool RGB_OK = NSW0 == 1 && NPX % 4 == 0 && H % 2 == 0 && W % 2 == 0 && (EPW / 2) % GR == 0;
   // TG_FLAG_FINAL_OBS (observation BOARD / FN only, never together with the dict staging): uint2 [2][EPW] behind BYTES —
   // the terminal piece of every env that ends its episode in this transition
   static constexpr int OFF_FIN = BYTES;
@@ -150,10 +182,14 @@ struct BitsGeo {
   // key-chain look-ahead — uint2 keys [128] | uint32 permutations [128] — behind the FINAL_OBS records
   static constexpr int OFF_FNX = BYTES_FIN;
   static constexpr int BYTES_FNX = BYTES_FIN + 128 * 8 + 128 * 4;
+#ifndef TG_EPW_OVERRIDE
+  static_assert(BYTES_FNX == bits_lds_bytes_max(W, H, EPW), "bits_lds_bytes_max restates this layout");
+  static_assert(NSW0 == 1 || BYTES_FNX <= 65536, "two stream waves' worth of envs only while the workgroup's LDS stays within 64 KiB");
+#endif
   static constexpr int WC = bits_cols_words<W, H>();  // column-mask words per env in HBM
   // two stream waves per workgroup (each owns half of the envs and their slabs: no exchange between them) when the halves
   // are whole 16-byte chunks
-  static constexpr bool SPLIT_OK = EPW == 64 && ((EPW / 2) * S) % 16 == 0;
+  static constexpr bool SPLIT_OK = NSW0 == 1 && EPW == 64 && ((EPW / 2) * S) % 16 == 0;
 };
 
 
@@ -478,6 +514,7 @@ __device__ __forceinline__ u32x4 nib_pack(const u32x4 a, const u32x4 b) {
 }
 template <int W, int H>
 constexpr int bits_stream_waves(const int feat) {
+  if (BitsGeo<W, H>::NSW0 > 1) return BitsGeo<W, H>::NSW0;  // (boards above 320 cells: every instantiation)
   return ((feat & kFeatSplit) && BitsGeo<W, H>::SPLIT_OK && !(feat & (kFeatSample | kFeatFinal | kFeatRgb | kFeatWide)) &&
           (!(feat & kFeatDict) || (BitsGeo<W, H>::DICT_OK && (BitsGeo<W, H>::EPW / 2) % BitsGeo<W, H>::GD == 0))) ? 2 : 1;
 }
@@ -1237,7 +1274,7 @@ void step_kernel_bits(
       if (FINAL && final_obs) {
         // TG_FLAG_FINAL_OBS: the slab still holds the terminal board of an env that ends its episode here — draw the
         // terminal piece (if the reference would project it), let the env's lane copy it out, un-draw
-        const u32x2 pf = postF[(step & 1) * EPW + slot];
+        const u32x2 pf = postF[(step & 1) * EPW_WG + (int)sbase + slot];  // (the workgroup's array: this wave's envs start at sbase)
         const bool fin = do_reset && ((pf.x >> 25) & 1u);
         if (__any(fin)) {
           const bool showf = fin && ((pf.x >> 24) & 1u);
