@@ -99,6 +99,14 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
   // (one transition per launch: 4 096 envs 8.50 -> 6.73 us, 32 768 10.2 -> 8.65, 65 536 17.1 -> 15.6, 131 072 30.7 -> 29.9; launches of 16
   // transitions 13.7 -> 13.9 per transition, and two stream waves beside it only help at 4 096 envs: profiles/r04/ab_dict_mask_wave.log)
   if (g_mask_wave && RS == TG_RULESET_NUMPY && base == tg::kFeatDict) return feat | tg::kFeatMaskWave;
+  // RGB, one transition per launch: two helper waves (the images by quarters).  Up to ~32 768 envs the launch is the chain of its packing
+  // waves: 18.6 -> 12.6 us at 1 024 / 4 096 envs, 20.0 -> 14.2 at 16 384, 23.4 -> 18.4 at 32 768; 31.2 -> 30.8 at 65 536, 47.4 -> 49.0 at
+  // 98 304, 86.6 -> 70.3 at 131 072 (profiles/r04/ab_rgb_helper_waves.log)
+#ifndef TG_RGB_HELPER_CAP  // (A/B knob: step workgroups up to which the helper waves are used)
+#define TG_RGB_HELPER_CAP (1 << 30)
+#endif
+  if (g_mask_wave && RS == TG_RULESET_NUMPY && base == tg::kFeatRgb && epw == 64 && (long)((p.batch + epw - 1) / epw) <= (long)(TG_RGB_HELPER_CAP))
+    return feat | tg::kFeatMaskWave;
   // ... and in the instantiation with the transition loop while the launch is bound by its chain, not by bytes: per transition of a
   // 16-transition launch 6.0 -> 3.7 us at 4 096 envs, 6.6 -> 4.2 at 32 768, 8.0 -> 7.2 at 49 152, but 10.1 -> 10.6 at 65 536
   if (g_mask_wave && RS == TG_RULESET_NUMPY && base == (M | T | tg::kFeatDict) && (long)((p.batch + epw - 1) / epw) * 4 <= 3L * g_simds)
@@ -176,7 +184,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     const int feat = bits_feat<W, H, RS>(p);
     const size_t lds = RS == TG_RULESET_FUNCTIONAL ? BG::BYTES_FNX
                        : ((feat & D) ? ((feat & tg::kFeatSplit) ? BG::BYTES_DICT_SPLIT : BG::BYTES_DICT)
-                                     : ((feat & R) ? BG::BYTES_RGB : ((feat & F) ? BG::BYTES_FIN : BG::BYTES)));
+                                     : ((feat & R) ? ((feat & tg::kFeatMaskWave) ? BG::BYTES_RGB_X : BG::BYTES_RGB) : ((feat & F) ? BG::BYTES_FIN : BG::BYTES)));
 #define TG_LAUNCH_BITS(FT)                                                                                                  \
   hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(64 * tg::bits_wg_waves<W, H>(FT)), lds, s, (p.pboard ? p.pboard : p.board), p.rec, p.cols, bp.ring_rd, bp.hbuf_rd, \
                      p.actions, p.batch, bits_hot_misc(p, RS, n_step_wgs), \
@@ -195,6 +203,9 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     }
     if constexpr (RS == TG_RULESET_NUMPY) {
       if (feat == R) { TG_LAUNCH_BITS(R); return; }
+      if constexpr (tg::bits_rgb_helpers<W, H>(R | tg::kFeatMaskWave)) {
+        if (feat == (R | tg::kFeatMaskWave)) { TG_LAUNCH_BITS(R | tg::kFeatMaskWave); return; }
+      }
       if (feat == (M | T | S | R)) { TG_LAUNCH_BITS(M | T | S | R); return; }
       if (feat == (M | T | S)) { TG_LAUNCH_BITS(M | T | S); return; }
       if (feat == (T | S)) { TG_LAUNCH_BITS(T | S); return; }
@@ -341,7 +352,7 @@ std::vector<int> rtc_feats(int RS, int W = 0, int H = 0) {
   constexpr int P = tg::kFeatSplit, Wd = tg::kFeatWide, K = tg::kFeatPacked;
   if (RS == TG_RULESET_NUMPY) {
     std::vector<int> v = {0, M, M | T, F, M | T | F, D, M | T | D, T | S, M | T | S, R, M | T | S | R, P, P | M, P | M | T, P | D, P | M | T | D,
-                          D | tg::kFeatMaskWave, M | T | D | tg::kFeatMaskWave};
+                          D | tg::kFeatMaskWave, M | T | D | tg::kFeatMaskWave, R | tg::kFeatMaskWave};
     if (W && packed_geometry(W, H))
       for (int f : {K, K | M, K | M | T, K | T | S, K | M | T | S}) v.push_back(f);
     return v;
@@ -523,7 +534,8 @@ Launchers rtc_launchers(const RtcSize* r) {
     const int feat = bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, split_ok);
     const size_t lds = RS == TG_RULESET_FUNCTIONAL ? r->geo[5]
                        : ((feat & D) ? r->geo[2] + ((feat & tg::kFeatSplit) ? 16 * (W + 8) * (H + 4) : 0)  // (BYTES_DICT_SPLIT: + GD * PC)
-                                     : ((feat & R) ? r->geo[3] : ((feat & F) ? r->geo[4] : r->geo[1])));
+                                     : ((feat & R) ? r->geo[3] + ((feat & tg::kFeatMaskWave) ? 2 * 4 * ((((H + 4) * (W + 24)) + 15) / 16 * 16) : 0)  // (BYTES_RGB_X: + 2 GR IDB)
+                                                   : ((feat & F) ? r->geo[4] : r->geo[1])));
     auto it = r->step.find(feat);
     if (it == r->step.end()) return;
     uint8_t* a0 = p.pboard ? p.pboard : p.board; uint32_t* a1 = p.rec; void* a2 = p.cols; const uint4* a3 = bp.ring_rd; const uint32_t* a4 = bp.hbuf_rd;
@@ -532,7 +544,7 @@ Launchers rtc_launchers(const RtcSize* r) {
     tg::KParams kp = p;
     void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &kp, &bp};
     // (threads per workgroup: tg::bits_stream_waves of this size and instantiation)
-    (void)hipModuleLaunchKernel(it->second, (unsigned)(nrb + n_step_wgs), 1, 1, 64 * (1 + r->geo[10] * ((feat & tg::kFeatSplit) ? 2 : 1) + ((feat & tg::kFeatMaskWave) ? 1 : 0)), 1, 1, (unsigned)lds, s, args, nullptr);
+    (void)hipModuleLaunchKernel(it->second, (unsigned)(nrb + n_step_wgs), 1, 1, 64 * (1 + r->geo[10] * ((feat & tg::kFeatSplit) ? 2 : 1) + ((feat & tg::kFeatMaskWave) ? ((feat & R) ? 2 : 1) : 0)), 1, 1, (unsigned)lds, s, args, nullptr);
   };
   L.step_name = [=](const tg::KParams& p, char* buf, size_t n) {
     snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, r->geo[11] != 0));

@@ -173,6 +173,7 @@ struct BitsGeo {
   static constexpr int GR = 4;
   static constexpr int OFF_RGB = BYTES;
   static constexpr int BYTES_RGB = BYTES + EPW * 16 + 2 * GR * IDB;
+  static constexpr int BYTES_RGB_X = BYTES_RGB + 2 * GR * IDB;  // (kFeatMaskWave with kFeatRgb: two helper waves with a staging buffer each)
   static constexpr bool RGB_OK = NSW0 == 1 && NPX % 4 == 0 && H % 2 == 0 && W % 2 == 0 && (EPW / 2) % GR == 0;
   // TG_FLAG_FINAL_OBS (observation BOARD / FN only, never together with the dict staging): uint2 [2][EPW] behind BYTES —
   // the terminal piece of every env that ends its episode in this transition
@@ -527,8 +528,18 @@ template <int W, int H>
 constexpr bool bits_mask_wave(const int feat) {
   return (feat & kFeatMaskWave) && (feat & kFeatDict) && BitsGeo<W, H>::DICT_OK && !(feat & kFeatSplit);
 }
+// ... and with kFeatRgb the same bit gives the one-transition RGB instantiation TWO helper waves: the logic wave, the stream wave and
+// the helpers pack a quarter of the workgroup's images each.  Below ~32 768 envs the RgbObservation launch is the chain of its packing
+// waves (18.6 us at 4 096 envs, of which 16 are two waves packing 32 images each): profiles/r04/ab_rgb_helper_waves.log.
 template <int W, int H>
-constexpr int bits_wg_waves(const int feat) { return 1 + bits_stream_waves<W, H>(feat) + (bits_mask_wave<W, H>(feat) ? 1 : 0); }
+constexpr bool bits_rgb_helpers(const int feat) {
+  return (feat & kFeatMaskWave) && (feat & kFeatRgb) && BitsGeo<W, H>::RGB_OK && (BitsGeo<W, H>::EPW / 4) % BitsGeo<W, H>::GR == 0 &&
+         !(feat & kFeatSplit);
+}
+template <int W, int H>
+constexpr int bits_wg_waves(const int feat) {
+  return 1 + bits_stream_waves<W, H>(feat) + (bits_mask_wave<W, H>(feat) ? 1 : 0) + (bits_rgb_helpers<W, H>(feat) ? 2 : 0);
+}
 
 // bytes: 0xFF (active) stays -1, other non-zero → 1  (the functional observation, envs/tetris_fn.py:137-158).  Board cells
 // are 0 or a tetromino value 2..8 (tg_set_state rejects bytes >= 0x80 for this rule-set), so the only byte with its top bit
@@ -960,7 +971,9 @@ void step_kernel_bits(
 #ifndef TG_RGB_ELOG
 #define TG_RGB_ELOG (EPW / 2)
 #endif
-  constexpr int ELOG = TG_RGB_ELOG;  // RGB: the logic wave packs the envs below, the stream wave those from ELOG on
+  constexpr bool RGBX = bits_rgb_helpers<W, H>(FEAT);  // RGB with two helper waves: quarters instead of halves
+  constexpr int ELOG = RGBX ? EPW / 4 : TG_RGB_ELOG;  // RGB: the logic wave packs the envs below, the stream wave those from ELOG on
+  constexpr int ESTR = RGBX ? EPW / 2 : EPW;          // ... up to here; the helper waves [ESTR, 3 EPW / 4) and [3 EPW / 4, EPW)
   constexpr int WP = W + 8, HP = H + 4, PC = BG::PC;
   // p.nsteps consecutive transitions in this launch (tg_step_k): records / masks / slabs stay in registers and LDS in
   // between, only actions come in and observations go out per transition; one s_barrier per transition, and the
@@ -1112,6 +1125,37 @@ void step_kernel_bits(
           const uint32_t nlg = nlive > (uint32_t)g0 ? nlive - (uint32_t)g0 : 0u;
           dict_mask_group<W, H, GD>(grpm, post + (step & 1) * EPW + g0, nlg, lane, d0 + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC,
                                     d1 ? d1 + Bt * BG::PC + ((size_t)base_env + g0) * BG::PC : nullptr);
+        }
+      }
+      TG_ROLE_END();
+    }
+  }
+  if constexpr (bits_rgb_helpers<W, H>(FEAT)) {
+    if (wave >= 2) {
+      // =====================================================================================================
+      // RGB HELPER WAVES (kFeatMaskWave | kFeatRgb): a quarter of the workgroup's RgbObservation images each, from the slabs the
+      // stream wave has finished (second barrier of the transition) and the queue / holder words the logic wave published.
+      // =====================================================================================================
+      __builtin_amdgcn_s_setprio(1);
+      TG_LATE_ARGS();
+      constexpr size_t IMG = (size_t)BG::NPX * 3;
+      const int e_lo = ESTR + (wave - 2) * (EPW / 4);
+      uint8_t* ids = lds + BG::OFF_RGB + EPW * 16 + wave * BG::GR * BG::IDB;  // (buffers 0 / 1: logic / stream wave)
+      for (int step = 0; step < nsteps; ++step) {
+        const bool lastt = step == nsteps - 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();  // published
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();  // the slabs are final, the pieces drawn
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        uint8_t* dst0 = (obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs) + (size_t)base_env * IMG;
+        uint8_t* dst1 = (lastt && obs_traj) ? p.obs + (size_t)base_env * IMG : nullptr;
+        rgb_pack<W, H, BG::GR>(lds, post2, cell_tab + 24, lut_l, ids, e_lo, e_lo + EPW / 4, nlive, lane, dst0, dst1);
+        if (!lastt) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+          __builtin_amdgcn_s_barrier();  // everybody is done with the slabs
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         }
       }
       TG_ROLE_END();
@@ -1572,7 +1616,7 @@ void step_kernel_bits(
       constexpr size_t IMG = (size_t)BG::NPX * 3;
       uint8_t* dst0 = (obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs) + (size_t)base_env * IMG;
       uint8_t* dst1 = (last && obs_traj) ? p.obs + (size_t)base_env * IMG : nullptr;
-      rgb_pack<W, H, BG::GR>(lds, post2, cell_tab + 24, lut_l, lds + BG::OFF_RGB + EPW * 16 + BG::GR * BG::IDB, ELOG, EPW, nlive, lane, dst0, dst1);
+      rgb_pack<W, H, BG::GR>(lds, post2, cell_tab + 24, lut_l, lds + BG::OFF_RGB + EPW * 16 + BG::GR * BG::IDB, ELOG, ESTR, nlive, lane, dst0, dst1);
       if (!last) {  // both waves are done with the slabs: un-draw below
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         __builtin_amdgcn_s_barrier();
