@@ -107,6 +107,12 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
 #endif
   if (g_mask_wave && RS == TG_RULESET_NUMPY && base == tg::kFeatRgb && epw == 64 && (long)((p.batch + epw - 1) / epw) <= (long)(TG_RGB_HELPER_CAP))
     return feat | tg::kFeatMaskWave;
+#ifndef TG_RGB_HELPER_CAP_MULTI  // ... and in the instantiation with the transition loop (workgroups up to which)
+#define TG_RGB_HELPER_CAP_MULTI 768
+#endif
+  if (g_mask_wave && RS == TG_RULESET_NUMPY && base == (M | T | tg::kFeatSample | tg::kFeatRgb) && epw == 64 &&
+      (long)((p.batch + epw - 1) / epw) <= (long)(TG_RGB_HELPER_CAP_MULTI))
+    return feat | tg::kFeatMaskWave;
   // ... and in the instantiation with the transition loop while the launch is bound by its chain, not by bytes: per transition of a
   // 16-transition launch 6.0 -> 3.7 us at 4 096 envs, 6.6 -> 4.2 at 32 768, 8.0 -> 7.2 at 49 152, but 10.1 -> 10.6 at 65 536
   if (g_mask_wave && RS == TG_RULESET_NUMPY && base == (M | T | tg::kFeatDict) && (long)((p.batch + epw - 1) / epw) * 4 <= 3L * g_simds)
@@ -205,6 +211,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
       if (feat == R) { TG_LAUNCH_BITS(R); return; }
       if constexpr (tg::bits_rgb_helpers<W, H>(R | tg::kFeatMaskWave)) {
         if (feat == (R | tg::kFeatMaskWave)) { TG_LAUNCH_BITS(R | tg::kFeatMaskWave); return; }
+        if (feat == (M | T | S | R | tg::kFeatMaskWave)) { TG_LAUNCH_BITS(M | T | S | R | tg::kFeatMaskWave); return; }
       }
       if (feat == (M | T | S | R)) { TG_LAUNCH_BITS(M | T | S | R); return; }
       if (feat == (M | T | S)) { TG_LAUNCH_BITS(M | T | S); return; }
@@ -352,7 +359,7 @@ std::vector<int> rtc_feats(int RS, int W = 0, int H = 0) {
   constexpr int P = tg::kFeatSplit, Wd = tg::kFeatWide, K = tg::kFeatPacked;
   if (RS == TG_RULESET_NUMPY) {
     std::vector<int> v = {0, M, M | T, F, M | T | F, D, M | T | D, T | S, M | T | S, R, M | T | S | R, P, P | M, P | M | T, P | D, P | M | T | D,
-                          D | tg::kFeatMaskWave, M | T | D | tg::kFeatMaskWave, R | tg::kFeatMaskWave};
+                          D | tg::kFeatMaskWave, M | T | D | tg::kFeatMaskWave, R | tg::kFeatMaskWave, M | T | S | R | tg::kFeatMaskWave};
     if (W && packed_geometry(W, H))
       for (int f : {K, K | M, K | M | T, K | T | S, K | M | T | S}) v.push_back(f);
     return v;
