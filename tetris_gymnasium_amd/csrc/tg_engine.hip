@@ -105,8 +105,11 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
 #ifndef TG_RGB_HELPER_CAP  // (A/B knob: step workgroups up to which the helper waves are used)
 #define TG_RGB_HELPER_CAP (1 << 30)
 #endif
+#ifndef TG_RGB_MANY_CAP  // (... up to which there are six helper waves: one workgroup per CU at most)
+#define TG_RGB_MANY_CAP (g_simds / 4)
+#endif
   if (g_mask_wave && RS == TG_RULESET_NUMPY && base == tg::kFeatRgb && epw == 64 && (long)((p.batch + epw - 1) / epw) <= (long)(TG_RGB_HELPER_CAP))
-    return feat | tg::kFeatMaskWave;
+    return feat | tg::kFeatMaskWave | ((long)((p.batch + epw - 1) / epw) <= (long)(TG_RGB_MANY_CAP) ? tg::kFeatMany : 0);
 #ifndef TG_RGB_HELPER_CAP_MULTI  // ... and in the instantiation with the transition loop (workgroups up to which)
 #define TG_RGB_HELPER_CAP_MULTI 768
 #endif
@@ -190,7 +193,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     const int feat = bits_feat<W, H, RS>(p);
     const size_t lds = RS == TG_RULESET_FUNCTIONAL ? BG::BYTES_FNX
                        : ((feat & D) ? ((feat & tg::kFeatSplit) ? BG::BYTES_DICT_SPLIT : BG::BYTES_DICT)
-                                     : ((feat & R) ? ((feat & tg::kFeatMaskWave) ? BG::BYTES_RGB_X : BG::BYTES_RGB) : ((feat & F) ? BG::BYTES_FIN : BG::BYTES)));
+                                     : ((feat & R) ? ((feat & tg::kFeatMaskWave) ? ((feat & tg::kFeatMany) ? BG::BYTES_RGB_X6 : BG::BYTES_RGB_X) : BG::BYTES_RGB) : ((feat & F) ? BG::BYTES_FIN : BG::BYTES)));
 #define TG_LAUNCH_BITS(FT)                                                                                                  \
   hipLaunchKernelGGL((tg::step_kernel_bits<W, H, RS, (FT)>), grid, dim3(64 * tg::bits_wg_waves<W, H>(FT)), lds, s, (p.pboard ? p.pboard : p.board), p.rec, p.cols, bp.ring_rd, bp.hbuf_rd, \
                      p.actions, p.batch, bits_hot_misc(p, RS, n_step_wgs), \
@@ -211,6 +214,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
       if (feat == R) { TG_LAUNCH_BITS(R); return; }
       if constexpr (tg::bits_rgb_helpers<W, H>(R | tg::kFeatMaskWave)) {
         if (feat == (R | tg::kFeatMaskWave)) { TG_LAUNCH_BITS(R | tg::kFeatMaskWave); return; }
+        if (feat == (R | tg::kFeatMaskWave | tg::kFeatMany)) { TG_LAUNCH_BITS(R | tg::kFeatMaskWave | tg::kFeatMany); return; }
         if (feat == (M | T | S | R | tg::kFeatMaskWave)) { TG_LAUNCH_BITS(M | T | S | R | tg::kFeatMaskWave); return; }
       }
       if (feat == (M | T | S | R)) { TG_LAUNCH_BITS(M | T | S | R); return; }
@@ -359,7 +363,7 @@ std::vector<int> rtc_feats(int RS, int W = 0, int H = 0) {
   constexpr int P = tg::kFeatSplit, Wd = tg::kFeatWide, K = tg::kFeatPacked;
   if (RS == TG_RULESET_NUMPY) {
     std::vector<int> v = {0, M, M | T, F, M | T | F, D, M | T | D, T | S, M | T | S, R, M | T | S | R, P, P | M, P | M | T, P | D, P | M | T | D,
-                          D | tg::kFeatMaskWave, M | T | D | tg::kFeatMaskWave, R | tg::kFeatMaskWave, M | T | S | R | tg::kFeatMaskWave};
+                          D | tg::kFeatMaskWave, M | T | D | tg::kFeatMaskWave, R | tg::kFeatMaskWave, R | tg::kFeatMaskWave | tg::kFeatMany, M | T | S | R | tg::kFeatMaskWave};
     if (W && packed_geometry(W, H))
       for (int f : {K, K | M, K | M | T, K | T | S, K | M | T | S}) v.push_back(f);
     return v;
@@ -541,7 +545,7 @@ Launchers rtc_launchers(const RtcSize* r) {
     const int feat = bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, split_ok);
     const size_t lds = RS == TG_RULESET_FUNCTIONAL ? r->geo[5]
                        : ((feat & D) ? r->geo[2] + ((feat & tg::kFeatSplit) ? 16 * (W + 8) * (H + 4) : 0)  // (BYTES_DICT_SPLIT: + GD * PC)
-                                     : ((feat & R) ? r->geo[3] + ((feat & tg::kFeatMaskWave) ? 2 * 4 * ((((H + 4) * (W + 24)) + 15) / 16 * 16) : 0)  // (BYTES_RGB_X: + 2 GR IDB)
+                                     : ((feat & R) ? r->geo[3] + ((feat & tg::kFeatMaskWave) ? ((feat & tg::kFeatMany) ? 6 : 2) * 4 * ((((H + 4) * (W + 24)) + 15) / 16 * 16) : 0)  // (BYTES_RGB_X: + 2 GR IDB)
                                                    : ((feat & F) ? r->geo[4] : r->geo[1])));
     auto it = r->step.find(feat);
     if (it == r->step.end()) return;
@@ -551,7 +555,7 @@ Launchers rtc_launchers(const RtcSize* r) {
     tg::KParams kp = p;
     void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &kp, &bp};
     // (threads per workgroup: tg::bits_stream_waves of this size and instantiation)
-    (void)hipModuleLaunchKernel(it->second, (unsigned)(nrb + n_step_wgs), 1, 1, 64 * (1 + r->geo[10] * ((feat & tg::kFeatSplit) ? 2 : 1) + ((feat & tg::kFeatMaskWave) ? ((feat & R) ? 2 : 1) : 0)), 1, 1, (unsigned)lds, s, args, nullptr);
+    (void)hipModuleLaunchKernel(it->second, (unsigned)(nrb + n_step_wgs), 1, 1, 64 * (1 + r->geo[10] * ((feat & tg::kFeatSplit) ? 2 : 1) + ((feat & tg::kFeatMaskWave) ? ((feat & R) ? ((feat & tg::kFeatMany) ? 6 : 2) : 1) : 0)), 1, 1, (unsigned)lds, s, args, nullptr);
   };
   L.step_name = [=](const tg::KParams& p, char* buf, size_t n) {
     snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, r->geo[11] != 0));

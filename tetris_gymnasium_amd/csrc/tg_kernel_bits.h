@@ -174,6 +174,7 @@ struct BitsGeo {
   static constexpr int OFF_RGB = BYTES;
   static constexpr int BYTES_RGB = BYTES + EPW * 16 + 2 * GR * IDB;
   static constexpr int BYTES_RGB_X = BYTES_RGB + 2 * GR * IDB;  // (kFeatMaskWave with kFeatRgb: two helper waves with a staging buffer each)
+  static constexpr int BYTES_RGB_X6 = BYTES_RGB + 6 * GR * IDB; // (... | kFeatMany: six)
   static constexpr bool RGB_OK = NSW0 == 1 && NPX % 4 == 0 && H % 2 == 0 && W % 2 == 0 && (EPW / 2) % GR == 0;
   // TG_FLAG_FINAL_OBS (observation BOARD / FN only, never together with the dict staging): uint2 [2][EPW] behind BYTES —
   // the terminal piece of every env that ends its episode in this transition
@@ -536,9 +537,17 @@ constexpr bool bits_rgb_helpers(const int feat) {
   return (feat & kFeatMaskWave) && (feat & kFeatRgb) && BitsGeo<W, H>::RGB_OK && (BitsGeo<W, H>::EPW / 4) % BitsGeo<W, H>::GR == 0 &&
          !(feat & kFeatSplit);
 }
+// kFeatMany (with kFeatMaskWave | kFeatRgb): SIX helper waves — eight waves pack an eighth of the workgroup's images each; for the
+// launches with one workgroup per CU at most (up to 16 384 envs at 10x20), where the packing chain is all there is
+constexpr int kFeatMany = 1024;
+template <int W, int H>
+constexpr int bits_rgb_helper_count(const int feat) {
+  if (!bits_rgb_helpers<W, H>(feat)) return 0;
+  return ((feat & kFeatMany) && (BitsGeo<W, H>::EPW / 8) % BitsGeo<W, H>::GR == 0) ? 6 : 2;
+}
 template <int W, int H>
 constexpr int bits_wg_waves(const int feat) {
-  return 1 + bits_stream_waves<W, H>(feat) + (bits_mask_wave<W, H>(feat) ? 1 : 0) + (bits_rgb_helpers<W, H>(feat) ? 2 : 0);
+  return 1 + bits_stream_waves<W, H>(feat) + (bits_mask_wave<W, H>(feat) ? 1 : 0) + bits_rgb_helper_count<W, H>(feat);
 }
 
 // bytes: 0xFF (active) stays -1, other non-zero → 1  (the functional observation, envs/tetris_fn.py:137-158).  Board cells
@@ -971,9 +980,9 @@ void step_kernel_bits(
 #ifndef TG_RGB_ELOG
 #define TG_RGB_ELOG (EPW / 2)
 #endif
-  constexpr bool RGBX = bits_rgb_helpers<W, H>(FEAT);  // RGB with two helper waves: quarters instead of halves
-  constexpr int ELOG = RGBX ? EPW / 4 : TG_RGB_ELOG;  // RGB: the logic wave packs the envs below, the stream wave those from ELOG on
-  constexpr int ESTR = RGBX ? EPW / 2 : EPW;          // ... up to here; the helper waves [ESTR, 3 EPW / 4) and [3 EPW / 4, EPW)
+  constexpr int RGBH = bits_rgb_helper_count<W, H>(FEAT);  // RGB helper waves (0 / 2 / 6): quarters / eighths instead of halves
+  constexpr int ELOG = RGBH ? EPW / (2 + RGBH) : TG_RGB_ELOG;  // RGB: the logic wave packs the envs below, the stream wave those from ELOG on
+  constexpr int ESTR = RGBH ? 2 * ELOG : EPW;                  // ... up to here; helper wave w the ELOG envs from ESTR + (w - 2) ELOG on
   constexpr int WP = W + 8, HP = H + 4, PC = BG::PC;
   // p.nsteps consecutive transitions in this launch (tg_step_k): records / masks / slabs stay in registers and LDS in
   // between, only actions come in and observations go out per transition; one s_barrier per transition, and the
@@ -1139,7 +1148,7 @@ void step_kernel_bits(
       __builtin_amdgcn_s_setprio(1);
       TG_LATE_ARGS();
       constexpr size_t IMG = (size_t)BG::NPX * 3;
-      const int e_lo = ESTR + (wave - 2) * (EPW / 4);
+      const int e_lo = ESTR + (wave - 2) * ELOG;
       uint8_t* ids = lds + BG::OFF_RGB + EPW * 16 + wave * BG::GR * BG::IDB;  // (buffers 0 / 1: logic / stream wave)
       for (int step = 0; step < nsteps; ++step) {
         const bool lastt = step == nsteps - 1;
@@ -1151,7 +1160,7 @@ void step_kernel_bits(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         uint8_t* dst0 = (obs_traj ? obs_traj + (size_t)step * p.obs_traj_stride : p.obs) + (size_t)base_env * IMG;
         uint8_t* dst1 = (lastt && obs_traj) ? p.obs + (size_t)base_env * IMG : nullptr;
-        rgb_pack<W, H, BG::GR>(lds, post2, cell_tab + 24, lut_l, ids, e_lo, e_lo + EPW / 4, nlive, lane, dst0, dst1);
+        rgb_pack<W, H, BG::GR>(lds, post2, cell_tab + 24, lut_l, ids, e_lo, e_lo + ELOG, nlive, lane, dst0, dst1);
         if (!lastt) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
           __builtin_amdgcn_s_barrier();  // everybody is done with the slabs
