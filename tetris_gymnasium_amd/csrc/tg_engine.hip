@@ -89,7 +89,7 @@ uint32_t bits_hot_misc(const tg::KParams& p, const int RS, const int n_step_wgs)
 
 // which instantiation of the bits kernel a launch with these parameters uses (FEAT flags, tg_kernel_bits.h)
 int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw, const bool split_ok);
-int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw, const bool split_ok) {
+int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw, const bool split_ok, const int rgb_helpers_max) {
   constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj;
   const int feat = bits_feat_base(p, RS, dict_ok, rgb_ok, epw, split_ok);
   // two stream waves per workgroup (kFeatSplit) while all workgroups of the launch — the RNG role's included — are resident
@@ -108,12 +108,12 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
 #ifndef TG_RGB_MANY_CAP  // (... up to which there are six helper waves: one workgroup per CU at most)
 #define TG_RGB_MANY_CAP (g_simds / 4)
 #endif
-  if (g_mask_wave && RS == TG_RULESET_NUMPY && base == tg::kFeatRgb && epw == 64 && (long)((p.batch + epw - 1) / epw) <= (long)(TG_RGB_HELPER_CAP))
-    return feat | tg::kFeatMaskWave | ((long)((p.batch + epw - 1) / epw) <= (long)(TG_RGB_MANY_CAP) ? tg::kFeatMany : 0);
+  if (g_mask_wave && RS == TG_RULESET_NUMPY && base == tg::kFeatRgb && rgb_helpers_max >= 2 && (long)((p.batch + epw - 1) / epw) <= (long)(TG_RGB_HELPER_CAP))
+    return feat | tg::kFeatMaskWave | ((rgb_helpers_max >= 6 && (long)((p.batch + epw - 1) / epw) <= (long)(TG_RGB_MANY_CAP)) ? tg::kFeatMany : 0);
 #ifndef TG_RGB_HELPER_CAP_MULTI  // ... and in the instantiation with the transition loop (workgroups up to which)
 #define TG_RGB_HELPER_CAP_MULTI 768
 #endif
-  if (g_mask_wave && RS == TG_RULESET_NUMPY && base == (M | T | tg::kFeatSample | tg::kFeatRgb) && epw == 64 &&
+  if (g_mask_wave && RS == TG_RULESET_NUMPY && base == (M | T | tg::kFeatSample | tg::kFeatRgb) && rgb_helpers_max >= 2 &&
       (long)((p.batch + epw - 1) / epw) <= (long)(TG_RGB_HELPER_CAP_MULTI))
     return feat | tg::kFeatMaskWave;
   // ... and in the instantiation with the transition loop while the launch is bound by its chain, not by bytes: per transition of a
@@ -167,7 +167,8 @@ int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const
 
 template <int W, int H, int RS>
 int bits_feat(const tg::KParams& p) {
-  return bits_feat_rt(p, RS, tg::BitsGeo<W, H>::DICT_OK, tg::BitsGeo<W, H>::RGB_OK, tg::BitsGeo<W, H>::EPW, tg::BitsGeo<W, H>::SPLIT_OK);
+  return bits_feat_rt(p, RS, tg::BitsGeo<W, H>::DICT_OK, tg::BitsGeo<W, H>::RGB_OK, tg::BitsGeo<W, H>::EPW, tg::BitsGeo<W, H>::SPLIT_OK,
+                      tg::bits_rgb_helper_count<W, H>(tg::kFeatRgb | tg::kFeatMaskWave | tg::kFeatMany));
 }
 
 template <int W, int H, int RS>
@@ -531,6 +532,9 @@ Launchers rtc_launchers(const RtcSize* r) {
   Launchers L;
   const int EPW = r->geo[0], W = r->W, H = r->H, RS = r->RS;
   const bool dict_ok = r->geo[6] != 0, rgb_ok = r->geo[7] != 0;
+  // (tg::bits_rgb_helper_count: 0 / 2 / 6 helper waves by what fits the 64 KiB beside BYTES_RGB)
+  const int rgb_idb4 = 4 * ((((H + 4) * (W + 24)) + 15) / 16 * 16);
+  const int rgb_helpers_max = !(rgb_ok && EPW == 64) ? 0 : (r->geo[3] + 6 * rgb_idb4 <= 65536 ? 6 : (r->geo[3] + 2 * rgb_idb4 <= 65536 ? 2 : 0));
   L.cols_bytes = (size_t)r->geo[8];
   L.dict_ok = dict_ok; L.rgb_ok = rgb_ok;
   L.step = [=](const tg::KParams& p, hipStream_t s) {
@@ -542,7 +546,7 @@ Launchers rtc_launchers(const RtcSize* r) {
                       p.hbuf + hrd, p.hbuf + hwr, p.inl, nrb, p.ring_fill};
     const int n_step_wgs = (p.batch + EPW - 1) / EPW;
     const bool split_ok = r->geo[11] != 0;  // (BitsGeo::SPLIT_OK)
-    const int feat = bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, split_ok);
+    const int feat = bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, split_ok, rgb_helpers_max);
     const size_t lds = RS == TG_RULESET_FUNCTIONAL ? r->geo[5]
                        : ((feat & D) ? r->geo[2] + ((feat & tg::kFeatSplit) ? 16 * (W + 8) * (H + 4) : 0)  // (BYTES_DICT_SPLIT: + GD * PC)
                                      : ((feat & R) ? r->geo[3] + ((feat & tg::kFeatMaskWave) ? ((feat & tg::kFeatMany) ? 6 : 2) * 4 * ((((H + 4) * (W + 24)) + 15) / 16 * 16) : 0)  // (BYTES_RGB_X: + 2 GR IDB)
@@ -558,7 +562,7 @@ Launchers rtc_launchers(const RtcSize* r) {
     (void)hipModuleLaunchKernel(it->second, (unsigned)(nrb + n_step_wgs), 1, 1, 64 * (1 + r->geo[10] * ((feat & tg::kFeatSplit) ? 2 : 1) + ((feat & tg::kFeatMaskWave) ? ((feat & R) ? ((feat & tg::kFeatMany) ? 6 : 2) : 1) : 0)), 1, 1, (unsigned)lds, s, args, nullptr);
   };
   L.step_name = [=](const tg::KParams& p, char* buf, size_t n) {
-    snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, r->geo[11] != 0));
+    snprintf(buf, n, "tg::step_kernel_bits<%d, %d, %d, %d>", W, H, RS, bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, r->geo[11] != 0, rgb_helpers_max));
   };
   L.reset = [=](const tg::ResetParams& p, hipStream_t s) { rtc_launch(r->reset, dim3(grid_for(p.batch)), dim3(tg::kBlock), 0, s, p); };
   L.observe = [=](const tg::ObserveParams& p, hipStream_t s) {

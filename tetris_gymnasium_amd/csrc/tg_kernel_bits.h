@@ -535,15 +535,18 @@ constexpr bool bits_mask_wave(const int feat) {
 template <int W, int H>
 constexpr bool bits_rgb_helpers(const int feat) {
   return (feat & kFeatMaskWave) && (feat & kFeatRgb) && BitsGeo<W, H>::RGB_OK && (BitsGeo<W, H>::EPW / 4) % BitsGeo<W, H>::GR == 0 &&
-         !(feat & kFeatSplit);
+         !(feat & kFeatSplit) && BitsGeo<W, H>::BYTES_RGB_X <= 65536;
 }
+// (Board helper waves for the DICT observation — the four groups of 16 padded boards packed by four waves instead of one after the
+// other by the stream wave, started by a word in LDS — were built and measured at the end of round 4: 6.7 -> 6.5 us at 4 096 envs,
+// and factoring the group body out for them cost the default kernel six spilled registers (14.3 -> 14.7 us at 65 536 envs): not kept.)
 // kFeatMany (with kFeatMaskWave | kFeatRgb): SIX helper waves — eight waves pack an eighth of the workgroup's images each; for the
 // launches with one workgroup per CU at most (up to 16 384 envs at 10x20), where the packing chain is all there is
 constexpr int kFeatMany = 1024;
 template <int W, int H>
 constexpr int bits_rgb_helper_count(const int feat) {
   if (!bits_rgb_helpers<W, H>(feat)) return 0;
-  return ((feat & kFeatMany) && (BitsGeo<W, H>::EPW / 8) % BitsGeo<W, H>::GR == 0) ? 6 : 2;
+  return ((feat & kFeatMany) && (BitsGeo<W, H>::EPW / 8) % BitsGeo<W, H>::GR == 0 && BitsGeo<W, H>::BYTES_RGB_X6 <= 65536) ? 6 : 2;
 }
 template <int W, int H>
 constexpr int bits_wg_waves(const int feat) {
