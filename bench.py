@@ -570,6 +570,11 @@ def rank_main(args) -> int:
         blocks["config2_fused"] = run_block(D, "config2_fused16", W=10, H=20, Q=4, B=4096, obs="board", grouped=False, fuse=16,
                                             ruleset="numpy", steps=(ks + 15) // 16 * 16, warmup=64, reps=reps, local=local,
                                             want_cpu=False)
+        # the two packed observation surfaces at config 2's batch (4 096 envs: the regime RL runs with pixel / dict observations
+        # live in): there the launch is the chain of its packing waves, which helper waves shorten
+        for oname in ("dict", "rgb"):
+            blocks[f"config2_{oname}"] = run_block(D, f"config2_{oname}", W=10, H=20, Q=4, B=4096, obs=oname, grouped=False,
+                                                    ruleset="numpy", steps=ks, warmup=kw, reps=reps, local=local, want_cpu=False)
         # the functional rule-set (envs/tetris_fn.py step / batched_step: the subsystem north_star names as replaced)
         fcommon = dict(W=10, H=20, Q=7, B=65536, obs="fn", grouped=False, ruleset="functional", reps=reps, local=local)
         blocks["functional"] = run_block(D, "functional", steps=ks, warmup=kw, want_cpu=want_cpu, cpu_budget=3.0, **fcommon)
