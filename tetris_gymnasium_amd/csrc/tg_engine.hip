@@ -128,6 +128,9 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
 #endif
   const long cap = (long)(g_simds / 4) * (4 * per_simd / 3) + TG_SPLIT_CAP_EXTRA;
   const long wgs = (p.batch + epw - 1) / epw + rng_blocks(p, RS);
+#ifdef TG_SPLIT4_CAP  // (A/B: four stream waves in the plain one-transition kernel up to this many workgroups)
+  if (wgs <= cap && base == 0 && wgs <= (long)(TG_SPLIT4_CAP)) return feat | tg::kFeatSplit | 1024;
+#endif
   return wgs <= cap ? (feat | tg::kFeatSplit) : feat;
 }
 int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw, const bool split_ok) {
@@ -245,6 +248,9 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
       if (feat == (P | M | T)) { TG_LAUNCH_BITS(P | M | T); return; }
       if (feat == (P | M)) { TG_LAUNCH_BITS(P | M); return; }
       if (feat == P) { TG_LAUNCH_BITS(P); return; }
+#ifdef TG_SPLIT4_CAP
+      if (feat == (P | 1024)) { TG_LAUNCH_BITS(P | 1024); return; }
+#endif
     }
     if (feat == (M | T)) TG_LAUNCH_BITS(M | T);
     else if (feat == M) TG_LAUNCH_BITS(M);

@@ -517,8 +517,11 @@ __device__ __forceinline__ u32x4 nib_pack(const u32x4 a, const u32x4 b) {
 template <int W, int H>
 constexpr int bits_stream_waves(const int feat) {
   if (BitsGeo<W, H>::NSW0 > 1) return BitsGeo<W, H>::NSW0;  // (boards above 320 cells: every instantiation)
-  return ((feat & kFeatSplit) && BitsGeo<W, H>::SPLIT_OK && !(feat & (kFeatSample | kFeatFinal | kFeatRgb | kFeatWide)) &&
-          (!(feat & kFeatDict) || (BitsGeo<W, H>::DICT_OK && (BitsGeo<W, H>::EPW / 2) % BitsGeo<W, H>::GD == 0))) ? 2 : 1;
+  const bool split = (feat & kFeatSplit) && BitsGeo<W, H>::SPLIT_OK && !(feat & (kFeatSample | kFeatFinal | kFeatRgb | kFeatWide)) &&
+                     (!(feat & kFeatDict) || (BitsGeo<W, H>::DICT_OK && (BitsGeo<W, H>::EPW / 2) % BitsGeo<W, H>::GD == 0));
+  // (kFeatSplit | 1024 = kFeatMany, plain instantiations: FOUR stream waves of 16 envs each — A/B for launches of one workgroup per CU)
+  if (split && (feat & 1024) && !(feat & (kFeatDict | kFeatMulti)) && ((BitsGeo<W, H>::EPW / 4) * BitsGeo<W, H>::S) % 16 == 0) return 4;
+  return split ? 2 : 1;
 }
 // kFeatMaskWave (round 4, dict instantiations): a THIRD wave per workgroup that does nothing but obs["active_tetromino_mask"]
 // (28 of the 62 MB a dict transition stores at 65 536 envs).  The array needs only the post records — no slab, no lock stamp —
