@@ -16,11 +16,14 @@ library and makes no HIP call — a process that has touched the GPU must not fo
 devices (`--gpus 2` on a 1-GPU box) ranks share devices round-robin: that exercises the N > 1 path, it is not a
 scaling number.
 
-Rank 0 prints ONE JSON line.  At N = 1 the line also carries one block per further BASELINE config (`blocks`:
-config 2 = 4 096 envs (one and sixteen transitions per launch), config 5 = 20x40 / queue 7 / grouped action set, the
-reference's dict observation, the RGB wrapper's image, the fused rollout, the functional rule-set (one and sixteen
-transitions per launch)), each with its own `roofline` and `cpu_baseline`, and `vector_env`: the rate through the
-gymnasium.vector adapter with host and with device-resident observations.
+Output (rank 0).  The LAST line of stdout is ONE COMPACT JSON object (< 4 KB: metric, value, unit, n_gpus, steps, warmup,
+ms_per_step, dtype, config, roofline, cpu_baseline, hbm_copy_gbps, per-rank timings and shard checksums, `blocks_file`, and a
+three-number summary per further block).  At N = 1 the further BASELINE configs are measured as BLOCKS (config 2 = 4 096 envs,
+one and sixteen transitions per launch; config 5 = 20x40 / queue 7 / grouped action set; the reference's dict observation; the
+RGB wrapper's image; the fused rollout WITH its trajectory; the functional rule-set; the gymnasium.vector adapter; the
+single-env drop-in class): each block is printed in full on its own EARLIER line, prefixed `[bench-block] <name> `, and the
+whole set (with the notes, said once) is written to `bench_blocks.json` beside this file (TG_BENCH_BLOCKS_FILE overrides the
+path).  Round 4 put everything into the last line; at 22 KB the driver no longer parsed it.
 """
 from __future__ import annotations
 
@@ -135,6 +138,17 @@ class Dist:
         self.pg.all_gather(parts, mine)
         return [float(p[0]) for p in parts]
 
+    def gather_u64(self, value: int):
+        """A 64-bit integer of every rank, in rank order (the shard checksums: metadata, not data path)."""
+        if self.pg is None:
+            return [int(value)]
+        import torch
+
+        mine = torch.tensor([int(value) - (1 << 64) if value >= (1 << 63) else int(value)], dtype=torch.int64)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.pg.all_gather(parts, mine)
+        return [int(p[0]) & 0xFFFFFFFFFFFFFFFF for p in parts]
+
     def shard(self, envs_per_rank):
         """Weak scaling: rank r owns global envs [r*B, (r+1)*B), seeds 1 + global index."""
         lo = self.rank * envs_per_rank
@@ -149,6 +163,59 @@ class Dist:
 def throughput(world, envs_per_rank, steps, max_elapsed_s):
     """Whole-job env steps/s: units all ranks processed / max-over-ranks time."""
     return world * envs_per_rank * steps / max_elapsed_s
+
+
+def global_actions(T, lo, hi, n_act, salt=0):
+    """Uniform pseudo-random actions int8 [T][hi - lo] that are a function of (transition t, GLOBAL env index) only — a 64-bit
+    mix of both — so every sharding of the batch over ranks plays the same game in env i ("1-GPU vs 8-GPU boards
+    identical"; the shard checksums below are what shows it)."""
+    t = np.arange(T, dtype=np.uint64)[:, None]
+    g = np.arange(lo, hi, dtype=np.uint64)[None, :]
+    x = (t << np.uint64(32)) ^ g ^ (np.uint64(salt) << np.uint64(56))
+    x = x + np.uint64(0x9E3779B97F4A7C15)
+    x ^= x >> np.uint64(30)
+    x *= np.uint64(0xBF58476D1CE4E5B9)
+    x ^= x >> np.uint64(27)
+    x *= np.uint64(0x94D049BB133111EB)
+    x ^= x >> np.uint64(31)
+    return ((x >> np.uint64(33)) % np.uint64(n_act)).astype(np.int8)
+
+
+def shard_checksum(board, rec, rng) -> int:
+    """64 bits over a shard's final state as tg_get_state returns it (boards, env records, generator states)."""
+    import hashlib
+
+    h = hashlib.blake2b(digest_size=8)
+    for a in (board, rec, rng):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return int.from_bytes(h.digest(), "little")
+
+
+NOTES = {
+    "roofline": ("achieved = algorithmic bytes per env-step (SURVEY 8(d); DESIGN.md §3a) x envs / kernel time per launch; `clock` names "
+                 "the time used: the committed rocprofv3 kernel-trace mean (profiles/latest.json) when it is <= this run's wall-clock "
+                 "ms_per_step, else this run's HIP-event median over `reps` repetitions of the timed region (both are always listed: "
+                 "kernel_us_rocprof / kernel_us_hip_events).  Handles that keep the board as nibbles (kFeatPacked) are priced by "
+                 "the bytes of THAT format; the uint8-formula figure is `frac_uint8_formula`, never `frac`."),
+    "resident": ("blocks whose working set fits the 256 MB Infinity Cache (`resident: Infinity Cache`) are launch-floor + latency "
+                 "bound; their HBM-peak fraction is nominal"),
+    "fused": ("fused blocks run tg_rollout with per-transition trajectory slots (kFeatTraj): every observation and output record "
+              "written is readable by a consumer; `last_obs_only_us_per_step` is the same launch through tg_step_k, where each "
+              "transition overwrites TG_BUF_OBS (round 4's figure, dead stores)"),
+    "cpu_baseline": ("the oracle's C restatement (kind `port`), the same workload as the GPU block (same B, seeds 1 + i, actions of "
+                     "the same generator, same-step autoreset, observation packed every step), OpenMP over envs; the reference's own "
+                     "NumPy Tetris.step runs ~3.4k steps/s on one core (survey container, BASELINE.md §2)"),
+    "vector_env": ("TetrisVectorEnv.step at 65 536 envs on one GPU, median of three regions: `host` returns NumPy observations "
+                   "(gymnasium contract; `host_pinned`: copy=False, views of page-locked buffers), `device` returns DeviceArray views "
+                   "(__cuda_array_interface__ / DLPack) and copies nothing back, `device_actions` additionally takes the actions from a "
+                   "device pointer; Python overhead included"),
+    "single_env": ("BASELINE config 1 through the drop-in class Tetris(): one env per launch is all launch boundary + PCIe latency; "
+                   "the reference's NumPy Tetris.step: ~3.4k steps/s on one 2.6 GHz Xeon core (survey container)"),
+    "vector_env_shards": ("8 192 envs per shard, step(actions, to_host=False) with per-shard device action pointers; host_us_per_step = "
+                          "time to enqueue (Python + one tg_step_fetch_many call for all shards); k shards on ONE GPU serialise their "
+                          "kernels"),
+    "functional": "functional rule-set: the jax threefry piece sequence is parity-unpinned (no jax in the image, DESIGN §5); engine == oracle is tested",
+}
 
 
 def alg_bytes_per_step(W, H, obs, Q=4):
@@ -176,7 +243,7 @@ def host_threads() -> int:
     return max(1, min(avail, 64))
 
 
-def cpu_baseline(W, H, Q, B, *, grouped=False, obs="board", budget_s=6.0, action_seed=0, ruleset="numpy"):
+def cpu_baseline(W, H, Q, B, *, grouped=False, obs="board", budget_s=6.0, ruleset="numpy"):
     """SURVEY §8d(i) / BASELINE.md §3: the oracle's C restatement (kind "port") on this host, the SAME workload as the GPU
     block (same B, seeds 1 + i, actions of the same generator, same-step autoreset, observation packed every step),
     timed at 1 thread and at all usable cores on a bounded number of steps (`budget_s` seconds per thread count).
@@ -189,9 +256,9 @@ def cpu_baseline(W, H, Q, B, *, grouped=False, obs="board", budget_s=6.0, action
     if grouped:  # the wrapper's step re-derives the legal mask from all 4W placements (wrappers/grouped.py:124-207,
         B = min(B, 8192)  # as the reference does): ~40 us per env-step on one core — sample the first 8 192 envs
     seeds = np.arange(1, B + 1, dtype=np.uint64)
-    rng = np.random.default_rng(action_seed)
+    rng = np.random.default_rng(0)
     T = 64
-    acts = rng.integers(0, 7 if fn else 8, (T, B)).astype(np.int32)
+    acts = global_actions(T, 0, B, 7 if fn else 8).astype(np.int32)
     res = {}
     cores = host_threads()
     for nt in ([1] if cores == 1 else [1, cores]):
@@ -224,13 +291,8 @@ def cpu_baseline(W, H, Q, B, *, grouped=False, obs="board", budget_s=6.0, action
     one_rate, one_n = res[1]
     return {"value": all_rate, "unit": "env steps/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
             "single_thread": {"value": one_rate, "cores": 1, "steps": one_n},
-            "sample": f"{'first ' if B != full_B else ''}{B} envs x {all_n} steps at {cores} threads, x {one_n} steps at 1 thread: the same workload as the "
-                      f"GPU block (C oracle, OpenMP over envs, step + observation pack"
-                      f"{'; legal-action draw not timed' if grouped else ''})",
-            "reference_python_single_env": "~3.4k steps/s on one 2.6 GHz Xeon core (NumPy Tetris.step), measured in the "
-                                           "survey container, not on this host (BASELINE.md §2)",
-            **({"parity_note": "functional rule-set: the oracle's jax threefry / permutation restatement is parity-unpinned "
-                               "(no jax in the build container, DESIGN §5); engine == oracle is tested"} if fn else {})}
+            "sample": f"{'first ' if B != full_B else ''}{B} envs x {all_n} steps at {cores} threads, x {one_n} at 1 thread"
+                      f"{' (legal-action draw not timed)' if grouped else ''}"}
 
 
 def profiled(block: str) -> dict:
@@ -242,10 +304,11 @@ def profiled(block: str) -> dict:
 
 
 def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, warmup, reps, fuse=1, local=0,
-              want_cpu=True, cpu_budget=6.0, copy_first=False):
+              want_cpu=True, cpu_budget=6.0, copy_first=False, traj=False, checksum=False):
     """One benchmark block on every rank: W warm-up launches, EXACTLY `steps` timed launches bracketed by barrier + device
     sync on both sides (wall clock → value), then `reps` further repetitions of the same region timed with HIP events on
-    the engine's stream (median → roofline)."""
+    the engine's stream (median → roofline).  `traj` (fused blocks): the launches go through tg_rollout with a [fuse][B]
+    trajectory of observations and output records — every transition's stores are readable by a consumer."""
     from tetris_gymnasium_amd import Engine, _native as N
 
     rs = N.RULESET_NUMPY if ruleset == "numpy" else N.RULESET_FUNCTIONAL
@@ -255,12 +318,16 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
     e = Engine(B, W, H, ruleset=rs, queue_size=(Q if rs == N.RULESET_NUMPY else 7), obs_mode=obs_mode,
                autoreset=N.AUTORESET_SAME_STEP, device=local, env_offset=lo, grouped=grouped, fuse=fuse)  # (tg_config.fuse)
     e.reset(seeds)
-    # pre-generated uniform random actions, uploaded once: [T][B] int8 resident in HBM
+    # pre-generated uniform random actions, uploaded once: [T][B] int8 resident in HBM, a function of the GLOBAL env index
     T = min(max(warmup + steps, fuse), 512)
     T = (T + fuse - 1) // fuse * fuse
-    acts = np.random.default_rng(D.rank).integers(0, n_act, (T, B)).astype(np.int8)
+    acts = global_actions(T, lo, hi, n_act)
     d_acts = e.dev_alloc(acts.nbytes)
     e.dev_upload(d_acts, acts)
+    traj = bool(traj and fuse > 1 and not grouped)
+    obs_bytes = e.lib.tg_obs_bytes_per_env(e.cfg) if traj else 0
+    d_obs_traj = e.dev_alloc(fuse * B * obs_bytes) if traj and obs_bytes else 0
+    d_out_traj = e.dev_alloc(fuse * B * 8) if traj else 0
     copy_gbps = None
     if copy_first:  # the practical ceiling, measured right before the warm-up (it also brings the clocks up: with the host-side
         try:        # action generation behind it the GPU idled for milliseconds before a short timed region)
@@ -268,7 +335,7 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
         except Exception:  # pragma: no cover
             copy_gbps = None
 
-    def run(k0, k):
+    def run(k0, k, last_obs_only=False):
         if grouped:  # legal placements drawn on the device inside the step kernel (tg_grouped_rollout)
             e.grouped_rollout(k, seed=D.rank + 1, counter0=k0, fetch=False)
             return
@@ -276,7 +343,11 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
         while done < k:  # cycle through the resident action rows
             row = (k0 + done) % T
             n = min(k - done, T - row)
-            e.step_k_device(d_acts + row * B, n)
+            if traj and not last_obs_only:  # one launch per call: its trajectory slots are the consumer's to read
+                n = min(n, fuse)
+                e.rollout_device(d_acts + row * B, n, d_obs_traj, d_out_traj)
+            else:
+                e.step_k_device(d_acts + row * B, n)
             done += n
 
     run(0, warmup)
@@ -291,8 +362,7 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
     (elapsed,) = D.max(t1 - t0)
     per_rank_ms = D.gather((t1 - t0) / steps * 1e3)
     # repetitions of the same region timed with HIP events on the engine's own stream (kept out of the wall-clock region
-    # above: two event records and their host round trips are a measurable share of a 20-launch region): the median is
-    # what the roofline figure uses
+    # above: two event records and their host round trips are a measurable share of a 20-launch region)
     rep_us = []
     k0 = warmup + steps
     for _ in range(max(1, reps)):
@@ -300,23 +370,47 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
         run(k0, steps)
         rep_us.append(e.timer_stop() / steps * 1e3)
         k0 += steps
-    kernel_us = statistics.median(rep_us)
-    (kernel_us,) = D.max(kernel_us)
-    launches_per_step = 1.0 / fuse
+    last_only_us = None
+    if traj:  # the same launches through tg_step_k (every transition overwrites TG_BUF_OBS): round 4's figure, kept as a secondary
+        lo_us = []
+        for _ in range(3):
+            e.timer_start()
+            run(k0, steps, last_obs_only=True)
+            lo_us.append(e.timer_stop() / steps * 1e3)
+            k0 += steps
+        last_only_us = statistics.median(lo_us)
+    hip_us = statistics.median(rep_us)
+    (hip_us,) = D.max(hip_us)
     rank_devices = [int(x) for x in D.gather(float(local))]  # HIP device ordinal of every rank
+    sums = None
+    if checksum:  # what this shard's envs look like after warmup + (1 + reps) x steps transitions (deterministic)
+        sums = D.gather_u64(shard_checksum(*e.get_state()))
     out = None
     if D.rank == 0:
+        sym = e.step_kernel_name(fuse, grouped, traj)
+        try:  # packed handles (kFeatPacked, FEAT bit 256): the board crosses HBM as nibbles
+            feat_bits = int(sym.rstrip(">").split(",")[-1])
+        except ValueError:
+            feat_bits = 0
+        packed = bool(feat_bits & 256)
+        board_io = (H * W) // 2 if packed else H * W  # bytes of one board read / one write-back
         if fuse == 1:
-            bytes_alg = alg_bytes_per_step(W, H, obs, Q)
-        else:  # obs write + action per transition; board read / write-back, record, outputs once per launch
-            bytes_alg = H * W + 1 + (2 * H * W + 64 + 8) / fuse
-        achieved = bytes_alg * B / (kernel_us * 1e-6) / 1e9
+            bytes_alg = alg_bytes_per_step(W, H, obs, Q) - 2 * (H * W - board_io)
+            bytes_u8 = alg_bytes_per_step(W, H, obs, Q)
+        else:  # per transition: observation + action (+ the 8-byte output record with a trajectory); per launch: board read /
+            #    write-back, env record, last outputs
+            bytes_alg = H * W + 1 + (8 if traj else 0) + (2 * board_io + 64 + 8) / fuse
+            bytes_u8 = H * W + 1 + (8 if traj else 0) + (2 * H * W + 64 + 8) / fuse
         prof = profiled(name)
+        wall_us = elapsed / steps * 1e6
+        prof_us = prof.get("kernel_us")
+        prof_us_step = None if prof_us is None else prof_us / fuse
+        use_prof = prof_us_step is not None and prof_us_step <= wall_us
+        kernel_us = prof_us_step if use_prof else hip_us
+        achieved = bytes_alg * B / (kernel_us * 1e-6) / 1e9
         # the same time against the bytes the counters saw (committed profile of this block; per launch): the algorithmic
         # figure charges a board write-back per transition (p_lock = 1.0) that the kernel only does on a lock
         traffic = prof.get("hbm_bytes_per_launch")
-        measured = None if not traffic else traffic / fuse / (kernel_us * 1e-6) / 1e9
-        sym = e.step_kernel_name(fuse, grouped)
         out = {
             "value": throughput(D.world, B, steps, elapsed), "unit": "env steps/s", "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3, "per_rank_ms_per_step": per_rank_ms,
@@ -325,43 +419,39 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
                                     + ("grouped action set (column*4+rotation -> teleport + hard drop), legal actions drawn "
                                        "on device inside the step kernel, " if grouped else
                                        f"{ruleset} rule-set, uniform random actions (int8, resident in HBM), ")
-                                    + f"obs={obs}, same-step autoreset, {fuse} transition(s) per launch"),
+                                    + f"obs={obs}, same-step autoreset, {fuse} transition(s) per launch"
+                                    + (" with per-transition trajectory slots (tg_rollout)" if traj else "")),
                        "envs_per_gpu": B, "total_envs": D.world * B,
                        "parallelism": f"env-sharded x{D.world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": prof.get("traffic_source"),
-                         "achieved_measured_bytes": measured,
-                         "frac_measured_bytes": None if measured is None else measured / HBM_PEAK_GBPS,
-                         "kernel": sym, "kernel_ms": kernel_us * 1e-3 / launches_per_step if fuse > 1 else kernel_us * 1e-3,
+                         "kernel": sym, "kernel_us": kernel_us * fuse,
+                         "clock": (f"rocprofv3 kernel trace ({prof.get('kernel_source')})" if use_prof
+                                   else "HIP events on the engine's stream, this run"),
+                         "kernel_us_hip_events": hip_us * fuse, "kernel_us_rocprof": prof_us,
+                         "frac_hip_events": bytes_alg * B / (hip_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                          "kernel_us_per_step_reps": [round(x, 3) for x in rep_us],
-                         "kernel_us_rocprof": prof.get("kernel_us"), "rocprof_source": prof.get("kernel_source"),
                          "alg_bytes_per_env_step": bytes_alg,
-                         "resident": "Infinity Cache" if bytes_alg * B < 200e6 else "HBM",
-                         "note": "achieved = algorithmic bytes x envs / median HIP-event launch time over "
-                                 f"{len(rep_us)} repetitions of the timed region ({steps} launches each: with the driver's "
-                                 "--steps 20 a repetition is ~0.13 ms and the median reads 0.2-0.4 us per launch above a "
-                                 "1 024-launch region); " +
-                                 ("at this batch the working set fits the 256 MB Infinity Cache, so the HBM-peak fraction is "
-                                  "nominal (launch floor + latency bound)" if bytes_alg * B < 200e6 else
-                                  "the working set exceeds the 256 MB Infinity Cache: bytes are the bound")},
+                         "resident": "Infinity Cache" if bytes_alg * B < 200e6 else "HBM"},
         }
-        try:  # packed handles (kFeatPacked, FEAT bit 256): the board crosses HBM as nibbles
-            feat_bits = int(sym.rstrip(">").split(",")[-1])
-        except ValueError:
-            feat_bits = 0
-        if feat_bits & 256 and fuse == 1:
-            packed_bytes = 2 * H * W + 76  # H*W/2 read + H*W observation + H*W/2 write-back (p_lock = 1.0) + 76
+        if traffic:
+            out["roofline"]["frac_measured_bytes"] = traffic / fuse / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBPS
+        if packed:
             out["roofline"]["board_format"] = "nibbles in HBM (kFeatPacked): half the board bytes of SURVEY 8(d)'s uint8 formula"
-            out["roofline"]["alg_bytes_per_env_step_packed"] = packed_bytes
-            out["roofline"]["frac_packed_bytes"] = packed_bytes * B / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBPS
+            out["roofline"]["frac_uint8_formula"] = bytes_u8 * B / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBPS
+        if last_only_us is not None:
+            out["roofline"]["last_obs_only_us_per_step"] = last_only_us
         if copy_gbps is not None:
             out["hbm_copy_gbps"] = copy_gbps
+        if sums is not None:
+            out["shard_checksums"] = [f"{v:016x}" for v in sums]
+            out["shard_transitions"] = warmup + (1 + max(1, reps)) * steps
         if want_cpu and obs in ("board", "dict", "rgb", "fn"):  # (rank 0 only, whatever the number of ranks)
             out["cpu_baseline"] = cpu_baseline(W, H, Q, B, grouped=grouped, obs=obs, budget_s=cpu_budget, ruleset=ruleset)
-        if ruleset == "functional":
-            out["parity_note"] = "functional rule-set: piece sequence (jax threefry) is parity-unpinned (DESIGN §5)"
-    e.dev_free(d_acts)
+    for d in (d_obs_traj, d_out_traj, d_acts):
+        if d:
+            e.dev_free(d)
     e.close()
     return out
 
@@ -410,10 +500,6 @@ def vector_env_block(local, *, B=65536, steps=64, warmup=8):
         res["device_actions"]["pcie_bytes_per_env_step"] = 0
         out[kind] = res
         v.close()
-    out["note"] = (f"TetrisVectorEnv.step at {B} envs on one GPU, median of three regions of {steps} steps after {warmup}: `host` returns NumPy observations "
-                   "(gymnasium contract; `host_pinned`: copy=False, views of page-locked buffers), `device` returns DeviceArray views (__cuda_array_interface__ / DLPack) and copies "
-                   "nothing back, `device_actions` additionally takes the actions from a device pointer; Python overhead "
-                   "included")
     return out
 
 
@@ -453,9 +539,6 @@ def single_env_block(local, *, steps=4000, warmup=200):
     dt = time.perf_counter() - t0
     out["cpu_port_single_env"] = {"value": steps / dt, "unit": "env steps/s", "cores": 1, "kind": "port",
                                   "sample": f"{steps} steps of ONE env through the C oracle's Python binding (step + dict observation)"}
-    out["reference_python_single_env"] = "~3.4k steps/s (NumPy Tetris.step on one 2.6 GHz Xeon core, survey container; BASELINE.md §2)"
-    out["note"] = ("one env per launch is all launch boundary + PCIe latency: this is the drop-in / debugging surface of config 1; "
-                   "throughput is the batched engine's job")
     return out
 
 
@@ -496,10 +579,6 @@ def shards_block(local, *, per_shard=8192, steps=256, warmup=32):
         for e, d in zip(v.engines, ptrs):
             e.dev_free(d)
         v.close()
-    out["note"] = (f"{per_shard} envs per shard, `step(actions, to_host=False)` with per-shard device action pointers; "
-                   "host_us_per_step = time to enqueue (Python + one tg_step_fetch_many call for all shards), us_per_step "
-                   "includes the final wait; k shards on ONE GPU serialise their kernels, so us_per_step grows with k by the "
-                   "kernel time — the host column is the cost the adapter adds per shard")
     return out
 
 
@@ -515,14 +594,79 @@ def parse(argv=None):
     ap.add_argument("--ruleset", choices=["numpy", "functional"], default="numpy")
     ap.add_argument("--reps", type=int, default=7, help="repetitions of the timed region for the roofline median (>= 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=6.0, help="seconds of CPU work per thread count of the headline's cpu_baseline")
     ap.add_argument("--fuse", type=int, default=1,
                     help="transitions per launch of the timed rollout (TG_FUSE). Default 1: `value` is the "
                          "one-launch-per-transition number; the fused rollout is reported in blocks")
+    ap.add_argument("--traj", action="store_true", help="with --fuse > 1: tg_rollout with per-transition trajectory slots")
     ap.add_argument("--no-blocks", action="store_true", help="only the headline block (profiling runs)")
+    ap.add_argument("--only-block", default=None, help="profiling runs: make this block of the default run the headline "
+                                                       "(config2, config5, dict, rgb, fused_rollout, config2_fused, config2_dict, "
+                                                       "config2_rgb, functional, functional_fused)")
     ap.add_argument("--config5", action="store_true",
                     help="make BASELINE config 5 the headline block: 20x40 board, queue_size 7, grouped hard-drop action "
                          "set, legal actions sampled on device")
     return ap.parse_args(argv)
+
+
+def block_specs(ks, kw):
+    """The further blocks of a default N = 1 run: name → run_block keyword arguments (profile name = key of profiles/latest.json)."""
+    f16 = (ks + 15) // 16 * 16
+    num = dict(W=10, H=20, Q=4, ruleset="numpy", grouped=False)
+    fn = dict(W=10, H=20, Q=7, B=65536, obs="fn", grouped=False, ruleset="functional")
+    return {
+        "config2": dict(prof="config2", B=4096, obs="board", steps=ks, warmup=kw, cpu=True, **num),
+        "config5": dict(prof="config5", W=20, H=40, Q=7, B=65536, obs="board", ruleset="numpy", grouped=True, steps=ks, warmup=kw, cpu=True),
+        "dict": dict(prof="dict", B=65536, obs="dict", steps=ks, warmup=kw, cpu=True, **num),
+        "rgb": dict(prof="rgb", B=65536, obs="rgb", steps=ks, warmup=kw, cpu=True, **num),
+        # tg_rollout, 16 transitions per launch, records / column masks / uint8 slabs resident on chip in between, every
+        # transition's observation and output record in its own trajectory slot
+        "fused_rollout": dict(prof="fused16_traj", B=65536, obs="board", fuse=16, traj=True, steps=f16, warmup=64, cpu=False, **num),
+        # config 2 again with 16 transitions per launch: at 4 096 envs (64 workgroups on 256 CUs) a one-transition launch is
+        # all launch boundary; the fused launch is what a rollout at that batch size should use
+        "config2_fused": dict(prof="config2_fused16_traj", B=4096, obs="board", fuse=16, traj=True, steps=f16, warmup=64, cpu=False, **num),
+        # the two packed observation surfaces at config 2's batch (the regime RL runs with pixel / dict observations live in)
+        "config2_dict": dict(prof="config2_dict", B=4096, obs="dict", steps=ks, warmup=kw, cpu=False, **num),
+        "config2_rgb": dict(prof="config2_rgb", B=4096, obs="rgb", steps=ks, warmup=kw, cpu=False, **num),
+        # the functional rule-set (envs/tetris_fn.py step / batched_step: the subsystem north_star names as replaced)
+        "functional": dict(prof="functional", steps=ks, warmup=kw, cpu=True, **fn),
+        "functional_fused": dict(prof="functional_fused16_traj", fuse=16, traj=True, steps=f16, warmup=64, cpu=False, **fn),
+    }
+
+
+def compact_line(out, blocks):
+    """The LAST stdout line: the contract's keys, `roofline` and `cpu_baseline` without prose, one [value, frac, us] triple per block."""
+    r = out["roofline"]
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data", "config", "per_rank_ms_per_step", "per_rank_device",
+                                "n_devices_visible") if k in out}
+    line["per_rank_ms_per_step"] = [round(x, 6) for x in line["per_rank_ms_per_step"]]
+    line["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_us", "clock",
+                                              "kernel_us_hip_events", "kernel_us_rocprof", "frac_hip_events", "frac_measured_bytes",
+                                              "alg_bytes_per_env_step", "resident") if r.get(k) is not None or k == "traffic"}
+    if "cpu_baseline" in out:
+        c = out["cpu_baseline"]
+        line["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"], "sample": c["sample"],
+                                "single_thread_value": c["single_thread"]["value"]}
+    for k in ("hbm_copy_gbps", "shard_checksums", "shard_transitions", "note", "blocks_file"):
+        if k in out:
+            line[k] = out[k]
+    if blocks:
+        mini = {}
+        for name, b in blocks.items():
+            if isinstance(b, dict) and "roofline" in b:
+                mini[name] = [float(f"{b['value']:.4g}"), round(b["roofline"]["frac"], 3), round(b["roofline"]["kernel_us"], 2)]
+            elif isinstance(b, dict) and "error" in b:
+                mini[name] = "error"
+            elif name == "vector_env":  # env steps/s: NumPy observations back to the host | everything device-resident
+                mini[name] = [float(f"{b['board']['host']['value']:.4g}"), float(f"{b['board']['device_actions']['value']:.4g}")]
+            elif name == "single_env":  # Tetris().step loop, steps/s
+                mini[name] = [float(f"{b['plain_loop']['value']:.4g}")]
+            elif name == "vector_env_shards":  # host microseconds per step driving 1 / 8 shards from one Python process
+                mini[name] = [round(b["k1"]["host_us_per_step"], 2), round(b["k8"]["host_us_per_step"], 2)]
+        line["blocks"] = mini
+        line["blocks_key"] = "[env steps/s, roofline.frac, kernel us per launch]; full blocks: blocks_file and the '[bench-block]' lines above"
+    return line
 
 
 def rank_main(args) -> int:
@@ -539,57 +683,45 @@ def rank_main(args) -> int:
         print("bench.py: no HIP device visible (this engine has no CPU fallback)", file=sys.stderr)
         return 3
     local = D.local % ndev  # more ranks than devices only when exercising the N > 1 path on a smaller box
-    W, H, B, Q = args.width, args.height, args.batch, 4
-    grouped = False
-    if args.config5:
-        W, H, Q, grouped = 20, 40, 7, True
     reps = max(5, args.reps)
     want_cpu = not args.no_cpu_baseline
-    head = run_block(D, "config5" if args.config5 else (args.obs if args.obs in ("dict", "rgb") else "config3"), W=W, H=H, Q=Q, B=B,
-                     obs=args.obs, ruleset=args.ruleset, grouped=grouped, steps=args.steps, warmup=args.warmup,
-                     reps=reps, fuse=args.fuse, local=local, want_cpu=want_cpu, copy_first=True)
     blocks = {}
-    std_head = not args.config5 and args.obs == "board" and args.ruleset == "numpy" and args.fuse == 1 \
-        and (W, H, B) == (10, 20, 65536)
+    if args.only_block:  # a block of the default run as the headline of a profiling run (same arguments, same instantiation)
+        spec = dict(block_specs(max(args.steps, 16), args.warmup)[args.only_block])
+        spec.update(steps=(args.steps + spec.get("fuse", 1) - 1) // spec.get("fuse", 1) * spec.get("fuse", 1), warmup=args.warmup)
+        prof, cpu = spec.pop("prof"), spec.pop("cpu")
+        head = run_block(D, prof, reps=reps, local=local, want_cpu=want_cpu and cpu, cpu_budget=args.cpu_budget, copy_first=True, **spec)
+        std_head = False
+    else:
+        W, H, B, Q = args.width, args.height, args.batch, 4
+        grouped = False
+        if args.config5:
+            W, H, Q, grouped = 20, 40, 7, True
+        pname = "config5" if args.config5 else (args.obs if args.obs in ("dict", "rgb") else
+                                                ("functional" if args.ruleset == "functional" else "config3"))
+        if args.fuse > 1:
+            pname = {"config3": "fused", "functional": "functional_fused"}.get(pname, pname) + f"{args.fuse}" + ("_traj" if args.traj else "")
+        head = run_block(D, pname, W=W, H=H, Q=Q, B=B, obs=args.obs, ruleset=args.ruleset, grouped=grouped, steps=args.steps,
+                         warmup=args.warmup, reps=reps, fuse=args.fuse, local=local, want_cpu=want_cpu,
+                         cpu_budget=args.cpu_budget, copy_first=True, traj=args.traj, checksum=not grouped)
+        std_head = not args.config5 and args.obs == "board" and args.ruleset == "numpy" and args.fuse == 1 \
+            and (W, H, B) == (10, 20, 65536)
     if D.world == 1 and not args.no_blocks and std_head:
-        ks, kw = max(args.steps, 256), max(args.warmup, 64)
-        common = dict(ruleset="numpy", steps=ks, warmup=kw, reps=reps, local=local, want_cpu=want_cpu, cpu_budget=3.0)
-        blocks["config2"] = run_block(D, "config2", W=10, H=20, Q=4, B=4096, obs="board", grouped=False, **common)
-        blocks["config5"] = run_block(D, "config5", W=20, H=40, Q=7, B=65536, obs="board", grouped=True, **common)
-        blocks["dict"] = run_block(D, "dict", W=10, H=20, Q=4, B=65536, obs="dict", grouped=False, **common)
-        blocks["rgb"] = run_block(D, "rgb", W=10, H=20, Q=4, B=65536, obs="rgb", grouped=False, **common)
-        blocks["fused_rollout"] = run_block(D, "fused16", W=10, H=20, Q=4, B=65536, obs="board", grouped=False, fuse=16,
-                                            ruleset="numpy", steps=(ks + 15) // 16 * 16, warmup=64, reps=reps, local=local,
-                                            want_cpu=False)
-        if blocks["fused_rollout"]:
-            blocks["fused_rollout"]["note"] = ("tg_step_k with tg_config.fuse = 16 (the default): records, column masks and uint8 slabs stay in "
-                                               "registers/LDS across the 16 transitions of a launch; the observation of "
-                                               "every transition is still written; reported beside `value`, never as it")
-        # config 2 again with 16 transitions per launch: at 4 096 envs (64 workgroups on 256 CUs) a one-transition launch is
-        # all launch boundary; the fused launch is what a rollout at that batch size should use
-        blocks["config2_fused"] = run_block(D, "config2_fused16", W=10, H=20, Q=4, B=4096, obs="board", grouped=False, fuse=16,
-                                            ruleset="numpy", steps=(ks + 15) // 16 * 16, warmup=64, reps=reps, local=local,
-                                            want_cpu=False)
-        # the two packed observation surfaces at config 2's batch (4 096 envs: the regime RL runs with pixel / dict observations
-        # live in): there the launch is the chain of its packing waves, which helper waves shorten
-        for oname in ("dict", "rgb"):
-            blocks[f"config2_{oname}"] = run_block(D, f"config2_{oname}", W=10, H=20, Q=4, B=4096, obs=oname, grouped=False,
-                                                    ruleset="numpy", steps=ks, warmup=kw, reps=reps, local=local, want_cpu=False)
-        # the functional rule-set (envs/tetris_fn.py step / batched_step: the subsystem north_star names as replaced)
-        fcommon = dict(W=10, H=20, Q=7, B=65536, obs="fn", grouped=False, ruleset="functional", reps=reps, local=local)
-        blocks["functional"] = run_block(D, "functional", steps=ks, warmup=kw, want_cpu=want_cpu, cpu_budget=3.0, **fcommon)
-        blocks["functional_fused"] = run_block(D, "functional_fused16", fuse=16, steps=(ks + 15) // 16 * 16, warmup=64,
-                                               want_cpu=False, **fcommon)
+        for name, spec in block_specs(max(args.steps, 256), max(args.warmup, 64)).items():
+            spec = dict(spec)
+            prof, cpu = spec.pop("prof"), spec.pop("cpu")
+            blocks[name] = run_block(D, prof, reps=reps, local=local, want_cpu=want_cpu and cpu, cpu_budget=min(3.0, args.cpu_budget), **spec)
+            print(f"[bench-block] {name} " + json.dumps(blocks[name]), flush=True)
         for name, fn in (("vector_env", vector_env_block), ("single_env", single_env_block), ("vector_env_shards", shards_block)):
             try:
                 blocks[name] = fn(local)
             except Exception as ex:  # pragma: no cover - adapter problems must not lose the headline line
                 blocks[name] = {"error": repr(ex)}
-    elif D.world > 1 and not args.no_blocks and std_head:
-        pass  # the further configs are single-GPU cases (BASELINE.json configs[1], [4]); config 4 IS this run at N = 8
+            print(f"[bench-block] {name} " + json.dumps(blocks[name]), flush=True)
+    # (N > 1: the further configs are single-GPU cases (BASELINE.json configs[1], [4]); config 4 IS this run at N = 8)
     if D.rank == 0:
         out = {"metric": "env steps/sec (whole node), 10x20 board, batch=65536 per GPU",
-               "value": head["value"], "unit": "env steps/s", "n_gpus": D.world, "steps": args.steps,
+               "value": head["value"], "unit": "env steps/s", "n_gpus": D.world, "steps": head["steps"],
                "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "u8", "data": "synthetic", "config": head["config"],
                "per_rank_ms_per_step": head["per_rank_ms_per_step"], "per_rank_device": head["per_rank_device"],
@@ -597,15 +729,20 @@ def rank_main(args) -> int:
         if D.world > ndev:
             out["note"] = (f"{D.world} ranks on {ndev} visible device(s): ranks share devices round-robin — this exercises the "
                            f"N > 1 path, it is not a scaling measurement")
-        if "hbm_copy_gbps" in head:
-            out["hbm_copy_gbps"] = head["hbm_copy_gbps"]
-        if "cpu_baseline" in head:
-            out["cpu_baseline"] = head["cpu_baseline"]
-        if "parity_note" in head:
-            out["parity_note"] = head["parity_note"]
+        for k in ("hbm_copy_gbps", "cpu_baseline", "shard_checksums", "shard_transitions"):
+            if k in head:
+                out[k] = head[k]
+        full = dict(out, notes=NOTES)
         if blocks:
-            out["blocks"] = blocks
-        print(json.dumps(out), flush=True)
+            full["blocks"] = blocks
+            path = os.environ.get("TG_BENCH_BLOCKS_FILE", os.path.join(ROOT, "bench_blocks.json"))
+            try:
+                with open(path, "w") as f:
+                    json.dump(full, f, indent=1)
+                out["blocks_file"] = os.path.relpath(path, ROOT)
+            except OSError as ex:  # (a read-only checkout: the '[bench-block]' lines above carry the same content)
+                out["blocks_file"] = f"not written ({ex.__class__.__name__})"
+        print(json.dumps(compact_line(out, blocks), separators=(",", ":")), flush=True)
     D.close()
     return 0
 

@@ -27,8 +27,10 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 3 /* 2: tg_config launch knobs, tg_dev_copy, tg_get_state_dev / tg_set_state_dev
-                          * 3: TG_BUF_HOST_PACK, tg_host_pack_layout, tg_fetch_many, tg_step_fetch_many, tg_shape_mask */
+#define TG_ABI_VERSION 4 /* 2: tg_config launch knobs, tg_dev_copy, tg_get_state_dev / tg_set_state_dev
+                          * 3: TG_BUF_HOST_PACK, tg_host_pack_layout, tg_fetch_many, tg_step_fetch_many, tg_shape_mask
+                          * 4: tg_config.action_ids / rewards (ActionsMapping / RewardsMapping as per-handle data),
+                          *    TG_OUT_COMMITTED / TG_OUT_ILLEGAL in tg_step_out.flags */
 
 /* ---- rule-sets (the reference contains two different Tetris rule-sets) ---- */
 #define TG_RULESET_NUMPY 0      /* envs/tetris.py (the graded oracle) */
@@ -65,6 +67,8 @@ extern "C" {
 #define TG_FLAG_FINAL_OBS 2     /* SAME_STEP autoreset, TG_OBS_BOARD / TG_OBS_FN: also write the terminal observation to
                                  * TG_BUF_FINAL_OBS (gymnasium's infos["final_observation"]; valid where terminated) */
 #define TG_FLAG_FEATURES 4      /* allocate the feature buffers used by tg_features */
+#define TG_FLAG_CUSTOM_ACTIONS 8  /* NUMPY: tg_config.action_ids holds a non-stock ActionsMapping (mappings/actions.py:5-19) */
+#define TG_FLAG_CUSTOM_REWARDS 16 /* NUMPY: tg_config.rewards holds a non-stock RewardsMapping (mappings/rewards.py:5-15) */
 
 /* ---- error codes ---- */
 #define TG_OK 0
@@ -72,6 +76,19 @@ extern "C" {
 #define TG_EHIP (-2)        /* a HIP runtime call failed */
 #define TG_ENOMEM (-3)
 #define TG_EUNSUPPORTED (-4) /* e.g. board size not compiled in, custom tetromino tables */
+
+/* ---- environment variables the library reads (all of them; everything else is tg_config) ----
+ *   TG_FUSE=1..16      overrides tg_config.fuse        } launch knobs: results never depend on them; the tests set them to
+ *   TG_RNG_EVERY=1..3  overrides tg_config.rng_every   } drive the rare paths (in-line bag shuffle, RNG role in every launch,
+ *   TG_RING_FILL=0..3  overrides tg_config.ring_fill_p1 - 1 } one transition per launch of tg_step_k)
+ *   TG_FN_LAZY=0..7    FUNCTIONAL look-ahead test hook: bits 0-1 when a lock sorts the reset bag ahead (0 tall stack only,
+ *                      1 never, 2 always), bit 2 the key chain never catches up behind a reset
+ *   TG_SPLIT=0         never pick the instantiations with two stream waves per workgroup (tests: both builds must agree)
+ *   TG_PACKED=0|1      forbid / force the nibble-packed board format (default: handles of >= 20 Mi cells)
+ *   TG_KERNEL=bits     anything else needs the test-only legacy library (make -C csrc legacy) and is refused by the product
+ *   TG_CSRC_DIR, TG_CACHE_DIR   where the kernel headers are / where compiled code objects of non-built-in board sizes are
+ *                      cached (default: <library dir>/csrc, ~/.cache/tetris_gym_hip)
+ * (Python side: TG_LIB = path of the library to load, TG_HIP_RUNTIME = system | torch | auto, TG_VERBOSE.) */
 
 typedef struct tg_config {
   int32_t struct_size; /* = sizeof(tg_config); ABI guard */
@@ -97,7 +114,26 @@ typedef struct tg_config {
                            (1..3, default 3) */
   int32_t ring_fill_p1; /* NUMPY rules: 1 + look-ahead bag permutations kept per env (1..4, default 4 = 3 permutations);
                            smaller values exercise the in-line shuffle of the step kernel */
-  int32_t reserved2;
+  int32_t streams;      /* > 1: spread every transition of a large batch over this many HIP streams (contiguous env shards of
+                           >= 8 192 envs, one launch each; board / functional observations only).  0 / 1 = one launch (default:
+                           measured faster); kept for the tests that pin the shard arithmetic */
+  /* ---- ABI 4: the reference's two mapping dataclasses as per-handle DATA (envs/tetris.py:83-84, 189-190) ----
+   * action_ids (TG_FLAG_CUSTOM_ACTIONS, else ignored = the stock 0..7): the values of ActionsMapping's fields in declaration
+   *   order — move_left, move_right, move_down, rotate_clockwise, rotate_counterclockwise, hard_drop, swap, no_op
+   *   (mappings/actions.py:12-19).  Tetris.step compares the incoming action with the fields in the order of its elif chain
+   *   (envs/tetris.py:222-256: left, right, down, cw, ccw, swap, hard_drop, no_op; the first match wins, an id that matches
+   *   no field only takes gravity) and skips gravity iff action == hard_drop (:259).  The action space stays Discrete(8)
+   *   (:192), so only ids 0..7 are reachable; field values outside that range are legal and unreachable.  Refused
+   *   (TG_EUNSUPPORTED): a mapping in which hard_drop shares its value with a field earlier in the chain (that id would run
+   *   the other operation and then skip gravity — no entry of the kernel's action table says that).
+   * rewards (TG_FLAG_CUSTOM_REWARDS, else ignored = the stock 1, 1, 0, -0.1): alife, clear_line, game_over,
+   *   invalid_action (mappings/rewards.py:12-15).  A commit returns score(lines) + alife, or game_over when the piece
+   *   already collides / the spawn collides (envs/tetris.py:461-474); clear_line is a field the reference never reads
+   *   (score is rows^2 * width, :621-630) and is carried for completeness; invalid_action is the reward of a masked-out
+   *   action of the grouped action set (wrappers/grouped.py:238).  The step kernel works in float32; the exact Python value
+   *   (int + float in double precision) is what TG_BUF_HOST_PACK holds — recomputed from tg_step_out.flags / lines. */
+  int32_t action_ids[8];
+  double rewards[4];
 } tg_config;
 
 /* ---- per-env state records (tg_get_state / tg_set_state; also the device layout) ----
@@ -164,11 +200,15 @@ typedef struct tg_rng_rec { /* 48 bytes */
 #define TG_BUF_COUNT 12
 
 typedef struct tg_step_out { /* 8 bytes, written by the step kernel with one store per env */
-  float reward;        /* NUMPY rewards are integer-valued (envs/tetris.py:468-474); grouped illegal = -0.1f */
+  float reward;        /* NUMPY: integer-valued with the stock RewardsMapping (envs/tetris.py:468-474); grouped illegal = -0.1f */
   uint8_t terminated;
   uint8_t lines;       /* info["lines_cleared"] */
-  uint16_t reserved;
+  uint8_t flags;       /* TG_OUT_* (NUMPY rule-set) */
+  uint8_t reserved;
 } tg_step_out;
+#define TG_OUT_COMMITTED 1 /* commit_active_tetromino ran in this step (envs/tetris.py:450-479): reward = terminated ?
+                              rewards.game_over : score(lines) + rewards.alife */
+#define TG_OUT_ILLEGAL 2   /* grouped action set: the action was masked out, reward = rewards.invalid_action */
 
 typedef struct tg_episode_rec { /* 16 bytes: device-side RecordEpisodeStatistics */
   float ret;           /* running return of the current episode */

@@ -64,6 +64,8 @@ def lib() -> C.CDLL:
         L.tgo_create.restype = vp
         L.tgo_create.argtypes = [i32] * 8
         L.tgo_destroy.argtypes = [vp]
+        L.tgo_set_mappings.argtypes = [vp, vp, vp]
+        L.tgo_last_rewards.argtypes = [vp, vp]
         L.tgo_reset.argtypes = [vp, vp, vp]
         L.tgo_step.argtypes = [vp, vp, vp, vp, vp, i32, i32]
         L.tgo_grouped_step.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32]
@@ -105,7 +107,9 @@ class OracleBatch:
     """A batch of CPU oracle envs with the same call surface as the engine's `Engine` class."""
 
     def __init__(self, batch, width=10, height=20, ruleset=RULESET_NUMPY, gravity=True, queue_size=None,
-                 padding=4, env_offset=0, nthreads=1):
+                 padding=4, env_offset=0, nthreads=1, action_ids=None, rewards=None):
+        """action_ids / rewards: the field values of an ActionsMapping (8) / RewardsMapping (4) in declaration order
+        (mappings/actions.py:12-19, mappings/rewards.py:12-15); None = the stock dataclasses."""
         self.L = lib()
         if queue_size is None:
             queue_size = 4 if ruleset == RULESET_NUMPY else 7
@@ -116,6 +120,17 @@ class OracleBatch:
                                    env_offset)
         if not self.h:
             raise ValueError("tgo_create rejected the configuration")
+        if action_ids is not None or rewards is not None:
+            a = None if action_ids is None else np.ascontiguousarray(action_ids, dtype=np.int32)
+            r = None if rewards is None else np.ascontiguousarray(rewards, dtype=np.float64)
+            assert (a is None or a.shape == (8,)) and (r is None or r.shape == (4,))
+            self.L.tgo_set_mappings(self.h, _p(a), _p(r))
+
+    def last_rewards(self):
+        """The rewards of the last step as Python computes them (int score + float alife in double precision)."""
+        out = np.empty(self.B, np.float64)
+        self.L.tgo_last_rewards(self.h, _p(out))
+        return out
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -45,8 +45,22 @@ def matrix16(t) -> np.ndarray:
     return m.reshape(16)
 
 
-def make_env(ref, width, height, gravity, queue_size):
-    env = ref.Tetris(width=width, height=height, gravity=gravity)
+def mapping_kwargs(action_ids=None, rewards=None):
+    """Tetris(actions_mapping=..., rewards_mapping=...) from field values in declaration order (mappings/actions.py:12-19,
+    mappings/rewards.py:12-15)"""
+    from tetris_gymnasium.mappings.actions import ActionsMapping
+    from tetris_gymnasium.mappings.rewards import RewardsMapping
+
+    kw = {}
+    if action_ids is not None:
+        kw["actions_mapping"] = ActionsMapping(*[int(v) for v in action_ids])
+    if rewards is not None:
+        kw["rewards_mapping"] = RewardsMapping(*rewards)
+    return kw
+
+
+def make_env(ref, width, height, gravity, queue_size, action_ids=None, rewards=None):
+    env = ref.Tetris(width=width, height=height, gravity=gravity, **mapping_kwargs(action_ids, rewards))
     if queue_size != 4:
         # the reference's queue=/holder= kwargs are broken (envs/tetris.py:139-144 leave the attribute
         # unset); config 5 patches the queue after construction
@@ -102,9 +116,10 @@ class SeekPolicy:
     target column inside the stack's gap, rotate, walk there, hard-drop.  Its decisions are stored in the
     fixture as plain actions, so tests replay actions only."""
 
-    def __init__(self, rng, gap_lo, gap_hi, padding=4):
+    def __init__(self, rng, gap_lo, gap_hi, padding=4, action_ids=None):
         self.rng, self.lo, self.hi, self.p = rng, gap_lo, gap_hi, padding
         self.plan = False
+        self.ids = list(range(8)) if action_ids is None else [int(v) for v in action_ids]  # the env's ActionsMapping
 
     def act(self, env):
         if not self.plan:
@@ -114,22 +129,23 @@ class SeekPolicy:
             self.plan = True
         if self.rots > 0:
             self.rots -= 1
-            return 3
+            return self.ids[3]  # rotate_clockwise
         if env.x != self.tx and self.moves < 14:
             self.moves += 1
-            return 0 if env.x > self.tx else 1
+            return self.ids[0] if env.x > self.tx else self.ids[1]  # move_left / move_right
         self.plan = False
-        return 5 if self.rng.random() < 0.9 else int(self.rng.integers(0, 8))
+        return self.ids[5] if self.rng.random() < 0.9 else int(self.rng.integers(0, 8))  # hard_drop
 
 
 def run_trace(ref, name, width, height, gravity, queue_size, B, T, action_seed, n_actions=8,
-              snap_every=64, init_boards=None, action_p=None, seek=None):
+              snap_every=64, init_boards=None, action_p=None, seek=None, action_ids=None, rewards=None):
     rng = np.random.default_rng(action_seed)
     if action_p is None:
         actions = rng.integers(0, n_actions, size=(T, B)).astype(np.int8)
     else:
         actions = rng.choice(n_actions, size=(T, B), p=action_p).astype(np.int8)
     reward = np.zeros((T, B), np.int16)
+    reward_f64 = np.zeros((T, B), np.float64)  # the Python value (int score + RewardsMapping floats) for non-stock mappings
     done = np.zeros((T, B), np.uint8)
     lines = np.zeros((T, B), np.uint8)
     crc = np.zeros((T, B), np.uint32)
@@ -148,19 +164,20 @@ def run_trace(ref, name, width, height, gravity, queue_size, B, T, action_seed, 
     first_obs_crc = np.zeros(B, np.uint32)
     t0 = time.time()
     for i in range(B):
-        env = make_env(ref, width, height, gravity, queue_size)
+        env = make_env(ref, width, height, gravity, queue_size, action_ids, rewards)
         obs, _ = env.reset(seed=1 + i)
         if init_boards is not None:
             env.board = init_boards[i].copy()
             obs = env._get_obs()
         first_obs_crc[i] = obs_crc(obs)
-        pol = SeekPolicy(rng, *seek[i]) if seek is not None else None
+        pol = SeekPolicy(rng, *seek[i], action_ids=action_ids) if seek is not None else None
         for t in range(T):
             if pol is not None:
                 actions[t, i] = pol.act(env)
             obs, r, d, _, info = env.step(int(actions[t, i]))
-            assert r == int(r)
-            reward[t, i], done[t, i], lines[t, i] = int(r), int(d), int(info["lines_cleared"])
+            assert rewards is not None or r == int(r)
+            reward_f64[t, i] = float(r)
+            reward[t, i], done[t, i], lines[t, i] = (int(r) if r == int(r) else 0), int(d), int(info["lines_cleared"])
             crc[t, i] = obs_crc(obs)
             xs[t, i], ys[t, i], pieces[t, i] = env.x, env.y, env.active_tetromino.id - 2
             if (t % snap_every) == snap_every - 1:
@@ -187,6 +204,10 @@ def run_trace(ref, name, width, height, gravity, queue_size, B, T, action_seed, 
         out["snap_" + k] = np.array(v).astype(np.uint8)
     if init_boards is not None:
         out["init_boards"] = init_boards
+    if action_ids is not None or rewards is not None:
+        out["reward_f64"] = reward_f64
+        out["action_ids"] = np.array(list(range(8)) if action_ids is None else action_ids, np.int32)
+        out["rewards_mapping"] = np.array([1, 1, 0, -0.1] if rewards is None else rewards, np.float64)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(f"{name}: {B*T} steps in {time.time()-t0:.1f}s  episodes={int(done.sum())}  "
           f"lock-steps={(reward>0).sum()}  lines total={int(lines.sum())} max={int(lines.max())}")
@@ -214,13 +235,14 @@ def dense_boards(width, height, B, seed):
     return boards, gaps
 
 
-def gen_clears(ref, name, width, height, queue_size, B, T, seed, board_seed):
+def gen_clears(ref, name, width, height, queue_size, B, T, seed, board_seed, action_ids=None, rewards=None):
     boards, gaps = dense_boards(width, height, B, board_seed)
     run_trace(ref, name, width, height, True, queue_size, B, T, seed, snap_every=32, init_boards=boards,
-              seek=gaps)
+              seek=gaps, action_ids=action_ids, rewards=rewards)
 
 
-def gen_grouped(ref, name, width, height, queue_size, B, T, seed, n_enum, init_boards=None):
+def gen_grouped(ref, name, width, height, queue_size, B, T, seed, n_enum, init_boards=None, action_ids=None, rewards=None,
+                terminate_on_illegal=True, p_any=0.03):
     """Grouped wrapper traces (random LEGAL action, like examples/train_lin_grouped.py's epsilon branch)
     plus full enumerations (mask + 4W boards) on mid-game states."""
     rng = np.random.default_rng(seed)
@@ -228,6 +250,7 @@ def gen_grouped(ref, name, width, height, queue_size, B, T, seed, n_enum, init_b
     Hp, Wp = height + 4, width + 8
     actions = np.zeros((T, B), np.int16)
     reward = np.zeros((T, B), np.float32)
+    reward_f64 = np.zeros((T, B), np.float64)
     done = np.zeros((T, B), np.uint8)
     lines = np.zeros((T, B), np.uint8)
     masks = np.zeros((T, B, NA), np.uint8)
@@ -241,8 +264,8 @@ def gen_grouped(ref, name, width, height, queue_size, B, T, seed, n_enum, init_b
     reset_mask = np.zeros((B, NA), np.uint8)
     t0 = time.time()
     for i in range(B):
-        base = make_env(ref, width, height, True, queue_size)
-        env = ref.GroupedActionsObservations(base, terminate_on_illegal_action=True)
+        base = make_env(ref, width, height, True, queue_size, action_ids, rewards)
+        env = ref.GroupedActionsObservations(base, terminate_on_illegal_action=terminate_on_illegal)
         obs, info = env.reset(seed=1 + i)
         if init_boards is not None:
             base.board = init_boards[i].copy()
@@ -252,13 +275,14 @@ def gen_grouped(ref, name, width, height, queue_size, B, T, seed, n_enum, init_b
             mask = env.legal_actions_mask
             legal = np.flatnonzero(mask == 1)
             # mostly legal actions, sometimes any action (exercises the illegal → terminate branch)
-            if len(legal) == 0 or rng.random() < 0.03:
+            if len(legal) == 0 or rng.random() < p_any:
                 a = int(rng.integers(0, NA))
             else:
                 a = int(rng.choice(legal))
             actions[t, i] = a
             obs, r, d, _, info = env.step(a)
             reward[t, i], done[t, i], lines[t, i] = r, int(d), int(info["lines_cleared"])
+            reward_f64[t, i] = float(r)
             masks[t, i] = info["action_mask"]
             board_after[t, i] = base.board
             if ne < n_enum and not d and rng.random() < 0.08:
@@ -274,10 +298,15 @@ def gen_grouped(ref, name, width, height, queue_size, B, T, seed, n_enum, init_b
                     base.board = init_boards[i].copy()
                     env.observation(base._get_obs())
                 masks[t, i] = env.legal_actions_mask  # mask the next action is drawn from
+    extra = {}
+    if action_ids is not None or rewards is not None:
+        extra = dict(reward_f64=reward_f64, terminate_on_illegal=int(terminate_on_illegal),
+                     action_ids=np.array(list(range(8)) if action_ids is None else action_ids, np.int32),
+                     rewards_mapping=np.array([1, 1, 0, -0.1] if rewards is None else rewards, np.float64))
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"), width=width, height=height, queue_size=queue_size, B=B, T=T,
         actions=actions, reward=reward, done=done, lines=lines, masks=masks, board_after=board_after,
-        reset_mask=reset_mask, init_boards=(init_boards if init_boards is not None else np.zeros(0, np.uint8)),
+        reset_mask=reset_mask, **extra, init_boards=(init_boards if init_boards is not None else np.zeros(0, np.uint8)),
         enum_state_board=enum_state_board[:ne], enum_piece=enum_piece[:ne],
         enum_matrix=enum_matrix[:ne], enum_mask=enum_mask[:ne], enum_boards=enum_boards[:ne])
     print(f"{name}: {B*T} grouped steps in {time.time()-t0:.1f}s episodes={int(done.sum())} "
@@ -418,6 +447,12 @@ def gen_features(ref):
     print("features: ok", feats[:3])
 
 
+# ActionsMapping field values in declaration order: move_left, move_right, move_down, rotate_clockwise,
+# rotate_counterclockwise, hard_drop, swap, no_op
+MAP_PERM = (3, 7, 0, 5, 1, 2, 4, 6)
+MAP_DUP = (0, 1, 2, 3, 3, 5, 6, 12)  # ccw duplicates cw (unreachable), ids 4 and 7 belong to no field
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -440,6 +475,18 @@ def main():
         "grouped_features_20x40": lambda: gen_grouped_features(ref, "grouped_features_20x40", 20, 40, 7, 24, 42, dense=True),
         "ref_tests_grouped": lambda: gen_ref_tests_grouped(ref),
         "features": lambda: gen_features(ref),
+        # non-stock ActionsMapping / RewardsMapping (envs/tetris.py:83-84, 189-190): a permutation of the ids with float rewards;
+        # line clears with integer rewards; a mapping with a duplicate value (the first field of the elif chain wins,
+        # :222-256) and ids that no field holds (gravity only); the grouped wrapper's invalid_action reward (grouped.py:238)
+        "mapped_10x20_g1": lambda: run_trace(ref, "mapped_10x20_g1", 10, 20, True, 4, 48, 384, 12360,
+                                             action_ids=MAP_PERM, rewards=(0.5, 10, -5.25, -0.25)),
+        "mapped_10x20_g0": lambda: run_trace(ref, "mapped_10x20_g0", 10, 20, False, 4, 24, 256, 12361,
+                                             action_ids=MAP_DUP, rewards=(2, 1, -7, -0.1)),
+        "mapped_clears_10x20": lambda: gen_clears(ref, "mapped_clears_10x20", 10, 20, 4, 48, 256, 779, 7,
+                                                  action_ids=MAP_PERM, rewards=(0, 10, -5, -1)),
+        "mapped_grouped_10x20": lambda: gen_grouped(ref, "mapped_grouped_10x20", 10, 20, 4, 16, 96, 34, 0,
+                                                    action_ids=MAP_PERM, rewards=(3, 1, -4, -0.375),
+                                                    terminate_on_illegal=False, p_any=0.25),
         "rgb_10x20": lambda: gen_rgb(ref, "rgb_10x20", 10, 20, 4, 8, 160, 51),
         "rgb_20x40": lambda: gen_rgb(ref, "rgb_20x40", 20, 40, 7, 2, 200, 52),
     }

@@ -280,7 +280,17 @@ void tgo_fn_matrix(int piece, int rot, uint8_t out[16]) {
 /* ------------------------------------------------------------------------------------------------
  * Env state (both rule-sets share the struct; unused members stay zero)
  * ---------------------------------------------------------------------------------------------- */
+/* mappings/actions.py:5-19 ActionsMapping and mappings/rewards.py:5-15 RewardsMapping: per-batch data
+ * (envs/tetris.py:83-84, 189-190).  Field order = declaration order of the dataclasses. */
 typedef struct {
+  int move_left, move_right, move_down, rotate_clockwise, rotate_counterclockwise, hard_drop, swap, no_op;
+  double alife, clear_line, game_over, invalid_action;
+} mappings_t;
+static const mappings_t STOCK_MAPPINGS = {0, 1, 2, 3, 4, 5, 6, 7, 1.0, 1.0, 0.0, -0.1};
+
+typedef struct {
+  const mappings_t* map;
+  double last_reward; /* the reward of the last step as Python computes it (int + float in double precision) */
   int W, H, P, Wp, Hp, gravity, qsize;
   uint8_t board[MAXCELLS]; /* padded (H+P) x (W+2P), bedrock = 1 */
   tetromino active;
@@ -301,6 +311,7 @@ typedef struct {
 struct tgo_batch {
   int ruleset, batch, env_offset;
   env_t* e;
+  mappings_t map;
 };
 
 /* envs/tetris.py:632-641 create_board / functional/core.py:46-63 */
@@ -412,10 +423,10 @@ static void np_project(const env_t* e, const tetromino* t, int x, int y, uint8_t
 }
 
 /* envs/tetris.py:450-479 commit_active_tetromino */
-static void commit_active_tetromino(env_t* e, int* reward, int* lines_cleared) {
+static void commit_active_tetromino(env_t* e, double* reward, int* lines_cleared) {
   *lines_cleared = 0;
   if (collision(e, &e->active, e->x, e->y)) {
-    *reward = 0; /* rewards.game_over */
+    *reward = e->map->game_over; /* :462 */
     e->game_over = 1;
   } else {
     while (!collision(e, &e->active, e->x, e->y + 1)) e->y += 1; /* :445-448 */
@@ -425,8 +436,8 @@ static void commit_active_tetromino(env_t* e, int* reward, int* lines_cleared) {
     *lines_cleared = np_clear_filled_rows(e, e->board);
     *reward = tgo_np_score(*lines_cleared, e->W);
     e->game_over = !spawn_tetromino(e);
-    *reward += 1; /* rewards.alife */
-    if (e->game_over) *reward = 0;
+    *reward += e->map->alife;                          /* :472 */
+    if (e->game_over) *reward = e->map->game_over;     /* :473-474 */
     e->has_swapped = 0;
   }
 }
@@ -445,23 +456,24 @@ static void np_reset(env_t* e, uint64_t seed, uint64_t default_seed) {
 }
 
 /* envs/tetris.py:203-272 step.  Returns reward; *lines out. */
-static int np_step(env_t* e, int action, int* lines) {
-  int reward = 0;
+static double np_step(env_t* e, int action, int* lines) {
+  double reward = 0;
+  const mappings_t* A = e->map; /* self.actions: the elif chain compares with the mapping's fields, in this order */
   *lines = 0;
   tetromino* t = &e->active;
-  if (action == 0) { /* move_left */
+  if (action == A->move_left) {
     if (!collision(e, t, e->x - 1, e->y)) e->x -= 1;
-  } else if (action == 1) { /* move_right */
+  } else if (action == A->move_right) {
     if (!collision(e, t, e->x + 1, e->y)) e->x += 1;
-  } else if (action == 2) { /* move_down */
+  } else if (action == A->move_down) {
     if (!collision(e, t, e->x, e->y + 1)) e->y += 1;
-  } else if (action == 3) { /* rotate_clockwise = np.rot90(k=1) */
+  } else if (action == A->rotate_clockwise) { /* np.rot90(k=1) */
     tetromino r = rotate(t, 1);
     if (!collision(e, &r, e->x, e->y)) e->active = r;
-  } else if (action == 4) { /* rotate_counterclockwise = np.rot90(k=-1) */
+  } else if (action == A->rotate_counterclockwise) { /* np.rot90(k=-1) */
     tetromino r = rotate(t, 0);
     if (!collision(e, &r, e->x, e->y)) e->active = r;
-  } else if (action == 6) { /* swap (:242-252, components/tetromino_holder.py:31-49) */
+  } else if (action == A->swap) { /* (:242-252, components/tetromino_holder.py:31-49) */
     if (!e->has_swapped) {
       tetromino cur = e->active;
       int had = e->holder_len;
@@ -476,17 +488,18 @@ static int np_step(env_t* e, int action, int* lines) {
         reset_position(e);
       }
     }
-  } else if (action == 5) { /* hard_drop */
+  } else if (action == A->hard_drop) {
     commit_active_tetromino(e, &reward, lines);
-  } /* 7: no_op */
+  } /* no_op, or an id no field holds: pass */
 
-  if (e->gravity && action != 5) { /* :259-264 */
+  if (e->gravity && action != A->hard_drop) { /* :259-264 */
     if (!collision(e, &e->active, e->x, e->y + 1)) {
       e->y += 1;
     } else {
       commit_active_tetromino(e, &reward, lines);
     }
   }
+  e->last_reward = reward;
   return reward;
 }
 
@@ -768,10 +781,11 @@ static float grouped_step(env_t* e, int action, int terminate_on_illegal, int* l
       *terminated = 1;
       *lines = 0;
     } else {
-      (void)np_step(e, 7, lines);
+      (void)np_step(e, e->map->no_op, lines); /* wrappers/grouped.py:234 */
       *terminated = e->game_over;
     }
-    return -0.1f;
+    e->last_reward = e->map->invalid_action;  /* :238 */
+    return (float)e->map->invalid_action;
   }
   int xb = action / 4, r = action % 4;
   int x = xb + e->P - e->active.n / 2;
@@ -779,7 +793,7 @@ static float grouped_step(env_t* e, int action, int terminate_on_illegal, int* l
   for (int i = 0; i < r; ++i) nt = rotate(&nt, 1);
   e->x = x;
   e->active = nt;
-  int reward = np_step(e, 5, lines);
+  double reward = np_step(e, e->map->hard_drop, lines); /* :257-259 */
   *terminated = e->game_over;
   return (float)reward;
 }
@@ -832,8 +846,10 @@ tgo_batch* tgo_create(int ruleset, int width, int height, int padding, int queue
   b->env_offset = env_offset;
   b->e = (env_t*)calloc((size_t)batch, sizeof(env_t));
   if (!b->e) { free(b); return NULL; }
+  b->map = STOCK_MAPPINGS;
   for (int i = 0; i < batch; ++i) {
     env_t* e = &b->e[i];
+    e->map = &b->map;
     e->W = width; e->H = height; e->P = padding;
     e->Wp = width + 2 * padding; e->Hp = height + padding;
     e->gravity = gravity; e->qsize = queue_size;
@@ -841,6 +857,23 @@ tgo_batch* tgo_create(int ruleset, int width, int height, int padding, int queue
     e->active = make_tetromino(0, 0, 2);
   }
   return b;
+}
+
+/* Tetris(actions_mapping=..., rewards_mapping=...) (envs/tetris.py:83-84): NULL keeps what is set */
+void tgo_set_mappings(tgo_batch* b, const int32_t action_ids[8], const double rewards[4]) {
+  if (action_ids) {
+    b->map.move_left = action_ids[0]; b->map.move_right = action_ids[1]; b->map.move_down = action_ids[2];
+    b->map.rotate_clockwise = action_ids[3]; b->map.rotate_counterclockwise = action_ids[4];
+    b->map.hard_drop = action_ids[5]; b->map.swap = action_ids[6]; b->map.no_op = action_ids[7];
+  }
+  if (rewards) {
+    b->map.alife = rewards[0]; b->map.clear_line = rewards[1]; b->map.game_over = rewards[2];
+    b->map.invalid_action = rewards[3];
+  }
+}
+
+void tgo_last_rewards(const tgo_batch* b, double* out) {
+  for (int i = 0; i < b->batch; ++i) out[i] = b->e[i].last_reward;
 }
 
 void tgo_destroy(tgo_batch* b) {
@@ -879,10 +912,11 @@ void tgo_step(tgo_batch* b, const int32_t* actions, float* reward, uint8_t* term
     if (autoreset == TG_AUTORESET_NEXT_STEP && e->pending_reset) {
       reset_one(b, i, 0, 0);
       reward[i] = 0.0f; terminated[i] = 0; lines[i] = 0;
+      e->last_reward = 0.0;
       continue;
     }
     if (b->ruleset == TG_RULESET_NUMPY) rw = (float)np_step(e, actions[i], &ln);
-    else rw = fn_step(e, actions[i], &ln);
+    else { rw = fn_step(e, actions[i], &ln); e->last_reward = (double)rw; }
     reward[i] = rw;
     terminated[i] = (uint8_t)e->game_over;
     lines[i] = (uint8_t)ln;
@@ -906,6 +940,7 @@ void tgo_grouped_step(tgo_batch* b, const int32_t* actions, float* reward, uint8
     if (autoreset == TG_AUTORESET_NEXT_STEP && e->pending_reset) {
       reset_one(b, i, 0, 0);
       reward[i] = 0.0f; terminated[i] = 0; lines[i] = 0;
+      e->last_reward = 0.0;
       if (illegal) illegal[i] = 0;
       continue;
     }

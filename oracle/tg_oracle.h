@@ -28,6 +28,11 @@ typedef struct tgo_batch tgo_batch;
 tgo_batch* tgo_create(int ruleset, int width, int height, int padding, int queue_size, int gravity,
                       int batch, int env_offset);
 void tgo_destroy(tgo_batch* b);
+/* Tetris(actions_mapping=..., rewards_mapping=...) (envs/tetris.py:83-84, mappings/actions.py:12-19, mappings/rewards.py:12-15):
+ * field values in declaration order; NULL keeps what is set (default: the stock dataclasses) */
+void tgo_set_mappings(tgo_batch* b, const int32_t action_ids[8], const double rewards[4]);
+/* the rewards of the last tgo_step / tgo_grouped_step as Python computes them (double precision) */
+void tgo_last_rewards(const tgo_batch* b, double* out);
 
 /* same semantics as tg_reset / tg_step (include/tetris_gym_hip.h) */
 void tgo_reset(tgo_batch* b, const uint64_t* seeds, const uint8_t* mask);

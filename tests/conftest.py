@@ -10,10 +10,15 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# The device-resident tests hand engine buffers to torch tensors inside THIS process, engine first and torch later: that is
-# the case the opt-in TG_HIP_RUNTIME=torch exists for (_native._share_torch_hip_runtime; the default is the system runtime
-# the engine was built against).  The SONAME check there still applies.
-os.environ.setdefault("TG_HIP_RUNTIME", "torch")
+# (No TG_HIP_RUNTIME here: the session runs on the HIP runtime the engine picks by default — the system one it was built
+# against.  The two torch zero-copy cases run in child processes: tests/test_gpu_torch_interop.py.)
+
+
+def pytest_report_header(config):
+    mode = os.environ.get("TG_HIP_RUNTIME", "auto")
+    return (f"tetris_gymnasium_amd: TG_HIP_RUNTIME={mode} "
+            f"({'system libamdhip64 unless torch is already imported' if mode == 'auto' else mode}); "
+            f"_native.HIP_RUNTIME is printed per process with TG_VERBOSE=1")
 
 
 def pytest_configure(config):

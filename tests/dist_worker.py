@@ -40,6 +40,9 @@ def main():
     (mx,) = D.max(elapsed)
     assert mx == 1.5
     assert D.gather(elapsed) == [0.5, 1.5]
+    # shard checksums travel as full 64-bit integers (top bit included) and equal those of the unsharded run's halves
+    assert D.gather_u64((0xF000000000000001 if D.rank else 0x7FFFFFFFFFFFFFFF)) == [0x7FFFFFFFFFFFFFFF, 0xF000000000000001]
+    sums = D.gather_u64(bench.shard_checksum(*o.get_state()))
     assert bench.throughput(D.world, B, T, mx) == 2 * B * T / 1.5
     mine = torch.from_numpy(o.get_state()[0].copy())
     parts = [torch.empty_like(mine) for _ in range(2)]
@@ -50,6 +53,8 @@ def main():
         for t in range(T):
             full.step(acts_all[t], autoreset=po.AUTORESET_SAME_STEP)
         assert np.array_equal(torch.cat(parts).numpy(), full.get_state()[0]), "sharded != unsharded"
+        fb, fr, fg = full.get_state()
+        assert sums == [bench.shard_checksum(fb[k * B:(k + 1) * B], fr[k * B:(k + 1) * B], fg[k * B:(k + 1) * B]) for k in range(2)]
         print("DIST_OK")
     D.close()
 

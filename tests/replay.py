@@ -48,7 +48,9 @@ def replay_trace(make_backend, fx, max_steps=None, check_state_every=1):
     W, H, B, T = int(fx["width"]), int(fx["height"]), int(fx["B"]), int(fx["T"])
     if max_steps:
         T = min(T, max_steps)
-    be = make_backend(batch=B, width=W, height=H, gravity=bool(fx["gravity"]), queue_size=int(fx["queue_size"]))
+    mapped = "action_ids" in fx.files  # fixtures made with a non-stock ActionsMapping / RewardsMapping (envs/tetris.py:83-84)
+    kw = dict(action_ids=fx["action_ids"], rewards=fx["rewards_mapping"]) if mapped else {}
+    be = make_backend(batch=B, width=W, height=H, gravity=bool(fx["gravity"]), queue_size=int(fx["queue_size"]), **kw)
     be.reset(seeds=1 + np.arange(B, dtype=np.uint64))
     init = fx["init_boards"] if "init_boards" in fx.files else None
     if init is not None:
@@ -59,7 +61,11 @@ def replay_trace(make_backend, fx, max_steps=None, check_state_every=1):
     snap_steps = list(fx["snap_steps"])
     for t in range(T):
         rew, term, lines = be.step(fx["actions"][t].astype(np.int32))
-        np.testing.assert_array_equal(rew.astype(np.int64), fx["reward"][t].astype(np.int64), err_msg=f"reward t={t}")
+        if mapped:  # the Python value (int score + the mapping's floats, double precision) and its float32 rounding
+            np.testing.assert_array_equal(be.rewards_f64(), fx["reward_f64"][t], err_msg=f"reward (f64) t={t}")
+            np.testing.assert_array_equal(rew, fx["reward_f64"][t].astype(np.float32), err_msg=f"reward (f32) t={t}")
+        else:
+            np.testing.assert_array_equal(rew.astype(np.int64), fx["reward"][t].astype(np.int64), err_msg=f"reward t={t}")
         np.testing.assert_array_equal(term, fx["done"][t], err_msg=f"terminated t={t}")
         np.testing.assert_array_equal(lines, fx["lines"][t], err_msg=f"lines t={t}")
         obs = be.observe_dict()

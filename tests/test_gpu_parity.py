@@ -318,13 +318,12 @@ def test_sharded_streams_engine_vs_oracle(ruleset, B, monkeypatch):
     """Batches large enough for the engine to spread a transition over several streams (contiguous env shards, one
     launch each, ragged last shard) must give exactly the single-launch result: host actions, device int8 action
     rows through tg_step_k, masked resets in between, state and generator compared at the end."""
-    monkeypatch.setenv("TG_STREAMS", "4")  # read by tg_create (off by default: see DESIGN.md)
     W, H, T = 10, 20, 60
     numpy_rules = ruleset == N.RULESET_NUMPY
     obs = N.OBS_BOARD if numpy_rules else N.OBS_FN
     po_obs = po.OBS_BOARD if numpy_rules else po.OBS_FN
     na = 8 if numpy_rules else 7
-    e = Engine(B, W, H, ruleset=ruleset, obs_mode=obs, autoreset=N.AUTORESET_NONE, episode_stats=True)
+    e = Engine(B, W, H, ruleset=ruleset, obs_mode=obs, autoreset=N.AUTORESET_NONE, episode_stats=True, streams=4)  # (tg_config.streams; off by default: see DESIGN.md)
     o = po.OracleBatch(B, W, H, ruleset)
     seeds = np.arange(5, 5 + B, dtype=np.uint64)
     e.reset(seeds); o.reset(seeds)
@@ -845,3 +844,97 @@ def test_board_size_that_cannot_be_compiled_is_refused():
     from tetris_gymnasium_amd import EngineError
     with pytest.raises(EngineError, match="outside"):
         Engine(8, 10, 60)
+
+
+# ---- ActionsMapping / RewardsMapping as per-handle data (ABI 4; reference envs/tetris.py:83-84, 189-190, 461-474) ----------------
+class MappedEngineBackend(EngineBackend):
+    def __init__(self, batch, width, height, gravity, queue_size, action_ids=None, rewards=None):
+        self.e = Engine(batch, width, height, ruleset=N.RULESET_NUMPY, gravity=gravity, queue_size=queue_size,
+                        obs_mode=N.OBS_DICT, actions_mapping=action_ids, rewards_mapping=rewards)
+
+    def rewards_f64(self):
+        return self.e.host_pack()["rewards"]
+
+
+@pytest.mark.parametrize("name", ["mapped_10x20_g1", "mapped_10x20_g0", "mapped_clears_10x20"])
+def test_engine_replays_reference_trace_with_custom_mappings(golden_dir, name):
+    """Outputs of the reference's Tetris(actions_mapping=..., rewards_mapping=...): a permutation of the action ids with float
+    rewards, a mapping with a duplicate value and ids that no field holds, line clears with integer rewards.  Rewards are
+    compared as float32 (tg_step_out) and as the exact Python value (TG_BUF_HOST_PACK)."""
+    be = replay.replay_trace(MappedEngineBackend, replay.load(golden_dir, name))
+    assert be.e.cfg.flags & (N.FLAG_CUSTOM_ACTIONS | N.FLAG_CUSTOM_REWARDS)
+
+
+def test_grouped_trace_with_custom_mappings(golden_dir):
+    """GroupedActionsObservations over a Tetris with non-stock mappings, terminate_on_illegal_action=False (wrappers/grouped.py:
+    225-239): the masked-out action runs the env's own no_op and returns rewards.invalid_action."""
+    fx = replay.load(golden_dir, "mapped_grouped_10x20")
+    W, H, B, T, Q = int(fx["width"]), int(fx["height"]), int(fx["B"]), int(fx["T"]), int(fx["queue_size"])
+    e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_BOARD, grouped=True, terminate_on_illegal=bool(fx["terminate_on_illegal"]),
+               actions_mapping=fx["action_ids"], rewards_mapping=fx["rewards_mapping"])
+    e.reset(1 + np.arange(B, dtype=np.uint64))
+    np.testing.assert_array_equal(e.legal_mask(), fx["reset_mask"])
+    for t in range(T):
+        rew, term, lines = e.step(fx["actions"][t].astype(np.int32))
+        np.testing.assert_array_equal(rew, fx["reward_f64"][t].astype(np.float32), err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(e.host_pack()["rewards"], fx["reward_f64"][t], err_msg=f"reward (f64) t={t}")
+        np.testing.assert_array_equal(term, fx["done"][t], err_msg=f"t={t}")
+        np.testing.assert_array_equal(lines, fx["lines"][t])
+        np.testing.assert_array_equal(e.get_state()[0], replay.crop(fx["board_after"][t]), err_msg=f"board t={t}")
+        if term.any():
+            e.reset(mask=term)
+        np.testing.assert_array_equal(e.legal_mask(), fx["masks"][t], err_msg=f"mask t={t}")
+
+
+@pytest.mark.parametrize("autoreset", [N.AUTORESET_NONE, N.AUTORESET_SAME_STEP, N.AUTORESET_NEXT_STEP])
+@pytest.mark.parametrize("B,W,H", [(4096, 10, 20), (300, 20, 40)])
+def test_custom_mappings_engine_vs_oracle_one_and_sixteen_transitions_per_launch(B, W, H, autoreset):
+    """Random permutations of the action ids and random rewards: one transition per launch and the fused rollout (every
+    instantiation reads the handle's action table), against the oracle with the same tables."""
+    rng = np.random.default_rng(B + autoreset)
+    ids = tuple(int(v) for v in rng.permutation(8))
+    rws = (float(rng.integers(-3, 4)), 1.0, float(rng.integers(-9, 0)) - 0.5, -0.75)
+    e = Engine(B, W, H, obs_mode=N.OBS_BOARD, autoreset=autoreset, actions_mapping=ids, rewards_mapping=rws)
+    o = po.OracleBatch(B, W, H, action_ids=ids, rewards=rws)
+    seeds = np.arange(5, 5 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    for t in range(60):
+        a = rng.integers(0, 8, B)
+        re_, te, le = e.step(a)
+        ro, to, lo = o.step(a, autoreset=autoreset)
+        np.testing.assert_array_equal(re_, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(e.host_pack()["rewards"], o.last_rewards(), err_msg=f"reward f64 t={t}")
+        np.testing.assert_array_equal(te, to); np.testing.assert_array_equal(le, lo)
+        if autoreset == N.AUTORESET_NONE and te.any():
+            e.reset(mask=te); o.reset(mask=te)
+    if autoreset != N.AUTORESET_NONE:
+        K = 48
+        acts = rng.integers(0, 8, (K, B)).astype(np.int8)
+        obs, rew, term, lines = e.rollout(acts)
+        for k in range(K):
+            ro, to, lo = o.step(acts[k].astype(np.int32), autoreset=autoreset)
+            np.testing.assert_array_equal(rew[k], ro, err_msg=f"rollout reward k={k}")
+            np.testing.assert_array_equal(term[k], to); np.testing.assert_array_equal(lines[k], lo)
+            np.testing.assert_array_equal(obs[k], o.observe(po.OBS_BOARD), err_msg=f"rollout obs k={k}")
+    _cmp_state(e, o, "end")
+
+
+def test_tetris_class_with_custom_mappings_returns_the_references_python_rewards(golden_dir):
+    from tetris_gymnasium_amd.envs.tetris import Tetris
+    from tetris_gymnasium_amd.mappings.actions import ActionsMapping
+    from tetris_gymnasium_amd.mappings.rewards import RewardsMapping
+
+    fx = replay.load(golden_dir, "mapped_10x20_g1")
+    env = Tetris(actions_mapping=ActionsMapping(*[int(v) for v in fx["action_ids"]]),
+                 rewards_mapping=RewardsMapping(*[float(v) for v in fx["rewards_mapping"]]))
+    assert env.actions.hard_drop == 2 and env.reward_range == (-5.25, 10.0)
+    for i in (0, 7):
+        obs, _ = env.reset(seed=1 + i)
+        assert replay.obs_crc({k: v[None] for k, v in obs.items()}, 0) == int(fx["first_obs_crc"][i])
+        for t in range(200):
+            obs, r, d, _, info = env.step(int(fx["actions"][t, i]))
+            assert r == fx["reward_f64"][t, i] and d == bool(fx["done"][t, i]) and info["lines_cleared"] == fx["lines"][t, i]
+            assert replay.obs_crc({k: v[None] for k, v in obs.items()}, 0) == int(fx["crc"][t, i])
+            if d:
+                env.reset()
+    env.close()

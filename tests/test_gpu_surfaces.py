@@ -660,6 +660,25 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 2 * 8192 and len(d["per_rank_ms_per_step"]) == 2
     assert d["config"]["parallelism"] == "env-sharded x2, no collective" and d["value"] > 0
     assert d["roofline"]["kernel"].startswith("tg::step_kernel_bits<10, 20, 0, ")  # (the FEAT flags depend on the batch size)
+    # The SCALE line proves by itself that the result does not depend on the number of ranks (SURVEY §8e "1-GPU vs 8-GPU boards
+    # identical"): the shard checksums of the two ranks equal those of the two halves of ONE engine of 2 x 8192 envs that
+    # plays the same transitions (actions are a function of the global env index, seeds 1 + global index).
+    import bench
+    from tetris_gymnasium_amd import Engine, _native as N
+
+    assert len(d["shard_checksums"]) == 2 and d["shard_checksums"][0] != d["shard_checksums"][1]
+    B, T = 2 * 8192, d["shard_transitions"]
+    assert T == 4 + (1 + 7) * 16
+    e = Engine(B, 10, 20, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP)
+    e.reset(np.arange(1, B + 1, dtype=np.uint64))
+    rows = 20  # bench.run_block's action table: T = min(max(warmup + steps, fuse), 512) rows, cycled
+    acts = bench.global_actions(rows, 0, B, 8)
+    for t in range(T):
+        e.step_async(acts[t % rows].astype(np.int32))
+    board, rec, rng = e.get_state()
+    halves = [f"{bench.shard_checksum(board[lo:lo + 8192], rec[lo:lo + 8192], rng[lo:lo + 8192]):016x}" for lo in (0, 8192)]
+    assert halves == d["shard_checksums"]
+    e.close()
 
 
 def test_bench_four_ranks_on_one_gpu_carry_cpu_baseline_and_device_list():

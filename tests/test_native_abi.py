@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol():
 def test_record_layouts_match_header():
     assert N.ENV_REC.itemsize == 32 and N.RNG_REC.itemsize == 48
     assert N.ENV_REC.fields["bag"][1] == 10 and N.ENV_REC.fields["queue"][1] == 17 and N.ENV_REC.fields["score"][1] == 24
-    assert C.sizeof(N.TgConfig) == 20 * 4 and N.STEP_OUT.itemsize == 8
+    assert C.sizeof(N.TgConfig) == 20 * 4 + 8 * 4 + 4 * 8 and N.STEP_OUT.itemsize == 8  # (ABI 4: + action_ids[8], rewards[4])
+    assert N.TgConfig.action_ids.offset == 80 and N.TgConfig.rewards.offset == 112 and N.STEP_OUT.fields["flags"][1] == 6
 
 
 def test_shape_table_matches_reference_matrices():
@@ -88,3 +89,36 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in src and "tg_oracle" not in src and "from oracle" not in src, f
+
+
+def test_custom_action_mappings_are_validated_before_any_device_call():
+    """tg_create checks an ActionsMapping on the host: hard_drop sharing its value with a field Tetris.step tests earlier
+    (envs/tetris.py:222-256) is refused; any other assignment gets as far as the device lookup (no GPU here)."""
+    import ctypes as C
+
+    lib = N.load()
+
+    def create(ids, rewards=None):
+        cfg = N.TgConfig()
+        cfg.struct_size = C.sizeof(N.TgConfig)
+        cfg.width, cfg.height, cfg.padding, cfg.queue_size, cfg.gravity, cfg.batch = 10, 20, 4, 4, 1, 4
+        cfg.obs_mode = N.OBS_BOARD
+        cfg.flags = N.FLAG_CUSTOM_ACTIONS | (N.FLAG_CUSTOM_REWARDS if rewards else 0)
+        cfg.action_ids[:] = ids
+        if rewards:
+            cfg.rewards[:] = rewards
+        h = C.c_void_p()
+        rc = lib.tg_create(C.byref(cfg), C.byref(h))
+        msg = lib.tg_last_error(None).decode()
+        if rc == 0:
+            lib.tg_destroy(h)
+        return rc, msg
+
+    rc, msg = create((5, 1, 2, 3, 4, 5, 6, 7))  # move_left == hard_drop
+    assert rc == N.EUNSUPPORTED and "hard_drop" in msg
+    rc, msg = create((0, 1, 2, 3, 4, 5, 5, 7))  # swap == hard_drop: swap is tested first
+    assert rc == N.EUNSUPPORTED and "hard_drop" in msg
+    rc, msg = create((0, 1, 2, 3, 3, 5, 6, 12))  # a duplicate among the others and an unreachable value: fine
+    assert rc in (0, N.EHIP) and "hard_drop" not in msg
+    rc, msg = create((3, 7, 0, 5, 1, 2, 4, 6), (0.5, 10, float("nan"), -0.25))
+    assert rc == N.EINVAL and "rewards[2]" in msg

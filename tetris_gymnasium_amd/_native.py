@@ -13,7 +13,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TG_LIB") or os.path.join(_PKG, "libtetris_gym_hip.so")  # TG_LIB: the test-only legacy build
 
-ABI_VERSION = 3  # include/tetris_gym_hip.h TG_ABI_VERSION
+ABI_VERSION = 4  # include/tetris_gym_hip.h TG_ABI_VERSION
 RULESET_NUMPY, RULESET_FUNCTIONAL = 0, 1
 OBS_NONE, OBS_BOARD, OBS_DICT, OBS_FN, OBS_RGB = 0, 1, 2, 3, 4
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = 0, 1, 2
@@ -21,8 +21,10 @@ ACTIONS_BASE, ACTIONS_GROUPED = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 (BUF_OBS, BUF_STEP_OUT, BUF_ACTIONS, BUF_BOARD, BUF_REC, BUF_RNG, BUF_LEGAL_MASK, BUF_FINAL_OBS,
  BUF_EPISODE, BUF_PLACEMENT_FEATS, BUF_FEATS, BUF_HOST_PACK) = range(12)
-FLAG_EPISODE_STATS, FLAG_FINAL_OBS, FLAG_FEATURES = 1, 2, 4
+FLAG_EPISODE_STATS, FLAG_FINAL_OBS, FLAG_FEATURES, FLAG_CUSTOM_ACTIONS, FLAG_CUSTOM_REWARDS = 1, 2, 4, 8, 16
+OUT_COMMITTED, OUT_ILLEGAL = 1, 2  # tg_step_out.flags
 NONE = 0xFF
+OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4  # TG_E*
 F_GAME_OVER, F_HAS_SWAPPED, F_PENDING_RESET = 1, 2, 4
 
 ENV_REC = np.dtype(
@@ -39,7 +41,7 @@ RNG_REC = np.dtype(
     ]
 )
 EPISODE_REC = np.dtype([("ret", "<f4"), ("len", "<u4"), ("last_ret", "<f4"), ("last_len", "<u4")])
-STEP_OUT = np.dtype([("reward", "<f4"), ("terminated", "u1"), ("lines", "u1"), ("reserved", "<u2")])
+STEP_OUT = np.dtype([("reward", "<f4"), ("terminated", "u1"), ("lines", "u1"), ("flags", "u1"), ("reserved", "u1")])
 assert ENV_REC.itemsize == 32 and RNG_REC.itemsize == 48 and EPISODE_REC.itemsize == 16 and STEP_OUT.itemsize == 8
 
 
@@ -51,7 +53,10 @@ class TgConfig(C.Structure):
         ("env_offset", C.c_int32), ("grouped_terminate_on_illegal", C.c_int32), ("flags", C.c_int32),
         ("reserved", C.c_int32),
         # launch knobs (0 = default): transitions per launch of tg_step_k / tg_rollout, cadence and depth of the NUMPY bag look-ahead
-        ("fuse", C.c_int32), ("rng_every", C.c_int32), ("ring_fill_p1", C.c_int32), ("reserved2", C.c_int32),
+        ("fuse", C.c_int32), ("rng_every", C.c_int32), ("ring_fill_p1", C.c_int32), ("streams", C.c_int32),
+        # ABI 4: ActionsMapping field values in declaration order (FLAG_CUSTOM_ACTIONS) / RewardsMapping alife, clear_line,
+        # game_over, invalid_action (FLAG_CUSTOM_REWARDS)
+        ("action_ids", C.c_int32 * 8), ("rewards", C.c_double * 4),
     ]
 
 

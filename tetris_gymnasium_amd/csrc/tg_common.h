@@ -68,14 +68,15 @@ struct KParams {
   int dict_in_kernel;       // bits kernel only: TG_OBS_DICT is packed by the step kernel's two waves (sizes with (H+4)(W+8) % 16 == 0)
   uint8_t* pboard;          // bits kernel, packed handles (kFeatPacked): the board as nibbles [B][H*W/2] — what the step kernel streams
                             // instead of `board`; null otherwise
-#ifdef TG_KPAD  // (A/B knob: the struct's layout decides how the compiler groups its scalar loads)
-  int kpad[TG_KPAD];
-#endif
   int fn_lazy;              // bits kernel, FUNCTIONAL (TG_FN_LAZY, tests): bits 0-1: 0 = a lock sorts the reset bag ahead only when the stack is
                             // within reach of the spawn rows, 1 = never (every episode end takes the in-line sort), 2 = always (round 3);
                             // bit 2: the look-ahead never catches up behind a reset (the chain stays one key deep)
   uint32_t* nib_over;       // bits kernel, packed FUNCTIONAL handles: host-visible flag word, set when a lock's `board += id` leaves the
                             // nibble range (only a piece uploaded on top of filled cells does: functional/core.py:103-121 adds)
+  // bits kernel, NUMPY: the handle's ActionsMapping as the per-action table (kActLutNumpy for the stock mapping; tg_engine.hip
+  // act_lut_from_ids) and its RewardsMapping (mappings/rewards.py:12-15; stock 1, 0, -0.1) — data, not constants, since ABI 4
+  uint64_t act_lut;
+  float r_alife, r_game_over, r_invalid;
 };
 
 struct ResetParams {

@@ -67,17 +67,14 @@ int g_step_blocks = 0;  // persistent grid size (blocks); set once per process f
 // 1 = "lanes": 64 envs per wave, one per lane (both legacy/tg_kernel_lanes.h); 0 = "wave": one env per wavefront (legacy/tg_kernel_wave.h)
 int g_kernel_lanes = 16;
 #ifdef TG_LEGACY_KERNELS
-int g_block_waves = 4;  // TG_BLOCK_WAVES: waves per workgroup of the block kernel (4 → 64 envs, 8 → 128 envs)
+constexpr int g_block_waves = 4;  // waves per workgroup of the block kernel (4 → 64 envs)
+constexpr size_t g_lds_pad = 0;
+constexpr int g_groups_per_wave = 1;
 #endif
-int g_stagger = 0;  // TG_STAGGER: odd waves of the lane kernels start this many x64 cycles late
-size_t g_lds_pad = 0;       // TG_LDS_PAD: extra dynamic LDS per wave of the lane kernels = occupancy limiter
-int g_groups_per_wave = 1;  // TG_GROUPS_PER_WAVE: 2 = lane kernels' pipelined pair of groups per wave (measured slower:
-                            // the prefetched inputs spill), 1 = off
+constexpr int g_stagger = 0;
 
 int g_simds = 1024;  // SIMDs of the device (4 per CU), set by tg_create
-int g_mask_wave = 1; // TG_MASK_WAVE=0: dict instantiations without the third (mask) wave
 int g_split = 1;     // TG_SPLIT=0: never pick the instantiations with two stream waves per workgroup (kFeatSplit)
-int g_wide = 1;      // TG_WIDE=0: never pick the instantiations compiled for fewer waves per SIMD (kFeatWide)
 
 // RNG-role workgroups of a launch (128 envs each)
 int rng_blocks(const tg::KParams& p, const int RS) { return (RS == TG_RULESET_NUMPY && p.rng_role) ? (p.batch + 127) / 128 : 0; }
@@ -98,39 +95,26 @@ int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const b
   // dict instantiations: a third wave for the mask array instead of a second stream wave (tg_kernel_bits.h kFeatMaskWave)
   // (one transition per launch: 4 096 envs 8.50 -> 6.73 us, 32 768 10.2 -> 8.65, 65 536 17.1 -> 15.6, 131 072 30.7 -> 29.9; launches of 16
   // transitions 13.7 -> 13.9 per transition, and two stream waves beside it only help at 4 096 envs: profiles/r04/ab_dict_mask_wave.log)
-  if (g_mask_wave && RS == TG_RULESET_NUMPY && base == tg::kFeatDict) return feat | tg::kFeatMaskWave;
+  if (RS == TG_RULESET_NUMPY && base == tg::kFeatDict) return feat | tg::kFeatMaskWave;
   // RGB, one transition per launch: two helper waves (the images by quarters).  Up to ~32 768 envs the launch is the chain of its packing
   // waves: 18.6 -> 12.6 us at 1 024 / 4 096 envs, 20.0 -> 14.2 at 16 384, 23.4 -> 18.4 at 32 768; 31.2 -> 30.8 at 65 536, 47.4 -> 49.0 at
   // 98 304, 86.6 -> 70.3 at 131 072 (profiles/r04/ab_rgb_helper_waves.log)
-#ifndef TG_RGB_HELPER_CAP  // (A/B knob: step workgroups up to which the helper waves are used)
-#define TG_RGB_HELPER_CAP (1 << 30)
-#endif
-#ifndef TG_RGB_MANY_CAP  // (... up to which there are six helper waves: one workgroup per CU at most)
-#define TG_RGB_MANY_CAP (g_simds / 4)
-#endif
-  if (g_mask_wave && RS == TG_RULESET_NUMPY && base == tg::kFeatRgb && rgb_helpers_max >= 2 && (long)((p.batch + epw - 1) / epw) <= (long)(TG_RGB_HELPER_CAP))
-    return feat | tg::kFeatMaskWave | ((rgb_helpers_max >= 6 && (long)((p.batch + epw - 1) / epw) <= (long)(TG_RGB_MANY_CAP)) ? tg::kFeatMany : 0);
-#ifndef TG_RGB_HELPER_CAP_MULTI  // ... and in the instantiation with the transition loop (workgroups up to which)
-#define TG_RGB_HELPER_CAP_MULTI 768
-#endif
-  if (g_mask_wave && RS == TG_RULESET_NUMPY && base == (M | T | tg::kFeatSample | tg::kFeatRgb) && rgb_helpers_max >= 2 &&
-      (long)((p.batch + epw - 1) / epw) <= (long)(TG_RGB_HELPER_CAP_MULTI))
+  // (six helper waves while there is one workgroup per CU at most)
+  if (RS == TG_RULESET_NUMPY && base == tg::kFeatRgb && rgb_helpers_max >= 2)
+    return feat | tg::kFeatMaskWave | ((rgb_helpers_max >= 6 && (long)((p.batch + epw - 1) / epw) <= (long)(g_simds / 4)) ? tg::kFeatMany : 0);
+  // ... and in the instantiation with the transition loop up to 768 workgroups
+  if (RS == TG_RULESET_NUMPY && base == (M | T | tg::kFeatSample | tg::kFeatRgb) && rgb_helpers_max >= 2 &&
+      (long)((p.batch + epw - 1) / epw) <= 768L)
     return feat | tg::kFeatMaskWave;
   // ... and in the instantiation with the transition loop while the launch is bound by its chain, not by bytes: per transition of a
   // 16-transition launch 6.0 -> 3.7 us at 4 096 envs, 6.6 -> 4.2 at 32 768, 8.0 -> 7.2 at 49 152, but 10.1 -> 10.6 at 65 536
-  if (g_mask_wave && RS == TG_RULESET_NUMPY && base == (M | T | tg::kFeatDict) && (long)((p.batch + epw - 1) / epw) * 4 <= 3L * g_simds)
+  if (RS == TG_RULESET_NUMPY && base == (M | T | tg::kFeatDict) && (long)((p.batch + epw - 1) / epw) * 4 <= 3L * g_simds)
     return feat | tg::kFeatMaskWave;
   if (!g_split || !split_ok || RS != TG_RULESET_NUMPY || (feat & tg::kFeatPacked) ||
       !(base == 0 || base == M || base == (M | T) || base == tg::kFeatDict || base == (M | T | tg::kFeatDict))) return feat;
   const int per_simd = tg::bits_waves_per_simd(RS, feat);
-#ifndef TG_SPLIT_CAP_EXTRA  // (A/B knob: workgroups beyond residency that still take the two-stream-wave build)
-#define TG_SPLIT_CAP_EXTRA 0
-#endif
-  const long cap = (long)(g_simds / 4) * (4 * per_simd / 3) + TG_SPLIT_CAP_EXTRA;
+  const long cap = (long)(g_simds / 4) * (4 * per_simd / 3);
   const long wgs = (p.batch + epw - 1) / epw + rng_blocks(p, RS);
-#ifdef TG_SPLIT4_CAP  // (A/B: four stream waves in the plain one-transition kernel up to this many workgroups)
-  if (wgs <= cap && base == 0 && wgs <= (long)(TG_SPLIT4_CAP)) return feat | tg::kFeatSplit | 1024;
-#endif
   return wgs <= cap ? (feat | tg::kFeatSplit) : feat;
 }
 int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw, const bool split_ok) {
@@ -140,18 +124,15 @@ int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const
   // beyond residency the 4-waves build wins: profiles/r03/ab_select_waves.log)
   // FUNCTIONAL, plain launches: two stream waves per workgroup (kFeatSplit, compiled for 3 waves per SIMD) while every
   // workgroup of the launch is resident that way — up to 65 536 envs on 256 CUs (7.53 -> 6.92 us per launch there)
-#ifndef TG_FN_SPLIT_CAP  // (A/B knob: workgroups up to which FUNCTIONAL launches take the two-stream-wave build; default = residency)
-#define TG_FN_SPLIT_CAP g_simds
-#endif
   if (RS == TG_RULESET_FUNCTIONAL && p.pboard) {  // packed handles (batches beyond residency): the plain builds
     const bool trj = p.obs_traj || p.out_traj || p.act_traj;
     return (trj ? (M | T) : (p.nsteps > 1 ? M : 0)) | tg::kFeatPacked;
   }
-  if (RS == TG_RULESET_FUNCTIONAL && g_split && !p.final_obs && split_ok && (long)(p.batch + epw - 1) / epw <= (long)(TG_FN_SPLIT_CAP)) {
+  if (RS == TG_RULESET_FUNCTIONAL && g_split && !p.final_obs && split_ok && (long)(p.batch + epw - 1) / epw <= (long)g_simds) {
     const bool trj = p.obs_traj || p.out_traj || p.act_traj;
     return (trj ? (M | T) : (p.nsteps > 1 ? M : 0)) | tg::kFeatSplit;
   }
-  if (RS == TG_RULESET_FUNCTIONAL && g_wide && !p.final_obs && !(p.obs_traj || p.out_traj || p.act_traj) && split_ok &&
+  if (RS == TG_RULESET_FUNCTIONAL && !p.final_obs && !(p.obs_traj || p.out_traj || p.act_traj) && split_ok &&
       (p.batch + epw - 1) / epw * 2 <= 2 * g_simds)
     return (p.nsteps > 1 ? M : 0) | tg::kFeatWide;
   const bool dict = p.obs_mode == TG_OBS_DICT && p.dict_in_kernel && dict_ok;
@@ -248,9 +229,6 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
       if (feat == (P | M | T)) { TG_LAUNCH_BITS(P | M | T); return; }
       if (feat == (P | M)) { TG_LAUNCH_BITS(P | M); return; }
       if (feat == P) { TG_LAUNCH_BITS(P); return; }
-#ifdef TG_SPLIT4_CAP
-      if (feat == (P | 1024)) { TG_LAUNCH_BITS(P | 1024); return; }
-#endif
     }
     if (feat == (M | T)) TG_LAUNCH_BITS(M | T);
     else if (feat == M) TG_LAUNCH_BITS(M);
@@ -601,6 +579,9 @@ struct PackParams {
   uint8_t* pack;
   size_t off[5];
   int batch;
+  int custom;        // TG_FLAG_CUSTOM_REWARDS: rewards recomputed in double precision from tg_step_out.flags / lines
+  int width;
+  double r_alife, r_game_over, r_invalid;
 };
 
 __global__ __launch_bounds__(256) void host_pack_kernel(const PackParams p) {
@@ -618,7 +599,13 @@ __global__ __launch_bounds__(256) void host_pack_kernel(const PackParams p) {
   }
   // (the only negative reward is rewards.invalid_action of the grouped action set, mappings/rewards.py: the host hands out
   // the Python float -0.1, not float32(-0.1))
-  reinterpret_cast<double*>(p.pack + p.off[0])[i] = r < 0.0f ? -0.1 : (double)r;
+  double rd = r < 0.0f ? -0.1 : (double)r;
+  if (p.custom) {  // what Python computes: int score + rewards.alife in double precision (envs/tetris.py:461-474, grouped.py:238)
+    const uint32_t fl = (o.y >> 16) & 0xFFu;
+    rd = (fl & TG_OUT_ILLEGAL) ? p.r_invalid
+         : ((fl & TG_OUT_COMMITTED) ? (term ? p.r_game_over : (double)(lines * lines * (uint32_t)p.width) + p.r_alife) : 0.0);
+  }
+  reinterpret_cast<double*>(p.pack + p.off[0])[i] = rd;
   reinterpret_cast<double*>(p.pack + p.off[1])[i] = er;
   reinterpret_cast<int32_t*>(p.pack + p.off[2])[i] = (int32_t)lines;
   reinterpret_cast<int32_t*>(p.pack + p.off[3])[i] = el;
@@ -719,6 +706,8 @@ struct tg_handle {
   int fuse_max = tg::kMaxFuse; // TG_FUSE: transitions per launch in tg_step_k (1..16)
   int ring_fill = tg::kRing - 1;  // TG_RING_FILL (tests): fewer look-ahead permutations → the consumer's in-line shuffle runs
   int fn_lazy = 0;             // TG_FN_LAZY (tests): KParams.fn_lazy
+  uint64_t act_lut = tg::kActLutNumpy;           // the handle's ActionsMapping as the kernel's per-action table
+  double rewards[4] = {1.0, 1.0, 0.0, -0.1};     // ... its RewardsMapping: alife, clear_line, game_over, invalid_action
   bool dict_in_kernel = false; // TG_OBS_DICT packed by the bits step kernel itself (no observe launch after a transition)
   // TG_STREAMS=n (default 1) spreads the step launches of one transition over n streams (contiguous env shards).
   // Kept as a tested knob, off by default — measured on MI355X: every launch costs ≈2.8-3.4 µs of
@@ -843,8 +832,31 @@ int alloc_buf(tg_handle* h, int which, size_t n) {
   return TG_OK;
 }
 
+// The per-action table of the step kernel for a handle's ActionsMapping (tg_config.action_ids: field values in declaration
+// order move_left, move_right, move_down, rotate_clockwise, rotate_counterclockwise, hard_drop, swap, no_op).  Entry a =
+// what Tetris.step does with action id a: the FIRST field of its elif chain (envs/tetris.py:222-256: left, right, down, cw,
+// ccw, swap, hard_drop, no_op) whose value equals a; none → only gravity, like no_op.  Returns false for the one shape the
+// table cannot say: hard_drop sharing its value with an earlier field of the chain (the other operation, then no gravity).
+bool act_lut_from_ids(const int32_t ids[8], uint64_t* lut) {
+  static const int chain[8] = {0, 1, 2, 3, 4, 6, 5, 7};  // declaration index of the chain's k-th comparison
+  uint64_t v = 0;
+  for (int a = 0; a < 8; ++a) {
+    int op = 7;  // no_op
+    for (int k = 0; k < 8; ++k)
+      if (ids[chain[k]] == a) { op = chain[k]; break; }
+    if (ids[5] == a && op != 5) return false;
+    v |= ((tg::kActLutNumpy >> (8 * op)) & 0xFFull) << (8 * a);
+  }
+  *lut = v;
+  return true;
+}
+
 tg::KParams step_params(tg_handle* h) {
   tg::KParams p{};
+  p.act_lut = h->act_lut;
+  p.r_alife = (float)h->rewards[0];
+  p.r_game_over = (float)h->rewards[2];
+  p.r_invalid = (float)h->rewards[3];
   p.board = (uint8_t*)h->buf[TG_BUF_BOARD];
   p.rec = (uint32_t*)h->buf[TG_BUF_REC];
   p.rng = (tg_rng_rec*)h->buf[TG_BUF_RNG];
@@ -1052,6 +1064,9 @@ int launch_host_pack(tg_handle* h) {
   host_pack_layout((size_t)h->B, off);
   for (int i = 0; i < 5; ++i) q.off[i] = off[i];
   q.batch = h->B;
+  q.custom = (h->cfg.flags & TG_FLAG_CUSTOM_REWARDS) ? 1 : 0;
+  q.width = h->W;
+  q.r_alife = h->rewards[0]; q.r_game_over = h->rewards[2]; q.r_invalid = h->rewards[3];
   hipLaunchKernelGGL(host_pack_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, q);
   HIPCHK(h, hipGetLastError());
   return TG_OK;
@@ -1100,15 +1115,14 @@ int enqueue_fetches(tg_handle* h, int m, const int* which, void* const* host_dst
 // issued side by side instead of one after the other (a launch is ~3 us of host time; eight in a row are 27 us, measured
 // with eight shards of one GPU: bench.py `vector_env_shards`).  A worker spins for its next job for a short while after it
 // finished one (a stepping loop hands it the next within microseconds) and blocks on a condition variable otherwise, so
-// an idle process burns nothing.  TG_STEP_THREADS=0 keeps everything on the calling thread.
+// an idle process burns nothing.
 // ---------------------------------------------------------------------------------------------------------------------
 class EnqueuePool {
  public:
   static EnqueuePool& get() { static EnqueuePool p; return p; }
   // run job(k) for k = 0 .. n - 1 (k = 0 on the calling thread); returns the first non-zero result
   int run(int n, const std::function<int(int)>& job) {
-    static const bool enabled = !(getenv("TG_STEP_THREADS") && atoi(getenv("TG_STEP_THREADS")) == 0);
-    if (n <= 1 || !enabled) {
+    if (n <= 1) {
       for (int k = 0; k < n; ++k) { const int rc = job(k); if (rc != TG_OK) return rc; }
       return TG_OK;
     }
@@ -1230,6 +1244,18 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     return fail(nullptr, TG_EINVAL, "tg_create: unknown action_set %d", cfg->action_set);
   if (cfg->action_set == TG_ACTIONS_GROUPED && cfg->ruleset != TG_RULESET_NUMPY)
     return fail(nullptr, TG_EINVAL, "tg_create: the grouped action set wraps the NUMPY rule-set (wrappers/grouped.py)");
+  if ((cfg->flags & (TG_FLAG_CUSTOM_ACTIONS | TG_FLAG_CUSTOM_REWARDS)) && cfg->ruleset != TG_RULESET_NUMPY)
+    return fail(nullptr, TG_EINVAL, "tg_create: ActionsMapping / RewardsMapping belong to the NUMPY rule-set (envs/tetris.py:83-84)");
+  if ((cfg->flags & (TG_FLAG_CUSTOM_ACTIONS | TG_FLAG_CUSTOM_REWARDS)) && g_kernel_lanes != 16)
+    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: custom mappings need the default step kernel (TG_KERNEL=bits)");
+  uint64_t act_lut = tg::kActLutNumpy;
+  if ((cfg->flags & TG_FLAG_CUSTOM_ACTIONS) && !act_lut_from_ids(cfg->action_ids, &act_lut))
+    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: ActionsMapping.hard_drop (%d) shares its value with a field that Tetris.step "
+                "tests earlier (envs/tetris.py:222-256): that id would run the other operation and skip gravity", cfg->action_ids[5]);
+  if (cfg->flags & TG_FLAG_CUSTOM_REWARDS)
+    for (int i = 0; i < 4; ++i)
+      if (!(cfg->rewards[i] == cfg->rewards[i]) || cfg->rewards[i] > 3.0e38 || cfg->rewards[i] < -3.0e38)
+        return fail(nullptr, TG_EINVAL, "tg_create: rewards[%d] is not a finite float32-range number", i);
   Launchers L{};
   const bool built_in = find_launchers(cfg->width, cfg->height, cfg->ruleset, &L);
   if (!built_in && (cfg->width < 4 || cfg->width > 32 || cfg->height < 4 || cfg->height > 58))
@@ -1253,6 +1279,8 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   tg_handle* h = new (std::nothrow) tg_handle();
   if (!h) return fail(nullptr, TG_ENOMEM, "tg_create: out of host memory");
   h->cfg = *cfg;
+  h->act_lut = act_lut;
+  if (cfg->flags & TG_FLAG_CUSTOM_REWARDS) for (int i = 0; i < 4; ++i) h->rewards[i] = cfg->rewards[i];
   h->B = cfg->batch; h->W = cfg->width; h->H = cfg->height; h->Q = cfg->queue_size;
   h->cells = (size_t)h->W * h->H;
   h->L = L;
@@ -1276,34 +1304,28 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     // Grid of the step kernel.  Default: one wave per env (measured fastest for the one-env-per-wavefront
     // kernel, profiles/r01_*).  TG_BLOCKS_PER_CU=n makes it persistent: n blocks of 4 waves per CU, each wave
     // looping over its envs with the next env's loads in flight.
-    int per_cu = 0;
-    if (const char* e = getenv("TG_BLOCKS_PER_CU")) per_cu = atoi(e);
-    if (const char* e2 = getenv("TG_LDS_PAD")) g_lds_pad = (size_t)atoi(e2);
-    if (const char* e4 = getenv("TG_STAGGER")) g_stagger = atoi(e4);
-    if (const char* e3 = getenv("TG_GROUPS_PER_WAVE")) g_groups_per_wave = atoi(e3) > 0 ? atoi(e3) : 1;
+    const int per_cu = 0;
+    if (const char* k = getenv("TG_KERNEL")) {
 #ifdef TG_LEGACY_KERNELS
-    if (const char* k = getenv("TG_KERNEL"))
       g_kernel_lanes = strcmp(k, "wave") == 0    ? 0
                        : strcmp(k, "lanes") == 0 ? 1
                        : strcmp(k, "pair") == 0  ? 2
                        : strcmp(k, "quad") == 0  ? 4
                        : strcmp(k, "block") == 0 ? 8
                                                  : 16;
-    if (const char* bw = getenv("TG_BLOCK_WAVES")) g_block_waves = atoi(bw) == 8 ? 8 : 4;
 #else
-    if (const char* k = getenv("TG_KERNEL"))
       if (strcmp(k, "bits") != 0) {
         h->err = std::string("tg_create: TG_KERNEL=") + k + " needs the test-only library with the earlier step kernels "
                  "(make -C tetris_gymnasium_amd/csrc legacy; TG_LIB=<path>/libtetris_gym_hip_legacy.so)";
         return bail(TG_EUNSUPPORTED);
       }
 #endif
+    }
     g_step_blocks = per_cu > 0 ? prop.multiProcessorCount * per_cu : -1;
     g_simds = 4 * prop.multiProcessorCount;
-    if (const char* w = getenv("TG_WIDE")) g_wide = atoi(w) != 0;
     if (const char* w = getenv("TG_SPLIT")) g_split = atoi(w) != 0;
-    if (const char* w = getenv("TG_MASK_WAVE")) g_mask_wave = atoi(w) != 0;
   }
+  const int n_streams_env = cfg->streams > 1 ? cfg->streams : 1;  // tg_config.streams: spread a transition of a large batch over this many streams
   CRCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CRCHK(hipEventCreate(&h->ev0));
   CRCHK(hipEventCreate(&h->ev1));
@@ -1321,7 +1343,6 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
       /*HOST_PACK*/ host_pack_layout(B, nullptr)};
   {
     h->arena_skew = 0;
-    if (const char* e = getenv("TG_ALLOC_SKEW")) h->arena_skew = (size_t)(atol(e) > 0 ? atol(e) : 0);
     const int n_pieces = TG_BUF_COUNT + 11;
     size_t total = 0;
     for (int i = 0; i < TG_BUF_COUNT; ++i) total += sizes[i] + kTailPad + 4096;
@@ -1358,7 +1379,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
       const bool can = packed_geometry(cfg->width, cfg->height) && !want_final &&
                        (cfg->obs_mode == TG_OBS_BOARD || cfg->obs_mode == TG_OBS_NONE ||
                         (cfg->obs_mode == TG_OBS_FN && cfg->ruleset == TG_RULESET_FUNCTIONAL)) &&
-                       !(getenv("TG_STREAMS") && atoi(getenv("TG_STREAMS")) > 1);
+                       n_streams_env <= 1;
       // (measured, profiles/r04/ab_packed_board.log: config 5 24.3 -> 21.7 us, 524 288 envs at 10x20 46.7 -> 41.7, 131 072
       // 11.7 -> 11.1; at 65 536 x 10x20 — Infinity-Cache resident, bound by instruction issue — 6.30 -> 6.87: hence the size rule;
       // FUNCTIONAL, ab_fn_packed_board.log: 524 288 envs 49.8 -> 45.0, 262 144 26.2 -> 24.5, 131 072 14.7 -> 14.4)
@@ -1384,7 +1405,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     CRCHK(hipStreamSynchronize(h->stream));
   }
   {
-    h->dict_in_kernel = h->d_cols && !(getenv("TG_DICT_KERNEL") && atoi(getenv("TG_DICT_KERNEL")) == 0) &&
+    h->dict_in_kernel = h->d_cols &&
                         ((cfg->obs_mode == TG_OBS_DICT && L.dict_ok) ||
                          (cfg->obs_mode == TG_OBS_RGB && L.rgb_ok && cfg->queue_size == 4));  // (the in-kernel RGB image is laid out for four queue pieces)
     // launch knobs: tg_config (0 = default), overridden by the environment (test hooks)
@@ -1396,8 +1417,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     if (const char* e = getenv("TG_FN_LAZY")) { const int v = atoi(e); h->fn_lazy = v < 0 ? 0 : (v & 7); }
     if (const char* e = getenv("TG_FUSE")) { const int v = atoi(e); h->fuse_max = v < 1 ? 1 : (v > tg::kMaxFuse ? tg::kMaxFuse : v); }
     // shards only for the plain step path of the bits kernel (observation written by the step kernel itself)
-    int want = 1;
-    if (const char* e = getenv("TG_STREAMS")) want = atoi(e);
+    int want = n_streams_env;
     if (!h->d_cols || cfg->obs_mode == TG_OBS_DICT || cfg->obs_mode == TG_OBS_RGB || (cfg->flags & TG_FLAG_FINAL_OBS)) want = 1;
     while (want > 1 && (B + want - 1) / want < 8192) --want;  // small shards only add launches
     if (want > 1) {

@@ -41,6 +41,22 @@
 
 #include "tg_lane.h"
 
+// -DTG_PHASE_TIMING (tools/phase_timing_bits.py, tools/phase_timeline_bits.py; never the shipped build): eight time stamps per wave,
+// written to KParams::dbg at the end.  s_memtime = shader cycles of THIS CU's counter (phases of one wave); with
+// -DTG_STAMP_REALTIME the device-wide 100 MHz counter instead (absolute timeline across workgroups).
+#ifdef TG_PHASE_TIMING
+#ifdef TG_STAMP_REALTIME
+#define TG_NOW() __builtin_amdgcn_s_memrealtime()
+#else
+#define TG_NOW() __builtin_amdgcn_s_memtime()
+#endif
+#define TG_BITS_STAMP(i) tstamp[i] = TG_NOW()
+#define TG_TIMING(...) __VA_ARGS__
+#else
+#define TG_BITS_STAMP(i) do {} while (0)
+#define TG_TIMING(...)
+#endif
+
 namespace tg {
 
 // per (piece, rot): four column nibbles — nibble c holds, as bits k, the filled cells (k, c) of the 4x4 box
@@ -111,34 +127,17 @@ constexpr size_t bits_cols_bytes() { return (size_t)bits_cols_words<W, H>() * si
 // Envs per workgroup.  ONE STREAM WAVE carries at most EPS0 envs — its slab block has to fit the staging registers: 64 envs up
 // to 320 cells, 32 up to 640, 16 above — and by default a workgroup has one stream wave, so the LOGIC wave of a large board runs
 // with idle lanes.  A logic wave with idle lanes costs the SIMD as many issue slots as a full one: a 10x20 launch at the byte
-// volume of config 5 (52 Mi cells) takes 22.4 / 26.0 / 36.1 us with 64 / 32 / 16 envs per workgroup (-DTG_EPW_OVERRIDE).
-// -DTG_NSW0 (A/B, measured and NOT adopted) gives boards above 320 cells twice the envs per workgroup and TWO stream waves
-// (the two-stream-wave layout of kFeatSplit in every instantiation): config 5 21.9 -> 21.2 us only, and the dict / RGB staging
-// buffers no longer fit beside the slabs (those surfaces would go back to the observe kernel at 20x40).
-// profiles/r04/ab_envs_per_workgroup.log
+// volume of config 5 (52 Mi cells) takes 22.4 / 26.0 / 36.1 us with 64 / 32 / 16 envs per workgroup.
+// (Twice the envs per workgroup and TWO stream waves for boards above 320 cells — measured and not adopted: config 5
+// 21.9 -> 21.2 us only, and the dict / RGB staging buffers no longer fit beside the slabs.  profiles/r04/ab_envs_per_workgroup.log)
 constexpr int bits_eps0(const int W, const int H) { return W * H <= 320 ? 64 : (W * H <= 640 ? 32 : 16); }
 constexpr int bits_lds_bytes_max(const int W, const int H, const int epw) {  // (BitsGeo::BYTES_FNX, the largest plain layout)
   const int slabs = ((epw * W * H + 15) / 16) * 16, cst = (W + 2) | 1, tsz = (H + 6 <= 32) ? 4 : 8;
   return ((slabs + 320 + 2 * epw * 16 + epw * cst * tsz + 15) / 16) * 16 + 2 * epw * 8 + 128 * 12;
 }
-constexpr int bits_epw(const int W, const int H) {
-#ifdef TG_EPW_OVERRIDE  // (A/B only: what fewer envs per workgroup — logic waves with idle lanes — cost at a given byte volume)
-  return TG_EPW_OVERRIDE;
-#else
-  const int e0 = bits_eps0(W, H);
-#ifdef TG_NSW0
-  return (e0 < 64 && bits_lds_bytes_max(W, H, 2 * e0) <= 65536) ? 2 * e0 : e0;
-#else
-  return e0;
-#endif
-#endif
-}
+constexpr int bits_epw(const int W, const int H) { return bits_eps0(W, H); }
 constexpr int bits_nsw0(const int W, const int H) {  // stream waves a workgroup of this board size has at least
-#ifdef TG_EPW_OVERRIDE
-  return 1;
-#else
   return bits_epw(W, H) / bits_eps0(W, H);
-#endif
 }
 // dynamic LDS of one workgroup of step_kernel_bits
 template <int W, int H>
@@ -184,10 +183,8 @@ struct BitsGeo {
   // key-chain look-ahead — uint2 keys [128] | uint32 permutations [128] — behind the FINAL_OBS records
   static constexpr int OFF_FNX = BYTES_FIN;
   static constexpr int BYTES_FNX = BYTES_FIN + 128 * 8 + 128 * 4;
-#ifndef TG_EPW_OVERRIDE
   static_assert(BYTES_FNX == bits_lds_bytes_max(W, H, EPW), "bits_lds_bytes_max restates this layout");
   static_assert(NSW0 == 1 || BYTES_FNX <= 65536, "two stream waves' worth of envs only while the workgroup's LDS stays within 64 KiB");
-#endif
   static constexpr int WC = bits_cols_words<W, H>();  // column-mask words per env in HBM
   // two stream waves per workgroup (each owns half of the envs and their slabs: no exchange between them) when the halves
   // are whole 16-byte chunks
@@ -294,10 +291,7 @@ struct BitsParams {
 
 // native 16-byte vector for the slab stream: HIP's uint4 is a struct whose copies become memcpy intrinsics, which
 // kept the staging array in scratch memory (and made the kernel wait for every slab load right after issuing it)
-#ifndef TG_MAX_FUSE
-#define TG_MAX_FUSE 16
-#endif
-constexpr int kMaxFuse = TG_MAX_FUSE;  // transitions per launch (tg_config.fuse): the action bytes of a launch travel in one or two 64-bit words
+constexpr int kMaxFuse = 16;  // transitions per launch (tg_config.fuse): the action bytes of a launch travel in one or two 64-bit words
 constexpr int kRing = 4;  // slots per permutation ring: kRing - 1 entries ahead + the last consumed one
 __device__ __forceinline__ int ring_diff(const int a, const int b) { return ((a - b) << 24) >> 24; }  // counters are mod 256
 // where the generator state (FUNCTIONAL: the key) after the last consumed entry lives (`loc` field of hbuf)
@@ -371,48 +365,27 @@ typedef u32x4 __attribute__((aligned(8))) u32x4_a8;  // 16-byte access at 8-byte
 // (observations, outputs) leaves with the nontemporal hint so that it drains while the kernel still computes
 template <typename V>
 __device__ __forceinline__ void st_stream(V* dst, const V v) {
-#ifdef TG_NO_NT
-  *dst = v;
-#else
   __builtin_nontemporal_store(v, dst);
-#endif
 }
 
 // the two padded arrays of the dict observation (62 MB per transition at 65 536 envs)
 template <typename V>
 __device__ __forceinline__ void st_dict(V* dst, const V v) {
-#ifdef TG_DICT_PLAIN  // (measured: nontemporal 17.9 us, plain 19.2 us per transition; the 160 MB RGB stream is the other way round)
-  *dst = v;
-#else
   __builtin_nontemporal_store(v, dst);
-#endif
 }
 // ... of which the mask array (28 MB, almost all zeros, the same lines every transition) leaves with PLAIN stores since round 4: with
 // the mask wave 15.5 -> 14.3 us per transition at 65 536 envs, 30.2 -> 26.1 at 131 072, 54.8 -> 48.5 at 262 144, 13.9 -> 10.1 per
 // transition of a 16-transition launch; the board array plain as well: 14.6 / 27.4 / 60.3 / 9.8 (profiles/r04/ab_dict_mask_wave.log)
 template <typename V>
 __device__ __forceinline__ void st_dict_mask(V* dst, const V v) {
-#if defined(TG_DICT_MASK_NT) && !defined(TG_DICT_PLAIN)
-  __builtin_nontemporal_store(v, dst);
-#else
   *dst = v;
-#endif
 }
 
 // state that the NEXT launch reads again (board, records, rings).  TG_STATE_ST: 0 = plain stores (dirty in the XCD's L2
 // until the end-of-kernel write-back), 1 = nontemporal (default: measured -0.45 us per launch with the chunk-major
 // write-back, profiles/r02 — the dirty lines leave while the kernel still runs, the boundary to the next launch gets
 // shorter), 2 = write-through (sc1; measured +0.3 us).  The column masks stay plain 8-byte stores (nontemporal: no gain).
-#ifndef TG_STATE_ST
-#define TG_STATE_ST 1
-#endif
-// TG_EXP_SKIP (bit mask, timing ablations only — the results are wrong): 1 observation stores, 2 board write-back,
-// 4 record stores, 8 column-mask stores, 16 output store, 64 the whole observation block of the stream wave, 128 its
-// lock / clear / reset block, 256 the un-draw between the transitions of a launch, 512 the logic wave's bookkeeping
-#ifndef TG_EXP_SKIP
-#define TG_EXP_SKIP 0
-#endif
-#define TG_SKIP(bit) ((TG_EXP_SKIP & (bit)) != 0 && p.batch >= 0)
+constexpr int TG_STATE_ST = 1;
 template <typename V>
 __device__ __forceinline__ void st_state(V* dst, const V v) {
   static_assert(sizeof(V) == 16 || sizeof(V) == 8, "state stores are 8 or 16 bytes");
@@ -433,7 +406,6 @@ __device__ __forceinline__ void st_state(V* dst, const V v) {
 // `base` = a wave-uniform address, `bytes` what may be written behind it (< 2 GiB), `off` the lane's byte offset.
 // (The same idea for the piece stamps in LDS — cells that are not drawn go to a dump dword of the lane — is SLOWER, 6.39 ->
 // 6.54 us: few lanes draw, and an LDS store of 64 active lanes costs more than the exec-mask region around one of 10.)
-#ifndef TG_NO_BUFFER_ST
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t st_window(void* base, const uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);  // (gfx9 raw buffer: 32-bit data format, no swizzle)
 }
@@ -444,16 +416,7 @@ __device__ __forceinline__ void st_state_if(const __amdgpu_buffer_rsrc_t win, co
 __device__ __forceinline__ void st_b64_if(const __amdgpu_buffer_rsrc_t win, const uint32_t off, const u32x2 v, const bool on) {
   __builtin_amdgcn_raw_buffer_store_b64(v, win, on ? off : 0x80000000u, 0, 0);
 }
-#endif
-#ifdef TG_COLS_NT
-#define TG_ST_COLS(ptr, val) st_state(ptr, val)
-#else
 #define TG_ST_COLS(ptr, val) (*(ptr) = (val))
-#endif
-#ifdef TG_REC_PLAIN
-#undef TG_ST_STATE
-#define TG_ST_STATE(ptr, val) (*(ptr) = (val))
-#endif
 
 // FEAT selects what an instantiation carries (the optional features cost registers and instructions in the hot loops
 // even when switched off at run time: measured +4 % on the one-transition launch, +18 % on fused rollouts):
@@ -519,8 +482,8 @@ constexpr int bits_stream_waves(const int feat) {
   if (BitsGeo<W, H>::NSW0 > 1) return BitsGeo<W, H>::NSW0;  // (boards above 320 cells: every instantiation)
   const bool split = (feat & kFeatSplit) && BitsGeo<W, H>::SPLIT_OK && !(feat & (kFeatSample | kFeatFinal | kFeatRgb | kFeatWide)) &&
                      (!(feat & kFeatDict) || (BitsGeo<W, H>::DICT_OK && (BitsGeo<W, H>::EPW / 2) % BitsGeo<W, H>::GD == 0));
-  // (kFeatSplit | 1024 = kFeatMany, plain instantiations: FOUR stream waves of 16 envs each — A/B for launches of one workgroup per CU)
-  if (split && (feat & 1024) && !(feat & (kFeatDict | kFeatMulti)) && ((BitsGeo<W, H>::EPW / 4) * BitsGeo<W, H>::S) % 16 == 0) return 4;
+  // (four stream waves of 16 envs each for launches of one workgroup per CU: measured 2-3 % at 4 096 envs, not kept —
+  // profiles/r04/ab_split4.log)
   return split ? 2 : 1;
 }
 // kFeatMaskWave (round 4, dict instantiations): a THIRD wave per workgroup that does nothing but obs["active_tetromino_mask"]
@@ -572,7 +535,6 @@ __device__ __forceinline__ uint32_t bits_bin1(const uint32_t x) {
 // before the register is read again; inline assembly is outside the compiler's hazard recogniser — back to back the third
 // byte came out wrong), and the trailing s_nop covers whatever the compiler places behind the block.
 // Checked against bits_bin1 on 65 536 random dwords (profiles/r03/ab_bin4_sdwa.log) and by the FUNCTIONAL parity tests.
-#ifndef TG_NO_SDWA_BIN
 __device__ __forceinline__ u32x4 bits_bin4(const u32x4 v) {
   uint32_t a = v.x, b = v.y, c = v.z, d = v.w;
 #define TG_R(B) "v_min_i16_sdwa %0, sext(%0), %4 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #B " src1_sel:WORD_0\n\t" \
@@ -583,9 +545,6 @@ __device__ __forceinline__ u32x4 bits_bin4(const u32x4 v) {
 #undef TG_R
   return u32x4{a, b, c, d};
 }
-#else
-__device__ __forceinline__ u32x4 bits_bin4(const u32x4 v) { return u32x4{bits_bin1(v.x), bits_bin1(v.y), bits_bin1(v.z), bits_bin1(v.w)}; }
-#endif
 
 // Two playfield rows (2 W bytes = 2 W / 4 dwords, row pairs start dword-aligned because W is even) → the same two rows of
 // the padded board (bedrock | row | bedrock, W + 8 bytes each; envs/tetris.py:632-641).  Both rows map source byte → output
@@ -722,13 +681,8 @@ __device__ __forceinline__ void rgb_pack(const uint8_t* slabs, const uint4* post
       if (q < NQ && (uint32_t)(e0 + el) < nlive) {
         const u32x3 px = u32x3{c4[0] | (c4[1] << 24), (c4[1] >> 8) | (c4[2] << 16), (c4[2] >> 16) | (c4[3] << 8)};
         const size_t off = (size_t)(e0 + el) * (size_t)(NPX * 3) + 12u * (size_t)qq;
-#ifdef TG_RGB_NT  // (plain stores measured faster than nontemporal ones for this 160 MB write stream: tools/ubench/write_ceiling.hip)
-        __builtin_nontemporal_store(px, reinterpret_cast<u32x3_a4*>(dst0 + off));
-        if (dst1) __builtin_nontemporal_store(px, reinterpret_cast<u32x3_a4*>(dst1 + off));
-#else
         *reinterpret_cast<u32x3_a4*>(dst0 + off) = px;
         if (dst1) *reinterpret_cast<u32x3_a4*>(dst1 + off) = px;
-#endif
       }
     }
     wave_sync();
@@ -769,9 +723,6 @@ __device__ __forceinline__ void dict_mask_group(uint8_t* buf, const uint4* post_
 #pragma unroll
   for (int i = 0; i < CT; ++i) {
     const int c = lane + 64 * i;
-#ifdef TG_ABL_NO_MASK  // (timing ablation: the mask array is not stored at all)
-    if (nlive_g > 9999u)
-#endif
     if (c < NCHG && (uint32_t)c / (PC / 16) < nlive_g) {
       st_dict_mask(reinterpret_cast<u32x4*>(dst0 + 16 * (size_t)c), v[i]);
       if (dst1) st_dict_mask(reinterpret_cast<u32x4*>(dst1 + 16 * (size_t)c), v[i]);
@@ -784,72 +735,9 @@ __device__ __forceinline__ void dict_mask_group(uint8_t* buf, const uint4* post_
   wave_sync();
 }
 
-// The same into TG_BUF_OBS, which keeps its content from transition to transition: only the 16-byte chunks that the box
-// of the previous observation (`oldpw`, to be cleared) or the new one covers are stored — at most five contiguous chunks
-// each at 10x20 (a box spans (n - 1) Wp + n <= 58 bytes), typically seven of an env's 27 altogether.  The full array is 28 MB of the
-// 62 MB a dict observation writes per transition at 65 536 envs, and that transition is bound by its stores: without the
-// mask stores it takes 12.1 instead of 17.1 us.  MEASURED AND REJECTED (-DTG_DICT_INCR_MASK, profiles/r03/
-// ab_dict_incremental_mask.log): the ~7 scattered 16-byte chunks per env cost 18.0 us per transition against 17.1 us for
-// the whole array as one contiguous full-line stream — partial-line stores are several times dearer per byte here.
-template <int W, int H, int GD>
-__device__ __forceinline__ void dict_mask_group_incr(uint8_t* buf, const uint4* post_g, uint32_t* oldpw_g, const uint32_t nlive_g,
-                                                     const int lane, uint8_t* dst) {
-  constexpr int WP = W + 8, HP = H + 4, PC = WP * HP, ST = GD * 16 / 64;
-  constexpr int NB = (3 * WP + 4 + 15) / 16 + 1;  // 16-byte chunks a box can touch: it spans at most 3 Wp + 4 bytes (five at 10x20)
-  constexpr int NT = GD * 2 * NB, TT = (NT + 63) / 64;
-  int addr[ST];
-  uint32_t pws[ST];
-#pragma unroll
-  for (int i = 0; i < ST; ++i) pws[i] = post_g[(lane + 64 * i) >> 4].w;
-#pragma unroll
-  for (int i = 0; i < ST; ++i) {
-    const int t = lane + 64 * i;
-    const int el = t >> 4, k = (t >> 2) & 3, c = t & 3;
-    const uint32_t pw = pws[i];
-    const int x = (int)(pw & 0xFFu), y = (int)((pw >> 8) & 0xFFu), pc = (int)((pw >> 16) & 0xFFu);
-    const int n = pc == 0 ? 4 : (pc == 1 ? 2 : 3);
-    const bool ok = (uint32_t)el < nlive_g && k < n && c < n && y + k < HP && x + c < WP;
-    addr[i] = ok ? el * PC + (y + k) * WP + x + c : -1;
-  }
-#pragma unroll
-  for (int i = 0; i < ST; ++i)
-    if (addr[i] >= 0) buf[addr[i]] = 1;
-  wave_sync();
-  // tasks (env of the group, j): j < NB the chunks of the old box, j >= NB those of the new one that the old range does not hold
-  auto range = [&](const uint32_t pw, int& q0, int& q1) {
-    const int x = (int)(pw & 0xFFu), y = (int)((pw >> 8) & 0xFFu), pc = (int)((pw >> 16) & 0xFFu);
-    const int n = pc == 0 ? 4 : (pc == 1 ? 2 : 3);
-    const int kr = (HP - y < n ? HP - y : n) - 1, kc = (WP - x < n ? WP - x : n) - 1;  // rows / columns of the box inside the array
-    q0 = (y * WP + x) >> 4;
-    q1 = (kr < 0 || kc < 0) ? -1 : (((y + kr) * WP + x + kc) >> 4);
-  };
-  u32x4 v[TT];
-  int qq[TT];
-#pragma unroll
-  for (int i = 0; i < TT; ++i) {
-    const int t = lane + 64 * i;
-    const int el = t / (2 * NB), j = t - el * (2 * NB);
-    const int e = el < GD ? el : GD - 1;
-    const uint32_t po = oldpw_g[e], pn = post_g[e].w;
-    int o0, o1, n0, n1;
-    range(po, o0, o1);
-    range(pn, n0, n1);
-    const bool isnew = j >= NB;
-    const int q = (isnew ? n0 : o0) + (isnew ? j - NB : j);
-    const bool ok = t < NT && (uint32_t)el < nlive_g && q <= (isnew ? n1 : o1) && !(isnew && q >= o0 && q <= o1);
-    qq[i] = ok ? e * (PC / 16) + q : -1;
-    v[i] = reinterpret_cast<const u32x4*>(buf)[ok ? e * (PC / 16) + q : 0];
-  }
-#pragma unroll
-  for (int i = 0; i < TT; ++i)
-    if (qq[i] >= 0) st_dict(reinterpret_cast<u32x4*>(dst + 16 * (size_t)qq[i]), v[i]);
-  wave_sync();
-  if (lane < GD && (uint32_t)lane < nlive_g) oldpw_g[lane] = post_g[lane].w;  // what TG_BUF_OBS shows from now on
-#pragma unroll
-  for (int i = 0; i < ST; ++i)
-    if (addr[i] >= 0) buf[addr[i]] = 0;
-  wave_sync();
-}
+// (Storing into TG_BUF_OBS only the 16-byte chunks that the previous / the new bounding box covers was measured in round 3 and
+// rejected: ~7 scattered chunks per env cost 18.0 us per transition against 17.1 us for the whole array as one contiguous
+// full-line stream — partial-line stores are several times dearer per byte.  profiles/r03/ab_dict_incremental_mask.log)
 
 // one lane copies its env's slab LDS → HBM (8-byte aligned on both sides): batches of 8-byte LDS reads, all reads of a
 // batch in flight before its 16-byte stores.  BIN: through the functional observation's byte map.
@@ -891,15 +779,9 @@ __device__ __forceinline__ void bits_copy_slab(const uint8_t* src_lds, uint8_t* 
   }
 }
 
-#ifndef TG_ONE_WAVES
-#define TG_ONE_WAVES 4  // waves per SIMD the one-transition kernels are compiled for (4 → 128 VGPRs, 3 → 168)
-#endif
-#ifndef TG_MULTI_WAVES
-#define TG_MULTI_WAVES 3  // ... the kernels of several transitions per launch (NUMPY: at 4 the plain one spilled 12 registers: 2.90 -> 2.73 us per transition)
-#endif
-#ifndef TG_WIDE_WAVES
-#define TG_WIDE_WAVES 2  // ... the kFeatWide instantiations (FUNCTIONAL, up to 65 536 envs: one logic + one stream wave per SIMD)
-#endif
+constexpr int TG_ONE_WAVES = 4;    // waves per SIMD the one-transition kernels are compiled for (4 → 128 VGPRs, 3 → 168)
+constexpr int TG_MULTI_WAVES = 3;  // ... the kernels of several transitions per launch (NUMPY: at 4 the plain one spilled 12 registers: 2.90 -> 2.73 us per transition)
+constexpr int TG_WIDE_WAVES = 2;   // ... the kFeatWide instantiations (FUNCTIONAL, up to 65 536 envs: one logic + one stream wave per SIMD)
 constexpr int bits_waves_per_simd(const int ruleset, const int feat) {
   if (ruleset == TG_RULESET_FUNCTIONAL && (feat & kFeatSplit)) return 3;  // (three waves per workgroup, one workgroup's worth per SIMD at 65 536 envs)
   return (feat & kFeatWide) ? TG_WIDE_WAVES
@@ -941,10 +823,6 @@ void step_kernel_bits(
   // 65 536 envs, 3-10 % loss at 32 768 / 131 072; even switched off, its scalar arithmetic in front of the first loads cost the
   // headline launch 0.07 us.  Removed again: commit c0175b2 has it, profiles/r04/ab_rng_thirds.log the numbers.)
   // role split by blockIdx: the RNG workgroups lead (placing them last measured the same)
-#ifdef TG_RNG_FIRST
-  const bool rng_role = (int)blockIdx.x < bp.nrb;
-  const uint32_t step_block = blockIdx.x - (uint32_t)bp.nrb, rng_block = blockIdx.x;
-#else
   // the step workgroups are dispatched first (a grid of this size starts first → last within 0.3-0.7 us, and the step
   // workgroups are the longer pole since the RNG role produces one entry per launch)
   const uint32_t n_step = hot_misc & 0xFFFFFFu;
@@ -952,7 +830,6 @@ void step_kernel_bits(
   // the scalar loads at the top of the kernel, see TG_LATE_ARGS)
   const bool rng_role = RULESET == TG_RULESET_NUMPY && blockIdx.x >= n_step;
   const uint32_t step_block = blockIdx.x, rng_block = blockIdx.x - n_step;
-#endif
   const uint32_t base_env = step_block * (uint32_t)EPW;  // (meaningless in the RNG role)
   const uint32_t nlive = B - base_env < (uint32_t)EPW ? B - base_env : (uint32_t)EPW;
   const bool live = (uint32_t)lane < nlive;
@@ -983,11 +860,8 @@ void step_kernel_bits(
   (void)need_slab; (void)dict; (void)rgb; (void)obs_traj; (void)out_traj; (void)act_traj; (void)final_obs
   uint4* post2 = reinterpret_cast<uint4*>(lds + BG::OFF_RGB);                      // (RGB instantiations only)
   const uint32_t* lut_l = reinterpret_cast<const uint32_t*>(lds + BG::OFF_TAB + 256);  // colour table (RGB)
-#ifndef TG_RGB_ELOG
-#define TG_RGB_ELOG (EPW / 2)
-#endif
   constexpr int RGBH = bits_rgb_helper_count<W, H>(FEAT);  // RGB helper waves (0 / 2 / 6): quarters / eighths instead of halves
-  constexpr int ELOG = RGBH ? EPW / (2 + RGBH) : TG_RGB_ELOG;  // RGB: the logic wave packs the envs below, the stream wave those from ELOG on
+  constexpr int ELOG = RGBH ? EPW / (2 + RGBH) : (EPW / 2);  // RGB: the logic wave packs the envs below, the stream wave those from ELOG on
   constexpr int ESTR = RGBH ? 2 * ELOG : EPW;                  // ... up to here; helper wave w the ELOG envs from ESTR + (w - 2) ELOG on
   constexpr int WP = W + 8, HP = H + 4, PC = BG::PC;
   // p.nsteps consecutive transitions in this launch (tg_step_k): records / masks / slabs stay in registers and LDS in
@@ -998,25 +872,7 @@ void step_kernel_bits(
   const int nsteps = MULTI ? (hot_nsteps > 1 ? hot_nsteps : 1) : 1;
   const bool sample_mode = SAMPLE && p.sample_mode;  // (device-side action sampling: the kernels that carry it wait here)
 
-#ifdef TG_PHASE_TIMING
-  unsigned long long tstamp[8];  // kept in SGPRs and written at the very end: a store per stamp would itself be waited on
-  // s_memtime = shader cycles of THIS CU's counter (phases of one wave); TG_STAMP_REALTIME: the device-wide 100 MHz
-  // counter instead (absolute timeline across workgroups, tools/phase_timeline_bits.py)
-#ifdef TG_STAMP_REALTIME
-#define TG_NOW() __builtin_amdgcn_s_memrealtime()
-#else
-#define TG_NOW() __builtin_amdgcn_s_memtime()
-#endif
-#define TG_BITS_STAMP(i) tstamp[i] = TG_NOW()
-#ifdef TG_FINE_LOCK  // finer stamps inside the lock path instead of the post-barrier ones: 4 = drop row known, 5 = full rows known, 6 = lock path done, 7 = published
-#define TG_LOCK_STAMP(i) TG_BITS_STAMP(i)
-#endif
-#else
-#define TG_BITS_STAMP(i) do {} while (0)
-#endif
-#ifndef TG_LOCK_STAMP
-#define TG_LOCK_STAMP(i) do {} while (0)
-#endif
+  TG_TIMING(unsigned long long tstamp[8];)  // kept in SGPRs and written at the very end: a store per stamp would itself be waited on
   // A role ends with s_endpgm, not with a return: a return joins the function's single exit, and the wait-count pass then
   // treats the RNG role's loads as possibly pending where the logic wave starts — depending on register allocation it put
   // an s_waitcnt vmcnt(0) between the logic wave's table loads and its record loads (6.4 -> 6.9 us per launch).
@@ -1029,9 +885,7 @@ void step_kernel_bits(
     // RNG ROLE (leading workgroups, 128 envs each): refill every ring that holds fewer than kRing permutations.
     // Generator.shuffle on the 7-bag = numpy PCG64 + masked rejection (components/tetromino_randomizer.py:42-46, 84).
     // =====================================================================================================
-#ifdef TG_PHASE_TIMING
-    const unsigned long long rng_t0 = TG_NOW();
-#endif
+    TG_TIMING(const unsigned long long rng_t0 = TG_NOW();)
     if (bits_wg_waves<W, H>(FEAT) > 2 && threadIdx.x >= 128) TG_ROLE_END();  // (a third wave of the workgroup has no RNG range)
     const uint32_t e = rng_block * 128u + threadIdx.x;
     const bool on = e < B;
@@ -1041,10 +895,7 @@ void step_kernel_bits(
     const int Hraw = hot_hbuf_rd[ee];
     const int Hn = Hraw & 0xFF;
     const int loc = (Hraw >> 8) & 7;
-#ifndef TG_RNG_PRIO
-#define TG_RNG_PRIO 2  // between the stream wave before its barrier (1) and the logic wave (3): A/B in profiles/r02
-#endif
-    __builtin_amdgcn_s_setprio(TG_RNG_PRIO);
+    __builtin_amdgcn_s_setprio(2);  // between the stream wave before its barrier (1) and the logic wave (3): A/B in profiles/r02
     // One-transition launches: ONE entry per env and launch (a second one waits for the next launch: 13 % of the waves
     // would otherwise run two shuffles back to back and become the tail of the launch — measured 7.0 us vs 5.8 us for the
     // step workgroups).  Launches of several transitions consume more per env and are long anyway: refill completely.
@@ -1093,27 +944,15 @@ void step_kernel_bits(
     if (on) {
       u32x4* rdst = reinterpret_cast<u32x4*>(bp.ring_wr) + e;
       const u32x4 rv = u32x4{(uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32)};
-#ifdef TG_RING_PLAIN
-      *rdst = rv;
-#else
       st_state(rdst, rv);
-#endif
     }
-#ifdef TG_PHASE_TIMING
-    if (p.dbg && (threadIdx.x & 63) == 0) {  // lifetime of the RNG waves, behind the step workgroups' stamps
+    TG_TIMING(if (p.dbg && (threadIdx.x & 63) == 0) {  // lifetime of the RNG waves, behind the step workgroups' stamps
       const size_t slot = (size_t)(gridDim.x - bp.nrb) * 16 + (size_t)rng_block * 4 + (threadIdx.x >> 6) * 2;
       p.dbg[slot] = rng_t0;
       p.dbg[slot + 1] = TG_NOW();
-    }
-#endif
+    })
     TG_ROLE_END();
   }
-#ifdef TG_WG_STAGGER
-  // experiment: half of the step workgroups start late (k x 512 cycles) so that their load / store bursts fall into the
-  // other half's compute phase
-  if ((step_block >> 3) & 1u)
-    for (int i = 0; i < TG_WG_STAGGER; ++i) __builtin_amdgcn_s_sleep(8);
-#endif
   TG_BITS_STAMP(0);
 
   if constexpr (bits_mask_wave<W, H>(FEAT)) {
@@ -1122,10 +961,7 @@ void step_kernel_bits(
       // MASK WAVE (kFeatMaskWave): obs["active_tetromino_mask"] of the workgroup's envs, GD at a time, from the post records
       // the logic wave publishes — one barrier per transition, like the stream wave.
       // =====================================================================================================
-#ifndef TG_MASK_PRIO
-#define TG_MASK_PRIO 1
-#endif
-      __builtin_amdgcn_s_setprio(TG_MASK_PRIO);
+      __builtin_amdgcn_s_setprio(1);
       TG_LATE_ARGS();
       const size_t Bt = p.act_stride;  // the handle's batch
       constexpr int GD = BG::GD;
@@ -1189,10 +1025,7 @@ void step_kernel_bits(
     // loading at once, and the stream waves' 13 KB per workgroup queue in front of the logic waves' records — which are the
     // start of the critical path, while the slabs are not needed before the publish (6.41 -> 6.28 us, FUNCTIONAL 8.38 ->
     // 8.29; 16 x 64 cycles: half of that; 48: nothing.  profiles/r03/ab_stream_delay.log)
-#ifndef TG_STREAM_DELAY
-#define TG_STREAM_DELAY 32
-#endif
-    if (!MULTI && TG_STREAM_DELAY > 0) __builtin_amdgcn_s_sleep(TG_STREAM_DELAY);
+    if (!MULTI) __builtin_amdgcn_s_sleep(32);
     constexpr int NSW = bits_stream_waves<W, H>(FEAT);
     constexpr int EPW_WG = BG::EPW, EPS = EPW_WG / NSW, NCHS = NSW == 1 ? BG::NCH : EPS * S / 16;
     const uint32_t sbase = NSW == 1 ? 0u : (uint32_t)(wave - 1) * (uint32_t)EPS;
@@ -1280,44 +1113,22 @@ void step_kernel_bits(
     bool dirty_any = false;  // this lane's env changed its slab in some transition of the launch
     for (int step = 0; step < nsteps; ++step) {
     const bool last = step == nsteps - 1;
-#ifdef TG_PHASE_TIMING
-#ifdef TG_FINE_FUSED_STREAM  // the stream wave's transition nsteps - 2 (no write-back in it): 1 top, 2 barrier passed,
-                             // 3 lock block done, 4 observation stored, 0 un-drawn (end of the iteration)
-#define TG_FS(i) do { if (step == nsteps - 2) TG_BITS_STAMP(i); } while (0)
-    TG_FS(1);
-#else
-#define TG_FS(i) do {} while (0)
-    if (MULTI && last && step > 0) TG_BITS_STAMP(1);  // launches of several transitions: the stamps describe the LAST one
-#endif
-#endif
-#ifndef TG_FS
-#define TG_FS(i) do {} while (0)
-#endif
+    TG_TIMING(if (MULTI && last && step > 0) TG_BITS_STAMP(1);)  // launches of several transitions: the stamps describe the LAST one
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();  // the logic wave has published what happened to every env in this transition
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-#ifndef TG_NO_PRIO_SWAP
     // from here on this wave is the workgroup's critical path (round 2 left the functional rule-set out: its logic waves
     // ran threefry in line in front of their publish and were the longer pole; that work now sits behind the publish)
-#ifdef TG_FN_NO_SWAP
-    if (RULESET == TG_RULESET_NUMPY)
-#else
     if (RULESET == TG_RULESET_NUMPY || !MULTI)  // (launches of several functional transitions: the logic wave's look-ahead is on the chain)
-#endif
     __builtin_amdgcn_s_setprio(3);
-#endif
-#ifdef TG_FINE_FUSED_STREAM
-    TG_FS(2);
-#else
     TG_BITS_STAMP(2);
-#endif
     // post record of this lane's env: x = lock {cells | val << 16 | place << 24 | clear << 25 | reset << 26},
     // y = lock {x | y << 8}, z = observation {cells | val << 16 | show << 24}, w = observation {x | y << 8}
     const uint4 po = post[(step & 1) * EPW_WG + slot];
     const bool place = live && ((po.x >> 24) & 1u), do_clear = live && ((po.x >> 25) & 1u), do_reset = live && ((po.x >> 26) & 1u);
     const bool dirty = place || do_reset;
     dirty_any = dirty_any || dirty;
-    if (__any(dirty) && !TG_SKIP(128)) {
+    if (__any(dirty)) {
       const bool nib_over = bd.template stamp<PACKED && RULESET == TG_RULESET_FUNCTIONAL>(
           po.x & 0xFFFFu, (int)(po.y & 0xFFu), (int)((po.y >> 8) & 0xFFu), (po.x >> 16) & 0xFFu, RULESET == TG_RULESET_FUNCTIONAL, place);
       if constexpr (PACKED && RULESET == TG_RULESET_FUNCTIONAL) {  // (never in play: the engine reports it at its next wait)
@@ -1364,10 +1175,6 @@ void step_kernel_bits(
       wave_sync();
     }
     if (last && __any(dirty_any)) {
-#ifdef TG_WB_PER_LANE
-      // board write-back: every changed env's lane copies its own slab (8-byte aligned in LDS and in HBM)
-      if (dirty_any) bits_copy_slab<S, false>(bd.my, hot_board + (size_t)env * S);
-#else
       // board write-back, chunk-major: lane l of pass k owns the 16-byte chunk l + 64 k of the workgroup's slab block and
       // stores it when it holds bytes of a changed env.  Neighbouring lanes write neighbouring chunks, so a changed
       // slab costs ~4 full cache-line writes instead of 13 partial ones from its own lane (the launch's store burst is
@@ -1399,7 +1206,7 @@ void step_kernel_bits(
             const uint32_t e1 = e1r < (uint32_t)EPW ? e1r : (uint32_t)EPW - 1u;
             const bool hit = keep_b0 ? differs(pw, stage[k0 + kk])
                                      : ((((dm >> (e0 < (uint32_t)EPW ? e0 : (uint32_t)EPW - 1u)) | (dm >> e1)) & 1ull) != 0);
-            st_state_if(pwin, 16u * c, pw, c < nchunks_p && hit && !TG_SKIP(2));
+            st_state_if(pwin, 16u * c, pw, c < nchunks_p && hit);
           }
         }
       } else if (keep_b0) {
@@ -1409,27 +1216,12 @@ void step_kernel_bits(
           const int c = lane + 64 * k;
           wv[k] = lds4[c < NCH ? c : NCH - 1];
         }
-#if !defined(TG_NO_BUFFER_ST) && !defined(TG_WB_PLAIN)
         const __amdgpu_buffer_rsrc_t win = st_window(bdst, (uint32_t)NCH * 16u);
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
           const int c = lane + 64 * k;
-          st_state_if(win, 16u * (uint32_t)c, wv[k], c < NCH && differs(wv[k], stage[k]) && !TG_SKIP(2));
+          st_state_if(win, 16u * (uint32_t)c, wv[k], c < NCH && differs(wv[k], stage[k]));
         }
-#else
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-          const int c = lane + 64 * k;
-          const bool wput = differs(wv[k], stage[k]);
-          if (c < NCH && wput && !TG_SKIP(2)) {
-#ifdef TG_WB_PLAIN
-            bdst[c] = wv[k];
-#else
-            st_state(&bdst[c], wv[k]);
-#endif
-          }
-        }
-#endif
       } else if (full_wave) {
         // the kernels with the transition loop, full workgroup: which envs own bytes of a chunk is plain index arithmetic
         // (the general path below also carries the ragged tail of a partial workgroup inside its loop: ~70 instructions
@@ -1449,27 +1241,13 @@ void step_kernel_bits(
             const uint32_t e0 = (16u * c) / (uint32_t)S, e1r = (16u * c + 15u) / (uint32_t)S;
             const uint32_t e1 = e1r < (uint32_t)EPW ? e1r : (uint32_t)EPW - 1u;
             const bool hit = c < (uint32_t)NCH && (((dm >> e0) | (dm >> e1)) & 1ull) != 0;
-#if !defined(TG_NO_BUFFER_ST) && !defined(TG_WB_PLAIN)
-            st_state_if(st_window(bdst, (uint32_t)NCH * 16u), 16u * c, wv[kk], hit && !TG_SKIP(2));
-#else
-            if (hit && !TG_SKIP(2)) {
-#ifdef TG_WB_PLAIN
-              bdst[c] = wv[kk];
-#else
-              st_state(&bdst[c], wv[kk]);
-#endif
-            }
-#endif
+            st_state_if(st_window(bdst, (uint32_t)NCH * 16u), 16u * c, wv[kk], hit);
           }
         }
       } else {
       // chunks in flight per lane: all of them in the one-transition kernel; in the transition loop of the fused kernels
       // that would cost 52 registers beside the observation pass's 52 (the kernel spilled)
-#ifdef TG_WBB
-      constexpr int WBB = TG_WBB;
-#else
       constexpr int WBB = MULTI ? 4 : NIT;
-#endif
 #pragma unroll 1
       for (int k0 = 0; k0 < NIT; k0 += WBB) {
         u32x4 wv[WBB];
@@ -1484,13 +1262,9 @@ void step_kernel_bits(
           const uint32_t e0 = (16u * c) / (uint32_t)S, e1r = (16u * c + 15u) / (uint32_t)S;
           const uint32_t e1 = e1r < (uint32_t)EPW ? e1r : (uint32_t)EPW - 1u;
           const bool hit = k0 + kk < NIT && c < nchunks && (((dm >> e0) | (dm >> e1)) & 1ull) != 0;
-          if (hit && !TG_SKIP(2)) {
+          if (hit) {
             if (c * 16u + 16u <= nbytes) {
-#ifdef TG_WB_PLAIN
-              bdst[c] = wv[kk];
-#else
               st_state(&bdst[c], wv[kk]);
-#endif
             } else {  // ragged tail of a partial wave
               const uint32_t w4[4] = {wv[kk].x, wv[kk].y, wv[kk].z, wv[kk].w};
               for (uint32_t i = 0; c * 16u + i < nbytes; ++i)
@@ -1500,14 +1274,9 @@ void step_kernel_bits(
         }
       }
       }
-#endif
     }
-#ifdef TG_FINE_FUSED_STREAM
-    TG_FS(3);
-#else
     TG_BITS_STAMP(3);
-#endif
-    if (need_slab && !TG_SKIP(64)) {
+    if (need_slab) {
       const bool show = live && ((po.z >> 24) & 1u);
       bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu),
                p.obs_mode == TG_OBS_FN ? 0xFFu : ((po.z >> 16) & 0xFFu), false, show);
@@ -1533,16 +1302,14 @@ void step_kernel_bits(
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
           const int c = lane + 64 * k;
-#if !defined(TG_NO_BUFFER_ST) && !defined(TG_NO_NT) && !defined(TG_NO_OBS_TAIL_BUF)
           if (64 * k + 63 >= NCH) {  // the last, partial pass: the window drops the lanes behind the block (no exec-mask region)
-            if (!TG_SKIP(1)) {
+            {
               __builtin_amdgcn_raw_buffer_store_b128(o[k], st_window(odst, (uint32_t)NCH * 16u), 16u * (uint32_t)c, 0, 2);
               if (last && obs_traj) __builtin_amdgcn_raw_buffer_store_b128(o[k], st_window(odst2, (uint32_t)NCH * 16u), 16u * (uint32_t)c, 0, 2);
             }
             continue;
           }
-#endif
-          if (c < NCH && !TG_SKIP(1)) {
+          if (c < NCH) {
             st_stream(&odst[c], o[k]);
             if (last && obs_traj) st_stream(&odst2[c], o[k]);
           }
@@ -1638,23 +1405,17 @@ void step_kernel_bits(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
       }
     }
-    TG_FS(4);
-    if ((need_slab || dict || rgb) && !last && !TG_SKIP(256)) {  // the slab in LDS is the board again: the drawn piece only ever covers free cells
+    if ((need_slab || dict || rgb) && !last) {  // the slab in LDS is the board again: the drawn piece only ever covers free cells
       wave_sync();
       bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu), 0u, false, live && ((po.z >> 24) & 1u));
       wave_sync();
     }
-    TG_FS(0);
     }  // transitions
-#ifndef TG_FINE_FUSED_STREAM
     TG_BITS_STAMP(4);
-#endif
-#ifdef TG_PHASE_TIMING
-    if (p.dbg && lane == 0) {
+    TG_TIMING(if (p.dbg && lane == 0) {
       for (int i = 0; i < 5; ++i) p.dbg[(size_t)step_block * 16 + 8 + i] = tstamp[i];
       p.dbg[(size_t)step_block * 16 + 14] = __builtin_amdgcn_s_getreg(63492);  // HW_ID: where the stream wave ran
-    }
-#endif
+    })
     TG_ROLE_END();
   }
 
@@ -1819,9 +1580,7 @@ void step_kernel_bits(
 
   bool cols_dirty_any = false;
   for (int step = 0; step < nsteps; ++step) {
-#ifdef TG_PHASE_TIMING
-  if (MULTI && step == nsteps - 1 && step > 0) TG_BITS_STAMP(1);  // (see the stream wave)
-#endif
+  TG_TIMING(if (MULTI && step == nsteps - 1 && step > 0) TG_BITS_STAMP(1);)  // (see the stream wave)
   // FUNCTIONAL: the look-ahead keys a lock of this transition will continue from — requested now (their address depends on
   // the record's position counter), consumed behind the publish (fn_book): as a dependent load there they stood in
   // front of three threefry levels while the memory system was busy with the stream waves' stores (3.3 us)
@@ -1831,11 +1590,7 @@ void step_kernel_bits(
   // the keys are requested behind the publish, by the event lanes only, and claimed in front of the first store (the logic
   // wave ends 1.4 us before its stream wave: it can wait).  98 304 envs 11.5 -> 9.9 us, 131 072 18.2 -> 16.6, 524 288
   // 57.9 -> 52.0; at 65 536 the same, at 4 096 +2 % — hence the threshold (profiles/r03/ab_functional_late_prefetch.log).
-#ifndef TG_FN_PREFETCH_ALL
   const bool fn_prefetch_late = RULESET == TG_RULESET_FUNCTIONAL && !MULTI && hot_batch > 49152;
-#else
-  constexpr bool fn_prefetch_late = false;
-#endif
   u32x2 pf_c1 = u32x2{0u, 0u}, pf_cf = pf_c1, pf_r1 = pf_c1;  // (native vectors: HIP's uint2 struct went to scratch memory)
   // position n on the key chain (mod 4) and how far the look-ahead reaches (1..3 keys; tg_env_rec.reserved holds 3 - depth in
   // bits 2-3, so a zeroed field = position 0 at full depth: what bits_prepare_kernel builds)
@@ -1934,7 +1689,10 @@ void step_kernel_bits(
   // action → tentative placement (branch-free LUT)
   uint32_t e;
   if (RULESET == TG_RULESET_NUMPY) {
-    e = (uint32_t)(kActLutNumpy >> (8 * (action & 7))) & 0xFFu;
+    // (the handle's ActionsMapping, mappings/actions.py:12-19; the grouped action set arrives here as the canonical ids 5 / 7 of
+    // the wrapper's own hard_drop / no_op: wrappers/grouped.py:234, 258)
+    const uint64_t lut = p.action_set == TG_ACTIONS_GROUPED ? kActLutNumpy : p.act_lut;
+    e = (uint32_t)(lut >> (8 * (action & 7))) & 0xFFu;
   } else {
     const int br = action < 0 ? 0 : (action > 6 ? 6 : action);
     e = (uint32_t)(kActLutFn >> (8 * br)) & 0xFFu;
@@ -2097,7 +1855,6 @@ void step_kernel_bits(
         s.y = (place & hard) ? yd : s.y;
       }
     }
-    TG_LOCK_STAMP(4);
     lock_cells = rot16(tcelF, frot);
     lock_x = s.x; lock_y = s.y;
     lock_val = RULESET == TG_RULESET_NUMPY ? s.val : s.piece + 2;  // functional/core.py:103-121 adds piece id
@@ -2138,7 +1895,6 @@ void step_kernel_bits(
     full = place ? full : T(0);
     lines = popc_t(full);
     do_clear = lines > 0;
-    TG_LOCK_STAMP(5);
     if (__any(do_clear)) {
       // compaction of the masks: delete the full rows top-down (rows above move down by one each time);
       // NUMPY (envs/tetris.py:500-510): vacated top rows are empty; FUNCTIONAL (functional/core.py:203-214): the
@@ -2180,7 +1936,8 @@ void step_kernel_bits(
       sc = hs != 0;
     }
     if (RULESET == TG_RULESET_NUMPY) {
-      reward = (place & !sc) ? (float)(lines * lines * W + 1) : 0.0f;  // score + rewards.alife; 0 when the spawn collides
+      // score + rewards.alife; rewards.game_over when the piece already collided or the spawn collides (envs/tetris.py:461-474)
+      reward = lock ? ((place & !sc) ? (float)(lines * lines * W) + p.r_alife : p.r_game_over) : 0.0f;
       s.flags = place ? ((s.flags & ~(TG_F_GAME_OVER | TG_F_HAS_SWAPPED)) | (sc ? TG_F_GAME_OVER : 0)) : s.flags;
       final_coll = place ? sc : final_coll;
     } else {
@@ -2196,13 +1953,9 @@ void step_kernel_bits(
     reward = stepped ? t - old : reward;  // tetris_fn.py:312
   }
 
-#ifdef TG_FINE_LOCK
-  TG_BITS_STAMP(6);
-#elif !defined(TG_FINE_FN)
   TG_BITS_STAMP(4);
-#endif
   // ---- termination / autoreset ----
-  reward = g_illegal ? -0.1f : reward;  // rewards.invalid_action
+  reward = g_illegal ? p.r_invalid : reward;  // rewards.invalid_action (wrappers/grouped.py:238)
   const int terminated = (!pending & (((s.flags & TG_F_GAME_OVER) != 0) | (g_illegal & (p.grouped_term != 0)))) ? 1 : 0;
   const bool do_reset = live & (pending | ((terminated != 0) & (p.autoreset == TG_AUTORESET_SAME_STEP)));
   s.flags |= ((terminated != 0) & (p.autoreset == TG_AUTORESET_NEXT_STEP) & !pending) ? TG_F_PENDING_RESET : 0;
@@ -2288,11 +2041,7 @@ void step_kernel_bits(
                             (uint32_t)(lock_x & 0xFF) | ((uint32_t)(lock_y & 0xFF) << 8),
                             ocells | ((uint32_t)(s.val & 0xFF) << 16) | ((show ? 1u : 0u) << 24),
                             (uint32_t)(s.x & 0xFF) | ((uint32_t)(s.y & 0xFF) << 8) | ((uint32_t)(s.piece & 0xFF) << 16));
-#ifdef TG_FINE_LOCK
-    TG_BITS_STAMP(7);
-#elif !defined(TG_FINE_FN)
     TG_BITS_STAMP(5);
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
   };
@@ -2350,16 +2099,6 @@ void step_kernel_bits(
   auto fn_book = [&]() {
     const bool ev = fn_lock || fn_reset;
     const bool cu = !ev && fn_d0 < 3 && !(p.fn_lazy & 4);  // (test knob: bit 2 = never catch up — the chain stays one key deep)
-#ifndef TG_FN_ABL  // timing ablations (results wrong): 2 no sorts, 4 nothing
-#define TG_FN_ABL 0
-#endif
-    if ((TG_FN_ABL & 4) && p.batch >= 0) return;
-#ifdef TG_FINE_FN  // (stamps: 3 = fn_book entered, 4 = level done, 6 = sorts done, 7 = fn_book left)
-#define TG_FN_STAMP(i) TG_BITS_STAMP(i)
-#else
-#define TG_FN_STAMP(i) do {} while (0)
-#endif
-    TG_FN_STAMP(3);
     if (!__any(ev | cu)) return;
     const int n = fn_n0, d = fn_d0;
     const bool lk = fn_lock && !fn_reset;           // stays on its chain: position n + 1
@@ -2394,12 +2133,7 @@ void step_kernel_bits(
       const bool shallow = d < 2;
       threefry2x32(shallow ? b0 : kb.x, shallow ? b1 : kb.y, 0u, 1u, z0, z1);
     }
-#ifdef TG_FINE_FN
-    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(z0), "+v"(z1));
-#endif
-    TG_FN_STAMP(4);
     const u32x2 c1 = u32x2{a0, a1}, r0 = u32x2{b0, b1};
-    TG_FN_STAMP(5);
     // The sorts, seven lanes each.  Round 4: only the bags the NEXT transition can deal are sorted now — S2' = sort7(R_{n+3}) of a
     // lock that leaves the stack within reach of the spawn rows (fn_hi), Q0' = sort7(f1(R_{n+1})) when the next lock refills;
     // a reset sorts nothing (its board is empty: S1 / S2 of the new chain stay kFnNone until a lock with a tall stack makes
@@ -2411,7 +2145,7 @@ void step_kernel_bits(
     const int qA = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u));
     const int qB = nA + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u));
     uint64_t p1 = kFnNone, p2 = 0;
-    if (nt > 0 && !((TG_FN_ABL & 2) && p.batch >= 0)) {
+    if (nt > 0) {
     uint2* xk = reinterpret_cast<uint2*>(lds + BG::OFF_FNX);
     uint32_t* xo = reinterpret_cast<uint32_t*>(lds + BG::OFF_FNX + 128 * 8);
     if (needs2) xk[qA] = make_uint2(b0, b1);
@@ -2461,10 +2195,6 @@ void step_kernel_bits(
     p1 = needs2 ? s1 : kFnNone; p2 = s2;
     wave_sync();
     }
-#ifdef TG_FINE_FN
-    asm volatile("" : "+v"(p1), "+v"(p2));
-#endif
-    TG_FN_STAMP(6);
     if (lk) {  // S2 -> S1, the new S2 (or none), the refill bag
       fnw = ((fnw >> 21) & 0x1FFFFFULL) | (p1 << 21) | (needq ? p2 << 42 : 0ULL);
       s.reserved = (s.reserved & ~3u) | (uint32_t)((n + 1) & 3);
@@ -2488,7 +2218,6 @@ void step_kernel_bits(
       fn_dirty = fn_dirty | evl;
     }
     fn_lock = false; fn_reset = false; fn_hi = false;
-    TG_FN_STAMP(7);
   };
   // obs["active_tetromino_mask"] of the workgroup's envs, GD at a time (dict_mask_group), into TG_BUF_OBS / the trajectory slot
   auto dict_masks = [&]() {
@@ -2508,18 +2237,15 @@ void step_kernel_bits(
     // (the kernels with the transition loop are at their register budget: one publish site, two passes)
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-      if (RULESET == TG_RULESET_NUMPY && (pass == 0) == book_first && !TG_SKIP(512)) bookkeeping();
+      if (RULESET == TG_RULESET_NUMPY && (pass == 0) == book_first) bookkeeping();
       if (pass == 0) publish();
-#ifdef TG_FINE_FUSED  // (last transition: 5 = published, 6 = barrier passed, 7 = bookkeeping done / end of the iteration)
-      if (pass == 0 && step == nsteps - 1) TG_BITS_STAMP(6);
-#endif
     }
   } else {
     if (!book_first) publish();
     // (the dict observation's mask array depends on nothing behind the publish — but stored HERE, in front of the bookkeeping, the
     // launch takes 23.5 instead of 17.3 us: the bookkeeping's loads then wait behind 28 store instructions per lane, vmcnt counts
     // both.  profiles/r04/ab_dict_mask_early_rejected.log)
-    if (RULESET == TG_RULESET_NUMPY && !TG_SKIP(512)) bookkeeping();
+    if (RULESET == TG_RULESET_NUMPY) bookkeeping();
     if (book_first) publish();
   }
   // (every load result the rest of the transition uses is claimed HERE, in front of the first store behind the publish: on
@@ -2529,9 +2255,7 @@ void step_kernel_bits(
     pf_c1 = cs[(fn_n0 + 1) & 3]; pf_cf = cs[(fn_n0 + fn_d0) & 3]; pf_r1 = cs[4 + ((fn_pend0 ? fn_n0 : fn_n0 + 1) & 3)];
   }
   if (RULESET == TG_RULESET_FUNCTIONAL) asm volatile("" : "+v"(pf_c1), "+v"(pf_cf), "+v"(pf_r1));
-#ifndef TG_NO_EP_CLAIM
   asm volatile("" : "+v"(ep.ret), "+v"(ep.len), "+v"(ep.last_ret), "+v"(ep.last_len));
-#endif
   if (pending) {  // the NEXT_STEP reset step belongs to no episode (gymnasium RecordEpisodeStatistics)
     ep.ret = 0.0f; ep.len = 0;
   } else {
@@ -2539,17 +2263,18 @@ void step_kernel_bits(
     ep.len += 1;
     if (terminated) { ep.last_ret = ep.ret; ep.last_len = ep.len; ep.ret = 0.0f; ep.len = 0; }
   }
-  if (step == nsteps - 1 && live && !TG_SKIP(16))  // the outputs of the LAST transition remain in the buffers
-    st_stream(reinterpret_cast<u32x2*>(p.out + env), u32x2{__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8)});
+  // tg_step_out: terminated | lines << 8 | flags << 16 (TG_OUT_COMMITTED: commit_active_tetromino ran; TG_OUT_ILLEGAL)
+  const uint32_t out_word = (uint32_t)terminated | ((uint32_t)lines << 8) |
+                            (RULESET == TG_RULESET_NUMPY ? ((lock ? (uint32_t)TG_OUT_COMMITTED << 16 : 0u) | (g_illegal ? (uint32_t)TG_OUT_ILLEGAL << 16 : 0u)) : 0u);
+  if (step == nsteps - 1 && live)  // the outputs of the LAST transition remain in the buffers
+    st_stream(reinterpret_cast<u32x2*>(p.out + env), u32x2{__float_as_uint(reward), out_word});
   if (out_traj && live)
     st_stream(reinterpret_cast<u32x2*>(out_traj + (size_t)step * p.act_stride + env),
-              u32x2{__float_as_uint(reward), (uint32_t)terminated | ((uint32_t)lines << 8)});
+              u32x2{__float_as_uint(reward), out_word});
   if (RULESET == TG_RULESET_FUNCTIONAL) {
     // (behind everything that waits for a load of the launch's start — the episode record above: a wait for it behind
     // fn_book's stores is a wait for those stores, a round trip through a memory system busy with the stream waves' tail)
-#if !defined(TG_FN_NO_SWAP) && !defined(TG_FN_KEEP_PRIO)
     if (!MULTI) __builtin_amdgcn_s_setprio(0);  // the look-ahead is nobody's critical path: the stream wave's tail goes first
-#endif
     fn_book();
   }
   if (rgb) {
@@ -2625,26 +2350,20 @@ void step_kernel_bits(
       }
     }
   }
-#ifdef TG_FINE_FUSED
-  if (step == nsteps - 1) TG_BITS_STAMP(7);
-#endif
   }  // transitions
-#ifndef TG_NO_PRIO_SWAP
   if (RULESET == TG_RULESET_NUMPY) __builtin_amdgcn_s_setprio(0);
-#endif
   // ---- D: per-env stores: first record half, episode statistics, column masks ----
   const bool cols_dirty = cols_dirty_any;
   uint4 oa, ob;
   lane_pack(s, oa, ob);
   uint4* rec_out = reinterpret_cast<uint4*>(hot_rec) + (size_t)env * 2;
-#ifndef TG_REC_PER_LANE
   // Records as whole cache lines (one-transition kernels; -0.15 ... -0.25 us per launch, profiles/r02/ab_rec_lines.log):
   // lane l of store s writes the 16-byte chunk l + 64 s of the workgroup's record block (= half (chunk & 1) of env
   // chunk >> 1), fetched from the owning lane by ds_bpermute — stores that cover full lines instead of two stores that
   // each cover half of every line (and the second half is no longer conditional).
   const bool rec_lines = !MULTI && nlive == (uint32_t)EPW;
   constexpr int REC_CHUNKS = 2 * EPW, REC_ST = (REC_CHUNKS + 63) / 64;
-  if (rec_lines && !TG_SKIP(4)) {
+  if (rec_lines) {
     u32x4* rblk = reinterpret_cast<u32x4*>(hot_rec) + (size_t)base_env * 2;
 #pragma unroll
     for (int st = 0; st < REC_ST; ++st) {
@@ -2658,20 +2377,13 @@ void step_kernel_bits(
       if (chunk < REC_CHUNKS) TG_ST_STATE(rblk + chunk, (u32x4{hi ? bx : ax, hi ? by : ay, hi ? bz : az, hi ? bw : aw}));
     }
   }
-  if (live && !rec_lines && !TG_SKIP(4)) TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out), (u32x4{oa.x, oa.y, oa.z, oa.w}));
-  if (live && p.episode && !TG_SKIP(4)) p.episode[env] = ep;
-#else
-  const bool rec_lines = false;
-  if (live && !TG_SKIP(4)) {
-    TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out), (u32x4{oa.x, oa.y, oa.z, oa.w}));
-    if (p.episode) p.episode[env] = ep;
-  }
-#endif
+  if (live && !rec_lines) TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out), (u32x4{oa.x, oa.y, oa.z, oa.w}));
+  if (live && p.episode) p.episode[env] = ep;
   if (__any(cols_dirty)) {
     T nv[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) nv[c] = (T)(colsL[1 + c] & PLAY);
-    if (cols_dirty && !TG_SKIP(8)) {
+    if (cols_dirty) {
       uint2* gc = reinterpret_cast<uint2*>(reinterpret_cast<T*>(hot_cols) + (size_t)env * BG::WC);
       if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -2684,9 +2396,7 @@ void step_kernel_bits(
     }
   }
 
-#if !defined(TG_FINE_LOCK) && !defined(TG_FINE_FUSED) && !defined(TG_FINE_FN)
   TG_BITS_STAMP(6);
-#endif
   // ---- E: consumed counter; the generator state only after an in-line shuffle (otherwise `ahead` holds it) ----
   if (RULESET == TG_RULESET_NUMPY) {
     if (live) bp.hbuf_wr[env] = (uint32_t)(Hc | (loc << 8));
@@ -2698,17 +2408,13 @@ void step_kernel_bits(
   } else if (live && fn_dirty) {
     reinterpret_cast<uint2*>(bp.hbuf_wr)[env] = make_uint2((uint32_t)fnw, (uint32_t)(fnw >> 32));
   }
-#if !defined(TG_FINE_LOCK) && !defined(TG_FINE_FUSED) && !defined(TG_FINE_FN)
   TG_BITS_STAMP(7);
-#endif
-#ifdef TG_PHASE_TIMING
-  if (p.dbg && lane == 0) {
+  TG_TIMING(if (p.dbg && lane == 0) {
     for (int i = 0; i < 8; ++i) p.dbg[(size_t)step_block * 16 + i] = tstamp[i];
     p.dbg[(size_t)step_block * 16 + 13] = __builtin_amdgcn_s_getreg(63492);  // HW_ID (wave / SIMD / CU / SE) of the logic wave
     p.dbg[(size_t)step_block * 16 + 15] = __builtin_amdgcn_s_getreg(63508);  // XCC_ID
-  }
-#endif
-  if (live && !rec_lines && (ob.x != rb.x || ob.y != rb.y || ob.z != rb.z || ob.w != rb.w) && !TG_SKIP(4))
+  })
+  if (live && !rec_lines && (ob.x != rb.x || ob.y != rb.y || ob.z != rb.z || ob.w != rb.w))
     TG_ST_STATE(reinterpret_cast<u32x4*>(rec_out + 1), (u32x4{ob.x, ob.y, ob.z, ob.w}));
 }
 

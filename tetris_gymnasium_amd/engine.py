@@ -177,6 +177,18 @@ class _PinnedBlock:
         return a if nbytes is None else a[:nbytes]
 
 
+def mapping_values(m, n, cast):
+    """The field values of a mappings dataclass in declaration order (or a plain sequence of them) as a tuple; None stays None."""
+    if m is None:
+        return None
+    import dataclasses
+
+    vals = [getattr(m, f.name) for f in dataclasses.fields(m)] if dataclasses.is_dataclass(m) else list(m)
+    if len(vals) != n:
+        raise ValueError(f"mapping with {len(vals)} fields: the engine implements the reference's {n} (mappings/*.py)")
+    return tuple(cast(v) for v in vals)
+
+
 class Engine:
     """Owns `batch` environments on one MI355X.  All arrays in/out are NumPy; state stays on the device.
 
@@ -187,9 +199,12 @@ class Engine:
     def __init__(self, batch, width=10, height=20, *, ruleset=N.RULESET_NUMPY, gravity=True, queue_size=None,
                  obs_mode=None, autoreset=N.AUTORESET_NONE, device=0, env_offset=0, padding=4, episode_stats=False,
                  final_obs=False, grouped=False, terminate_on_illegal=True, features=False, fuse=0, rng_every=0,
-                 ring_fill=None):
+                 ring_fill=None, actions_mapping=None, rewards_mapping=None, streams=0):
         """fuse / rng_every / ring_fill: launch knobs of the step kernel (tg_config; 0 / None = the defaults 16 / 3 / 3).
-        Results never depend on them."""
+        Results never depend on them.
+        actions_mapping / rewards_mapping (NUMPY rule-set): an ActionsMapping / RewardsMapping instance, or the field values in
+        declaration order (8 ints / 4 numbers) — per-handle data of the step kernel (reference envs/tetris.py:83-84, 189-190).
+        None, or a mapping equal to the stock one, = the stock tables."""
         import weakref
 
         self.lib = N.load()
@@ -211,6 +226,16 @@ class Engine:
                      | (N.FLAG_FEATURES if features else 0))
         cfg.fuse, cfg.rng_every = int(fuse), int(rng_every)
         cfg.ring_fill_p1 = 0 if ring_fill is None else int(ring_fill) + 1
+        cfg.streams = int(streams)  # (> 1: env shards on several streams — off by default, measured slower)
+        ids, rws = mapping_values(actions_mapping, 8, int), mapping_values(rewards_mapping, 4, float)
+        self.action_ids = tuple(range(8)) if ids is None else ids
+        self.rewards = (1.0, 1.0, 0.0, -0.1) if rws is None else rws
+        if ids is not None and ids != tuple(range(8)):
+            cfg.flags |= N.FLAG_CUSTOM_ACTIONS
+            cfg.action_ids[:] = ids
+        if rws is not None and rws != (1.0, 1.0, 0.0, -0.1):
+            cfg.flags |= N.FLAG_CUSTOM_REWARDS
+            cfg.rewards[:] = rws
         self.cfg = cfg
         self.B, self.W, self.H, self.P, self.Q = batch, width, height, padding, queue_size
         self.Wp, self.Hp = width + 2 * padding, height + padding
@@ -270,6 +295,13 @@ class Engine:
     def step_k_device(self, actions_dev_ptr, k):
         self._chk(self.lib.tg_step_k(self.h, C.c_void_p(actions_dev_ptr), int(k)), "tg_step_k")
 
+    def rollout_device(self, actions_dev_ptr, k, obs_traj_dev_ptr=None, out_traj_dev_ptr=None):
+        """tg_rollout between DEVICE buffers of the caller (asynchronous): actions int8[k][B]; the observation of transition j
+        goes to obs_traj + j * B * obs_bytes, its outputs to out_traj[j][B] (either may be None)."""
+        self._chk(self.lib.tg_rollout(self.h, C.c_void_p(actions_dev_ptr), int(k),
+                                      C.c_void_p(obs_traj_dev_ptr) if obs_traj_dev_ptr else None,
+                                      C.c_void_p(out_traj_dev_ptr) if out_traj_dev_ptr else None), "tg_rollout")
+
     def rollout(self, actions, want_obs=True):
         """K transitions with the given actions int8[K][B] in one call (tg_rollout: the default kernel runs up to 16 per
         launch with the state resident on chip).  Returns (obs[K][B]..., reward f32[K][B], terminated u8[K][B],
@@ -315,6 +347,25 @@ class Engine:
         """One transition; returns (reward f32[B], terminated u8[B], lines u8[B])."""
         self.step_async(actions)
         return self.fetch_outputs()
+
+    def fetch_step_out(self):
+        """TG_BUF_STEP_OUT of the last transition as a tg_step_out record array (reward f32, terminated, lines, flags)."""
+        out = self._host_array((self.B,), N.STEP_OUT, "out")
+        self._chk(self.lib.tg_fetch(self.h, N.BUF_STEP_OUT, N.ptr(out), out.nbytes), "tg_fetch(step_out)")
+        return out
+
+    def host_pack(self):
+        """TG_BUF_HOST_PACK of the last transition: what a gymnasium-contract step() returns beside the observation, in its final
+        dtypes — {"rewards": f64[B] (the Python value: int score + the RewardsMapping's floats), "episode_returns": f64[B],
+        "lines_cleared": i32[B], "episode_lengths": i32[B], "terminated": bool[B]}."""
+        off = (C.c_size_t * 6)()
+        self._chk(self.lib.tg_host_pack_layout(C.byref(self.cfg), off), "tg_host_pack_layout")
+        raw = np.empty(int(off[5]), np.uint8)
+        self._chk(self.lib.tg_fetch(self.h, N.BUF_HOST_PACK, N.ptr(raw), raw.nbytes), "tg_fetch(host_pack)")
+        B = self.B
+        return {"rewards": raw[off[0]:off[0] + 8 * B].view(np.float64), "episode_returns": raw[off[1]:off[1] + 8 * B].view(np.float64),
+                "lines_cleared": raw[off[2]:off[2] + 4 * B].view(np.int32), "episode_lengths": raw[off[3]:off[3] + 4 * B].view(np.int32),
+                "terminated": raw[off[4]:off[4] + B].view(np.bool_)}
 
     def fetch_outputs(self):
         out = self._host_array((self.B,), N.STEP_OUT, "out")

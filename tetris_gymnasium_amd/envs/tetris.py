@@ -98,8 +98,9 @@ class Tetris(EnvBase):
         if any(a is not None for a in (queue, holder, randomizer, base_pixels, tetrominoes)):
             raise NotImplementedError("custom queue/holder/randomizer/base_pixels/tetrominoes are not supported by the "
                                       "HIP engine (they are also broken in the reference: envs/tetris.py:114-144)")
-        if actions_mapping != ActionsMapping() or rewards_mapping != RewardsMapping():
-            raise NotImplementedError("the HIP engine implements the stock ActionsMapping / RewardsMapping")
+        if len(fields(actions_mapping)) != 8 or len(fields(rewards_mapping)) != 4:
+            raise NotImplementedError("mappings extended with further fields have no meaning to the HIP engine (the reference's "
+                                      "step reads the eight actions / four rewards of mappings/*.py)")
         self._hs, self._stale, self._dirty, self._engine = {}, False, False, None
         self.game_over = False
         self.height, self.width = int(height), int(width)
@@ -118,8 +119,10 @@ class Tetris(EnvBase):
         self.x = self.y = 0
         self.active_tetromino: Tetromino = None
         self.board = self.create_board()
+        # (the two mappings are per-handle data of the step kernel: envs/tetris.py:83-84, 189-190)
         self._engine = Engine(1, self.width, self.height, ruleset=N.RULESET_NUMPY, gravity=gravity,
-                              queue_size=queue_size, obs_mode=N.OBS_DICT, device=device)
+                              queue_size=queue_size, obs_mode=N.OBS_DICT, device=device,
+                              actions_mapping=actions_mapping, rewards_mapping=rewards_mapping)
         self._rec = None
         self._init_fast_step()
         self._stale, self._dirty = True, False  # (whatever the placeholders above were: the device state is the truth)
@@ -224,8 +227,11 @@ class Tetris(EnvBase):
         self._act1[0] = int(action)
         e._chk(e.lib.tg_step_fetch_many(1, hs, acts, N.MEM_HOST, 2, which, dst, nbytes, None), "tg_step_fetch_many")
         self._stale = True
-        rew, term, lines = float(self._out1["reward"][0]), bool(self._out1["terminated"][0]), int(self._out1["lines"][0])
-        reward = int(rew) if rew.is_integer() else rew
+        term, lines, fl = bool(self._out1["terminated"][0]), int(self._out1["lines"][0]), int(self._out1["flags"][0])
+        # the reward as the reference's Python computes it (envs/tetris.py:461-474): int score + the mapping's own numbers
+        reward = 0
+        if fl & N.OUT_COMMITTED:
+            reward = self.rewards.game_over if term else self.score(lines) + self.rewards.alife
         return {k: v.copy() for k, v in self._obs_views.items()}, reward, term, False, {"lines_cleared": lines}
 
     def reset(self, *, seed: "int | None" = None, options: "dict[str, Any] | None" = None):

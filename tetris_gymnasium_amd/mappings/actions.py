@@ -1,4 +1,6 @@
-"""Action ids of the NumPy rule-set (reference mappings/actions.py:5-19)."""
+"""Action ids of the NumPy rule-set (reference mappings/actions.py:5-19).  Per-handle data of the step kernel since ABI 4: any
+assignment of ids works as in the reference's elif chain (envs/tetris.py:222-259), except hard_drop sharing its value with a
+field tested before it (refused by tg_create)."""
 from dataclasses import dataclass
 
 

@@ -1,5 +1,6 @@
-"""Reward constants of the NumPy rule-set (reference mappings/rewards.py:5-15).  The engine implements
-exactly these values; other mappings are rejected by `Tetris`."""
+"""Rewards of the NumPy rule-set (reference mappings/rewards.py:5-15).  Per-handle data of the step kernel since ABI 4:
+`Tetris(rewards_mapping=RewardsMapping(alife=0, game_over=-5))` works as in the reference.  `clear_line` is a field the
+reference never reads (score is rows^2 * width, envs/tetris.py:621-630)."""
 from dataclasses import dataclass
 
 

@@ -236,7 +236,7 @@ class TetrisVectorEnv(VectorEnvBase):
                  ruleset: str = "numpy", observation: str = "dict", queue_size: int | None = None,
                  autoreset_mode: str = "next_step", devices=(0,), episode_stats: bool = True,
                  grouped: bool = False, terminate_on_illegal_action: bool = True, final_observation: bool = False,
-                 copy: bool = True):
+                 copy: bool = True, actions_mapping=None, rewards_mapping=None):
         """copy=False (gymnasium's SyncVectorEnv(copy=False), gymnasium/vector/sync_vector_env.py): the observations `reset` /
         `step` return are views of rotating page-locked host buffers — valid until the next-but-one call — instead of fresh
         NumPy arrays: the device-to-host copy becomes one DMA at PCIe rate and nothing is allocated per step (single-device
@@ -244,7 +244,9 @@ class TetrisVectorEnv(VectorEnvBase):
         final_observation: with autoreset_mode="same_step" and a board / functional observation, `infos` of a step in
         which episodes ended carries "final_observation" (the terminal observation of those envs, the reset observation is
         what `step` returns) and "_final_observation" — gymnasium's same-step autoreset convention
-        (examples/train_cnn.py:312-316)."""
+        (examples/train_cnn.py:312-316).
+        actions_mapping / rewards_mapping (numpy rule-set): what `Tetris(actions_mapping=..., rewards_mapping=...)` takes
+        (reference envs/tetris.py:83-84); the rewards `step` returns are the Python values (int score + the mapping's floats)."""
         self.num_envs = int(num_envs)
         self.width, self.height = width, height
         self.ruleset = N.RULESET_NUMPY if ruleset == "numpy" else N.RULESET_FUNCTIONAL
@@ -260,6 +262,7 @@ class TetrisVectorEnv(VectorEnvBase):
                    obs_mode=_OBS[observation], autoreset=_AUTORESET[autoreset_mode], device=dev, env_offset=lo,
                    episode_stats=episode_stats, grouped=grouped, terminate_on_illegal=terminate_on_illegal_action,
                    features=(observation == "placement_features"),
+                   actions_mapping=actions_mapping, rewards_mapping=rewards_mapping,
                    final_obs=(bool(final_observation) and autoreset_mode == "same_step" and observation in ("board", "functional")))
             for (lo, hi), dev in zip(self.ranges, devices) if hi > lo
         ]
@@ -443,7 +446,9 @@ class TetrisVectorEnv(VectorEnvBase):
 
         def one(e, lo, hi):  # launch, then collect everything this shard returns, on the shard's own thread
             e.step_async(actions[lo:hi])
-            out = e.fetch_outputs()
+            so = e.fetch_step_out()
+            out = (np.ascontiguousarray(so["reward"]), np.ascontiguousarray(so["terminated"]), np.ascontiguousarray(so["lines"]),
+                   np.ascontiguousarray(so["flags"]))
             ep = e.episode_stats() if (self.episode_stats and out[1].any()) else None
             lm = e.legal_mask() if self.grouped else None
             fo = e.final_observation() if (self.final_obs and out[1].any()) else None
@@ -467,8 +472,14 @@ class TetrisVectorEnv(VectorEnvBase):
             infos["_episode"] = terminations.copy()
         if self.grouped:  # the mask the NEXT action must be drawn from (wrappers/grouped.py:266-267)
             infos["action_mask"] = np.concatenate([p[2] for p in parts])
-            illegal = np.concatenate([o[0] for o in outs]) < 0
-            rewards[illegal] = -0.1  # rewards.invalid_action as a Python float, not float32(-0.1)
+            illegal = (np.concatenate([o[3] for o in outs]) & N.OUT_ILLEGAL) != 0
+            rewards[illegal] = self.engines[0].rewards[3]  # rewards.invalid_action as a Python float, not float32(-0.1)
+        if self.engines[0].cfg.flags & N.FLAG_CUSTOM_REWARDS:  # what Python computes: int score + the mapping's floats (envs/tetris.py:461-474)
+            fl = np.concatenate([o[3] for o in outs])
+            al, _, go, inv = self.engines[0].rewards
+            com = (fl & N.OUT_COMMITTED) != 0
+            rewards = np.where((fl & N.OUT_ILLEGAL) != 0, inv,
+                               np.where(com, np.where(terminations, go, (lines.astype(np.int64) ** 2 * self.width).astype(np.float64) + al), 0.0))
         truncations = np.zeros(self.num_envs, bool)
         if self.final_obs and terminations.any():  # (valid where terminated; zeros elsewhere)
             fo = np.zeros((self.num_envs, self.height, self.width), np.int8 if self.obs_kind == "functional" else np.uint8)

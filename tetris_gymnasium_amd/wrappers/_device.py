@@ -34,7 +34,7 @@ class WrapperBase:
 def aux_engine(env, **kw) -> Engine:
     u = env.unwrapped
     return Engine(1, u.width, u.height, ruleset=N.RULESET_NUMPY, gravity=u.gravity_enabled, queue_size=u.queue.size,
-                  device=u._engine.cfg.device, **kw)
+                  device=u._engine.cfg.device, actions_mapping=u.actions, rewards_mapping=u.rewards, **kw)
 
 
 def mirror(env, aux: Engine) -> None:

@@ -69,11 +69,17 @@ class GroupedActionsObservations(WrapperBase):
             observation = np.ones(self.observation_space.shape) * self.observation_space.high
             return observation, u.rewards.invalid_action, True, False, \
                 {"action_mask": self.legal_actions_mask, "lines_cleared": 0}
-        rew, term, lines = self._aux.step(np.array([int(action)], np.int32))  # grouped transition on the device
+        self._aux.step_async(np.array([int(action)], np.int32))  # grouped transition on the device
+        out = self._aux.fetch_step_out()
+        term, lines, fl = out["terminated"], out["lines"], int(out["flags"][0])
         b, r, g = self._aux.get_state()
         u.set_state(TetrisState(b, r, g))
-        illegal = float(rew[0]) < 0
-        reward = u.rewards.invalid_action if illegal else int(rew[0])
+        illegal = bool(fl & N.OUT_ILLEGAL)
+        reward = 0  # (as the reference's Python computes it: wrappers/grouped.py:238, envs/tetris.py:461-474)
+        if illegal:
+            reward = u.rewards.invalid_action
+        elif fl & N.OUT_COMMITTED:
+            reward = u.rewards.game_over if term[0] else u.score(int(lines[0])) + u.rewards.alife
         grouped, current = self._observe()
         info = {"lines_cleared": int(lines[0]), "action_mask": self.legal_actions_mask}
         if not illegal:

@@ -5,7 +5,7 @@ or the working tree) plus optional -D flags:
 
     tools/abn_bench.py tag[=srcdir][:-Dflag[:-Dflag...]][@ENV=value...] ...        env: AB_BATCH, AB_RULESET, AB_OBS, AB_STEPS, AB_ENGINES
 
-@ENV=value pairs are set while the variant's engines are created (knobs tg_create reads, e.g. TG_ALLOC_SKEW).
+@ENV=value pairs are set while the variant's engines are created (knobs tg_create reads, e.g. TG_SPLIT).
 
 srcdir is a directory holding tg_engine.hip (default: tetris_gymnasium_amd/csrc).  Prints median / min us per step and a
 checksum of the final state per variant (variants of the same rules must agree)."""

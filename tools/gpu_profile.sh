@@ -1,13 +1,14 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: the round's profile set → gpurun_out/<tag>/ (copy the summaries + latest.json into profiles/<round>/).
-#   per block (config3 = headline, config2, config5, dict, fused16, rgb, functional, functional_fused16, config2_fused16): rocprofv3
+#   per block (config3 = headline, then the blocks of bench.py's block_specs under their profiles/latest.json names): rocprofv3
 #   --kernel-trace --stats of the bench block's command
 #   every block: HBM traffic (FETCH_SIZE, WRITE_SIZE in separate --pmc passes, calibrated on the stream-copy kernel)
 #   config3: two SQ_* counter passes
 # usage: tools/gpu_profile.sh <tag> [blocks...]
-TAG=${1:-prof}; shift; BLOCKS=${@:-config3 config2 config5 dict fused16 rgb functional functional_fused16 config2_fused16}
+TAG=${1:-prof}; shift; BLOCKS=${@:-config3 config2 config5 dict fused16_traj rgb functional functional_fused16_traj config2_fused16_traj config2_dict config2_rgb}
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-declare -A ARGS=( [config3]="" [config2]="--batch 4096" [config5]="--config5" [dict]="--obs dict" [fused16]="--fuse 16" [rgb]="--obs rgb" [functional]="--ruleset functional --obs fn" [functional_fused16]="--ruleset functional --obs fn --fuse 16" [config2_fused16]="--batch 4096 --fuse 16" )
+# (every block but the headline through --only-block: the arguments, and so the instantiation, of the default bench run)
+declare -A ARGS=( [config3]="" [config2]="--only-block config2" [config5]="--only-block config5" [dict]="--only-block dict" [fused16_traj]="--only-block fused_rollout" [rgb]="--only-block rgb" [functional]="--only-block functional" [functional_fused16_traj]="--only-block functional_fused" [config2_fused16_traj]="--only-block config2_fused" [config2_dict]="--only-block config2_dict" [config2_rgb]="--only-block config2_rgb" [fused16]="--fuse 16" [functional_fused16]="--ruleset functional --obs fn --fuse 16" )
 COMMON="--no-cpu-baseline --no-blocks --steps 128 --warmup 16"
 for b in $BLOCKS; do
   rocprofv3 --kernel-trace --stats -d $OUT/${b}_kt -o kt -- python3 bench.py $COMMON ${ARGS[$b]} > $OUT/${b}_kt.log 2>&1
@@ -15,7 +16,7 @@ for b in $BLOCKS; do
   echo "== $b"; grep -h "step_kernel\|observe_kernel" $OUT/${b}_kt_summary.md | head -3 | cut -c1-140
 done
 for b in $BLOCKS; do
-  case $b in config3|config2|dict|config5|rgb|fused16|functional|functional_fused16|config2_fused16)
+  case $b in *)
     rocprofv3 --pmc FETCH_SIZE -d $OUT/${b}_f -o f -- python3 bench.py $COMMON --steps 32 --warmup 8 ${ARGS[$b]} > $OUT/${b}_f.log 2>&1
     rocprofv3 --pmc WRITE_SIZE -d $OUT/${b}_w -o w -- python3 bench.py $COMMON --steps 32 --warmup 8 ${ARGS[$b]} > $OUT/${b}_w.log 2>&1
   ;; esac
