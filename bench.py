@@ -304,7 +304,7 @@ def profiled(block: str) -> dict:
 
 
 def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, warmup, reps, fuse=1, local=0,
-              want_cpu=True, cpu_budget=6.0, copy_first=False, traj=False, checksum=False):
+              want_cpu=True, cpu_budget=6.0, copy_first=False, traj=False, checksum=False, secondary=True):
     """One benchmark block on every rank: W warm-up launches, EXACTLY `steps` timed launches bracketed by barrier + device
     sync on both sides (wall clock → value), then `reps` further repetitions of the same region timed with HIP events on
     the engine's stream (median → roofline).  `traj` (fused blocks): the launches go through tg_rollout with a [fuse][B]
@@ -371,7 +371,7 @@ def run_block(D: Dist, name: str, *, W, H, Q, B, obs, ruleset, grouped, steps, w
         rep_us.append(e.timer_stop() / steps * 1e3)
         k0 += steps
     last_only_us = None
-    if traj:  # the same launches through tg_step_k (every transition overwrites TG_BUF_OBS): round 4's figure, kept as a secondary
+    if traj and secondary:  # the same launches through tg_step_k (every transition overwrites TG_BUF_OBS): round 4's figure, kept as a secondary
         lo_us = []
         for _ in range(3):
             e.timer_start()
@@ -599,6 +599,8 @@ def parse(argv=None):
                     help="transitions per launch of the timed rollout (TG_FUSE). Default 1: `value` is the "
                          "one-launch-per-transition number; the fused rollout is reported in blocks")
     ap.add_argument("--traj", action="store_true", help="with --fuse > 1: tg_rollout with per-transition trajectory slots")
+    ap.add_argument("--no-secondary", action="store_true", help="profiling runs of the fused blocks: skip the tg_step_k (last observation "
+                                                                "only) secondary, so that the trace holds ONE instantiation")
     ap.add_argument("--no-blocks", action="store_true", help="only the headline block (profiling runs)")
     ap.add_argument("--only-block", default=None, help="profiling runs: make this block of the default run the headline "
                                                        "(config2, config5, dict, rgb, fused_rollout, config2_fused, config2_dict, "
@@ -690,7 +692,8 @@ def rank_main(args) -> int:
         spec = dict(block_specs(max(args.steps, 16), args.warmup)[args.only_block])
         spec.update(steps=(args.steps + spec.get("fuse", 1) - 1) // spec.get("fuse", 1) * spec.get("fuse", 1), warmup=args.warmup)
         prof, cpu = spec.pop("prof"), spec.pop("cpu")
-        head = run_block(D, prof, reps=reps, local=local, want_cpu=want_cpu and cpu, cpu_budget=args.cpu_budget, copy_first=True, **spec)
+        head = run_block(D, prof, reps=reps, local=local, want_cpu=want_cpu and cpu, cpu_budget=args.cpu_budget, copy_first=True,
+                         secondary=not args.no_secondary, **spec)
         std_head = False
     else:
         W, H, B, Q = args.width, args.height, args.batch, 4
@@ -703,7 +706,7 @@ def rank_main(args) -> int:
             pname = {"config3": "fused", "functional": "functional_fused"}.get(pname, pname) + f"{args.fuse}" + ("_traj" if args.traj else "")
         head = run_block(D, pname, W=W, H=H, Q=Q, B=B, obs=args.obs, ruleset=args.ruleset, grouped=grouped, steps=args.steps,
                          warmup=args.warmup, reps=reps, fuse=args.fuse, local=local, want_cpu=want_cpu,
-                         cpu_budget=args.cpu_budget, copy_first=True, traj=args.traj, checksum=not grouped)
+                         cpu_budget=args.cpu_budget, copy_first=True, traj=args.traj, checksum=not grouped, secondary=not args.no_secondary)
         std_head = not args.config5 and args.obs == "board" and args.ruleset == "numpy" and args.fuse == 1 \
             and (W, H, B) == (10, 20, 65536)
     if D.world == 1 and not args.no_blocks and std_head:

@@ -178,7 +178,10 @@ typedef struct tg_rng_rec { /* 48 bytes */
 #define TG_BUF_OBS 0        /* layout per obs_mode */
 #define TG_BUF_STEP_OUT 1   /* tg_step_out [B]: reward, terminated, info["lines_cleared"] of the last step */
 #define TG_BUF_ACTIONS 2    /* i32 [B] staging buffer used for TG_MEM_HOST actions */
-#define TG_BUF_BOARD 3      /* u8 [B][H][W] state boards */
+#define TG_BUF_BOARD 3      /* u8 [B][H][W] state boards.  Handles that keep their board as nibbles (>= 20 Mi cells, or TG_PACKED=1)
+                             * bring this buffer up to date only when it is asked for (tg_device_ptr / tg_fetch* / tg_get_state*):
+                             * a device pointer obtained earlier shows the boards as of THAT call — valid until the next
+                             * transition; ask again (Engine.device_array views do so at every export) */
 #define TG_BUF_REC 4        /* tg_env_rec [B] */
 #define TG_BUF_RNG 5        /* tg_rng_rec [B].  NUMPY rules: a transition leaves the generator state in the engine's
                              * look-ahead ring; tg_get_state / tg_fetch / tg_device_ptr of this buffer first enqueue the

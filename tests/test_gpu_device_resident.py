@@ -260,8 +260,12 @@ def test_set_state_device_is_range_checked_on_the_device():
     bad["piece"][3] = 9; bad["x"][5] = 200; bad["bag"][7, 2] = 11
     d = e.dev_alloc(bad.nbytes)
     e.dev_upload(d, bad)
-    with pytest.raises(EngineError, match="DeviceBuffers"):
+    with pytest.raises(EngineError, match="DeviceBuffer"):
         e.set_state_device(rec=d)                      # raw pointers need unchecked=True ...
+    with pytest.raises(EngineError, match="board"):
+        e.set_state_device(board=good[1])              # ... and a snapshot buffer only fits the slot it was made for (sizes differ)
+    with pytest.raises(EngineError, match="rng"):
+        e.set_state_device(rng=good[0])
     e.set_state_device(rec=d, unchecked=True)          # ... and are then checked on the device
     with pytest.raises(EngineError, match="tg_set_state_dev"):
         e.sync()

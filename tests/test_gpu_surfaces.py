@@ -183,6 +183,33 @@ def test_tetris_class_equals_oracle_trajectory():
     e.close()
 
 
+def test_looking_at_mutable_attributes_does_not_upload_but_changing_them_does(monkeypatch):
+    """A wrapper that only READS env.board / env.active_tetromino / env.queue every step (the reference's grouped and feature
+    wrappers do) must keep the one-call step path: the host copy is uploaded only when a handed-out object really changed."""
+    e = Tetris(); o = po.OracleBatch(1)
+    e.reset(seed=11); o.reset(np.array([11], np.uint64))
+    uploads = []
+    orig = type(e._engine).set_state
+    monkeypatch.setattr(type(e._engine), "set_state", lambda eng, **kw: (uploads.append(1), orig(eng, **kw))[1])
+    rng = np.random.default_rng(3)
+    for t in range(60):
+        a = int(rng.integers(0, 8))
+        _ = e.board.sum(), e.active_tetromino.id, list(e.queue.queue), e.holder.get_tetrominoes(), e.randomizer.index
+        obs, r, term, _, info = e.step(a)
+        ro, to, lo = o.step(np.array([a]))
+        assert r == ro[0] and term == bool(to[0])
+        np.testing.assert_array_equal(obs["board"], o.observe(po.OBS_DICT)["board"][0])
+        if term:
+            e.reset(); o.reset(mask=np.array([1], np.uint8))
+    assert uploads == []
+    e.board[19, 4:8] = 5                      # an in-place edit of a handed-out object: uploaded before the next transition
+    b, _, _ = o.get_state(); b[0, 19, 0:4] = 5; o.set_state(board=b)
+    obs, *_ = e.step(7); o.step(np.array([7]))
+    assert len(uploads) == 1
+    np.testing.assert_array_equal(obs["board"], o.observe(po.OBS_DICT)["board"][0])
+    e.close()
+
+
 # ---------------- functional surface ----------------
 CFG = EnvConfig(width=10, height=20, padding=4, queue_size=7, gravity_enabled=True)
 CFG_NG = EnvConfig(width=10, height=20, padding=4, queue_size=7, gravity_enabled=False)

@@ -1155,7 +1155,10 @@ class EnqueuePool {
       cv.notify_one();
     }
     int wait() {
-      while (state.load(std::memory_order_acquire) != 2) { /* the job is a handful of asynchronous HIP calls: microseconds */ }
+      // the job is normally a handful of asynchronous HIP calls (microseconds): spin briefly, then give the core away — with
+      // pageable destinations a worker's hipMemcpyAsync blocks for milliseconds
+      for (int spin = 0; state.load(std::memory_order_acquire) != 2; ++spin)
+        if (spin > 4000) std::this_thread::yield();
       state.store(0, std::memory_order_release);
       return rc;
     }
@@ -1522,6 +1525,16 @@ int tg_reset(tg_handle* h, const uint64_t* seeds, const uint8_t* mask) {
   return TG_OK;
 }
 
+// envs/tetris.py:215-217: the reference asserts action_space.contains(action)
+static int check_host_actions(tg_handle* h, const int32_t* actions) {
+  if (h->cfg.ruleset != TG_RULESET_NUMPY) return TG_OK;  // (functional: lax.switch clamps, tetris_fn.py:214-241)
+  const int na = tg_num_actions(&h->cfg);
+  for (int i = 0; i < h->B; ++i)
+    if (actions[i] < 0 || actions[i] >= na)
+      return fail(h, TG_EINVAL, "tg_step: action %d of env %d outside Discrete(%d)", actions[i], i, na);
+  return TG_OK;
+}
+
 int tg_step(tg_handle* h, const int32_t* actions, int kind) {
   if (!h || !actions) return h ? fail(h, TG_EINVAL, "tg_step: null actions") : TG_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1529,10 +1542,7 @@ int tg_step(tg_handle* h, const int32_t* actions, int kind) {
   if (kind == TG_MEM_HOST) {
     int rcj = join_shards(h);  // the staging copy runs on the handle's stream, behind the previous transition
     if (rcj != TG_OK) return rcj;
-    const int na = tg_num_actions(&h->cfg);
-    for (int i = 0; i < h->B; ++i)  // envs/tetris.py:215-217: the reference asserts action_space.contains(action)
-      if (h->cfg.ruleset == TG_RULESET_NUMPY && (actions[i] < 0 || actions[i] >= na))
-        return fail(h, TG_EINVAL, "tg_step: action %d of env %d outside Discrete(%d)", actions[i], i, na);
+    { const int rca = check_host_actions(h, actions); if (rca != TG_OK) return rca; }
     HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_ACTIONS], actions, (size_t)h->B * 4, hipMemcpyHostToDevice, h->stream));
     p.actions = h->buf[TG_BUF_ACTIONS];
   } else if (kind == TG_MEM_DEVICE) {
@@ -1699,6 +1709,13 @@ int tg_step_fetch_many(int n, tg_handle* const* hs, const void* const* actions, 
   if (n <= 0 || !hs || m < 0 || (m && (!which || !host_dst || !bytes))) return TG_EINVAL;
   for (int k = 0; k < n; ++k)
     if (!hs[k]) return TG_EINVAL;
+  // host actions of ALL handles are range-checked before anything is launched: a rejected action leaves no handle stepped
+  if (actions && kind == TG_MEM_HOST)
+    for (int k = 0; k < n; ++k) {
+      if (!actions[k]) return fail(hs[k], TG_EINVAL, "tg_step_fetch_many: null actions for handle %d", k);
+      const int rca = check_host_actions(hs[k], (const int32_t*)actions[k]);
+      if (rca != TG_OK) return rca;
+    }
   // phase 1: enqueue everything — handle 0 on this thread, the others on the pool's workers, side by side
   const std::function<int(int)> enqueue = [&](int k) -> int {
     tg_handle* h = hs[k];
@@ -1711,7 +1728,14 @@ int tg_step_fetch_many(int n, tg_handle* const* hs, const void* const* actions, 
     if (m) return enqueue_fetches(h, m, which, host_dst + (size_t)k * m, bytes + (size_t)k * m, src_off ? src_off + (size_t)k * m : nullptr);
     return TG_OK;
   };
-  { const int rc = EnqueuePool::get().run(n, enqueue); if (rc != TG_OK) return rc; }
+  {
+    const int rc = EnqueuePool::get().run(n, enqueue);
+    if (rc != TG_OK) {  // (a HIP error in one handle's enqueue: nothing of the others may still be in flight into the caller's arrays)
+      for (int k = 0; k < n; ++k)
+        if (hipSetDevice(hs[k]->cfg.device) == hipSuccess) (void)hipStreamSynchronize(hs[k]->stream);
+      return rc;
+    }
+  }
   for (int k = 0; k < n; ++k) {  // phase 2: one wait per handle
     tg_handle* h = hs[k];
     HIPCHK(h, hipSetDevice(h->cfg.device));

@@ -70,10 +70,11 @@ class DeviceArray:
     next transition overwrites — copy on the consumer's side to keep a value; an `owner` (a pooled device buffer) makes the
     view own its bytes.  Exporting waits for the engine's stream first (`sync=True`), so the consumer reads finished data."""
 
-    def __init__(self, engine, ptr, shape, dtype, strides=None, owner=None, sync=True, readonly=False):
+    def __init__(self, engine, ptr, shape, dtype, strides=None, owner=None, sync=True, readonly=False, refresh=None):
         self.engine, self.ptr, self.shape, self.dtype = engine, int(ptr), tuple(int(x) for x in shape), np.dtype(dtype)
         self.strides = None if strides is None else tuple(int(x) for x in strides)
         self._owner, self._sync, self._readonly = owner, sync, readonly
+        self._refresh = refresh  # engine buffer that is brought up to date on demand (TG_BUF_BOARD / TG_BUF_RNG / the legal mask)
 
     @property
     def nbytes(self):
@@ -86,6 +87,8 @@ class DeviceArray:
     def _ready(self):
         if not getattr(self.engine, "h", None) or (self._owner is not None and not self._owner.ptr):
             raise EngineError("this DeviceArray's engine has been closed: its device memory is gone")
+        if self._refresh is not None:  # e.g. the uint8 boards of a handle that keeps its board as nibbles: a view held across
+            self.engine.device_ptr(self._refresh)  # transitions would otherwise show the boards of the moment it was created
         if self._sync:
             self.engine.sync()
 
@@ -448,8 +451,8 @@ class Engine:
                     "lines": DeviceArray(self, ptr + 5, (B,), np.uint8, strides=(st,))}
         if which == N.BUF_LEGAL_MASK:
             return DeviceArray(self, ptr, (B, 4 * self.W), np.uint8)
-        if which == N.BUF_BOARD:
-            return DeviceArray(self, ptr, (B, self.H, self.W), np.uint8)
+        if which == N.BUF_BOARD:  # (materialised from the packed board on demand on handles of >= 20 Mi cells: re-done at every export)
+            return DeviceArray(self, ptr, (B, self.H, self.W), np.uint8, refresh=N.BUF_BOARD)
         if which == N.BUF_ACTIONS:
             return DeviceArray(self, ptr, (B,), np.int32)
         if which == N.BUF_FEATS:
@@ -468,8 +471,8 @@ class Engine:
                 DeviceBuffer(self, self.B * N.RNG_REC.itemsize))
         self._chk(self.lib.tg_get_state_dev(self.h, C.c_void_p(bufs[0].ptr), C.c_void_p(bufs[1].ptr), C.c_void_p(bufs[2].ptr)),
                   "tg_get_state_dev")
-        for b in bufs:
-            b._state_of = (self.B, self.W, self.H, self.ruleset)  # (what set_state_device accepts without `unchecked`)
+        for role, b in zip(("board", "rec", "rng"), bufs):
+            b._state_of = (role, self.B, self.W, self.H, self.ruleset)  # (what set_state_device accepts in that slot without `unchecked`)
         return bufs
 
     def set_state_device(self, board=None, rec=None, rng=None, unchecked=False):
@@ -478,12 +481,13 @@ class Engine:
         way tg_set_state_dev range-checks the records (and, where cell values are restricted, the boards) ON THE DEVICE: what
         tg_set_state would refuse is clamped so that nothing indexes out of range, and the next call that waits for the engine
         (sync / fetch / get_state / step with host results) raises EngineError once."""
-        for b in (board, rec, rng):
+        for role, b in zip(("board", "rec", "rng"), (board, rec, rng)):
             if b is None or unchecked:
                 continue
-            if not isinstance(b, DeviceBuffer) or getattr(b, "_state_of", None) != (self.B, self.W, self.H, self.ruleset):
-                raise EngineError("set_state_device takes the DeviceBuffers get_state_device returned for an engine of this shape "
-                                  "(device records are not validated); pass unchecked=True for anything else")
+            # (tagged per role: the rec buffer passed as `board` would make tg_set_state_dev read B*H*W bytes out of a B*32-byte allocation)
+            if not isinstance(b, DeviceBuffer) or getattr(b, "_state_of", None) != (role, self.B, self.W, self.H, self.ruleset):
+                raise EngineError(f"set_state_device({role}=...) takes the `{role}` DeviceBuffer get_state_device returned for an engine of "
+                                  "this shape (device records are not validated); pass unchecked=True for anything else")
         p = [None if b is None else C.c_void_p(b.ptr if isinstance(b, DeviceBuffer) else int(b)) for b in (board, rec, rng)]
         self._chk(self.lib.tg_set_state_dev(self.h, *p), "tg_set_state_dev")
 

@@ -65,8 +65,11 @@ def _state_attr(name, mutable):
 
     def get(self):
         self._sync_host()
-        if mutable:  # the caller may change the object in place: upload before the next transition
-            self._dirty = True
+        if mutable and not self._dirty and self._handed is None:
+            # the caller may change the object in place: remember what the mutable objects look like now — the next step() uploads
+            # the host copy only if they differ then (a wrapper that merely LOOKS at env.board / env.active_tetromino every step, as
+            # the reference's grouped and feature wrappers do, keeps the one-call step path)
+            self._handed = self._fingerprint()
         return self._hs[name]
 
     def set(self, value):
@@ -101,7 +104,7 @@ class Tetris(EnvBase):
         if len(fields(actions_mapping)) != 8 or len(fields(rewards_mapping)) != 4:
             raise NotImplementedError("mappings extended with further fields have no meaning to the HIP engine (the reference's "
                                       "step reads the eight actions / four rewards of mappings/*.py)")
-        self._hs, self._stale, self._dirty, self._engine = {}, False, False, None
+        self._hs, self._stale, self._dirty, self._engine, self._handed = {}, False, False, None, None
         self.game_over = False
         self.height, self.width = int(height), int(width)
         self.base_pixels = copy.deepcopy(self.BASE_PIXELS)
@@ -147,6 +150,21 @@ class Tetris(EnvBase):
             self._stale = False
             self._pull()
 
+    def _fingerprint(self):
+        """what the mutable host-side objects hold (board bytes, active piece, queue, holder, bag): cheap to compare"""
+        hs = self._hs
+        t = hs["active_tetromino"]
+        held = hs["holder"].get_tetrominoes()
+        return (hs["board"].tobytes(), None if t is None else (t.id, t.matrix.tobytes()), tuple(int(v) for v in hs["queue"].queue),
+                tuple((h.id, h.matrix.tobytes()) for h in held), np.asarray(hs["randomizer"].bag).tobytes(), int(hs["randomizer"].index))
+
+    def _changed_in_place(self) -> bool:
+        """a mutable attribute was handed out since the last download: did the caller change it?"""
+        if self._handed is None:
+            return False
+        old, self._handed = self._handed, None
+        return (not self._stale) and old != self._fingerprint()
+
     def _ro(self, name):
         """read an attribute without marking the host copy as changed (the helpers below only look)"""
         self._sync_host()
@@ -173,7 +191,7 @@ class Tetris(EnvBase):
         p = self.padding
         board = np.ascontiguousarray(hs["board"][: self.height, p: p + self.width], np.uint8)[None]
         e.set_state(board=board, rec=rec, rng=rng)  # (tg_set_state re-packs TG_BUF_OBS itself)
-        self._dirty = False
+        self._dirty, self._handed = False, None
 
     def _pull(self):
         board, rec, rng = self._engine.get_state()
@@ -220,13 +238,13 @@ class Tetris(EnvBase):
     def step(self, action):
         """reference envs/tetris.py:203-272"""
         assert self.action_space.contains(action), f"{action!r} ({type(action)}) invalid"
-        if self._dirty:
+        if self._dirty or self._changed_in_place():
             self._push()
         e = self._engine
         hs, acts, which, dst, nbytes = self._fs
         self._act1[0] = int(action)
         e._chk(e.lib.tg_step_fetch_many(1, hs, acts, N.MEM_HOST, 2, which, dst, nbytes, None), "tg_step_fetch_many")
-        self._stale = True
+        self._stale, self._handed = True, None
         term, lines, fl = bool(self._out1["terminated"][0]), int(self._out1["lines"][0]), int(self._out1["flags"][0])
         # the reward as the reference's Python computes it (envs/tetris.py:461-474): int score + the mapping's own numbers
         reward = 0
@@ -241,7 +259,7 @@ class Tetris(EnvBase):
         except TypeError:
             pass
         self._engine.reset(None if not seed else np.array([int(seed)], np.uint64))
-        self._stale, self._dirty = True, False
+        self._stale, self._dirty, self._handed = True, False, None
         return self._obs(), {"lines_cleared": 0}
 
     # ---- helpers the reference's wrappers / tests call ------------------------------------------
@@ -278,14 +296,14 @@ class Tetris(EnvBase):
 
     def get_state(self) -> TetrisState:
         """Clone the full state incl. the PCG64 generator (reference envs/tetris.py:694-708)."""
-        if self._dirty:
+        if self._dirty or self._changed_in_place():
             self._push()
         b, r, g = self._engine.get_state()
         return TetrisState(b.copy(), r.copy(), g.copy())
 
     def set_state(self, state: TetrisState) -> None:
         self._engine.set_state(board=state.board, rec=state.rec, rng=state.rng)
-        self._stale, self._dirty = True, False
+        self._stale, self._dirty, self._handed = True, False, None
 
     def render(self):
         if self.render_mode == "ansi":

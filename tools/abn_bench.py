@@ -7,6 +7,7 @@ or the working tree) plus optional -D flags:
 
 @ENV=value pairs are set while the variant's engines are created (knobs tg_create reads, e.g. TG_SPLIT).
 
+AB_TRAJ=1 (with TG_FUSE > 1): the timed launches go through tg_rollout with per-transition trajectory slots.
 srcdir is a directory holding tg_engine.hip (default: tetris_gymnasium_amd/csrc).  Prints median / min us per step and a
 checksum of the final state per variant (variants of the same rules must agree)."""
 import ctypes, os, statistics, subprocess, sys, zlib
@@ -56,10 +57,22 @@ for tag, _, _ in variants:
         for k in envs[tag]:
             os.environ.pop(k, None)
         eng[tag + rep] = (e, d)
+traj = os.environ.get("AB_TRAJ") == "1"
+F = int(os.environ["TG_FUSE"])
+if traj:
+    e0 = next(iter(eng.values()))[0]
+    ob = e0.lib.tg_obs_bytes_per_env(e0.cfg)
+    tb = {t: (e.dev_alloc(F * B * ob), e.dev_alloc(F * B * 8)) for t, (e, d) in eng.items()}
+def run(t, e, d):
+    if not traj:
+        e.step_k_device(d, K)
+        return
+    for k0 in range(0, K, F):
+        e.rollout_device(d + k0 * B, min(F, K - k0), *tb[t])
 res = {t: [] for t in eng}
 for rep in range(7):
     for t, (e, d) in eng.items():
-        e.timer_start(); e.step_k_device(d, K); res[t].append(e.timer_stop() / K * 1e3)
+        e.timer_start(); run(t, e, d); res[t].append(e.timer_stop() / K * 1e3)
 for t, (e, d) in eng.items():
     b, r, g = e.get_state()
     crc = zlib.crc32(b.tobytes()) ^ zlib.crc32(np.ascontiguousarray(r["bag"]).tobytes()) ^ zlib.crc32(g["state_lo"].tobytes())

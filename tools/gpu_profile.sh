@@ -9,7 +9,9 @@ TAG=${1:-prof}; shift; BLOCKS=${@:-config3 config2 config5 dict fused16_traj rgb
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 # (every block but the headline through --only-block: the arguments, and so the instantiation, of the default bench run)
 declare -A ARGS=( [config3]="" [config2]="--only-block config2" [config5]="--only-block config5" [dict]="--only-block dict" [fused16_traj]="--only-block fused_rollout" [rgb]="--only-block rgb" [functional]="--only-block functional" [functional_fused16_traj]="--only-block functional_fused" [config2_fused16_traj]="--only-block config2_fused" [config2_dict]="--only-block config2_dict" [config2_rgb]="--only-block config2_rgb" [fused16]="--fuse 16" [functional_fused16]="--ruleset functional --obs fn --fuse 16" )
-COMMON="--no-cpu-baseline --no-blocks --steps 128 --warmup 16"
+# (warm-up and steps are multiples of 16: every launch of a fused block then carries 16 transitions; --no-secondary keeps the
+# tg_step_k comparison launches — another instantiation — out of the fused blocks' traces)
+COMMON="--no-cpu-baseline --no-blocks --no-secondary --steps 128 --warmup 16"
 for b in $BLOCKS; do
   rocprofv3 --kernel-trace --stats -d $OUT/${b}_kt -o kt -- python3 bench.py $COMMON ${ARGS[$b]} > $OUT/${b}_kt.log 2>&1
   python3 profiles/summarize_rocprof.py $OUT/${b}_kt/kt_results.db > $OUT/${b}_kt_summary.md 2>&1
@@ -17,13 +19,13 @@ for b in $BLOCKS; do
 done
 for b in $BLOCKS; do
   case $b in *)
-    rocprofv3 --pmc FETCH_SIZE -d $OUT/${b}_f -o f -- python3 bench.py $COMMON --steps 32 --warmup 8 ${ARGS[$b]} > $OUT/${b}_f.log 2>&1
-    rocprofv3 --pmc WRITE_SIZE -d $OUT/${b}_w -o w -- python3 bench.py $COMMON --steps 32 --warmup 8 ${ARGS[$b]} > $OUT/${b}_w.log 2>&1
+    rocprofv3 --pmc FETCH_SIZE -d $OUT/${b}_f -o f -- python3 bench.py $COMMON --steps 32 --warmup 16 ${ARGS[$b]} > $OUT/${b}_f.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE -d $OUT/${b}_w -o w -- python3 bench.py $COMMON --steps 32 --warmup 16 ${ARGS[$b]} > $OUT/${b}_w.log 2>&1
   ;; esac
 done
 if [[ " $BLOCKS " == *" config3 "* ]]; then
-  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $OUT/pmc1 -o pmc1 -- python3 bench.py $COMMON --steps 32 --warmup 8 > $OUT/pmc1.log 2>&1
-  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc2 -o pmc2 -- python3 bench.py $COMMON --steps 32 --warmup 8 > $OUT/pmc2.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $OUT/pmc1 -o pmc1 -- python3 bench.py $COMMON --steps 32 --warmup 16 > $OUT/pmc1.log 2>&1
+  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc2 -o pmc2 -- python3 bench.py $COMMON --steps 32 --warmup 16 > $OUT/pmc2.log 2>&1
   for f in pmc1 pmc2; do python3 profiles/summarize_rocprof.py $OUT/$f/${f}_results.db step_kernel > $OUT/config3_${f}_summary.md 2>&1; done
 fi
 python3 - "$OUT" $BLOCKS <<'PY'

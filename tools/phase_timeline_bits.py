@@ -34,6 +34,9 @@ assert e.lib.tg_debug_phase_times(e.h, buf.ctypes.data_as(C.c_void_p), B // 16) 
 tl = buf[:nb, 0:8].astype(np.int64)    # logic wave stamps 0..7
 ts = buf[:nb, 8:13].astype(np.int64)   # stream wave stamps 0..4
 rb = buf.reshape(-1)[nb * 16: nb * 16 + nr * 4].reshape(nr, 2, 2).astype(np.int64)  # [rng block][wave][start, end]
+if fn or not rb.any():  # (FUNCTIONAL launches have no RNG-role workgroups: their slots stay zero — give them the step waves' range)
+    rb = np.stack([np.stack([tl[:nr, 0], tl[:nr, 0]], -1), np.stack([tl[:nr, 0], tl[:nr, 0]], -1)], 1).astype(np.int64) if nr <= nb else \
+        np.broadcast_to(np.array([tl[0, 0], tl[0, 0]], np.int64), (nr, 2, 2)).copy()
 if os.environ.get('TL_DEBUG'):
     print('min/max per logic stamp', tl.min(axis=0), tl.max(axis=0)); print('stream', ts.min(axis=0), ts.max(axis=0)); print('rng', rb.min(), rb.max(), (rb == 0).sum())
 step_blk = np.arange(nb)        # blockIdx of step workgroup i (the step workgroups lead the grid)
@@ -57,6 +60,9 @@ for x in range(8):
           f";  step WG start mean {(ss[:, 0] - t0).mean():.0f} max {(ss[:, 0] - t0).max()}")
 # which workgroups end last?  (stream wave end vs launch position)
 t00 = min(tl[:, 0].min(), ts[:, 0].min(), rb[:, :, 0].min())
+t_end = max(tl[:, 7].max(), ts[:, 4].max(), rb[:, :, 1].max())
+print(f"launch span on the device (first stamp of any wave -> last stamp of any wave, 100 MHz counter): {(t_end - t00) / 100:.2f} us "
+      f"(the stamped build itself runs {ms / 7 * 1e3:.2f} us per launch by HIP events: span + the launch boundary)")
 end = ts[:, 4] - t00
 start = ts[:, 0] - t00
 order = np.argsort(end)
