@@ -10,12 +10,13 @@ from oracle import pyoracle as po
 from tetris_gymnasium_amd import _native as N
 
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+MAPPED = {1, 6}  # cases that run with a non-stock ActionsMapping / RewardsMapping (a permutation of the ids; round 5: per-handle data)
 CASES = [  # (W, H, Q, B, grouped, fuse, ruleset)
     (10, 20, 4, 320, False, 1, N.RULESET_NUMPY), (10, 20, 4, 200, False, 16, N.RULESET_NUMPY), (10, 20, 7, 132, True, 3, N.RULESET_NUMPY),
     (20, 40, 7, 100, True, 1, N.RULESET_NUMPY), (6, 12, 2, 256, False, 8, N.RULESET_NUMPY), (10, 20, 7, 192, False, 16, N.RULESET_FUNCTIONAL),
     (7, 14, 4, 168, False, 1, N.RULESET_NUMPY), (7, 14, 7, 100, False, 8, N.RULESET_FUNCTIONAL),  # 98-byte slabs, ragged batches
 ]
-for W, H, Q, B, grouped, fuse, rs in CASES:
+for ci, (W, H, Q, B, grouped, fuse, rs) in enumerate(CASES):
     os.environ["TG_FUSE"] = str(fuse)
     from tetris_gymnasium_amd import Engine
     numpy_rules = rs == N.RULESET_NUMPY
@@ -23,8 +24,10 @@ for W, H, Q, B, grouped, fuse, rs in CASES:
     surf = os.environ.get("SOAK_OBS", "")  # SOAK_OBS=dict / rgb: the NUMPY cases with that observation packed in the step kernel
     if numpy_rules and not grouped and surf in ("dict", "rgb"):
         obs = N.OBS_DICT if surf == "dict" else N.OBS_RGB
-    e = Engine(B, W, H, ruleset=rs, queue_size=Q, obs_mode=obs, autoreset=N.AUTORESET_SAME_STEP, grouped=grouped)
-    o = po.OracleBatch(B, W, H, rs, True, Q)
+    ids, rws = ((3, 7, 0, 5, 1, 2, 4, 6), (0.5, 1.0, -5.25, -0.25)) if ci in MAPPED else (None, None)
+    e = Engine(B, W, H, ruleset=rs, queue_size=Q, obs_mode=obs, autoreset=N.AUTORESET_SAME_STEP, grouped=grouped,
+               actions_mapping=ids, rewards_mapping=rws)
+    o = po.OracleBatch(B, W, H, rs, True, Q, action_ids=ids, rewards=rws)
     seeds = np.arange(11, 11 + B, dtype=np.uint64)
     e.reset(seeds); o.reset(seeds)
     rng = np.random.default_rng(W * 100 + fuse)
@@ -52,5 +55,5 @@ for W, H, Q, B, grouped, fuse, rs in CASES:
                 assert np.array_equal(got[kk], ref[kk]), f"observation[{kk}] differs after {done} steps"
         else:
             assert np.array_equal(got, ref), f"observation differs after {done} steps"
-    print(f"ok  {W}x{H} Q={Q} B={B} grouped={grouped} fuse={fuse} ruleset={rs} obs={obs}: {STEPS} transitions per env  [{e.step_kernel_name(fuse, grouped)}]")
+    print(f"ok  {W}x{H} Q={Q} B={B} grouped={grouped} fuse={fuse} ruleset={rs} obs={obs}{' custom mappings' if ids else ''}: {STEPS} transitions per env  [{e.step_kernel_name(fuse, grouped)}]")
     e.close()

@@ -23,11 +23,19 @@ for b in $BLOCKS; do
     rocprofv3 --pmc WRITE_SIZE -d $OUT/${b}_w -o w -- python3 bench.py $COMMON --steps 32 --warmup 16 ${ARGS[$b]} > $OUT/${b}_w.log 2>&1
   ;; esac
 done
-if [[ " $BLOCKS " == *" config3 "* ]]; then
-  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $OUT/pmc1 -o pmc1 -- python3 bench.py $COMMON --steps 32 --warmup 16 > $OUT/pmc1.log 2>&1
-  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc2 -o pmc2 -- python3 bench.py $COMMON --steps 32 --warmup 16 > $OUT/pmc2.log 2>&1
-  for f in pmc1 pmc2; do python3 profiles/summarize_rocprof.py $OUT/$f/${f}_results.db step_kernel > $OUT/config3_${f}_summary.md 2>&1; done
-fi
+# SQ counters (two passes) for the headline, and the instruction-mix pass for the functional and the fused blocks (what backs "the launch
+# is bound by issue slots / by bytes" in DESIGN.md)
+for b in $BLOCKS; do
+  case $b in config3|functional|fused16_traj|functional_fused16_traj|config5)
+    rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d $OUT/pmc1 -o pmc1 -- python3 bench.py $COMMON --steps 32 --warmup 16 ${ARGS[$b]} > $OUT/${b}_pmc1.log 2>&1
+    python3 profiles/summarize_rocprof.py $OUT/pmc1/pmc1_results.db step_kernel > $OUT/${b}_pmc1_summary.md 2>&1
+    if [[ $b == config3 ]]; then
+      rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc2 -o pmc2 -- python3 bench.py $COMMON --steps 32 --warmup 16 > $OUT/pmc2.log 2>&1
+      python3 profiles/summarize_rocprof.py $OUT/pmc2/pmc2_results.db step_kernel > $OUT/config3_pmc2_summary.md 2>&1
+    fi
+    rm -rf $OUT/pmc1 $OUT/pmc2
+  ;; esac
+done
 python3 - "$OUT" $BLOCKS <<'PY'
 import json, os, sqlite3, sys
 out, blocks = sys.argv[1], sys.argv[2:]
@@ -77,4 +85,4 @@ for b in blocks:
 json.dump(latest, open(f"{out}/latest.json", "w"), indent=1)
 print(json.dumps(latest, indent=1))
 PY
-rm -rf $OUT/*_kt $OUT/*_f $OUT/*_w $OUT/pmc1 $OUT/pmc2
+rm -rf $OUT/*_kt $OUT/*_f $OUT/*_w
