@@ -95,7 +95,8 @@ typedef struct tg_config {
   int32_t width;       /* playfield columns (reference default 10) */
   int32_t height;      /* playfield rows    (reference default 20) */
   int32_t padding;     /* must be 4 (reference: max tetromino extent, envs/tetris.py:130) */
-  int32_t queue_size;  /* NUMPY: visible queue length 1..7 (reference 4); FUNCTIONAL: must be 7 */
+  int32_t queue_size;  /* NUMPY: visible queue length 1..7 (reference 4); FUNCTIONAL: EnvConfig.queue_size = the bag length, 1..7
+                          (functional/queue.py:35, 67; reference default 7) */
   int32_t gravity;     /* 0/1 */
   int32_t ruleset;     /* TG_RULESET_* */
   int32_t obs_mode;    /* TG_OBS_* */

@@ -84,6 +84,7 @@ def lib() -> C.CDLL:
         L.tgo_threefry2x32.argtypes = [vp, vp, vp]
         L.tgo_jax_split.argtypes = [vp, vp, vp]
         L.tgo_jax_permutation7.argtypes = [vp, vp]
+        L.tgo_jax_permutation.argtypes = [vp, i32, vp]
         L.tgo_set_threefry_partitionable.argtypes = [i32]
         L.tgo_fn_score.restype = i32
         L.tgo_fn_score.argtypes = [i32]

@@ -186,36 +186,38 @@ void tgo_jax_split(const uint32_t key[2], uint32_t out0[2], uint32_t out1[2]) {
   }
 }
 
-/* jax.random.permutation(key, arange(7)) → _shuffle: one round (ceil(3 ln 7 / ln(2^32-1)) = 1):
- * key, subkey = split(key); sort_keys = random_bits(subkey, 32, (7,)); stable sort by sort_keys */
-void tgo_jax_permutation7(const uint32_t key[2], uint8_t out[7]) {
+/* jax.random.permutation(key, arange(n)) → _shuffle (jax/_src/random.py): num_rounds = ceil(3 ln n / ln(2^32 - 1)) — one round for
+ * 2 <= n <= 7, none for n = 1 (the array comes back as it is); per round: key, subkey = split(key);
+ * sort_keys = random_bits(subkey, 32, (n,)); stable sort by sort_keys.  functional/queue.py:35 calls it with n = config.queue_size. */
+void tgo_jax_permutation(const uint32_t key[2], int n, uint8_t* out) {
   uint32_t k0[2], sub[2], bits[8];
+  for (int i = 0; i < n; ++i) out[i] = (uint8_t)i;
+  if (n < 2) return;
   tgo_jax_split(key, k0, sub);
   if (g_partitionable) {
-    for (uint32_t i = 0; i < 7; ++i) {
+    for (uint32_t i = 0; i < (uint32_t)n; ++i) {
       uint32_t c[2] = {0, i}, o[2];
       tgo_threefry2x32(sub, c, o);
       bits[i] = o[0] ^ o[1];
     }
   } else {
-    /* counts = iota(7) padded to 8, halves [0..3] / [4..6,0] */
-    for (uint32_t i = 0; i < 4; ++i) {
-      uint32_t c[2] = {i, i == 3 ? 0u : i + 4}, o[2];
+    /* counts = iota(n) padded to an even length, halves [0 .. m) / [m .. 2m) with m = ceil(n / 2) (n = 7: [0..3] / [4..6, 0]) */
+    const uint32_t m = ((uint32_t)n + 1u) / 2u;
+    for (uint32_t i = 0; i < m; ++i) {
+      uint32_t c[2] = {i, i + m < (uint32_t)n ? i + m : 0u}, o[2];
       tgo_threefry2x32(sub, c, o);
       bits[i] = o[0];
-      bits[4 + i] = o[1];
+      if (m + i < 8) bits[m + i] = o[1];
     }
   }
-  uint8_t idx[7];
-  for (int i = 0; i < 7; ++i) idx[i] = (uint8_t)i;
-  for (int i = 1; i < 7; ++i) { /* stable insertion sort */
-    uint8_t v = idx[i];
+  for (int i = 1; i < n; ++i) { /* stable insertion sort */
+    uint8_t v = out[i];
     int j = i - 1;
-    while (j >= 0 && bits[idx[j]] > bits[v]) { idx[j + 1] = idx[j]; --j; }
-    idx[j + 1] = v;
+    while (j >= 0 && bits[out[j]] > bits[v]) { out[j + 1] = out[j]; --j; }
+    out[j + 1] = v;
   }
-  memcpy(out, idx, 7);
 }
+void tgo_jax_permutation7(const uint32_t key[2], uint8_t out[7]) { tgo_jax_permutation(key, 7, out); }
 
 /* ------------------------------------------------------------------------------------------------
  * Tetromino tables
@@ -602,10 +604,11 @@ int tgo_fn_clear_rows(uint8_t* playfield, int W, int H) {
 /* functional/queue.py:38-67 bag_queue_get_next_element (returned key is discarded by the caller,
  * envs/tetris_fn.py:388-390) */
 static int fn_queue_next(env_t* e) {
-  if (e->bag_index >= NPIECES) {
+  if (e->bag_index >= e->qsize) { /* :67 queue_index >= config.queue_size */
     uint32_t nk[2], sub[2];
     tgo_jax_split(e->rng.key, nk, sub);
-    tgo_jax_permutation7(sub, e->bag);
+    memset(e->bag, 0, sizeof e->bag);
+    tgo_jax_permutation(sub, e->qsize, e->bag); /* :35 permutation(key, arange(config.queue_size)) */
     e->bag_index = 1;
     return e->bag[0];
   }
@@ -617,7 +620,8 @@ static void fn_reset(env_t* e, const uint32_t key_in[2]) {
   create_board(e);
   uint32_t key[2], subkey[2];
   tgo_jax_split(key_in, key, subkey);
-  tgo_jax_permutation7(key, e->bag);
+  memset(e->bag, 0, sizeof e->bag);
+  tgo_jax_permutation(key, e->qsize, e->bag);
   e->bag_index = 0;
   e->rng.key[0] = subkey[0];
   e->rng.key[1] = subkey[1];

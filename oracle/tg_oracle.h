@@ -67,6 +67,7 @@ void tgo_pcg64_shuffle7(tg_rng_rec* r, uint8_t* bag);               /* Generator
 void tgo_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]);
 void tgo_jax_split(const uint32_t key[2], uint32_t out0[2], uint32_t out1[2]);
 void tgo_jax_permutation7(const uint32_t key[2], uint8_t out[7]);
+void tgo_jax_permutation(const uint32_t key[2], int n, uint8_t* out);   /* permutation(key, arange(n)), 1 <= n <= 7 */
 void tgo_set_threefry_partitionable(int on); /* default 1 (jax >= 0.5.0 default) */
 
 /* single-function probes used by the restated reference unit tests */

@@ -27,6 +27,11 @@ def test_prng_matches_the_oracle_restatement():
         out = np.zeros(7, np.uint8)
         L.tgo_jax_permutation7(key.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
         np.testing.assert_array_equal(prng.permutation7(key), out)
+        for n in range(1, 8):  # permutation(key, arange(queue_size)) for every bag length the engine takes (functional/queue.py:35)
+            outn = np.full(7, 9, np.uint8)
+            L.tgo_jax_permutation(key.ctypes.data_as(C.c_void_p), n, outn.ctypes.data_as(C.c_void_p))
+            got = prng.permutation(key, n)
+            np.testing.assert_array_equal(got, outn[:n]); assert sorted(got) == list(range(n)) and (outn[n:] == 9).all()
     keys = rng.integers(0, 2**32, (300, 2), dtype=np.uint64).astype(np.uint32)
     for idx in (0, 1):
         np.testing.assert_array_equal(prng.split_batch(keys, idx), np.array([prng.split(k)[idx] for k in keys], np.uint32))

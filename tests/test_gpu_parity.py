@@ -938,3 +938,45 @@ def test_tetris_class_with_custom_mappings_returns_the_references_python_rewards
             if d:
                 env.reset()
     env.close()
+
+
+# ---- EnvConfig.queue_size as the bag length of the functional rule-set (functional/queue.py:35, 67) ---------------------------------
+@pytest.mark.parametrize("autoreset", [N.AUTORESET_NONE, N.AUTORESET_SAME_STEP, N.AUTORESET_NEXT_STEP])
+@pytest.mark.parametrize("k,B", [(1, 200), (2, 1000), (3, 4096), (5, 300), (6, 1000)])
+def test_functional_bag_length_engine_vs_oracle(k, B, autoreset, monkeypatch):
+    """queue_size k < 7: bags are permutations of 0..k-1 (sorts of k elements in the look-ahead pass, refill at queue_index >= k);
+    one transition per launch and fused rollouts, the in-line sort paths included (TG_FN_LAZY=1 for one size)."""
+    if k == 3:
+        monkeypatch.setenv("TG_FN_LAZY", "1")
+    e = Engine(B, 10, 20, ruleset=N.RULESET_FUNCTIONAL, queue_size=k, obs_mode=N.OBS_FN, autoreset=autoreset)
+    o = po.OracleBatch(B, 10, 20, po.RULESET_FUNCTIONAL, queue_size=k)
+    seeds = np.arange(3, 3 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_FN))
+    rng = np.random.default_rng(k * 10 + autoreset)
+    for t in range(80):
+        a = rng.integers(0, 7, B)
+        re_, te, le = e.step(a)
+        ro, to, lo = o.step(a, autoreset=autoreset)
+        np.testing.assert_array_equal(re_, ro, err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(te, to, err_msg=f"terminated t={t}"); np.testing.assert_array_equal(le, lo)
+        np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_FN), err_msg=f"obs t={t}")
+        if autoreset == N.AUTORESET_NONE and te.any():
+            e.reset(mask=te); o.reset(mask=te)
+    if autoreset != N.AUTORESET_NONE:
+        K = 64
+        acts = rng.integers(0, 7, (K, B)).astype(np.int8)
+        obs, rew, term, lines = e.rollout(acts)
+        for j in range(K):
+            ro, to, lo = o.step(acts[j].astype(np.int32), autoreset=autoreset)
+            np.testing.assert_array_equal(rew[j], ro, err_msg=f"rollout reward j={j}")
+            np.testing.assert_array_equal(term[j], to); np.testing.assert_array_equal(obs[j], o.observe(po.OBS_FN), err_msg=f"rollout obs j={j}")
+    ge, go = _cmp_state(e, o, "end")
+    np.testing.assert_array_equal(ge["key"], go["key"])
+    _, rec, _ = e.get_state()
+    assert (rec["piece"] < k).all() and (rec["bag"][:, k:] == 0).all()
+    # a state round trip rebuilds the look-ahead for this bag length (bits_prepare_kernel)
+    e.set_state(*e.get_state())
+    a = rng.integers(0, 7, B)
+    np.testing.assert_array_equal(e.step(a)[0], o.step(a, autoreset=autoreset)[0])
+    e.close()

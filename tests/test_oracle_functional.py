@@ -259,3 +259,25 @@ def test_shared_mechanics_match_numpy_ruleset(gravity):
             bb[:] = b0
             on.set_state(board=bb)
     assert locks > 500 and clears > 20
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 7])
+def test_bag_length_is_config_queue_size(k):
+    """functional/queue.py:35, 67: the bag is permutation(arange(queue_size)) and is refilled at queue_index >= queue_size — with
+    queue_size k < 7 only the first k tetrominoes are ever dealt, every k consecutive spawns are a permutation of 0..k-1."""
+    B = 16
+    o = po.OracleBatch(B, 10, 20, po.RULESET_FUNCTIONAL, queue_size=k)
+    o.reset(np.arange(1, B + 1, dtype=np.uint64))
+    _, rec, _ = o.get_state()
+    assert (rec["bag_index"] == 1).all() and (rec["piece"] == rec["bag"][:, 0]).all() and (rec["bag"][:, k:] == 0).all()
+    for b in rec["bag"]:
+        assert sorted(b[:k]) == list(range(k))
+    spawned = [rec["piece"].copy()]
+    for t in range(6 * k):
+        o.step(np.full(B, 6, np.int32), autoreset=po.AUTORESET_SAME_STEP)  # hard drop: a lock and a spawn per step
+        _, rec, _ = o.get_state()
+        assert (rec["piece"] < k).all() and (rec["bag_index"] >= 1).all() and (rec["bag_index"] <= k).all()
+        spawned.append(rec["piece"].copy())
+    seq = np.stack(spawned, 1)  # [B][1 + 6k]; the first k spawns of an episode are one whole bag
+    for i in range(B):
+        assert sorted(seq[i, :k]) == list(range(k))

@@ -230,8 +230,10 @@ __device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t 
   o1 = x1;
 }
 
-// permutation(key, arange(7)): key', sub = split(key); bits_i = hi^lo of threefry(sub, (0,i)); stable sort
-__device__ __forceinline__ uint64_t jax_permutation7(uint32_t k0, uint32_t k1) {
+// permutation(key, arange(n)), n = EnvConfig.queue_size in 1..7 (functional/queue.py:35): key', sub = split(key); bits_i = hi^lo of
+// threefry(sub, (0,i)); stable sort (jax _shuffle: one round for 2 <= n <= 7, none for n = 1 — a single element sorts to itself here too).
+// Entries n..6 of the result are 0.
+__device__ __forceinline__ uint64_t jax_permutation(uint32_t k0, uint32_t k1, const int n) {
   uint32_t s0, s1;
   threefry2x32(k0, k1, 0u, 1u, s0, s1);  // split(key)[1]
   uint32_t bits[7];
@@ -241,17 +243,18 @@ __device__ __forceinline__ uint64_t jax_permutation7(uint32_t k0, uint32_t k1) {
     threefry2x32(s0, s1, 0u, i, a, b);
     bits[i] = a ^ b;
   }
-  // rank of element i = #{j : bits[j] < bits[i] or (== and j < i)}  (stable)
+  // rank of element i = #{j < n : bits[j] < bits[i] or (== and j < i)}  (stable)
   uint64_t bag = 0;
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     int rank = 0;
 #pragma unroll
-    for (int j = 0; j < 7; ++j) rank += (bits[j] < bits[i] || (bits[j] == bits[i] && j < i)) ? 1 : 0;
-    bag |= (uint64_t)i << (8 * rank);
+    for (int j = 0; j < 7; ++j) rank += (j < n && (bits[j] < bits[i] || (bits[j] == bits[i] && j < i))) ? 1 : 0;
+    bag |= i < n ? (uint64_t)i << (8 * rank) : 0ull;
   }
   return bag;
 }
+__device__ __forceinline__ uint64_t jax_permutation7(uint32_t k0, uint32_t k1) { return jax_permutation(k0, k1, 7); }
 
 // ------------------------------------------------------------------------------------------------
 // wave-level board primitives (slab = this wave's LDS copy of the playfield, H*W bytes)
@@ -458,7 +461,7 @@ __device__ __forceinline__ void env_reset(EnvS& s, Rng& r, const tg_rng_rec* rp,
     uint32_t a0, a1, b0, b1;
     threefry2x32(r.k0, r.k1, 0u, 0u, a0, a1);  // key   = split(key_in)[0]
     threefry2x32(r.k0, r.k1, 0u, 1u, b0, b1);  // subkey = split(key_in)[1] → State.rng_key
-    s.bag = jax_permutation7(a0, a1);
+    s.bag = jax_permutation(a0, a1, Q);  // (FUNCTIONAL: Q = EnvConfig.queue_size, the bag length)
     s.queue = 0;
     s.piece = (int)(s.bag & 0xFF);
     s.bidx = 1;

@@ -1020,6 +1020,7 @@ int launch_prepare_bits(tg_handle* h, const uint8_t* d_mask, int force) {
   q.batch = h->B;
   q.ruleset = h->cfg.ruleset;
   q.force = force;
+  q.queue_size = h->Q;
   h->L.prepare(q, h->stream);
   HIPCHK(h, hipGetLastError());
   return TG_OK;
@@ -1238,9 +1239,12 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     return fail(nullptr, TG_EINVAL, "tg_create: unknown autoreset mode %d", cfg->autoreset);
   if (cfg->ruleset == TG_RULESET_NUMPY && (cfg->queue_size < 1 || cfg->queue_size > 7))
     return fail(nullptr, TG_EINVAL, "tg_create: NUMPY queue_size must be 1..7, got %d", cfg->queue_size);
-  if (cfg->ruleset == TG_RULESET_FUNCTIONAL && cfg->queue_size != 7)
-    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: FUNCTIONAL rule-set needs queue_size 7 (the 7-bag), got %d",
-                cfg->queue_size);
+  // (functional/queue.py:35 permutes arange(queue_size): 1..7 deals the first queue_size pieces from a bag of that length; larger values
+  // would index past the seven tetrominoes)
+  if (cfg->ruleset == TG_RULESET_FUNCTIONAL && (cfg->queue_size < 1 || cfg->queue_size > 7))
+    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: FUNCTIONAL queue_size (the bag length) must be 1..7, got %d", cfg->queue_size);
+  if (cfg->ruleset == TG_RULESET_FUNCTIONAL && cfg->queue_size != 7 && g_kernel_lanes != 16)
+    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: the earlier step kernels of the test-only library deal the 7-bag only");
   if ((cfg->obs_mode == TG_OBS_DICT || cfg->obs_mode == TG_OBS_RGB) && cfg->ruleset != TG_RULESET_NUMPY)
     return fail(nullptr, TG_EINVAL, "tg_create: TG_OBS_DICT / TG_OBS_RGB are observations of the NUMPY rule-set");
   if (cfg->action_set != TG_ACTIONS_BASE && cfg->action_set != TG_ACTIONS_GROUPED)

@@ -337,8 +337,9 @@ __device__ __forceinline__ uint64_t fn_expand21(const uint32_t p) {  // seven 3-
   };
   return (uint64_t)four(p & 0xFFFu) | ((uint64_t)four((p >> 12) & 0x1FFu) << 32);
 }
-// sort7 of one lane (bits_prepare_kernel; the step kernel spreads the seven blocks over lanes)
-__device__ __forceinline__ uint32_t fn_sort7(const uint32_t s0, const uint32_t s1) {
+// sort7 of one lane (bits_prepare_kernel; the step kernel spreads the seven blocks over lanes); n = the bag length (EnvConfig.queue_size,
+// 1..7: functional/queue.py:35 permutes arange(queue_size)) — fields n..6 of the result are 0
+__device__ __forceinline__ uint32_t fn_sort7(const uint32_t s0, const uint32_t s1, const int n) {
   uint32_t bits[7];
 #pragma unroll
   for (uint32_t i = 0; i < 7; ++i) {
@@ -351,8 +352,8 @@ __device__ __forceinline__ uint32_t fn_sort7(const uint32_t s0, const uint32_t s
   for (int i = 0; i < 7; ++i) {
     int rank = 0;
 #pragma unroll
-    for (int j = 0; j < 7; ++j) rank += (bits[j] < bits[i] || (bits[j] == bits[i] && j < i)) ? 1 : 0;
-    p |= (uint32_t)i << (3 * rank);
+    for (int j = 0; j < 7; ++j) rank += (j < n && (bits[j] < bits[i] || (bits[j] == bits[i] && j < i))) ? 1 : 0;
+    p |= i < n ? (uint32_t)i << (3 * rank) : 0u;
   }
   return p;
 }
@@ -1881,7 +1882,7 @@ void step_kernel_bits(
     if (RULESET != TG_RULESET_NUMPY) {  // envs/tetris_fn.py:370-413 place_active_tetromino
       // the lock moves the env one position along its key chain (rng_key = split(rng_key)[0], :399: owed until after the
       // publish) and, with the bag used up, deals permutation(split(rng_key)[1]) (functional/queue.py:59-67) = Q0
-      const bool refill = place & (s.bidx >= 7);
+      const bool refill = place & (s.bidx >= Q);  // (functional/queue.py:67: queue_index >= config.queue_size)
       const uint64_t nb = fn_expand21((uint32_t)(fnw >> 42) & 0x1FFFFFu);
       s.bag = refill ? nb : s.bag; s.bidx = refill ? 0 : s.bidx;
       s.piece = place ? (int)((s.bag >> (8 * (s.bidx & 7))) & 0xFF) : s.piece;
@@ -2002,7 +2003,7 @@ void step_kernel_bits(
         threefry2x32(ck.x, ck.y, 0u, 0u, x0, x1);                                   // c_{n+1}
         threefry2x32(x0, x1, 0u, 0u, y0, y1);                                       // c_{n+2}
         threefry2x32(fn_lock ? y0 : x0, fn_lock ? y1 : x1, 0u, 1u, r0_, r1_);       // R_{n+2} | R_{n+1}
-        const uint32_t srt = fn_sort7(r0_, r1_);
+        const uint32_t srt = fn_sort7(r0_, r1_, Q);
         f21 = unsorted ? srt : f21;
       }
       const uint64_t nb = fn_expand21(f21);
@@ -2102,7 +2103,7 @@ void step_kernel_bits(
     if (!__any(ev | cu)) return;
     const int n = fn_n0, d = fn_d0;
     const bool lk = fn_lock && !fn_reset;           // stays on its chain: position n + 1
-    const bool needq = lk && s.bidx >= 7;           // ... whose lock will refill the bag
+    const bool needq = lk && s.bidx >= Q;           // ... whose lock will refill the bag
     u32x2 kb = pf_r1;
     // The key a reset continues with: R_n — or R_{n+1} behind a lock of this transition (SAME_STEP).  The prefetch took R_n for
     // an env that was waiting for its reset (NEXT_STEP) and R_{n+1} otherwise; the two cases it cannot serve are rare and
@@ -2158,7 +2159,7 @@ void step_kernel_bits(
     // r + 8 delivers the same position of their own group): VALU latency instead of six LDS-crossbar round trips
     // (ds_bpermute: 1 200 of the sort's 2 200 cycles).  The idle eighth lane holds the maximum key: it ranks behind everybody.
     auto group_perm = [&](const uint32_t bits_in) -> uint32_t {
-      const uint32_t bits = j < 7 ? bits_in : 0xFFFFFFFFu;
+      const uint32_t bits = j < Q ? bits_in : 0xFFFFFFFFu;  // (Q = the bag length: elements Q..7 of the group rank behind everybody)
       int rank = 0;
 #define TG_ROR(r) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0x120 + (r), 0xF, 0xF, true)  // row_ror:r
 #define TG_OTHER(r)                                                                    \
@@ -2172,7 +2173,7 @@ void step_kernel_bits(
       TG_OTHER(1) TG_OTHER(2) TG_OTHER(3) TG_OTHER(4) TG_OTHER(5) TG_OTHER(6) TG_OTHER(7)
 #undef TG_OTHER
 #undef TG_ROR
-      uint32_t pm = j < 7 ? (uint32_t)j << (3 * rank) : 0u;
+      uint32_t pm = j < Q ? (uint32_t)j << (3 * rank) : 0u;
       pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
       pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
       pm |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pm, 0x141, 0xF, 0xF, true);  // row_half_mirror: the other quad of the 8
@@ -2437,6 +2438,7 @@ struct PrepareParams {
   int force;            // refill every ring
   int cur;              // ring parity the next launch reads
   int hcur;             // consumed-counter parity the next launch reads
+  int queue_size;       // FUNCTIONAL: the bag length (EnvConfig.queue_size)
 };
 
 template <int W, int H>
@@ -2477,11 +2479,12 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
       c = make_uint2(a0, a1);
       cs[m + 1] = c;                   // c_{m+1}
     }
-    uint64_t w = (uint64_t)fn_sort7(rr[1].x, rr[1].y) | ((uint64_t)fn_sort7(rr[2].x, rr[2].y) << 21);
-    if (((rec[2] >> 8) & 0xFFu) >= 7u) {  // the next lock refills the bag: Q0 = sort7(f1(R_0))
+    const int nq = p.queue_size;
+    uint64_t w = (uint64_t)fn_sort7(rr[1].x, rr[1].y, nq) | ((uint64_t)fn_sort7(rr[2].x, rr[2].y, nq) << 21);
+    if (((rec[2] >> 8) & 0xFFu) >= (uint32_t)nq) {  // the next lock refills the bag: Q0 = sort7(f1(R_0))
       uint32_t z0, z1;
       threefry2x32(rr[0].x, rr[0].y, 0u, 1u, z0, z1);
-      w |= (uint64_t)fn_sort7(z0, z1) << 42;
+      w |= (uint64_t)fn_sort7(z0, z1, nq) << 42;
     }
     reinterpret_cast<uint64_t*>(p.hbuf)[env] = w;
     rec[7] = 0;

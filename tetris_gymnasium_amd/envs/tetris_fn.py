@@ -132,7 +132,7 @@ _ids = itertools.count(1)
 class _Slot:
     def __init__(self, config: EnvConfig, batch: int):
         self.engine = Engine(batch, config.width, config.height, ruleset=N.RULESET_FUNCTIONAL,
-                             gravity=config.gravity_enabled, queue_size=7, obs_mode=N.OBS_FN,
+                             gravity=config.gravity_enabled, queue_size=int(config.queue_size), obs_mode=N.OBS_FN,
                              padding=config.padding)
         self.id = next(_ids)
         self.generation = 0
@@ -149,8 +149,8 @@ def _check(tetrominoes, config, *fns):
         if f not in (create_bag_queue, bag_queue_get_next_element):
             raise NotImplementedError("the HIP engine implements the stock 7-bag queue only "
                                       "(create_bag_queue / bag_queue_get_next_element)")
-    if config.padding != 4 or config.queue_size != 7:
-        raise NotImplementedError("the HIP engine needs padding=4 and queue_size=7 (stock tetromino set)")
+    if config.padding != 4 or not 1 <= int(config.queue_size) <= 7:
+        raise NotImplementedError("the HIP engine needs padding=4 and a bag length queue_size in 1..7 (stock tetromino set)")
 
 
 def _slot(config: EnvConfig, batch: int) -> _Slot:
@@ -171,7 +171,7 @@ def _download(slot: _Slot, config) -> dict:
     return dict(
         rng_key=rng["key"].copy(), board=_pad(board, config), active_tetromino=rec["piece"].astype(np.int32),
         rotation=rec["rot"].astype(np.int32), x=rec["x"].astype(np.int32), y=rec["y"].astype(np.int32),
-        queue=rec["bag"].astype(np.int32), queue_index=rec["bag_index"].astype(np.int32),
+        queue=rec["bag"][:, : config.queue_size].astype(np.int32), queue_index=rec["bag_index"].astype(np.int32),
         game_over=(rec["flags"] & N.F_GAME_OVER).astype(bool), score=rec["score"].astype(np.float32))
 
 
@@ -183,7 +183,8 @@ def _upload(slot: _Slot, config, leaves: dict):
     rec["x"] = leaves["x"]; rec["y"] = leaves["y"]; rec["val"] = np.asarray(leaves["active_tetromino"]) + 2
     rec["flags"] = np.where(np.asarray(leaves["game_over"], bool), N.F_GAME_OVER, 0)
     rec["holder_piece"] = N.NONE
-    rec["bag"] = leaves["queue"]; rec["bag_index"] = leaves["queue_index"]; rec["score"] = leaves["score"]
+    rec["bag"][:, : config.queue_size] = np.asarray(leaves["queue"]).reshape(B, -1)
+    rec["bag_index"] = leaves["queue_index"]; rec["score"] = leaves["score"]
     rng = np.zeros(B, N.RNG_REC)
     rng["key"] = leaves["rng_key"]
     board = np.asarray(leaves["board"]).reshape(B, config.height + p, config.width + 2 * p)
@@ -237,14 +238,14 @@ def _leaves_from_buffers(config, B, board, rec, rng) -> dict:
     return dict(
         rng_key=rng["key"].copy(), board=_pad(board, config), active_tetromino=rec["piece"].astype(np.int32),
         rotation=rec["rot"].astype(np.int32), x=rec["x"].astype(np.int32), y=rec["y"].astype(np.int32),
-        queue=rec["bag"].astype(np.int32), queue_index=rec["bag_index"].astype(np.int32),
+        queue=rec["bag"][:, : config.queue_size].astype(np.int32), queue_index=rec["bag_index"].astype(np.int32),
         game_over=(rec["flags"] & N.F_GAME_OVER).astype(bool), score=rec["score"].astype(np.float32))
 
 
 _LEAF_SPEC = {  # leaf → (trailing shape as a function of the config, dtype)
     "rng_key": (lambda c: (2,), np.uint32), "board": (lambda c: (c.height + c.padding, c.width + 2 * c.padding), np.int8),
     "active_tetromino": (lambda c: (), np.int32), "rotation": (lambda c: (), np.int32), "x": (lambda c: (), np.int32),
-    "y": (lambda c: (), np.int32), "queue": (lambda c: (7,), np.int32), "queue_index": (lambda c: (), np.int32),
+    "y": (lambda c: (), np.int32), "queue": (lambda c: (int(c.queue_size),), np.int32), "queue_index": (lambda c: (), np.int32),
     "game_over": (lambda c: (), np.bool_), "score": (lambda c: (), np.float32)}
 
 

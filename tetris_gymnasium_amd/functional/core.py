@@ -26,7 +26,7 @@ class State:
     rotation: np.ndarray
     x: np.ndarray
     y: np.ndarray
-    queue: np.ndarray  # int32 [7]
+    queue: np.ndarray  # int32 [queue_size]
     queue_index: np.ndarray
     game_over: np.ndarray  # bool
     score: np.ndarray  # float32

@@ -1,4 +1,4 @@
-"""Host-side jax.random pieces the functional surface needs (threefry2x32, PRNGKey, split, permutation of 7), restated from
+"""Host-side jax.random pieces the functional surface needs (threefry2x32, PRNGKey, split, permutation of up to 7), restated from
 jax 0.5.3 `_src/prng.py` / `_src/random.py` (partitionable threefry = the jax >= 0.5.0 default).  threefry2x32 itself is
 pinned by the Random123 known-answer vectors (tests/test_oracle_rng.py); split / permutation are PARITY UNPINNED against a
 live jax (none installable in the build container) — the device code and the oracle use the same restatement."""
@@ -63,10 +63,17 @@ def split_batch(keys, index: int = 0) -> np.ndarray:
     return np.stack([x0, x1], axis=1)
 
 
-def permutation7(key) -> np.ndarray:
-    """jax.random.permutation(key, arange(7)): key', sub = split(key); sort keys = 32 random bits per element from `sub`
-    (threefry(sub, (0, i)).x ^ .y); stable argsort."""
+def permutation(key, n: int) -> np.ndarray:
+    """jax.random.permutation(key, arange(n)) for 1 <= n <= 7 (jax `_shuffle`: one round for 2 <= n, none for n = 1): key', sub =
+    split(key); sort keys = 32 random bits per element from `sub` (threefry(sub, (0, i)).x ^ .y); stable argsort."""
+    n = int(n)
+    if n < 2:
+        return np.arange(n, dtype=np.int32)
     sub = split(key)[1]
-    x0, x1 = threefry2x32_batch(np.full(7, sub[0], np.uint32), np.full(7, sub[1], np.uint32), np.zeros(7, np.uint32),
-                                np.arange(7, dtype=np.uint32))
+    x0, x1 = threefry2x32_batch(np.full(n, sub[0], np.uint32), np.full(n, sub[1], np.uint32), np.zeros(n, np.uint32),
+                                np.arange(n, dtype=np.uint32))
     return np.argsort(x0 ^ x1, kind="stable").astype(np.int32)
+
+
+def permutation7(key) -> np.ndarray:
+    return permutation(key, 7)

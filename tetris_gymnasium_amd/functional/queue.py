@@ -1,4 +1,4 @@
-"""The 7-bag queue of the functional surface (reference functional/queue.py:20-67), on the host in NumPy.
+"""The bag queue (7-bag by default; `EnvConfig.queue_size` = the bag length, 1..7) of the functional surface (reference functional/queue.py:20-67), on the host in NumPy.
 
 `reset` / `step` / `batched_*` take these two callables as their queue plug points and evaluate the stock bag ON THE
 DEVICE (the engine implements exactly this queue; any other callable is rejected there).  Called directly they are the
@@ -8,14 +8,14 @@ from __future__ import annotations
 
 import numpy as np
 
-from .prng import permutation7, split
+from .prng import permutation, split
 
 
 def create_bag_queue(config, key):
     """→ (queue int32[queue_size], queue_index 0): a fresh permutation of the piece ids (functional/queue.py:20-35)."""
-    if config.queue_size != 7:
-        raise NotImplementedError("the bag holds the seven tetrominoes (queue_size == 7)")
-    return permutation7(np.asarray(key, np.uint32)), 0
+    if not 1 <= int(config.queue_size) <= 7:  # (arange(queue_size) beyond 7 would index past the seven tetrominoes)
+        raise NotImplementedError("queue_size (the bag length) must be 1..7")
+    return permutation(np.asarray(key, np.uint32), config.queue_size), 0
 
 
 def bag_queue_get_next_element(config, queue, queue_index, key):
