@@ -55,6 +55,12 @@ def main() -> int:
     out["keys"] = np.stack([np.asarray(k, np.uint32) for k in keys])
     out["split"] = np.stack([np.asarray(jax.random.split(k), np.uint32) for k in keys])
     out["perm"] = np.stack([np.asarray(jax.random.permutation(k, jnp.arange(7)), np.uint8) for k in keys])
+    # permutation(key, arange(n)) for every bag length EnvConfig.queue_size = n the engine accepts (functional/queue.py:35), padded with 255
+    pn = np.full((len(keys), 7, 7), 255, np.uint8)
+    for i, k in enumerate(keys):
+        for n in range(1, 8):
+            pn[i, n - 1, :n] = np.asarray(jax.random.permutation(k, jnp.arange(n)), np.uint8)
+    out["perm_n"] = pn
 
     # --- reset + refill chains -----------------------------------------------------------------------------------
     rq, ra, rk, rs = [], [], [], []

@@ -38,6 +38,13 @@ def test_split_and_permutation(fx):
         assert list(a) == list(sp[0]) and list(b) == list(sp[1])
         L.tgo_jax_permutation7(_p(kk), _p(out))
         assert list(out) == list(pm)
+    if "perm_n" in fx:  # every bag length 1..7 (EnvConfig.queue_size; fixtures generated since round 5 carry them)
+        for k, pn in zip(fx["keys"], fx["perm_n"]):
+            kk = np.ascontiguousarray(k, np.uint32)
+            for n in range(1, 8):
+                out = np.full(7, 255, np.uint8)
+                L.tgo_jax_permutation(_p(kk), n, _p(out))
+                assert list(out) == list(pn[n - 1])
 
 
 def test_reset_and_refill_chain(fx):
