@@ -14,7 +14,7 @@ K_EXPR="(replays_reference_trace and not in_step_observation) or numpy_rules_eng
     TG_KERNEL=$K timeout 300 python bench.py --steps 128 --warmup 16 --no-cpu-baseline --no-blocks 2>/dev/null | python3 -c "
 import sys,json
 try:
-    d=json.loads(sys.stdin.read()); print('bench: %.2f us per 65 536-env step, %.3e env steps/s, kernel %s' % (d['roofline']['kernel_ms']*1e3, d['value'], d['roofline']['kernel']))
+    d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print('bench: %.2f us per 65 536-env step, %.3e env steps/s, kernel %s' % (d['roofline']['kernel_us_hip_events'], d['value'], d['roofline']['kernel']))
 except Exception as e: print('bench failed', e)"
   done
 } > $OUT/legacy_kernels_check.log 2>&1
