@@ -5,7 +5,7 @@
 # block = two-phase workgroup kernel.  (The in-step dict pack of the reference traces is the bits kernel's own: not part of this.)  usage: tools/gpu_legacy_check.sh <tag>
 TAG=${1:-legacy}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 export TG_LIB=$PWD/tetris_gymnasium_amd/libtetris_gym_hip_legacy.so
-K_EXPR="(replays_reference_trace and not in_step_observation) or numpy_rules_engine_vs_oracle or functional_rules_engine_vs_oracle or line_clear_dense or swap_and_hold or post_game_over"
+K_EXPR="(replays_reference_trace and not in_step_observation and not custom_mappings) or numpy_rules_engine_vs_oracle or functional_rules_engine_vs_oracle or line_clear_dense or swap_and_hold or post_game_over"
 {
   echo "# earlier step kernels (csrc/legacy/, test-only library) on the core parity tests: pytest tests/test_gpu_parity.py -k \"$K_EXPR\""
   for K in wave lanes quad block; do
