@@ -465,6 +465,10 @@ def main():
         "trace_10x20_g0": lambda: run_trace(ref, "trace_10x20_g0", 10, 20, False, 4, 48, 512, 12346),
         "trace_20x40_g1": lambda: run_trace(ref, "trace_20x40_g1", 20, 40, True, 7, 32, 768, 12347),
         "trace_6x12_g1": lambda: run_trace(ref, "trace_6x12_g1", 6, 12, True, 4, 32, 256, 12348),
+        # sizes the engine compiles at run time (hiprtc), one with 98-byte slabs (7x14: env slabs at 2-byte alignment) and a 2-deep
+        # queue, one larger board with the longest queue and gravity off
+        "trace_7x14_q2_g1": lambda: run_trace(ref, "trace_7x14_q2_g1", 7, 14, True, 2, 40, 320, 12349),
+        "trace_12x24_q7_g0": lambda: run_trace(ref, "trace_12x24_q7_g0", 12, 24, False, 7, 24, 320, 12350),
         "clears_10x20": lambda: gen_clears(ref, "clears_10x20", 10, 20, 4, 96, 256, 777, 5),
         "clears_20x40": lambda: gen_clears(ref, "clears_20x40", 20, 40, 7, 32, 384, 778, 6),
         "grouped_10x20": lambda: gen_grouped(ref, "grouped_10x20", 10, 20, 4, 16, 96, 31, 48),

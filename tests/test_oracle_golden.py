@@ -30,7 +30,8 @@ class OracleBackend:
         self.o.set_state(**kw)
 
 
-TRACES = ["trace_10x20_g1", "trace_10x20_g0", "trace_20x40_g1", "trace_6x12_g1", "clears_10x20", "clears_20x40"]
+TRACES = ["trace_10x20_g1", "trace_10x20_g0", "trace_20x40_g1", "trace_6x12_g1", "clears_10x20", "clears_20x40",
+          "trace_7x14_q2_g1", "trace_12x24_q7_g0"]  # (the last two: board sizes the engine compiles at run time)
 
 
 @pytest.mark.parametrize("name", TRACES)
