@@ -21,6 +21,17 @@ def pytest_report_header(config):
             f"_native.HIP_RUNTIME is printed per process with TG_VERBOSE=1")
 
 
+def pytest_terminal_summary(terminalreporter):
+    """which HIP runtime the engine of THIS process actually ran on (the log of a GPU run shows what was tested)"""
+    try:
+        from tetris_gymnasium_amd import _native
+
+        if _native._lib is not None:
+            terminalreporter.write_line(f"tetris_gymnasium_amd: engine library {_native.LIB_PATH}, HIP runtime = {_native.HIP_RUNTIME}")
+    except Exception:  # pragma: no cover
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
 
