@@ -781,12 +781,13 @@ __device__ __forceinline__ void bits_copy_slab(const uint8_t* src_lds, uint8_t* 
 }
 
 constexpr int TG_ONE_WAVES = 4;    // waves per SIMD the one-transition kernels are compiled for (4 → 128 VGPRs, 3 → 168)
-constexpr int TG_MULTI_WAVES = 3;  // ... the kernels of several transitions per launch (NUMPY: at 4 the plain one spilled 12 registers: 2.90 -> 2.73 us per transition)
+constexpr int TG_MULTI_WAVES = 3;  // ... the kernels of several transitions per launch (NUMPY: at 4 the plain one spilled 12 registers: 2.90 -> 2.73 us per
+                                   // transition; FUNCTIONAL since round 5: at 4 its one-stream-wave builds spill, 98 304 envs 5.77 -> 4.75: profiles/r05/ab_fn_multi_waves_per_simd.log)
 constexpr int TG_WIDE_WAVES = 2;   // ... the kFeatWide instantiations (FUNCTIONAL, up to 65 536 envs: one logic + one stream wave per SIMD)
 constexpr int bits_waves_per_simd(const int ruleset, const int feat) {
   if (ruleset == TG_RULESET_FUNCTIONAL && (feat & kFeatSplit)) return 3;  // (three waves per workgroup, one workgroup's worth per SIMD at 65 536 envs)
   return (feat & kFeatWide) ? TG_WIDE_WAVES
-         : (feat & kFeatMulti) ? ((feat & (kFeatDict | kFeatSample)) ? 3 : (ruleset == TG_RULESET_NUMPY ? TG_MULTI_WAVES : 4))
+         : (feat & kFeatMulti) ? TG_MULTI_WAVES
                                : TG_ONE_WAVES;
 }
 template <int W, int H, int RULESET, int FEAT>
