@@ -176,7 +176,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     const dim3 grid(nrb + n_step_wgs);
     constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
     const int feat = bits_feat<W, H, RS>(p);
-    const size_t lds = RS == TG_RULESET_FUNCTIONAL ? BG::BYTES_FNX
+    const size_t lds = RS == TG_RULESET_FUNCTIONAL ? ((feat & F) ? BG::BYTES_FNX : BG::BYTES_FNX0)
                        : ((feat & D) ? ((feat & tg::kFeatSplit) ? BG::BYTES_DICT_SPLIT : BG::BYTES_DICT)
                                      : ((feat & R) ? ((feat & tg::kFeatMaskWave) ? ((feat & tg::kFeatMany) ? BG::BYTES_RGB_X6 : BG::BYTES_RGB_X) : BG::BYTES_RGB) : ((feat & F) ? BG::BYTES_FIN : BG::BYTES)));
 #define TG_LAUNCH_BITS(FT)                                                                                                  \
@@ -531,7 +531,7 @@ Launchers rtc_launchers(const RtcSize* r) {
     const int n_step_wgs = (p.batch + EPW - 1) / EPW;
     const bool split_ok = r->geo[11] != 0;  // (BitsGeo::SPLIT_OK)
     const int feat = bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, split_ok, rgb_helpers_max);
-    const size_t lds = RS == TG_RULESET_FUNCTIONAL ? r->geo[5]
+    const size_t lds = RS == TG_RULESET_FUNCTIONAL ? ((feat & F) ? r->geo[5] : r->geo[5] - 2 * r->geo[0] * 8)  // (BYTES_FNX / BYTES_FNX0)
                        : ((feat & D) ? r->geo[2] + ((feat & tg::kFeatSplit) ? 16 * (W + 8) * (H + 4) : 0)  // (BYTES_DICT_SPLIT: + GD * PC)
                                      : ((feat & R) ? r->geo[3] + ((feat & tg::kFeatMaskWave) ? ((feat & tg::kFeatMany) ? 6 : 2) * 4 * ((((H + 4) * (W + 24)) + 15) / 16 * 16) : 0)  // (BYTES_RGB_X: + 2 GR IDB)
                                                    : ((feat & F) ? r->geo[4] : r->geo[1])));

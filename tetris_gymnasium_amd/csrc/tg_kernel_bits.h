@@ -183,6 +183,11 @@ struct BitsGeo {
   // key-chain look-ahead — uint2 keys [128] | uint32 permutations [128] — behind the FINAL_OBS records
   static constexpr int OFF_FNX = BYTES_FIN;
   static constexpr int BYTES_FNX = BYTES_FIN + 128 * 8 + 128 * 4;
+  // ... directly behind BYTES in the instantiations without the FINAL_OBS records (round 5): at 10x20 that is 20 032 instead of 21 056
+  // bytes per workgroup — EIGHT workgroups per CU instead of seven fit the 160 KB, i.e. a one-transition launch of 131 072 envs (2 048
+  // workgroups of two waves, compiled for four waves per SIMD) is resident in one round: 14.4 -> 11.x us (profiles/r05/batch_sweep.log)
+  static constexpr int OFF_FNX0 = BYTES;
+  static constexpr int BYTES_FNX0 = BYTES + 128 * 8 + 128 * 4;
   static_assert(BYTES_FNX == bits_lds_bytes_max(W, H, EPW), "bits_lds_bytes_max restates this layout");
   static_assert(NSW0 == 1 || BYTES_FNX <= 65536, "two stream waves' worth of envs only while the workgroup's LDS stays within 64 KiB");
   static constexpr int WC = bits_cols_words<W, H>();  // column-mask words per env in HBM
@@ -2148,8 +2153,8 @@ void step_kernel_bits(
     const int qB = nA + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u));
     uint64_t p1 = kFnNone, p2 = 0;
     if (nt > 0) {
-    uint2* xk = reinterpret_cast<uint2*>(lds + BG::OFF_FNX);
-    uint32_t* xo = reinterpret_cast<uint32_t*>(lds + BG::OFF_FNX + 128 * 8);
+    uint2* xk = reinterpret_cast<uint2*>(lds + (FINAL ? BG::OFF_FNX : BG::OFF_FNX0));
+    uint32_t* xo = reinterpret_cast<uint32_t*>(lds + (FINAL ? BG::OFF_FNX : BG::OFF_FNX0) + 128 * 8);
     if (needs2) xk[qA] = make_uint2(b0, b1);
     if (needq) xk[qB] = make_uint2(z0, z1);
     wave_sync();
