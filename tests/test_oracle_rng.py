@@ -70,6 +70,32 @@ def test_threefry2x32_known_answers():
         assert tuple(int(v) for v in o) == exp
 
 
+def test_jax_split_of_key_zero_matches_the_published_values():
+    """`random.split(PRNGKey(0))` as printed in the JAX documentation ("Pseudo random numbers in JAX", the original
+    threefry split of jax < 0.5): key [4146024105 967050713], subkey [2718843009 1272950319].  Typed in from the
+    published page, not generated here (no jax in this image) - it pins threefry2x32 with jax's key schedule and the
+    half-split counter layout of `_threefry_split_original`.  The partitionable split (the jax >= 0.5 default the
+    reference's pinned 0.5.3 runs) is frozen below from this restatement; `oracle/refgen/make_golden_fn.py` is what
+    pins it against a live jax."""
+    L = po.lib()
+    L.tgo_jax_split.argtypes = [C.c_void_p] * 3
+    k = np.zeros(2, np.uint32)
+    a = np.zeros(2, np.uint32)
+    b = np.zeros(2, np.uint32)
+    try:
+        L.tgo_set_threefry_partitionable(0)
+        L.tgo_jax_split(_p(k), _p(a), _p(b))
+        assert (list(a), list(b)) == ([4146024105, 967050713], [2718843009, 1272950319])
+    finally:
+        L.tgo_set_threefry_partitionable(1)
+    L.tgo_jax_split(_p(k), _p(a), _p(b))
+    assert (list(a), list(b)) == ([1797259609, 2579123966], [928981903, 3453687069])
+    from tetris_gymnasium_amd.functional import prng
+
+    k0, k1 = prng.split(prng.PRNGKey(0))
+    assert (list(map(int, k0)), list(map(int, k1))) == ([1797259609, 2579123966], [928981903, 3453687069])
+
+
 def test_jax_permutation_is_a_permutation_and_deterministic():
     # mirrors reference tests/test_functional/test_queue.py:24-33 (set property; exact values unpinned)
     L = po.lib()
