@@ -60,8 +60,6 @@ struct Launchers {
 
 inline int grid_for(int batch) { return (batch + tg::kWavesPerBlock - 1) / tg::kWavesPerBlock; }
 
-int g_step_blocks = 0;  // persistent grid size (blocks); set once per process from the device's CU count
-
 // step kernel selection (TG_KERNEL): 16 = "bits": column-bitmask logic, one env per lane (default, tg_kernel_bits.h);
 // (legacy build only) 8 = "block": two-phase workgroup kernel (legacy/tg_kernel_block.h); 4 = "quad": 16 envs per wave, 4 lanes per env;
 // 1 = "lanes": 64 envs per wave, one per lane (both legacy/tg_kernel_lanes.h); 0 = "wave": one env per wavefront (legacy/tg_kernel_wave.h)
@@ -73,8 +71,32 @@ constexpr int g_groups_per_wave = 1;
 #endif
 constexpr int g_stagger = 0;
 
-int g_simds = 1024;  // SIMDs of the device (4 per CU), set by tg_create
+int g_simds = 1024;  // SIMDs of the device (4 per CU)
 int g_split = 1;     // TG_SPLIT=0: never pick the instantiations with two stream waves per workgroup (kFeatSplit)
+
+// Process-wide settings, read once (the first tg_create; the devices of a node are alike): the SIMD count the instantiation
+// rules above compare grids against, TG_SPLIT, and TG_KERNEL (which the product library only accepts as "bits").
+std::once_flag g_process_once;
+std::string g_process_err;
+void process_init(int device) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) g_simds = 4 * prop.multiProcessorCount;
+  if (const char* w = getenv("TG_SPLIT")) g_split = atoi(w) != 0;
+  if (const char* k = getenv("TG_KERNEL")) {
+#ifdef TG_LEGACY_KERNELS
+    g_kernel_lanes = strcmp(k, "wave") == 0    ? 0
+                     : strcmp(k, "lanes") == 0 ? 1
+                     : strcmp(k, "pair") == 0  ? 2
+                     : strcmp(k, "quad") == 0  ? 4
+                     : strcmp(k, "block") == 0 ? 8
+                                               : 16;
+#else
+    if (strcmp(k, "bits") != 0)
+      g_process_err = std::string("tg_create: TG_KERNEL=") + k + " needs the test-only library with the earlier step kernels "
+                      "(make -C tetris_gymnasium_amd/csrc legacy; TG_LIB=<path>/libtetris_gym_hip_legacy.so)";
+#endif
+  }
+}
 
 // RNG-role workgroups of a launch (128 envs each)
 int rng_blocks(const tg::KParams& p, const int RS) { return (RS == TG_RULESET_NUMPY && p.rng_role) ? (p.batch + 127) / 128 : 0; }
@@ -265,8 +287,7 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
       launch(tg::step_kernel_lanes<W, H, RS, 1, false>, tg::step_kernel_lanes<W, H, RS, 1, false>, 64);
     return;
   }
-  int grid = grid_for(p.batch);
-  if (g_step_blocks > 0 && grid > g_step_blocks) grid = g_step_blocks;
+  const int grid = grid_for(p.batch);
   hipLaunchKernelGGL((tg::step_kernel<W, H, RS>), dim3(grid), dim3(tg::kBlock), 0, s, p);
 #else
   (void)s;  // (unreachable: tg_create refuses handles without the column-mask state in the product build)
@@ -679,8 +700,7 @@ struct tg_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   Launchers L{};
   void* arena = nullptr;  // the one device allocation behind every buffer below
-  size_t arena_size = 0, arena_off = 0, arena_skew = 0;
-  int arena_count = 0;
+  size_t arena_size = 0, arena_off = 0;
   void* buf[TG_BUF_COUNT] = {};
   size_t bytes[TG_BUF_COUNT] = {};
   tg_rng_rec* d_new_rng = nullptr;
@@ -709,7 +729,7 @@ struct tg_handle {
   uint64_t act_lut = tg::kActLutNumpy;           // the handle's ActionsMapping as the kernel's per-action table
   double rewards[4] = {1.0, 1.0, 0.0, -0.1};     // ... its RewardsMapping: alife, clear_line, game_over, invalid_action
   bool dict_in_kernel = false; // TG_OBS_DICT packed by the bits step kernel itself (no observe launch after a transition)
-  // TG_STREAMS=n (default 1) spreads the step launches of one transition over n streams (contiguous env shards).
+  // tg_config.streams = n (default 1) spreads the step launches of one transition over n streams (contiguous env shards).
   // Kept as a tested knob, off by default — measured on MI355X: every launch costs ≈2.8-3.4 µs of
   // command-processor time whichever stream it is on, so n shards cost n launch floors per transition (8.3 µs →
   // 9.3 µs at n = 2, 13.8 µs at n = 4, also when the launches are replayed from a HIP graph).
@@ -814,14 +834,11 @@ constexpr size_t kTailPad = 4096;
 // All device state of a handle comes from ONE allocation (`arena`), carved in 4 KiB-aligned pieces in a fixed order:
 // where the buffers sit relative to each other is then the same for every handle (separate hipMalloc calls gave
 // launch times that differed by up to 0.5 us between two handles of the same process: profiles/r02 placement runs).
-// TG_ALLOC_SKEW=n (bytes, default below) adds n x (piece index) to the offsets so that streams read and written at the
-// same relative position (board / observation slabs) do not start on the same channel.
 hipError_t arena_take(tg_handle* h, void** out, size_t n) {
-  const size_t off = ((h->arena_off + 4095) / 4096) * 4096 + h->arena_skew * (size_t)h->arena_count;
+  const size_t off = ((h->arena_off + 4095) / 4096) * 4096;
   if (off + n > h->arena_size) return hipErrorOutOfMemory;
   *out = (uint8_t*)h->arena + off;
   h->arena_off = off + n;
-  h->arena_count += 1;
   return hipSuccess;
 }
 
@@ -1243,8 +1260,6 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   // would index past the seven tetrominoes)
   if (cfg->ruleset == TG_RULESET_FUNCTIONAL && (cfg->queue_size < 1 || cfg->queue_size > 7))
     return fail(nullptr, TG_EUNSUPPORTED, "tg_create: FUNCTIONAL queue_size (the bag length) must be 1..7, got %d", cfg->queue_size);
-  if (cfg->ruleset == TG_RULESET_FUNCTIONAL && cfg->queue_size != 7 && g_kernel_lanes != 16)
-    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: the earlier step kernels of the test-only library deal the 7-bag only");
   if ((cfg->obs_mode == TG_OBS_DICT || cfg->obs_mode == TG_OBS_RGB) && cfg->ruleset != TG_RULESET_NUMPY)
     return fail(nullptr, TG_EINVAL, "tg_create: TG_OBS_DICT / TG_OBS_RGB are observations of the NUMPY rule-set");
   if (cfg->action_set != TG_ACTIONS_BASE && cfg->action_set != TG_ACTIONS_GROUPED)
@@ -1253,8 +1268,6 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     return fail(nullptr, TG_EINVAL, "tg_create: the grouped action set wraps the NUMPY rule-set (wrappers/grouped.py)");
   if ((cfg->flags & (TG_FLAG_CUSTOM_ACTIONS | TG_FLAG_CUSTOM_REWARDS)) && cfg->ruleset != TG_RULESET_NUMPY)
     return fail(nullptr, TG_EINVAL, "tg_create: ActionsMapping / RewardsMapping belong to the NUMPY rule-set (envs/tetris.py:83-84)");
-  if ((cfg->flags & (TG_FLAG_CUSTOM_ACTIONS | TG_FLAG_CUSTOM_REWARDS)) && g_kernel_lanes != 16)
-    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: custom mappings need the default step kernel (TG_KERNEL=bits)");
   uint64_t act_lut = tg::kActLutNumpy;
   if ((cfg->flags & TG_FLAG_CUSTOM_ACTIONS) && !act_lut_from_ids(cfg->action_ids, &act_lut))
     return fail(nullptr, TG_EUNSUPPORTED, "tg_create: ActionsMapping.hard_drop (%d) shares its value with a field that Tetris.step "
@@ -1268,11 +1281,18 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   if (!built_in && (cfg->width < 4 || cfg->width > 32 || cfg->height < 4 || cfg->height > 58))
     return fail(nullptr, TG_EUNSUPPORTED, "tg_create: board %dx%d outside 4..32 x 4..58 (row masks are 32 bits, column masks 64)",
                 cfg->width, cfg->height);
+// (argument checks above need no device: a CPU-only machine gets the precise refusal, then the loud one below)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, TG_EHIP, "tg_create: no HIP device available (this engine has no CPU fallback)");
   if (cfg->device < 0 || cfg->device >= ndev)
     return fail(nullptr, TG_EINVAL, "tg_create: device %d out of range (0..%d)", cfg->device, ndev - 1);
+  std::call_once(g_process_once, process_init, cfg->device);
+  if (!g_process_err.empty()) return fail(nullptr, TG_EUNSUPPORTED, "%s", g_process_err.c_str());
+  if (cfg->ruleset == TG_RULESET_FUNCTIONAL && cfg->queue_size != 7 && g_kernel_lanes != 16)
+    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: the earlier step kernels of the test-only library deal the 7-bag only");
+  if ((cfg->flags & (TG_FLAG_CUSTOM_ACTIONS | TG_FLAG_CUSTOM_REWARDS)) && g_kernel_lanes != 16)
+    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: custom mappings need the default step kernel (TG_KERNEL=bits)");
   if (!built_in) {  // any other size: the same kernels, compiled for it now (or taken from the on-disk cache)
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, TG_EHIP, "tg_create: hipSetDevice failed");
     RtcSize* rs = nullptr;
@@ -1305,33 +1325,6 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     }                                                                                             \
   } while (0)
   CRCHK(hipSetDevice(cfg->device));
-  if (g_step_blocks == 0) {
-    hipDeviceProp_t prop;
-    CRCHK(hipGetDeviceProperties(&prop, cfg->device));
-    // Grid of the step kernel.  Default: one wave per env (measured fastest for the one-env-per-wavefront
-    // kernel, profiles/r01_*).  TG_BLOCKS_PER_CU=n makes it persistent: n blocks of 4 waves per CU, each wave
-    // looping over its envs with the next env's loads in flight.
-    const int per_cu = 0;
-    if (const char* k = getenv("TG_KERNEL")) {
-#ifdef TG_LEGACY_KERNELS
-      g_kernel_lanes = strcmp(k, "wave") == 0    ? 0
-                       : strcmp(k, "lanes") == 0 ? 1
-                       : strcmp(k, "pair") == 0  ? 2
-                       : strcmp(k, "quad") == 0  ? 4
-                       : strcmp(k, "block") == 0 ? 8
-                                                 : 16;
-#else
-      if (strcmp(k, "bits") != 0) {
-        h->err = std::string("tg_create: TG_KERNEL=") + k + " needs the test-only library with the earlier step kernels "
-                 "(make -C tetris_gymnasium_amd/csrc legacy; TG_LIB=<path>/libtetris_gym_hip_legacy.so)";
-        return bail(TG_EUNSUPPORTED);
-      }
-#endif
-    }
-    g_step_blocks = per_cu > 0 ? prop.multiProcessorCount * per_cu : -1;
-    g_simds = 4 * prop.multiProcessorCount;
-    if (const char* w = getenv("TG_SPLIT")) g_split = atoi(w) != 0;
-  }
   const int n_streams_env = cfg->streams > 1 ? cfg->streams : 1;  // tg_config.streams: spread a transition of a large batch over this many streams
   CRCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CRCHK(hipEventCreate(&h->ev0));
@@ -1349,12 +1342,9 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
       /*FEATS*/ (cfg->flags & TG_FLAG_FEATURES) ? B * (size_t)(cfg->width + 3) : 0,
       /*HOST_PACK*/ host_pack_layout(B, nullptr)};
   {
-    h->arena_skew = 0;
-    const int n_pieces = TG_BUF_COUNT + 11;
     size_t total = 0;
     for (int i = 0; i < TG_BUF_COUNT; ++i) total += sizes[i] + kTailPad + 4096;
     total += B * sizeof(tg_rng_rec) + 2 * B + B * L.cols_bytes + B * 32 * tg::kRing + 2 * B * 16 + 8 * B + 2 * B * 32 + B * h->cells / 2 + 64 + 11 * (kTailPad + 4096);
-    total += h->arena_skew * (size_t)n_pieces * (size_t)n_pieces;
     CRCHK(hipMalloc(&h->arena, total));
     h->arena_size = total;
     CRCHK(hipMemsetAsync(h->arena, 0, total, h->stream));
@@ -1595,8 +1585,8 @@ static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, u
                         int8_t* act_traj_dev, uint8_t* obs_traj_dev, tg_step_out* out_traj_dev) {
   HIPCHK(h, hipSetDevice(h->cfg.device));
   if (h->B % 4 != 0) return fail(h, TG_EINVAL, "tg_rollout: batch must be a multiple of 4 (packed int8 action rows)");
-  // Transitions per launch: the bits kernel keeps records, masks and slabs on chip across up to TG_FUSE (default and
-  // max 8) consecutive transitions of a rollout — one launch floor and one slab round trip per group instead of per
+  // Transitions per launch: the bits kernel keeps records, masks and slabs on chip across up to tg_config.fuse (default and
+  // max 16) consecutive transitions of a rollout — one launch floor and one slab round trip per group instead of per
   // transition.  tg_step always launches one transition.
   const int fuse_max = h->fuse_max;
   const bool post_kernel = (h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) && !h->dict_in_kernel;
