@@ -212,6 +212,65 @@ def test_vector_env_copy_false_returns_pinned_views_with_the_same_content(kind):
     a.close(); b.close()
 
 
+def _addr(a):
+    return a.__array_interface__["data"][0]
+
+
+@pytest.mark.parametrize("kind,shards", [("board", 1), ("dict", 1), ("dict", 2)])
+def test_vector_env_copy_true_pool_never_touches_an_array_somebody_holds(kind, shards):
+    """copy=True hands out arrays the caller owns.  They come from a pool of page-locked slots that is reused only when nothing
+    outside references an array of the slot: env `a` keeps EVERYTHING it was ever given (the pool runs dry, fresh arrays from then
+    on), env `b` keeps only a row VIEW of one early observation, env `c` copies at once — all three must tell the same story."""
+    import gc
+
+    B = 1000
+    mk = lambda: TetrisVectorEnv(B, observation=kind, autoreset_mode="same_step", copy=True, devices=(0,) * shards)
+    a, b, c = mk(), mk(), mk()
+    first = (lambda o: o["board"] if isinstance(o, dict) else o)
+    flat = (lambda o, r, t, info: [o[k] for k in sorted(o)] if isinstance(o, dict) else [o]) 
+    kept, truth = [], []
+    for env in (a, b, c):
+        env.reset(seed=5)
+    rng = np.random.default_rng(2)
+    b_view = b_view_copy = None
+    b_ptrs = []
+    for t in range(9):
+        act = rng.integers(0, 8, B)
+        oa, ra, ta, _, ia = a.step(act)
+        kept.append(flat(oa, ra, ta, ia) + [ra, ta, ia["lines_cleared"]])
+        ob, rb, tb, _, ib = b.step(act)
+        if t == 1:
+            b_view = first(ob)[3]  # a view of a view of the slot's block; everything else of this step is dropped
+            b_view_copy = b_view.copy()
+        b_ptrs.append(_addr(first(ob)))
+        del ob, rb, tb, ib
+        oc, rc, tc, _, ic = c.step(act)
+        truth.append([x.copy() for x in flat(oc, rc, tc, ic) + [rc, tc, ic["lines_cleared"]]])
+    for t, (k, tr) in enumerate(zip(kept, truth)):
+        for i, (x, y) in enumerate(zip(k, tr)):
+            np.testing.assert_array_equal(x, y, err_msg=f"array {i} handed out at step {t} changed while it was held")
+    np.testing.assert_array_equal(b_view, b_view_copy, err_msg="a held row view was overwritten")
+    if hasattr(__import__("sys"), "getrefcount"):
+        host = b._host
+        assert host.pool is not None and 2 <= len(host.pool) <= host._POOL_SLOTS
+        # b's loop: the slot of step 1 stays busy (the row view), the other slots take turns
+        busy = b_ptrs[1]
+        assert busy not in b_ptrs[2:], "the slot whose row view is held was written again"
+        assert len(set(b_ptrs[2:])) <= host._POOL_SLOTS - 1
+        # a's loop kept everything: pool exhausted, fresh arrays after that
+        assert len(a._host.pool) == a._host._POOL_SLOTS
+        del b_view
+        gc.collect()
+        ptrs = set()
+        for t in range(4):
+            ob, *_ = b.step(rng.integers(0, 8, B))
+            ptrs.add(_addr(first(ob)))
+            del ob
+        assert busy in ptrs, "a slot nobody references any more was not taken back into the rotation"
+    for env in (a, b, c):
+        env.close()
+
+
 def test_lifetimes_after_close_and_unconsumed_dlpack_capsules():
     """(round 3 advisor findings) Page-locked observation arrays outlive `close()` (they own their block, like gymnasium's
     copy=False arrays own theirs); a DLPack capsule that nobody consumes releases what it pinned; a DeviceArray / pooled
