@@ -262,6 +262,7 @@ class Engine:
                     self.lib.tg_dev_free(self.h, C.c_void_p(b.ptr))
                     b.ptr = 0
             self._pinned = {}  # (the page-locked blocks free themselves when the last array viewing them dies)
+            self._pin_state = None
             self.lib.tg_destroy(self.h)
             self.h = None
 
@@ -562,6 +563,17 @@ class Engine:
 
     # -- state snapshot / restore (envs/tetris.py:681-708 get_state / set_state, batched) --------
     def get_state(self):
+        nb, nr, ng = self.B * self.H * self.W, self.B * N.ENV_REC.itemsize, self.B * N.RNG_REC.itemsize
+        if nb + nr + ng <= (1 << 16):
+            # small handles (the single-env drop-in reads its state after every step): through one page-locked block — three
+            # copies into pageable memory are each staged and waited for inside the runtime
+            pin = getattr(self, "_pin_state", None)
+            if pin is None:
+                o1, o2 = (nb + 63) // 64 * 64, (nb + 63) // 64 * 64 + (nr + 63) // 64 * 64
+                raw = self.pinned_bytes(o2 + ng)
+                pin = self._pin_state = (raw[:nb].reshape(self.B, self.H, self.W), raw[o1:o1 + nr].view(N.ENV_REC), raw[o2:o2 + ng].view(N.RNG_REC))
+            self._chk(self.lib.tg_get_state(self.h, N.ptr(pin[0]), N.ptr(pin[1]), N.ptr(pin[2])), "tg_get_state")
+            return pin[0].copy(), pin[1].copy(), pin[2].copy()
         board = np.empty((self.B, self.H, self.W), np.uint8)
         rec = np.empty(self.B, N.ENV_REC)
         rng = np.empty(self.B, N.RNG_REC)
