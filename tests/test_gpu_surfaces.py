@@ -575,6 +575,59 @@ def test_wrapper_class_grouped(with_features):
     env.close()
 
 
+def test_wrappers_notice_a_state_changed_behind_their_back():
+    """The wrappers run their kernels on an auxiliary one-env engine that mirrors the wrapped env; the copy is skipped while the
+    env's state version says nobody touched it.  Every way the env can change outside the wrapper — base `step`, `set_state`,
+    an attribute write, an in-place edit of a handed-out array, `reset` — must be seen by the wrapper's next call."""
+    from tetris_gymnasium_amd.wrappers import FeatureVectorObservation, GroupedActionsObservations, RgbObservation
+    base = Tetris()
+    env = GroupedActionsObservations(base)
+    rgb = RgbObservation(base)
+    fv = FeatureVectorObservation(base)
+    o = po.OracleBatch(1)
+    env.reset(seed=21); o.reset(np.array([21], np.uint64))
+
+    def check(msg):
+        om, ob = o.grouped_enumerate(boards=True)
+        np.testing.assert_array_equal(env.observation(), ob[0], err_msg=msg)
+        np.testing.assert_array_equal(env.legal_actions_mask, om[0], err_msg=msg)
+        np.testing.assert_array_equal(rgb.observation(), o.observe(po.OBS_RGB)[0], err_msg=msg)
+        np.testing.assert_array_equal(fv.observation(), o.features()[0], err_msg=msg)
+
+    rng = np.random.default_rng(4)
+    for t in range(6):  # the wrapper's own loop (no copy between the steps)
+        a = int(rng.choice(np.flatnonzero(env.legal_actions_mask)))
+        env.step(a); o.grouped_step(np.array([a]))
+        check(f"grouped step {t}")
+    for t in range(5):  # base steps behind the wrapper's back
+        a = int(rng.integers(0, 8))
+        base.step(a); o.step(np.array([a]))
+        check(f"base step {t}")
+    snap = base.get_state()
+    osnap = o.get_state()
+    for a in (5, 5):
+        base.step(a); o.step(np.array([a]))
+    check("two more base steps")
+    base.set_state(snap); o.set_state(*osnap)
+    check("set_state")
+    a = int(rng.choice(np.flatnonzero(env.legal_actions_mask)))
+    env.step(a); o.grouped_step(np.array([a]))
+    check("grouped step after set_state")
+    assert not base.collision(base.active_tetromino, base.x, base.y + 1)  # (a fresh piece at the top of the board)
+    base.y = base.y + 1  # attribute write (host side, uploaded on demand)
+    b, r, g = o.get_state(); r["y"] += 1; o.set_state(b, r, g)
+    check("attribute write")
+    board = base.board  # handed out, then edited in place
+    board[base.height - 1, base.padding:base.padding + 3] = 5
+    b, r, g = o.get_state(); b[0, base.height - 1, 0:3] = 5; o.set_state(b, r, g)
+    check("in-place edit of the board")
+    base.reset(seed=3); o.reset(np.array([3], np.uint64))
+    check("reset")
+    for w in (env, rgb, fv):
+        w._aux.close(); w._aux = None
+    base.close()
+
+
 @pytest.mark.parametrize("W,H,Q,B", [(10, 20, 4, 1000), (20, 40, 7, 200), (10, 24, 1, 300), (6, 12, 2, 132), (12, 24, 4, 64)])
 def test_dict_observation_engine_vs_oracle(W, H, Q, B, monkeypatch):
     """TG_OBS_DICT = Tetris._get_obs (envs/tetris.py:566-615).  On the default kernel the four arrays are packed by the

@@ -262,7 +262,7 @@ class Engine:
                     self.lib.tg_dev_free(self.h, C.c_void_p(b.ptr))
                     b.ptr = 0
             self._pinned = {}  # (the page-locked blocks free themselves when the last array viewing them dies)
-            self._pin_state = None
+            self._pin_state = self._stage_blk = self._sfo = None
             self.lib.tg_destroy(self.h)
             self.h = None
 
@@ -352,11 +352,23 @@ class Engine:
         self.step_async(actions)
         return self.fetch_outputs()
 
+    def step_fetch_out(self, actions):
+        """One transition from host actions and its tg_step_out records, in ONE call into the C ABI (tg_step_fetch_many: upload,
+        launch, download, one wait) through page-locked buffers — what the single-env wrappers do per step."""
+        fs = getattr(self, "_sfo", None)
+        if fs is None:
+            act = self.pinned_bytes(4 * self.B).view(np.int32)
+            out = self.pinned_bytes(self.B * N.STEP_OUT.itemsize).view(N.STEP_OUT)
+            fs = self._sfo = (act, out, (C.c_void_p * 1)(self.h.value), (C.c_void_p * 1)(act.ctypes.data), (C.c_int * 1)(N.BUF_STEP_OUT),
+                              (C.c_void_p * 1)(out.ctypes.data), (C.c_size_t * 1)(out.nbytes))
+        act, out, hs, ap, which, dst, nb = fs
+        act[:] = np.asarray(actions, np.int32).reshape(self.B)
+        self._chk(self.lib.tg_step_fetch_many(1, hs, ap, N.MEM_HOST, 1, which, dst, nb, None), "tg_step_fetch_many")
+        return out.copy()
+
     def fetch_step_out(self):
         """TG_BUF_STEP_OUT of the last transition as a tg_step_out record array (reward f32, terminated, lines, flags)."""
-        out = self._host_array((self.B,), N.STEP_OUT, "out")
-        self._chk(self.lib.tg_fetch(self.h, N.BUF_STEP_OUT, N.ptr(out), out.nbytes), "tg_fetch(step_out)")
-        return out
+        return self._fetch(N.BUF_STEP_OUT, self._host_array((self.B,), N.STEP_OUT, "out"))
 
     def host_pack(self):
         """TG_BUF_HOST_PACK of the last transition: what a gymnasium-contract step() returns beside the observation, in its final
@@ -372,14 +384,30 @@ class Engine:
                 "terminated": raw[off[4]:off[4] + B].view(np.bool_)}
 
     def fetch_outputs(self):
-        out = self._host_array((self.B,), N.STEP_OUT, "out")
-        self._chk(self.lib.tg_fetch(self.h, N.BUF_STEP_OUT, N.ptr(out), out.nbytes), "tg_fetch(step_out)")
+        out = self._fetch(N.BUF_STEP_OUT, self._host_array((self.B,), N.STEP_OUT, "out"))
         return (np.ascontiguousarray(out["reward"]), np.ascontiguousarray(out["terminated"]),
                 np.ascontiguousarray(out["lines"]))
 
     # -- observations --------------------------------------------------------------------------
+    _SMALL = 1 << 16
+
+    def _stage(self, nbytes):
+        """uint8[nbytes] of one page-locked block kept for SMALL host transfers: a copy to or from pageable memory is staged and
+        waited for inside the runtime (≈20 us per call on a one-env handle, tools/single_env_latency.py); through this block it is
+        a plain DMA plus a memcpy of a few KB.  Every user of the block waits for its copy before it returns."""
+        blk = getattr(self, "_stage_blk", None)
+        if blk is None or blk.nbytes < nbytes:
+            blk = self._stage_blk = self.pinned_bytes(max(int(nbytes), self._SMALL))
+        return blk[:nbytes]
+
     def _fetch(self, which, arr):
-        self._chk(self.lib.tg_fetch(self.h, which, N.ptr(arr), arr.nbytes), f"tg_fetch({which})")
+        n = arr.nbytes
+        if 0 < n <= self._SMALL and not self._pin_slots and arr.flags.c_contiguous:
+            st = self._stage(n)
+            self._chk(self.lib.tg_fetch(self.h, which, N.ptr(st), n), f"tg_fetch({which})")  # (waits for the copy)
+            arr.reshape(-1).view(np.uint8)[:] = st
+            return arr
+        self._chk(self.lib.tg_fetch(self.h, which, N.ptr(arr), n), f"tg_fetch({which})")
         return arr
 
     def use_pinned_observations(self, slots=2):
@@ -505,7 +533,7 @@ class Engine:
         buf = DeviceBuffer(self, n)
         self._chk(self.lib.tg_grouped_enumerate(self.h, C.c_void_p(buf.ptr)), "tg_grouped_enumerate(boards)")
         boards = np.empty((self.B, 4 * self.W, self.Hp, self.Wp), np.uint8)
-        self._chk(self.lib.tg_dev_download(self.h, N.ptr(boards), C.c_void_p(buf.ptr), n), "tg_dev_download")
+        self.dev_download(buf.ptr, boards)
         del buf
         return self._fetch(N.BUF_LEGAL_MASK, np.empty((self.B, 4 * self.W), np.uint8)), boards
 
@@ -590,6 +618,18 @@ class Engine:
             raise ValueError(f"rec must have shape ({self.B},) of tg_env_rec (got {r.shape})")
         if g is not None and g.shape != (self.B,):
             raise ValueError(f"rng must have shape ({self.B},) of tg_rng_rec (got {g.shape})")
+        total = sum(0 if a is None else (a.nbytes + 63) // 64 * 64 for a in (b, r, g))
+        if 0 < total <= self._SMALL:  # (small handles: from the page-locked block; tg_set_state waits for its uploads)
+            st, o, staged = self._stage(total), 0, []
+            for a in (b, r, g):
+                if a is None:
+                    staged.append(None)
+                    continue
+                v = st[o:o + a.nbytes]
+                v[:] = a.reshape(-1).view(np.uint8)
+                staged.append(v.view(a.dtype).reshape(a.shape))
+                o += (a.nbytes + 63) // 64 * 64
+            b, r, g = staged
         self._chk(self.lib.tg_set_state(self.h, N.ptr(b), N.ptr(r), N.ptr(g)), "tg_set_state")
 
     def episode_stats(self):
@@ -614,7 +654,13 @@ class Engine:
         self._chk(self.lib.tg_dev_upload(self.h, C.c_void_p(dptr), N.ptr(a), a.nbytes), "tg_dev_upload")
 
     def dev_download(self, dptr, arr):
-        self._chk(self.lib.tg_dev_download(self.h, N.ptr(arr), C.c_void_p(dptr), arr.nbytes), "tg_dev_download")
+        n = arr.nbytes
+        if 0 < n <= self._SMALL and arr.flags.c_contiguous:
+            st = self._stage(n)
+            self._chk(self.lib.tg_dev_download(self.h, N.ptr(st), C.c_void_p(dptr), n), "tg_dev_download")  # (waits for the copy)
+            arr.reshape(-1).view(np.uint8)[:] = st
+            return arr
+        self._chk(self.lib.tg_dev_download(self.h, N.ptr(arr), C.c_void_p(dptr), n), "tg_dev_download")
         return arr
 
     def sync(self):

@@ -105,6 +105,7 @@ class Tetris(EnvBase):
             raise NotImplementedError("mappings extended with further fields have no meaning to the HIP engine (the reference's "
                                       "step reads the eight actions / four rewards of mappings/*.py)")
         self._hs, self._stale, self._dirty, self._engine, self._handed = {}, False, False, None, None
+        self._version = 0  # counts the changes of the DEVICE state (step / reset / set_state / an upload of host-side edits): wrappers/_device.py
         self.game_over = False
         self.height, self.width = int(height), int(width)
         self.base_pixels = copy.deepcopy(self.BASE_PIXELS)
@@ -165,6 +166,11 @@ class Tetris(EnvBase):
         old, self._handed = self._handed, None
         return (not self._stale) and old != self._fingerprint()
 
+    def _flush(self):
+        """host-side edits (attribute writes, in-place changes of handed-out objects) → device"""
+        if self._dirty or self._changed_in_place():
+            self._push()
+
     def _ro(self, name):
         """read an attribute without marking the host copy as changed (the helpers below only look)"""
         self._sync_host()
@@ -190,6 +196,7 @@ class Tetris(EnvBase):
         rec["bag_index"] = hs["randomizer"].index
         p = self.padding
         board = np.ascontiguousarray(hs["board"][: self.height, p: p + self.width], np.uint8)[None]
+        self._version += 1
         e.set_state(board=board, rec=rec, rng=rng)  # (tg_set_state re-packs TG_BUF_OBS itself)
         self._dirty, self._handed = False, None
 
@@ -243,11 +250,11 @@ class Tetris(EnvBase):
     def step(self, action):
         """reference envs/tetris.py:203-272"""
         assert self.action_space.contains(action), f"{action!r} ({type(action)}) invalid"
-        if self._dirty or self._changed_in_place():
-            self._push()
+        self._flush()
         e = self._engine
         hs, acts, which, dst, nbytes = self._fs
         self._act1[0] = int(action)
+        self._version += 1
         e._chk(e.lib.tg_step_fetch_many(1, hs, acts, N.MEM_HOST, 2, which, dst, nbytes, None), "tg_step_fetch_many")
         self._stale, self._handed = True, None
         term, lines, fl = bool(self._out1["terminated"][0]), int(self._out1["lines"][0]), int(self._out1["flags"][0])
@@ -263,6 +270,7 @@ class Tetris(EnvBase):
             super().reset(seed=seed, options=options)
         except TypeError:
             pass
+        self._version += 1
         self._engine.reset(None if not seed else np.array([int(seed)], np.uint64))
         self._stale, self._dirty, self._handed = True, False, None
         return self._obs(), {"lines_cleared": 0}
@@ -301,12 +309,12 @@ class Tetris(EnvBase):
 
     def get_state(self) -> TetrisState:
         """Clone the full state incl. the PCG64 generator (reference envs/tetris.py:694-708)."""
-        if self._dirty or self._changed_in_place():
-            self._push()
+        self._flush()
         b, r, g = self._engine.get_state()
         return TetrisState(b.copy(), r.copy(), g.copy())
 
     def set_state(self, state: TetrisState) -> None:
+        self._version += 1
         self._engine.set_state(board=state.board, rec=state.rec, rng=state.rng)
         self._stale, self._dirty, self._handed = True, False, None
 

@@ -37,7 +37,15 @@ def aux_engine(env, **kw) -> Engine:
                   device=u._engine.cfg.device, actions_mapping=u.actions, rewards_mapping=u.rewards, **kw)
 
 
-def mirror(env, aux: Engine) -> None:
-    """Copy the wrapped env's full state (board, record, generator) into the auxiliary engine."""
-    st = env.unwrapped.get_state()
+def mirror(env, aux: Engine, seen=None) -> int:
+    """Copy the wrapped env's full state (board, record, generator) into the auxiliary engine and return the env's state
+    version (`Tetris._version`: every change of its device state counts) that the auxiliary engine now holds.  `seen`: the
+    version it already holds — nothing is copied when that is still the env's state (a wrapper stepping in a loop would
+    otherwise spend a third of its time copying a state back and forth that nobody touched)."""
+    u = env.unwrapped
+    u._flush()  # (host-side edits of the env's attributes count as a change)
+    if seen is not None and seen == u._version:
+        return seen
+    st = u.get_state()
     aux.set_state(board=st.board, rec=st.rec, rng=st.rng)
+    return u._version

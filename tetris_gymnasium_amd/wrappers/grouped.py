@@ -32,6 +32,7 @@ class GroupedActionsObservations(WrapperBase):
         self.legal_actions_mask = np.ones(self.action_space.n)
         self._aux = aux_engine(env, obs_mode=N.OBS_NONE, grouped=True, features=bool(observation_wrappers),
                                terminate_on_illegal=terminate_on_illegal_action)
+        self._seen = None  # the state version of the wrapped env that the auxiliary engine holds (wrappers/_device.py mirror)
 
     def encode_action(self, x, r):
         return x * 4 + r
@@ -51,12 +52,12 @@ class GroupedActionsObservations(WrapperBase):
         return boards[0], None
 
     def observation(self, observation=None):
-        mirror(self.env, self._aux)
+        self._seen = mirror(self.env, self._aux, self._seen)
         return self._observe()[0]
 
     def reset(self, *, seed=None, options=None):
         obs, info = self.env.reset(seed=seed, options=options)
-        mirror(self.env, self._aux)
+        self._seen = mirror(self.env, self._aux, self._seen)
         grouped, current = self._observe()
         info["board"] = current if self.observation_wrappers else obs
         info["action_mask"] = self.legal_actions_mask
@@ -64,16 +65,17 @@ class GroupedActionsObservations(WrapperBase):
 
     def step(self, action):
         u = self.env.unwrapped
-        mirror(self.env, self._aux)
+        self._seen = mirror(self.env, self._aux, self._seen)
         if self.legal_actions_mask[action] == 0 and self.terminate_on_illegal_action:
             observation = np.ones(self.observation_space.shape) * self.observation_space.high
             return observation, u.rewards.invalid_action, True, False, \
                 {"action_mask": self.legal_actions_mask, "lines_cleared": 0}
-        self._aux.step_async(np.array([int(action)], np.int32))  # grouped transition on the device
-        out = self._aux.fetch_step_out()
+        out = self._aux.step_fetch_out([int(action)])  # grouped transition on the device
         term, lines, fl = out["terminated"], out["lines"], int(out["flags"][0])
+        self._seen = None
         b, r, g = self._aux.get_state()
         u.set_state(TetrisState(b, r, g))
+        self._seen = u._version  # (the auxiliary engine holds exactly what was written back)
         illegal = bool(fl & N.OUT_ILLEGAL)
         reward = 0  # (as the reference's Python computes it: wrappers/grouped.py:238, envs/tetris.py:461-474)
         if illegal:

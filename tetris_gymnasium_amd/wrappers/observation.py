@@ -31,7 +31,7 @@ class RgbObservation(_ObservationWrapper):
         self._aux = aux_engine(env, obs_mode=N.OBS_RGB)
 
     def observation(self, observation=None):
-        mirror(self.env, self._aux)
+        self._seen = mirror(self.env, self._aux, getattr(self, "_seen", None))
         self._aux.observe()
         return self._aux.observation()[0]
 
@@ -58,5 +58,5 @@ class FeatureVectorObservation(_ObservationWrapper):
         return np.ascontiguousarray(feats[..., idx])
 
     def observation(self, observation=None):
-        mirror(self.env, self._aux)
+        self._seen = mirror(self.env, self._aux, getattr(self, "_seen", None))
         return self.select(self._aux.features()[1][0])

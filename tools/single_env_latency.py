@@ -92,3 +92,25 @@ for nenv in (16, 256, 4096):
 
         print("TetrisVectorEnv(%5d, %-5s).step             median %.1f  min %.1f us" % ((nenv, kind) + med(vstep)))
         v.close()
+
+# the single-env wrappers the reference's training examples use (examples/train_lin_grouped.py: grouped actions + feature vectors)
+from tetris_gymnasium_amd.wrappers.grouped import GroupedActionsObservations  # noqa: E402
+from tetris_gymnasium_amd.wrappers.observation import FeatureVectorObservation, RgbObservation  # noqa: E402
+
+n = max(200, n // 10)
+for label, mk in (("GroupedActionsObservations(Tetris())", lambda: GroupedActionsObservations(Tetris())),
+                  ("... with [FeatureVectorObservation]", lambda: (lambda t: GroupedActionsObservations(t, observation_wrappers=[FeatureVectorObservation(t)]))(Tetris())),
+                  ("RgbObservation(Tetris())", lambda: RgbObservation(Tetris()))):
+    w = mk()
+    _, info = w.reset(seed=1)
+    st = {"info": info}
+
+    def wstep():
+        m = st["info"].get("action_mask")
+        a = int(rng.choice(np.flatnonzero(m))) if m is not None else int(rng.integers(0, 8))
+        _, _, term, _, st["info"] = w.step(a)
+        if term:
+            _, st["info"] = w.reset()
+
+    print("%-42s median %.1f  min %.1f us" % ((label + ".step",) + med(wstep, warm=50)))
+    w.close()
