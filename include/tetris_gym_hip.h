@@ -27,10 +27,11 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 4 /* 2: tg_config launch knobs, tg_dev_copy, tg_get_state_dev / tg_set_state_dev
+#define TG_ABI_VERSION 5 /* 2: tg_config launch knobs, tg_dev_copy, tg_get_state_dev / tg_set_state_dev
                           * 3: TG_BUF_HOST_PACK, tg_host_pack_layout, tg_fetch_many, tg_step_fetch_many, tg_shape_mask
                           * 4: tg_config.action_ids / rewards (ActionsMapping / RewardsMapping as per-handle data),
-                          *    TG_OUT_COMMITTED / TG_OUT_ILLEGAL in tg_step_out.flags */
+                          *    TG_OUT_COMMITTED / TG_OUT_ILLEGAL in tg_step_out.flags
+                          * 5: tg_observe_as, tg_features_as (a wrapper's observation of ANY handle's current state) */
 
 /* ---- rule-sets (the reference contains two different Tetris rule-sets) ---- */
 #define TG_RULESET_NUMPY 0      /* envs/tetris.py (the graded oracle) */
@@ -314,6 +315,13 @@ int tg_set_state_dev(tg_handle* h, const uint8_t* board_dev, const tg_env_rec* r
  * RGB surfaces themselves: between transitions the step kernel only stores what changed of the holder / queue strips.) */
 int tg_observe(tg_handle* h);
 
+/* The CURRENT state of any handle as observation surface `obs_mode` (TG_OBS_BOARD / TG_OBS_FN / TG_OBS_DICT / TG_OBS_RGB; the last two:
+ * NUMPY rule-set), packed into a caller-owned DEVICE buffer of at least batch x (bytes per env of that surface) — whatever
+ * obs_mode the handle was created with; TG_BUF_OBS is not touched.  This is what an ObservationWrapper around an env
+ * computes (RgbObservation: wrappers/observation.py:38-74) without a second handle that mirrors the env.  Asynchronous on the
+ * handle's stream (tg_dev_download / tg_sync order behind it). */
+int tg_observe_as(tg_handle* h, int obs_mode, void* obs_dev, size_t bytes);
+
 /* Grouped action surface: recompute TG_BUF_LEGAL_MASK and, if boards_dev != NULL, write the wrapper's observation —
  * all 4*W placement boards u8 [B][4W][Hp][Wp] (rotate, centre, hard drop from y = 0, project, clear rows; illegal
  * placement = all ones, game-over placement = all zeros) — into that caller-owned DEVICE buffer, for the current
@@ -339,6 +347,11 @@ int tg_grouped_rollout(tg_handle* h, uint32_t seed, uint32_t counter0, int K, in
  *    (wrappers/grouped.py:124-207 + wrappers/observation.py:236-278) — without building the 4W boards;
  *  - the same 13-entry vector for the current observation (info["board"] of the wrapper). */
 int tg_features(tg_handle* h);
+
+/* The same two feature observations for ANY NUMPY handle (no TG_FLAG_FEATURES needed), written to caller-owned DEVICE buffers:
+ * placement_feats_dev u8 [B][4W][W+3] or NULL, feats_dev u8 [B][W+3] or NULL (FeatureVectorObservation(env).observation:
+ * wrappers/observation.py:236-278).  Asynchronous on the handle's stream. */
+int tg_features_as(tg_handle* h, uint8_t* placement_feats_dev, uint8_t* feats_dev);
 
 int tg_sync(tg_handle* h);
 

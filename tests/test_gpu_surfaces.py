@@ -575,6 +575,53 @@ def test_wrapper_class_grouped(with_features):
     env.close()
 
 
+@pytest.mark.parametrize("W,H,Q,B,made_with", [(10, 20, 4, 300, N.OBS_BOARD), (10, 20, 7, 130, N.OBS_DICT), (7, 14, 2, 100, N.OBS_NONE),
+                                                (20, 40, 7, 70, N.OBS_RGB)])
+def test_observe_as_and_features_as_of_any_handle(W, H, Q, B, made_with):
+    """tg_observe_as / tg_features_as: every observation surface and both feature observations of the CURRENT state, from a
+    handle created with some other obs_mode and without TG_FLAG_FEATURES — what RgbObservation / FeatureVectorObservation compute
+    around an env (wrappers/observation.py:38-74, 236-278).  Against the oracle along a random run; TG_BUF_OBS stays what the
+    handle's own mode wrote."""
+    from tetris_gymnasium_amd.engine import EngineError
+    e = Engine(B, W, H, queue_size=Q, obs_mode=made_with, autoreset=N.AUTORESET_SAME_STEP)
+    o = po.OracleBatch(B, W, H, queue_size=Q)
+    seeds = np.arange(11, 11 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(W * H + Q)
+    for t in range(40):
+        a = rng.integers(0, 8, B)
+        e.step(a); o.step(a, autoreset=po.AUTORESET_SAME_STEP)
+        if t % 4:
+            continue
+        own = None if made_with == N.OBS_NONE else e.observation()
+        np.testing.assert_array_equal(e.observe_as(N.OBS_BOARD), o.observe(po.OBS_BOARD), err_msg=f"board t={t}")
+        np.testing.assert_array_equal(e.observe_as(N.OBS_RGB), o.observe(po.OBS_RGB), err_msg=f"rgb t={t}")
+        got, ref = e.observe_as(N.OBS_DICT), o.observe(po.OBS_DICT)
+        for k in ("board", "active_tetromino_mask", "holder", "queue"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"dict[{k}] t={t}")
+        pl, cu = e.features_as(placement=True, current=True)
+        np.testing.assert_array_equal(cu, o.features(), err_msg=f"features t={t}")
+        np.testing.assert_array_equal(pl, o.grouped_features(), err_msg=f"placement features t={t}")
+        assert e.features_as(placement=False, current=True)[0] is None
+        if own is not None:  # the handle's own observation buffer was not written
+            again = e.observation()
+            for k in (own if isinstance(own, dict) else [None]):
+                np.testing.assert_array_equal(again[k] if k else again, own[k] if k else own)
+    with pytest.raises(EngineError, match="null buffer"):
+        e._chk(e.lib.tg_observe_as(e.h, N.OBS_RGB, None, 0), "tg_observe_as")
+    tiny = e.dev_alloc(64)
+    with pytest.raises(EngineError, match="bytes given"):
+        e._chk(e.lib.tg_observe_as(e.h, N.OBS_RGB, tiny, 64), "tg_observe_as")
+    e.dev_free(tiny)
+    e.close()
+    f = Engine(8, 10, 20, ruleset=N.RULESET_FUNCTIONAL, obs_mode=N.OBS_FN)
+    with pytest.raises(EngineError):
+        f.observe_as(N.OBS_RGB)
+    with pytest.raises(EngineError):
+        f.features_as()
+    f.close()
+
+
 def test_wrappers_notice_a_state_changed_behind_their_back():
     """The wrappers run their kernels on an auxiliary one-env engine that mirrors the wrapped env; the copy is skipped while the
     env's state version says nobody touched it.  Every way the env can change outside the wrapper — base `step`, `set_state`,
@@ -599,6 +646,20 @@ def test_wrappers_notice_a_state_changed_behind_their_back():
         a = int(rng.choice(np.flatnonzero(env.legal_actions_mask)))
         env.step(a); o.grouped_step(np.array([a]))
         check(f"grouped step {t}")
+    # the wrapper steps its auxiliary engine and writes the state back only when somebody asks the env
+    for t in range(3):
+        a = int(rng.choice(np.flatnonzero(env.legal_actions_mask)))
+        env.step(a); o.grouped_step(np.array([a]))
+    assert base._deferred is not None
+    np.testing.assert_array_equal(base.board, o.padded_boards()[0])  # (reading an attribute settles it)
+    assert base._deferred is None
+    ob, orec, _ = o.get_state()
+    st = base.get_state()
+    np.testing.assert_array_equal(st.board, ob)
+    assert (int(st.rec["piece"][0]), int(st.rec["x"][0]), int(st.rec["y"][0])) == (int(orec["piece"][0]), int(orec["x"][0]), int(orec["y"][0]))
+    a = int(rng.choice(np.flatnonzero(env.legal_actions_mask)))
+    env.step(a); o.grouped_step(np.array([a]))
+    assert base._deferred is not None  # ... and a base step right behind a wrapper step starts from the wrapper's result
     for t in range(5):  # base steps behind the wrapper's back
         a = int(rng.integers(0, 8))
         base.step(a); o.step(np.array([a]))
@@ -623,8 +684,7 @@ def test_wrappers_notice_a_state_changed_behind_their_back():
     check("in-place edit of the board")
     base.reset(seed=3); o.reset(np.array([3], np.uint64))
     check("reset")
-    for w in (env, rgb, fv):
-        w._aux.close(); w._aux = None
+    env._aux.close(); env._aux = None  # (the two observation wrappers have no engine of their own)
     base.close()
 
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_record_layouts_match_header():
     assert N.ENV_REC.itemsize == 32 and N.RNG_REC.itemsize == 48
     assert N.ENV_REC.fields["bag"][1] == 10 and N.ENV_REC.fields["queue"][1] == 17 and N.ENV_REC.fields["score"][1] == 24
-    assert C.sizeof(N.TgConfig) == 20 * 4 + 8 * 4 + 4 * 8 and N.STEP_OUT.itemsize == 8  # (ABI 4: + action_ids[8], rewards[4])
+    assert C.sizeof(N.TgConfig) == 20 * 4 + 8 * 4 + 4 * 8 and N.STEP_OUT.itemsize == 8  # (since ABI 4: + action_ids[8], rewards[4])
     assert N.TgConfig.action_ids.offset == 80 and N.TgConfig.rewards.offset == 112 and N.STEP_OUT.fields["flags"][1] == 6
 
 

@@ -13,7 +13,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TG_LIB") or os.path.join(_PKG, "libtetris_gym_hip.so")  # TG_LIB: the test-only legacy build
 
-ABI_VERSION = 4  # include/tetris_gym_hip.h TG_ABI_VERSION
+ABI_VERSION = 5  # include/tetris_gym_hip.h TG_ABI_VERSION
 RULESET_NUMPY, RULESET_FUNCTIONAL = 0, 1
 OBS_NONE, OBS_BOARD, OBS_DICT, OBS_FN, OBS_RGB = 0, 1, 2, 3, 4
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = 0, 1, 2
@@ -87,6 +87,8 @@ SYMBOLS = {
     "tg_grouped_enumerate": (_i, [_vp, _vp]),
     "tg_grouped_sample": (_i, [_vp, C.c_uint32, C.c_uint32]),
     "tg_features": (_i, [_vp]),
+    "tg_observe_as": (_i, [_vp, _i, _vp, C.c_size_t]),
+    "tg_features_as": (_i, [_vp, _vp, _vp]),
     "tg_sync": (_i, [_vp]),
     "tg_timer_start": (_i, [_vp]),
     "tg_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),

@@ -765,10 +765,10 @@ int fail(tg_handle* h, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail((h), TG_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
   } while (0)
 
-size_t obs_bytes_per_env(const tg_config* c) {
+size_t obs_bytes_per_env(const tg_config* c, int obs_mode) {
   const size_t cells = (size_t)c->width * c->height;
   const size_t pc = (size_t)(c->width + 8) * (c->height + 4);
-  switch (c->obs_mode) {
+  switch (obs_mode) {
     case TG_OBS_BOARD:
     case TG_OBS_FN: return cells;
     case TG_OBS_DICT: return 2 * pc + 16 + 16 * (size_t)c->queue_size;
@@ -776,6 +776,7 @@ size_t obs_bytes_per_env(const tg_config* c) {
     default: return 0;
   }
 }
+size_t obs_bytes_per_env(const tg_config* c) { return obs_bytes_per_env(c, c->obs_mode); }
 
 // numpy SeedSequence(seed).generate_state(4, uint64) → PCG64 seeding (numpy/random/bit_generator.pyx,
 // _pcg64.pyx, src/pcg64/pcg64.h pcg_setseq_128_srandom_r).  Host-only set-up code, pinned by tests.
@@ -1917,6 +1918,49 @@ static int run_grouped(tg_handle* h, bool mask, bool sample, uint32_t seed, uint
 }  // extern "C"
 namespace { int run_grouped_mask(tg_handle* h) { return run_grouped(h, true, false, 0, 0); } }
 extern "C" {
+
+int tg_observe_as(tg_handle* h, int obs_mode, void* obs_dev, size_t bytes) {
+  if (!h) return TG_EINVAL;
+  if (!obs_dev) return fail(h, TG_EINVAL, "tg_observe_as: null buffer");
+  if (obs_mode != TG_OBS_BOARD && obs_mode != TG_OBS_FN && obs_mode != TG_OBS_DICT && obs_mode != TG_OBS_RGB)
+    return fail(h, TG_EINVAL, "tg_observe_as: unknown obs_mode %d", obs_mode);
+  if ((obs_mode == TG_OBS_DICT || obs_mode == TG_OBS_RGB) && h->cfg.ruleset != TG_RULESET_NUMPY)
+    return fail(h, TG_EINVAL, "tg_observe_as: TG_OBS_DICT / TG_OBS_RGB are observations of the NUMPY rule-set");
+  const size_t need = (size_t)h->B * obs_bytes_per_env(&h->cfg, obs_mode);
+  if (bytes < need) return fail(h, TG_EINVAL, "tg_observe_as: %zu bytes given, this surface takes %zu", bytes, need);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
+  { int rcb = ensure_board(h); if (rcb != TG_OK) return rcb; }
+  tg::ObserveParams o{};
+  o.board = (const uint8_t*)h->buf[TG_BUF_BOARD];
+  o.rec = (const uint32_t*)h->buf[TG_BUF_REC];
+  o.obs = (uint8_t*)obs_dev;
+  o.batch = h->B;
+  o.obs_mode = obs_mode;
+  o.queue_size = h->Q;
+  o.ruleset = h->cfg.ruleset;
+  h->L.observe(o, h->stream);
+  HIPCHK(h, hipGetLastError());
+  return TG_OK;
+}
+
+int tg_features_as(tg_handle* h, uint8_t* placement_feats_dev, uint8_t* feats_dev) {
+  if (!h) return TG_EINVAL;
+  if (h->cfg.ruleset != TG_RULESET_NUMPY) return fail(h, TG_EINVAL, "tg_features_as: NUMPY rule-set only (wrappers/observation.py wraps envs/tetris.py)");
+  if (!placement_feats_dev && !feats_dev) return TG_OK;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
+  { int rcb = ensure_board(h); if (rcb != TG_OK) return rcb; }
+  tg::FeatureParams f{};
+  f.board = (const uint8_t*)h->buf[TG_BUF_BOARD];
+  f.rec = (const uint32_t*)h->buf[TG_BUF_REC];
+  f.placement_feats = placement_feats_dev;
+  f.feats = feats_dev;
+  f.batch = h->B;
+  h->L.features(f, h->stream);
+  HIPCHK(h, hipGetLastError());
+  return TG_OK;
+}
 
 int tg_grouped_enumerate(tg_handle* h, uint8_t* boards_dev) {
   if (!h) return TG_EINVAL;

@@ -581,6 +581,47 @@ class Engine:
         cf = self._fetch(N.BUF_FEATS, np.empty((self.B, self.W + 3), np.uint8))
         return pf, cf
 
+    def _obs_shapes(self, mode):
+        """[(name, per-env shape, dtype)] of observation surface `mode` for this engine's geometry"""
+        if mode == N.OBS_DICT:
+            return [("board", (self.Hp, self.Wp), np.uint8), ("active_tetromino_mask", (self.Hp, self.Wp), np.uint8),
+                    ("holder", (self.P, self.P), np.uint8), ("queue", (self.P, self.P * self.Q), np.uint8)]
+        if mode == N.OBS_RGB:
+            return [("", (self.Hp, self.Wp + self.P * max(1, self.Q), 3), np.uint8)]
+        if mode in (N.OBS_BOARD, N.OBS_FN):
+            return [("", (self.H, self.W), np.int8 if mode == N.OBS_FN else np.uint8)]
+        raise EngineError(f"no observation surface {mode}")
+
+    def observe_as(self, mode):
+        """The current state as observation surface `mode` (N.OBS_BOARD / OBS_FN / OBS_DICT / OBS_RGB), whatever obs_mode the engine
+        was created with (tg_observe_as): an array [B, ...] or, for OBS_DICT, the dict of four — what an ObservationWrapper around
+        the env returns, without a second engine."""
+        fields = self._obs_shapes(mode)
+        sizes = [self.B * int(np.prod(sh)) * np.dtype(dt).itemsize for _, sh, dt in fields]
+        buf = DeviceBuffer(self, sum(sizes))
+        self._chk(self.lib.tg_observe_as(self.h, mode, C.c_void_p(buf.ptr), buf.nbytes), "tg_observe_as")
+        raw = self.dev_download(buf.ptr, np.empty(buf.nbytes, np.uint8))
+        del buf
+        out, o = {}, 0
+        for (name, sh, dt), n in zip(fields, sizes):
+            out[name] = raw[o:o + n].view(dt).reshape((self.B,) + sh)
+            o += n
+        return out[""] if "" in out else out
+
+    def features_as(self, placement=False, current=True):
+        """(placement_features u8 [B, 4W, W+3] or None, current_features u8 [B, W+3] or None) of the current state for ANY numpy
+        rule-set engine (tg_features_as; `features()` is the same for engines created with features=True)."""
+        npl, ncu = self.B * 4 * self.W * (self.W + 3), self.B * (self.W + 3)
+        buf = DeviceBuffer(self, (npl if placement else 0) + (ncu if current else 0))
+        p_pl = C.c_void_p(buf.ptr) if placement else None
+        p_cu = C.c_void_p(buf.ptr + (npl if placement else 0)) if current else None
+        self._chk(self.lib.tg_features_as(self.h, p_pl, p_cu), "tg_features_as")
+        raw = self.dev_download(buf.ptr, np.empty(buf.nbytes, np.uint8))
+        del buf
+        pl = raw[:npl].reshape(self.B, 4 * self.W, self.W + 3) if placement else None
+        cu = raw[(npl if placement else 0):].reshape(self.B, self.W + 3) if current else None
+        return pl, cu
+
     def final_observation(self):
         return self.observation(N.BUF_FINAL_OBS)
 

@@ -105,6 +105,7 @@ class Tetris(EnvBase):
             raise NotImplementedError("mappings extended with further fields have no meaning to the HIP engine (the reference's "
                                       "step reads the eight actions / four rewards of mappings/*.py)")
         self._hs, self._stale, self._dirty, self._engine, self._handed = {}, False, False, None, None
+        self._deferred = None  # a wrapper's pending write-back of this env's state (_defer / _settle)
         self._version = 0  # counts the changes of the DEVICE state (step / reset / set_state / an upload of host-side edits): wrappers/_device.py
         self.game_over = False
         self.height, self.width = int(height), int(width)
@@ -145,8 +146,22 @@ class Tetris(EnvBase):
         self.render_scaling_factor = render_upscale
 
     # ---- host <-> device state ----------------------------------------------------------------
+    def _defer(self, writeback):
+        """A wrapper advanced its mirror of this env (wrappers/grouped.py steps an auxiliary engine): the env's state is now what
+        `writeback()` will upload.  It runs before anything reads or changes this env (_settle) — in a loop that only talks to the
+        wrapper it never runs, and the state is not copied back and forth once per step."""
+        self._deferred = writeback
+        self._stale, self._dirty, self._handed = True, False, None
+        self._version += 1
+
+    def _settle(self):
+        d, self._deferred = self._deferred, None
+        if d is not None:
+            d()
+
     def _sync_host(self):
         """fill the host-side attributes from the device state if a transition has run since the last download"""
+        self._settle()
         if self._stale:
             self._stale = False
             self._pull()
@@ -168,6 +183,7 @@ class Tetris(EnvBase):
 
     def _flush(self):
         """host-side edits (attribute writes, in-place changes of handed-out objects) → device"""
+        self._settle()
         if self._dirty or self._changed_in_place():
             self._push()
 
@@ -221,6 +237,7 @@ class Tetris(EnvBase):
 
     def _obs(self) -> "dict[str, Any]":
         # TG_BUF_OBS is what the step kernel wrote (after a transition) or what tg_reset / tg_set_state re-packed
+        self._settle()
         o = self._engine.observation()
         return {k: v[0].copy() for k, v in o.items()}
 
@@ -270,6 +287,7 @@ class Tetris(EnvBase):
             super().reset(seed=seed, options=options)
         except TypeError:
             pass
+        self._settle()  # (an unseeded reset continues the generator of the state as it stands)
         self._version += 1
         self._engine.reset(None if not seed else np.array([int(seed)], np.uint64))
         self._stale, self._dirty, self._handed = True, False, None
@@ -314,6 +332,7 @@ class Tetris(EnvBase):
         return TetrisState(b.copy(), r.copy(), g.copy())
 
     def set_state(self, state: TetrisState) -> None:
+        self._deferred = None  # (everything a pending write-back would bring is replaced)
         self._version += 1
         self._engine.set_state(board=state.board, rec=state.rec, rng=state.rng)
         self._stale, self._dirty, self._handed = True, False, None

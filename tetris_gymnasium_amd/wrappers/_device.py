@@ -23,6 +23,9 @@ class WrapperBase:
         return getattr(self.env, name)
 
     def close(self):
+        u = self.unwrapped
+        if getattr(u, "_deferred", None) is not None and self.__dict__.get("_aux") is not None:
+            u._settle()  # (a pending write-back reads the auxiliary engine that is closed below)
         for a in ("_aux",):
             e = self.__dict__.get(a)
             if e is not None:

@@ -33,6 +33,7 @@ class GroupedActionsObservations(WrapperBase):
         self._aux = aux_engine(env, obs_mode=N.OBS_NONE, grouped=True, features=bool(observation_wrappers),
                                terminate_on_illegal=terminate_on_illegal_action)
         self._seen = None  # the state version of the wrapped env that the auxiliary engine holds (wrappers/_device.py mirror)
+        self._wb = self._writeback  # (ONE bound-method object: the env keeps it while our write-back is pending, Tetris._defer)
 
     def encode_action(self, x, r):
         return x * 4 + r
@@ -51,13 +52,26 @@ class GroupedActionsObservations(WrapperBase):
         self.legal_actions_mask = mask[0].astype(np.float64)
         return boards[0], None
 
+    def _writeback(self):
+        """the auxiliary engine's state → the wrapped env (runs when somebody asks the env: Tetris._settle)"""
+        u = self.env.unwrapped
+        b, r, g = self._aux.get_state()
+        u.set_state(TetrisState(b, r, g))
+        self._seen = u._version  # (the auxiliary engine holds exactly what was written back)
+
+    def _mirror(self):
+        """make the auxiliary engine hold the env's state; nothing to do while our own write-back is still pending (nobody has
+        read or changed the env since this wrapper's last step: the auxiliary engine IS its state)"""
+        if self.env.unwrapped._deferred is not self._wb:
+            self._seen = mirror(self.env, self._aux, self._seen)
+
     def observation(self, observation=None):
-        self._seen = mirror(self.env, self._aux, self._seen)
+        self._mirror()
         return self._observe()[0]
 
     def reset(self, *, seed=None, options=None):
         obs, info = self.env.reset(seed=seed, options=options)
-        self._seen = mirror(self.env, self._aux, self._seen)
+        self._mirror()
         grouped, current = self._observe()
         info["board"] = current if self.observation_wrappers else obs
         info["action_mask"] = self.legal_actions_mask
@@ -65,7 +79,7 @@ class GroupedActionsObservations(WrapperBase):
 
     def step(self, action):
         u = self.env.unwrapped
-        self._seen = mirror(self.env, self._aux, self._seen)
+        self._mirror()
         if self.legal_actions_mask[action] == 0 and self.terminate_on_illegal_action:
             observation = np.ones(self.observation_space.shape) * self.observation_space.high
             return observation, u.rewards.invalid_action, True, False, \
@@ -73,9 +87,7 @@ class GroupedActionsObservations(WrapperBase):
         out = self._aux.step_fetch_out([int(action)])  # grouped transition on the device
         term, lines, fl = out["terminated"], out["lines"], int(out["flags"][0])
         self._seen = None
-        b, r, g = self._aux.get_state()
-        u.set_state(TetrisState(b, r, g))
-        self._seen = u._version  # (the auxiliary engine holds exactly what was written back)
+        u._defer(self._wb)  # the env's state is the auxiliary engine's now; it is written back when somebody asks the env
         illegal = bool(fl & N.OUT_ILLEGAL)
         reward = 0  # (as the reference's Python computes it: wrappers/grouped.py:238, envs/tetris.py:461-474)
         if illegal:
@@ -85,5 +97,6 @@ class GroupedActionsObservations(WrapperBase):
         grouped, current = self._observe()
         info = {"lines_cleared": int(lines[0]), "action_mask": self.legal_actions_mask}
         if not illegal:
-            info["board"] = current if self.observation_wrappers else u._obs()
+            # (the base env's observation after the transition, wrappers/grouped.py:261-264 — packed from the auxiliary engine's state)
+            info["board"] = current if self.observation_wrappers else {k: v[0] for k, v in self._aux.observe_as(N.OBS_DICT).items()}
         return grouped, reward, bool(term[0]), False, info

@@ -5,7 +5,7 @@ import numpy as np
 
 from .. import _native as N
 from .._gym_compat import spaces
-from ._device import WrapperBase, aux_engine, mirror
+from ._device import WrapperBase
 
 
 class _ObservationWrapper(WrapperBase):
@@ -20,7 +20,7 @@ class _ObservationWrapper(WrapperBase):
 
 class RgbObservation(_ObservationWrapper):
     """Board on the left, queue strip top right, holder bottom right, as one RGB image (reference
-    wrappers/observation.py:11-74).  Packed on the device (obs_mode TG_OBS_RGB)."""
+    wrappers/observation.py:11-74).  Packed on the device from the wrapped env's own state (tg_observe_as, surface TG_OBS_RGB)."""
 
     def __init__(self, env):
         super().__init__(env)
@@ -28,18 +28,17 @@ class RgbObservation(_ObservationWrapper):
         self.observation_space = spaces.Box(
             low=0, high=255,
             shape=(u.height_padded, u.width_padded + max(u.holder.size, u.queue.size) * u.padding, 3), dtype=np.uint8)
-        self._aux = aux_engine(env, obs_mode=N.OBS_RGB)
 
     def observation(self, observation=None):
-        self._seen = mirror(self.env, self._aux, getattr(self, "_seen", None))
-        self._aux.observe()
-        return self._aux.observation()[0]
+        u = self.env.unwrapped
+        u._flush()  # (host-side edits of the env's attributes → device)
+        return u._engine.observe_as(N.OBS_RGB)[0]
 
 
 class FeatureVectorObservation(_ObservationWrapper):
     """Column heights, max height, holes, bumpiness as uint8 (reference wrappers/observation.py:118-278, incl. its
     row-wipe quirk: `board[active_tetromino_mask] = 0` indexes ROWS with the uint8 mask).  Computed on bit masks on
-    the device (tg_features)."""
+    the device from the wrapped env's own state (tg_features_as)."""
 
     def __init__(self, env, report_height=True, report_max_height=True, report_holes=True, report_bumpiness=True):
         super().__init__(env)
@@ -48,7 +47,6 @@ class FeatureVectorObservation(_ObservationWrapper):
         self.report_holes, self.report_bumpiness = report_holes, report_bumpiness
         n = (u.width if report_height else 0) + int(report_max_height) + int(report_holes) + int(report_bumpiness)
         self.observation_space = spaces.Box(low=0, high=len(u.tetrominoes), shape=(n,), dtype=np.uint8)
-        self._aux = aux_engine(env, obs_mode=N.OBS_NONE, grouped=True, features=True)
 
     def select(self, feats):
         """Pick the reported entries out of [..., W + 3] vectors (heights | max | holes | bumpiness)."""
@@ -58,5 +56,6 @@ class FeatureVectorObservation(_ObservationWrapper):
         return np.ascontiguousarray(feats[..., idx])
 
     def observation(self, observation=None):
-        self._seen = mirror(self.env, self._aux, getattr(self, "_seen", None))
-        return self.select(self._aux.features()[1][0])
+        u = self.env.unwrapped
+        u._flush()
+        return self.select(u._engine.features_as(placement=False, current=True)[1][0])
