@@ -44,3 +44,16 @@ def test_vector_env_under_record_episode_statistics(mode):
     assert n > 0
     assert len(envs.get_attr("width")) == 64 and envs.call("height")[0] == 20
     wrapped.close()
+
+
+def test_gym_make_builds_the_registered_drop_in():
+    """the reference's examples start with gym.make("tetris_gymnasium/Tetris", ...) (envs/__init__.py:10-14)"""
+    import tetris_gymnasium_amd.envs  # noqa: F401  (registers the id)
+    from tetris_gymnasium_amd.envs.tetris import Tetris
+
+    env = gym.make("tetris_gymnasium_amd/Tetris", width=8, height=16)
+    assert isinstance(env.unwrapped, Tetris) and env.unwrapped.width == 8
+    obs, info = env.reset(seed=1)
+    assert env.observation_space.contains(obs)
+    env.close()
+
