@@ -522,6 +522,14 @@ def test_wrapper_classes_rgb_and_features():
             obs, _ = env.reset(); o.reset()
             np.testing.assert_array_equal(obs, o.observe(po.OBS_RGB)[0])
     env.close()
+    # render_mode="rgb_array" is that image, upscaled (envs/tetris.py:364-373: np.kron(get_rgb(_get_obs()), ones(k, k, 1)))
+    r = Tetris(render_mode="rgb_array", render_upscale=3)
+    r.reset(seed=42); o.reset(np.array([42], np.uint64))
+    r.step(6); o.step(np.array([6]))
+    frame = r.render()
+    assert frame.shape == (72, 102, 3) and frame.dtype == np.uint8
+    np.testing.assert_array_equal(frame, np.kron(o.observe(po.OBS_RGB)[0], np.ones((3, 3, 1), np.uint8)))
+    r.close()
 
     fx = replay.load(os.path.join(os.path.dirname(__file__), "golden"), "ref_tests_grouped")
     env = FeatureVectorObservation(Tetris())

@@ -342,8 +342,9 @@ class Tetris(EnvBase):
             proj = self.crop_padding(self.project_tetromino())
             return "\n".join("".join(row) for row in np.where(proj == 0, ".", proj.astype(str)))
         if self.render_mode == "rgb_array":
-            colors = np.array([p.color_rgb for p in self.pixels], np.uint8)
-            img = colors[self.crop_padding(self.project_tetromino())]
+            # reference envs/tetris.py:364-373: get_rgb(_get_obs()) — board | queue strip / holder, the RgbObservation image — upscaled
+            self._flush()
+            img = self._engine.observe_as(N.OBS_RGB)[0]
             k = self.render_scaling_factor
             return np.kron(img, np.ones((k, k, 1), np.uint8))
         return None
