@@ -529,6 +529,17 @@ def test_wrapper_classes_rgb_and_features():
     frame = r.render()
     assert frame.shape == (72, 102, 3) and frame.dtype == np.uint8
     np.testing.assert_array_equal(frame, np.kron(o.observe(po.OBS_RGB)[0], np.ones((3, 3, 1), np.uint8)))
+    # the host-side helpers foreign wrappers call (wrappers/observation.py:82 get_rgb(_get_obs()); wrappers/grouped.py:174)
+    np.testing.assert_array_equal(r.get_rgb(r._get_obs()), o.observe(po.OBS_RGB)[0])
+    assert r._get_info() == {"lines_cleared": 0}
+    pb = r.create_board()
+    pb[19, 4:14] = 3; pb[17, 4:14] = 5; pb[18, 4:9] = 2; pb[16, 6] = 7
+    want = r.create_board()
+    want[19, 4:9] = 2; want[18, 6] = 7
+    got, n = r.clear_filled_rows(pb)
+    assert n == 2 and got is pb
+    np.testing.assert_array_equal(got, want)
+    assert r.clear_filled_rows(r.create_board())[1] == 0
     r.close()
 
     fx = replay.load(os.path.join(os.path.dirname(__file__), "golden"), "ref_tests_grouped")

@@ -325,6 +325,33 @@ class Tetris(EnvBase):
     def score(self, rows_cleared) -> int:
         return (rows_cleared ** 2) * self.width
 
+    # (further helpers of the reference class that foreign wrappers call on HOST arrays: wrappers/grouped.py:174 clears the rows of a
+    # projected copy, wrappers/observation.py:82 renders `_get_obs()`; the env's own transition — incl. its row clears — is the step kernel)
+    def clear_filled_rows(self, board):
+        """reference envs/tetris.py:481-512: rows without a free cell that are not bedrock leave, empty rows enter at the top (in place)"""
+        full = np.all(board != 0, axis=1) & np.any(board != 1, axis=1)
+        n = int(np.count_nonzero(full))
+        if n:
+            board[n:] = board[~full]
+            board[:n] = 1
+            board[:n, self.padding: self.padding + self.width] = 0
+        return board, n
+
+    def _get_obs(self):
+        """reference envs/tetris.py:566-615 (packed on the device)"""
+        return self._obs()
+
+    def _get_info(self):
+        return {"lines_cleared": 0}
+
+    def get_rgb(self, observation):
+        """reference envs/tetris.py:309-343: an observation dict as ONE image — board left, queue strip top right, holder bottom right"""
+        b, h, q = (np.asarray(observation[k]) for k in ("board", "holder", "queue"))
+        side = np.ones((b.shape[0], max(h.shape[1], q.shape[1])), np.int64)
+        side[: q.shape[0], : q.shape[1]] = q
+        side[b.shape[0] - h.shape[0]:, : h.shape[1]] = h
+        return np.array([p.color_rgb for p in self.pixels], np.uint8)[np.hstack((b.astype(np.int64), side))]
+
     def get_state(self) -> TetrisState:
         """Clone the full state incl. the PCG64 generator (reference envs/tetris.py:694-708)."""
         self._flush()
