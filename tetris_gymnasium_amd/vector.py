@@ -142,6 +142,7 @@ class _HostStep:
             per_slot = max(1, sum(int(b) for b in self.nbytes))
             self.pool_slots = min(self._POOL_SLOTS, self._POOL_BYTES // per_slot)
         self.act_ptrs = (C.c_void_p * self.n)()
+        self._act_stage = None
 
     # -- destination memory ---------------------------------------------------------------------------------------------
     _POOL_SLOTS = 3
@@ -252,7 +253,12 @@ class _HostStep:
         slot = self._next_slot()
         acts = None
         if actions is not None:
-            base = actions.ctypes.data
+            # through a page-locked copy: an upload from pageable memory is staged and waited for inside the runtime (the call waits
+            # for every stream before it returns, so the block is free again at the next step)
+            if self._act_stage is None:
+                self._act_stage = v.engines[0].pinned_bytes(4 * v.num_envs).view(np.int32)
+            self._act_stage[:] = actions
+            base = self._act_stage.ctypes.data
             for k, (lo, _) in enumerate(v.ranges):
                 self.act_ptrs[k] = base + 4 * lo
             acts = self.act_ptrs
