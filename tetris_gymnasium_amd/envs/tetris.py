@@ -295,8 +295,14 @@ class Tetris(EnvBase):
 
     # ---- helpers the reference's wrappers / tests call ------------------------------------------
     def create_board(self) -> np.ndarray:
-        b = np.zeros((self.height, self.width), np.uint8)
-        return np.pad(b, ((0, self.padding), (self.padding, self.padding)), constant_values=1)
+        """reference envs/tetris.py:623-641: the empty playfield inside its bedrock frame (a copy of a template: np.pad costs 25 us,
+        and the host copy of the board is rebuilt after every transition somebody looks at)"""
+        t = self.__dict__.get("_board_tmpl")
+        if t is None or t.shape != (self.height + self.padding, self.width + 2 * self.padding):
+            t = np.ones((self.height + self.padding, self.width + 2 * self.padding), np.uint8)
+            t[: self.height, self.padding: self.padding + self.width] = 0
+            self.__dict__["_board_tmpl"] = t
+        return t.copy()
 
     def get_tetromino_slices(self, tetromino, x, y):
         h, w = tetromino.matrix.shape
