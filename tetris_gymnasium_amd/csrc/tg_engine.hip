@@ -1294,6 +1294,9 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
     return fail(nullptr, TG_EUNSUPPORTED, "tg_create: the earlier step kernels of the test-only library deal the 7-bag only");
   if ((cfg->flags & (TG_FLAG_CUSTOM_ACTIONS | TG_FLAG_CUSTOM_REWARDS)) && g_kernel_lanes != 16)
     return fail(nullptr, TG_EUNSUPPORTED, "tg_create: custom mappings need the default step kernel (TG_KERNEL=bits)");
+  if (!built_in && g_kernel_lanes != 16)  // (the run-time compiled module holds the default step kernel only: launching it for a handle without column masks faults)
+    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: board %dx%d is not built in (%s); the earlier step kernels of the test-only library exist for the "
+                "built-in sizes only", cfg->width, cfg->height, built_sizes().c_str());
   if (!built_in) {  // any other size: the same kernels, compiled for it now (or taken from the on-disk cache)
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, TG_EHIP, "tg_create: hipSetDevice failed");
     RtcSize* rs = nullptr;
