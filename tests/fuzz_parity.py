@@ -62,7 +62,11 @@ for ci in range(NCFG):
     grouped = numpy_rules and r.random() < 0.25
     toi = bool(r.random() < 0.5)
     obs = (N.OBS_BOARD if grouped else [N.OBS_BOARD, N.OBS_DICT, N.OBS_RGB, N.OBS_NONE][int(r.integers(4))]) if numpy_rules else N.OBS_FN
-    B = int(r.choice([1, 3, 17, 64, 100, 129, 200, 333]))
+    B = int(r.choice([1, 3, 17, 64, 100, 129, 200, 333, 2048 if W * H <= 240 else 260]))
+    streams = 1
+    if r.random() < 0.06 and W * H <= 200 and not grouped and obs in (N.OBS_BOARD, N.OBS_FN, N.OBS_NONE):
+        B, streams = 16384 + 128 * int(r.integers(0, 3)), 2  # env shards on two streams (tg_config.streams)
+    packed = r.random() < 0.2  # TG_PACKED=1: the board as nibbles in HBM where the geometry has that build (else ignored)
     if grouped:
         B = (B + 3) // 4 * 4  # (tg_rollout: int8 action rows of a grouped handle are packed by fours)
     fuse, ring_fill, rng_every = int(r.choice([1, 2, 5, 16])), int(r.integers(0, 4)), int(r.integers(1, 4))
@@ -71,19 +75,20 @@ for ci in range(NCFG):
         ids = tuple(int(v) for v in r.permutation(8))
         rws = (float(r.integers(-4, 5)) / 2, 1.0, float(r.integers(-9, 1)), -0.25)
     tag = (f"{W}x{H} {'numpy' if numpy_rules else 'functional'} Q={Q} g={int(gravity)} autoreset={autoreset} obs={obs} grouped={int(grouped)}"
-           f"{'/toi' if grouped and toi else ''} B={B} fuse={fuse} ring={ring_fill} rng_every={rng_every}{' mapped' if ids else ''}")
+           f"{'/toi' if grouped and toi else ''} B={B}{' streams=2' if streams > 1 else ''}{' packed' if packed else ''} fuse={fuse} ring={ring_fill} rng_every={rng_every}{' mapped' if ids else ''}")
+    os.environ["TG_PACKED"] = "1" if packed else "0"
     try:
         e = Engine(B, W, H, ruleset=rs, gravity=gravity, queue_size=Q, obs_mode=obs, autoreset=autoreset, grouped=grouped,
-                   terminate_on_illegal=toi, fuse=fuse, ring_fill=ring_fill, rng_every=rng_every, actions_mapping=ids, rewards_mapping=rws)
+                   terminate_on_illegal=toi, fuse=fuse, ring_fill=ring_fill, rng_every=rng_every, actions_mapping=ids, rewards_mapping=rws, streams=streams)
     except Exception as ex:  # (a configuration tg_create refuses is not a parity failure: say so and go on)
         print(f"skip {tag}: {str(ex)[:120]}")
         continue
-    o = po.OracleBatch(B, W, H, rs, gravity, Q, action_ids=ids, rewards=rws)
+    o = po.OracleBatch(B, W, H, rs, gravity, Q, action_ids=ids, rewards=rws, nthreads=8 if B > 1000 else 1)
     seeds = r.integers(1, 1 << 40, B).astype(np.uint64)
     e.reset(seeds); o.reset(seeds)
     same_state(e, o, numpy_rules, f"after reset [{tag}]")
     na = 4 * W if grouped else (8 if numpy_rules else 7)
-    done, total = 0, int(os.environ.get("FUZZ_STEPS", 260))
+    done, total = 0, int(os.environ.get("FUZZ_STEPS", 260)) // (4 if B > 1000 else 1)
     while done < total:
         K = int(r.choice([1, 1, 3, 16, 40]))
         acts = r.integers(0, na, (K, B))
@@ -92,7 +97,7 @@ for ci in range(NCFG):
             got = (None, re_[None], te[None], le[None])
             got_obs_last = e.observation() if obs != N.OBS_NONE else None
         else:
-            if B % 4 and True:  # (tg_rollout needs a batch that is a multiple of 4: single steps otherwise)
+            if B % 4:  # (tg_rollout needs a batch that is a multiple of 4: single steps otherwise)
                 res = [e.step(a.astype(np.int32)) for a in acts]
                 got = (None, np.stack([x[0] for x in res]), np.stack([x[1] for x in res]), np.stack([x[2] for x in res]))
             else:
