@@ -313,10 +313,13 @@ def gen_grouped(ref, name, width, height, queue_size, B, T, seed, n_enum, init_b
           f"lines={int(lines.sum())} enums={ne} illegal={(reward<0).sum()}")
 
 
-def gen_grouped_features(ref, name, width, height, queue_size, n_states, seed, dense=False):
+def gen_grouped_features(ref, name, width, height, queue_size, n_states, seed, dense=False, prefull=False):
     """GroupedActionsObservations(env, observation_wrappers=[FeatureVectorObservation(env)]) — the observation
     examples/train_lin_grouped.py trains on: for each of the 4W placements the 13-entry feature vector of the
-    resulting board (wrappers/grouped.py:124-207 + wrappers/observation.py:236-278), plus info["board"]."""
+    resulting board (wrappers/grouped.py:124-207 + wrappers/observation.py:236-278), plus info["board"].
+    prefull: every recorded state gets one to three rows that are ALREADY full (a board only a caller can provide — during play a
+    full row never survives its lock): `clear_filled_rows` of every placement takes them too (wrappers/grouped.py:174,
+    envs/tetris.py:493); the placement boards of the wrapper WITHOUT observation wrappers are recorded beside the features."""
     rng = np.random.default_rng(seed)
     NA, Hp, Wp = 4 * width, height + 4, width + 8
     boards = np.zeros((n_states, Hp, Wp), np.uint8)
@@ -327,6 +330,8 @@ def gen_grouped_features(ref, name, width, height, queue_size, n_states, seed, d
     masks = np.zeros((n_states, NA), np.uint8)
     base = make_env(ref, width, height, True, queue_size)
     env = ref.GroupedActionsObservations(base, observation_wrappers=[ref.FeatureVectorObservation(base)])
+    plain = ref.GroupedActionsObservations(base) if prefull else None
+    pboards = np.zeros((n_states, NA, Hp, Wp), np.uint8) if prefull else None
     dense_boards_, _ = dense_boards(width, height, 64, seed + 1)
     obs, info = env.reset(seed=seed)
     k = 0
@@ -335,6 +340,12 @@ def gen_grouped_features(ref, name, width, height, queue_size, n_states, seed, d
             base.board = dense_boards_[int(rng.integers(0, 64))].copy()
             obs = env.observation(base._get_obs())
             info = {"board": ref.FeatureVectorObservation(base).observation(base._get_obs())}
+        if prefull:
+            for row in rng.choice(np.arange(height // 2, height), size=int(rng.integers(1, 4)), replace=False):
+                base.board[row, 4:4 + width] = rng.integers(2, 9, width)
+            obs = env.observation(base._get_obs())
+            info = {"board": ref.FeatureVectorObservation(base).observation(base._get_obs())}
+            pboards[k] = plain.observation(base._get_obs())
         boards[k] = base.board
         pieces[k] = base.active_tetromino.id - 2
         mats[k] = matrix16(base.active_tetromino)
@@ -346,8 +357,9 @@ def gen_grouped_features(ref, name, width, height, queue_size, n_states, seed, d
         obs, r, d, _, info = env.step(int(rng.choice(legal)))
         if d:
             obs, info = env.reset()
+    extra = {"pboards": pboards} if prefull else {}
     np.savez_compressed(os.path.join(OUT, name + ".npz"), width=width, height=height, queue_size=queue_size,
-                        boards=boards, pieces=pieces, mats=mats, feats=feats, masks=masks, cur_feats=cur_feats)
+                        boards=boards, pieces=pieces, mats=mats, feats=feats, masks=masks, cur_feats=cur_feats, **extra)
     print(f"{name}: {n_states} states, feature tensors {feats.shape}, max feature {feats.max()}")
 
 
@@ -477,6 +489,8 @@ def main():
                                                     init_boards=dense_boards(10, 20, 16, 8)[0]),
         "grouped_features_10x20": lambda: gen_grouped_features(ref, "grouped_features_10x20", 10, 20, 4, 192, 41, dense=True),
         "grouped_features_20x40": lambda: gen_grouped_features(ref, "grouped_features_20x40", 20, 40, 7, 24, 42, dense=True),
+        "grouped_features_prefull_6x12": lambda: gen_grouped_features(ref, "grouped_features_prefull_6x12", 6, 12, 4, 48, 43, prefull=True),
+        "grouped_features_prefull_10x20": lambda: gen_grouped_features(ref, "grouped_features_prefull_10x20", 10, 20, 4, 32, 44, prefull=True),
         "ref_tests_grouped": lambda: gen_ref_tests_grouped(ref),
         "features": lambda: gen_features(ref),
         # non-stock ActionsMapping / RewardsMapping (envs/tetris.py:83-84, 189-190): a permutation of the ids with float rewards;

@@ -86,7 +86,8 @@ def test_device_side_legal_sampling():
     assert (seen > 0).sum() > 3 * W  # covers most of the action space
 
 
-@pytest.mark.parametrize("name", ["grouped_features_10x20", "grouped_features_20x40"])
+@pytest.mark.parametrize("name", ["grouped_features_10x20", "grouped_features_20x40", "grouped_features_prefull_6x12",
+                                  "grouped_features_prefull_10x20"])
 def test_placement_features_against_reference_fixture(golden_dir, name):
     """[4W][W+3] feature tensor of GroupedActionsObservations + FeatureVectorObservation, computed on bit masks."""
     fx = replay.load(golden_dir, name)
@@ -105,6 +106,8 @@ def test_placement_features_against_reference_fixture(golden_dir, name):
     np.testing.assert_array_equal(pf, fx["feats"])
     np.testing.assert_array_equal(cf, fx["cur_feats"])
     np.testing.assert_array_equal(e.legal_mask(), fx["masks"])
+    if "pboards" in fx:  # (the *_prefull fixtures: rows that were full BEFORE the placement leave with every placement, envs/tetris.py:493)
+        np.testing.assert_array_equal(e.placement_boards()[1], fx["pboards"])
 
 
 @pytest.mark.parametrize("W,H", [(10, 20), (7, 14), (6, 9)])

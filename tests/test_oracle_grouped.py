@@ -82,7 +82,8 @@ def test_feature_vector(golden_dir):
     assert list(f[:10]) == list(g["heights"]) and f[10] == 11 and f[11] == 3 and f[12] == 14
 
 
-@pytest.mark.parametrize("name", ["grouped_features_10x20", "grouped_features_20x40"])
+@pytest.mark.parametrize("name", ["grouped_features_10x20", "grouped_features_20x40", "grouped_features_prefull_6x12",
+                                  "grouped_features_prefull_10x20"])
 def test_grouped_placement_features(golden_dir, name):
     """What examples/train_lin_grouped.py trains on: [4W][W+3] feature tensor per state + info["board"]."""
     fx = replay.load(golden_dir, name)
@@ -97,3 +98,5 @@ def test_grouped_placement_features(golden_dir, name):
     np.testing.assert_array_equal(o.grouped_enumerate(), fx["masks"])
     np.testing.assert_array_equal(o.grouped_features(), fx["feats"])
     np.testing.assert_array_equal(o.features(), fx["cur_feats"])
+    if "pboards" in fx:  # (the *_prefull fixtures: boards with rows that were full BEFORE the placement — every placement clears them too)
+        np.testing.assert_array_equal(o.grouped_enumerate(boards=True)[1], fx["pboards"])

@@ -109,8 +109,10 @@ __global__ __launch_bounds__(kBlock) void features_kernel(const FeatureParams p)
     }
     if (lane < H) rm[lane] = rowbits;
   }
-  wave_sync();
   constexpr uint32_t FULL = W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u);
+  // rows that are ALREADY full (only a caller-provided board holds one): clear_filled_rows takes them with every placement
+  const M PRE = (M)__ballot(lane < H && (rowbits & FULL) == FULL);
+  wave_sync();
   const M FLOOR = (M)(M(1) << H);
 
   const int n_half = s.piece == 0 ? 2 : 1;  // matrix.shape[1] // 2
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(kBlock) void features_kernel(const FeatureParams p)
           // collides where it lands (only possible at y = 0): "game over placement" → zero board
 #pragma unroll
           for (int j = 0; j < 4; ++j) zero = zero || ((colm[j] >> (y + kk[j])) & 1);
-          if (!zero) {  // completed rows among the rows the piece touches
+          if (!zero) {  // completed rows among the rows the piece touches (+ the rows that were full before)
+            F = PRE;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int rj = y + kk[j];

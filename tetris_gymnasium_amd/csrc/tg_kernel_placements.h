@@ -60,6 +60,7 @@ __global__ __launch_bounds__(kBlock) void placements_kernel(const PlacementParam
   wave_sync();
 
   // board → bit masks (lane r owns row r; one ballot per column), and the padded base board (envs/tetris.py:632-641)
+  bool pre_full = false;  // a row that is ALREADY full (only a caller-provided board holds one): clear_filled_rows takes it with every placement
   {
     uint32_t rowbits = 0;
     const int r = lane < H ? lane : H - 1;
@@ -71,6 +72,10 @@ __global__ __launch_bounds__(kBlock) void placements_kernel(const PlacementParam
       if (lane == c) cm[c] = (M)colm;
     }
     if (lane < H) rm[lane] = rowbits;
+    {
+      constexpr uint32_t FULLC = W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u);
+      pre_full = __ballot(lane < H && (rowbits & FULLC) == FULLC) != 0;
+    }
     for (int i = lane; i < PB; i += 64) {
       const int R = i / WP, C = i - R * WP;
       const bool inb = R < H && C >= 4 && C < W + 4;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void placements_kernel(const PlacementParam
         }
       }
       // (phase 2 recomputes the full-row mask from the row masks, so tall boards need no 64-bit field here)
-      desc[a] = make_uint4(kind | (y << 8) | ((uint32_t)s.val << 16) | ((F != 0 ? 1u : 0u) << 24), pos01, pos23, 0u);
+      desc[a] = make_uint4(kind | (y << 8) | ((uint32_t)s.val << 16) | (((F != 0 || (pre_full && kind == 0)) ? 1u : 0u) << 24), pos01, pos23, 0u);
     }
   }
   wave_sync();

@@ -344,7 +344,8 @@ class Tetris(EnvBase):
         return board, n
 
     def _get_obs(self):
-        """reference envs/tetris.py:566-615 (packed on the device)"""
+        """reference envs/tetris.py:566-615 (packed on the device; host-side edits of the attributes are uploaded first)"""
+        self._flush()
         return self._obs()
 
     def _get_info(self):
