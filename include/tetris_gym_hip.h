@@ -311,8 +311,8 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
 int tg_get_state_dev(tg_handle* h, uint8_t* board_dev, tg_env_rec* rec_dev, tg_rng_rec* rng_dev);
 int tg_set_state_dev(tg_handle* h, const uint8_t* board_dev, const tg_env_rec* rec_dev, const tg_rng_rec* rng_dev);
 
-/* Re-pack the observation buffer from the current state without stepping.  (tg_reset and tg_set_state re-pack the DICT /
- * RGB surfaces themselves: between transitions the step kernel only stores what changed of the holder / queue strips.) */
+/* Re-pack the observation buffer from the current state without stepping.  (tg_reset, tg_set_state and tg_set_state_dev re-pack
+ * it themselves; between transitions the step kernel stores only what changed of the DICT / RGB surfaces' holder / queue strips.) */
 int tg_observe(tg_handle* h);
 
 /* The CURRENT state of any handle as observation surface `obs_mode` (TG_OBS_BOARD / TG_OBS_FN / TG_OBS_DICT / TG_OBS_RGB; the last two:

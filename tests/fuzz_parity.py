@@ -118,6 +118,16 @@ for ci in range(NCFG):
         if got_obs_last is not None:
             same_obs(got_obs_last, o.observe(PO_OBS[obs]), f"after {done} transitions [{tag}]")
         same_state(e, o, numpy_rules, f"after {done} transitions [{tag}]")
+        if numpy_rules and r.random() < 0.3:  # the wrappers' views of the current state, from whatever handle this is
+            w = f"after {done} transitions [{tag}]"
+            same_obs(e.observe_as(N.OBS_DICT), o.observe(po.OBS_DICT), "observe_as(dict) " + w)
+            same_obs(e.observe_as(N.OBS_RGB), o.observe(po.OBS_RGB), "observe_as(rgb) " + w)
+            pl, cu = e.features_as(placement=True, current=True)
+            assert np.array_equal(pl, o.grouped_features()) and np.array_equal(cu, o.features()), "features_as differ " + w
+            if grouped:
+                m, bds = e.placement_boards()
+                mo, bo_ = o.grouped_enumerate(boards=True)
+                assert np.array_equal(m, mo) and np.array_equal(bds, bo_), "placement boards / action mask differ " + w
         u = r.random()
         if u < 0.15:  # masked reset, some envs with a new seed (NUMPY: 0 keeps the running generator)
             mask = (r.random(B) < 0.3).astype(np.uint8)
@@ -126,7 +136,18 @@ for ci in range(NCFG):
                 sd = r.integers(1, 1 << 40, B).astype(np.uint64)
             e.reset(sd, mask); o.reset(sd, mask)
             same_state(e, o, numpy_rules, f"after a masked reset at {done} [{tag}]")
-        elif u < 0.25:  # the state through the host and back: nothing may change, the look-ahead is rebuilt
+        elif u < 0.33 and not (packed and not numpy_rules):
+            # a caller-provided board: random cells, some rows completely full (play never leaves one: the next lock clears them,
+            # envs/tetris.py:493), the active piece wherever it is — possibly on top of filled cells.  (Packed FUNCTIONAL handles
+            # refuse the sums such an overlap makes: tests/test_gpu_parity.py covers that refusal.)
+            bb = np.where(r.random((B, H, W)) < r.uniform(0.1, 0.6), r.integers(2, 9, (B, H, W)), 0).astype(np.uint8)
+            bb[:, : H // 3] = 0
+            for i in np.flatnonzero(r.random(B) < 0.5):
+                for row in r.choice(np.arange(H // 3, H), size=int(r.integers(1, 4)), replace=False):
+                    bb[i, row] = r.integers(2, 9, W)
+            e.set_state(board=bb); o.set_state(board=bb)
+            same_state(e, o, numpy_rules, f"after a board upload at {done} [{tag}]")
+        elif u < 0.43:  # the state through the host and back: nothing may change, the look-ahead is rebuilt
             st = e.get_state()
             e.set_state(*st)
             same_state(e, o, numpy_rules, f"after a get_state / set_state round trip at {done} [{tag}]")

@@ -983,3 +983,43 @@ def test_functional_bag_length_engine_vs_oracle(k, B, autoreset, monkeypatch):
     a = rng.integers(0, 7, B)
     np.testing.assert_array_equal(e.step(a)[0], o.step(a, autoreset=autoreset)[0])
     e.close()
+
+
+@pytest.mark.parametrize("gravity", [False, True])
+@pytest.mark.parametrize("fuse", [1, 16])
+def test_functional_piece_uploaded_on_top_of_filled_cells(gravity, fuse):
+    """A state only an upload makes (found by tests/fuzz_parity.py): the active piece of the functional rule-set lying ON filled
+    cells.  It stays there while nothing moves it (every move into a collision is refused: envs/tetris_fn.py:161-273; with gravity
+    off for as long as the caller likes), the observation is (board > 0) + (-1) * piece cell by cell — 1 - 1 = 0 under the piece
+    (envs/tetris_fn.py:148-155) — and un-drawing the piece inside a launch of several transitions must give the covered cells back.
+    Also: TG_BUF_OBS shows the uploaded state right after tg_set_state, for the BOARD / FN surfaces too."""
+    B, W, H = 96, 10, 20
+    e = Engine(B, W, H, ruleset=N.RULESET_FUNCTIONAL, gravity=gravity, queue_size=7, obs_mode=N.OBS_FN, fuse=fuse)
+    o = po.OracleBatch(B, W, H, po.RULESET_FUNCTIONAL, gravity, 7)
+    seeds = np.arange(21, 21 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(5)
+    for round_ in range(3):
+        b, _, _ = o.get_state()
+        b[:] = np.where(rng.random(b.shape) < 0.5, rng.integers(2, 9, b.shape), 0)
+        b[:, :4] = np.where(rng.random((B, 4, W)) < 0.7, 3, 0)  # dense where the pieces spawn: most of them lie on filled cells
+        b[B // 2:, :3] = 0                                       # ... the other half of the batch plays on
+        e.set_state(board=b); o.set_state(board=b)
+        np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_FN), err_msg="TG_BUF_OBS after tg_set_state")
+        acts = rng.integers(0, 7, (24, B))
+        obs, rew, term, lines = e.rollout(acts.astype(np.int8))
+        for k in range(24):
+            ro, to, lo = o.step(acts[k])
+            np.testing.assert_array_equal(obs[k], o.observe(po.OBS_FN), err_msg=f"observation of transition {k}, round {round_}")
+            np.testing.assert_array_equal(term[k], to); np.testing.assert_array_equal(rew[k], ro)
+        be, re_, _ = e.get_state(); bo, ro_, _ = o.get_state()
+        np.testing.assert_array_equal(be, bo)
+        for f in ("piece", "rot", "x", "y", "flags", "score"):
+            np.testing.assert_array_equal(re_[f], ro_[f], err_msg=f)
+    e.reset(seeds); o.reset(seeds)  # (a full reset: the plain draw is back — nothing to compare but the results)
+    acts = rng.integers(0, 7, (16, B))
+    obs, rew, term, lines = e.rollout(acts.astype(np.int8))
+    for k in range(16):
+        o.step(acts[k])
+        np.testing.assert_array_equal(obs[k], o.observe(po.OBS_FN))
+    e.close()

@@ -481,7 +481,16 @@ __device__ __forceinline__ void emit_obs(uint8_t* slab, int lane, uint8_t* dst_e
   if (mode != TG_OBS_BOARD && mode != TG_OBS_FN) return;
   // the piece is only ever drawn onto free cells (NUMPY: hidden when it collides, envs/tetris.py:558-560;
   // FUNCTIONAL: hidden when game over), so a plain byte write equals the reference's `+=`
-  if (show) stamp<W, H>(slab, lane, shape, x, y, mode == TG_OBS_FN ? 0xFFu : (uint32_t)val, false);
+  if (show && mode == TG_OBS_FN) {
+    // (board > 0) + (-1) * piece (envs/tetris_fn.py:148-155): -1 on a free cell, 1 - 1 = 0 on a filled one (a piece uploaded on top of
+    // filled cells)
+    const int cell = lane & 15;
+    const int row = y + (cell >> 2), col = x + (cell & 3) - 4;
+    if (lane < 16 && ((shape >> cell) & 1u) && (unsigned)col < (unsigned)W && (unsigned)row < (unsigned)H)
+      slab[row * W + col] = slab[row * W + col] ? (uint8_t)0 : (uint8_t)0xFF;
+  } else if (show) {
+    stamp<W, H>(slab, lane, shape, x, y, (uint32_t)val, false);
+  }
   wave_sync();
   const uint32_t* slab_dw = reinterpret_cast<const uint32_t*>(slab);
 #pragma unroll

@@ -682,6 +682,41 @@ __global__ __launch_bounds__(256) void sanitize_state_kernel(const SanitizeParam
   if (bad) atomicOr(p.err, bad);
 }
 
+// FUNCTIONAL handles, after a state upload: does any env's piece lie ON TOP of filled cells (and would be drawn: not game over)?  Only an
+// upload makes such a state — every move into a collision is refused (envs/tetris_fn.py:161-273), and it lasts for as long as nothing
+// moves the piece.  The step kernel draws the piece for the observation by plain byte writes and un-draws it with zeros, which is the
+// reference's `(board > 0) + (-1) * piece` (envs/tetris_fn.py:148-155) only on free cells; doing it cell by cell in the kernel costs every
+// launch 2-8 % (profiles/r05/ab_fn_exact_marker.log).  So the rare state is detected here and handled by the host: while a handle may hold
+// one (tg_handle::fn_overlap), a transition is one launch of one transition (nothing is un-drawn) followed by the observe kernel, whose
+// draw is exact (tg_common.h emit_obs).  Raises word 4 of tg_handle::d_err.
+struct FnOverlapParams {
+  const uint8_t* board;
+  const uint32_t* rec;
+  uint32_t* word;
+  int batch, W, H;
+  uint64_t shapes[7];  // KParams::shapes
+};
+__global__ __launch_bounds__(256) void fn_overlap_kernel(const FnOverlapParams q) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= q.batch) return;
+  const uint32_t* rec = q.rec;
+  const int W = q.W, H = q.H;
+  const uint64_t* shapes = q.shapes;
+  const uint8_t* board = q.board;
+  uint32_t* word = q.word;
+  const uint32_t d0 = rec[(size_t)env * 8], d1 = rec[(size_t)env * 8 + 1];
+  const int piece = d0 & 0xFF, rot = (d0 >> 8) & 3, x = (d0 >> 16) & 0xFF, y = (d0 >> 24) & 0xFF;
+  if (piece > 6 || ((d1 >> 8) & TG_F_GAME_OVER)) return;
+  const uint32_t mask = (uint32_t)(shapes[piece] >> (16 * rot)) & 0xFFFFu;
+  const uint8_t* b = board + (size_t)env * W * H;
+  bool over = false;
+  for (int c = 0; c < 16; ++c) {
+    const int row = y + (c >> 2), col = x + (c & 3) - 4;
+    if (((mask >> c) & 1u) && (unsigned)col < (unsigned)W && (unsigned)row < (unsigned)H) over = over || b[row * W + col] != 0;
+  }
+  if (over) atomicOr(word, 1u);
+}
+
 std::string built_sizes() {
   std::string s;
 #define X(w, h) s += std::string(s.empty() ? "" : ", ") + #w "x" #h;
@@ -716,7 +751,9 @@ struct tg_handle {
                                // kernel keeps THIS current, TG_BUF_BOARD is brought up to date on demand (ensure_board)
   bool board_stale = false;    // TG_BUF_BOARD is behind d_pboard
   uint32_t* h_nib_over = nullptr;  // packed FUNCTIONAL handles: page-locked flag word the step kernel raises (KParams::nib_over)
-  int* d_err = nullptr;        // flag word of sanitize_state_kernel (tg_set_state_dev)
+  int* d_err = nullptr;        // flag word of sanitize_state_kernel (tg_set_state_dev); word 4: fn_overlap_kernel
+  bool fn_overlap = false;         // FUNCTIONAL: the uploaded state holds a piece on top of filled cells (fn_overlap_kernel's word, read back)
+  bool fn_overlap_pending = false; // ... a tg_set_state_dev has been enqueued whose word nobody has read yet (treated as "may hold one")
   bool dev_state_pending = false;  // a tg_set_state_dev has been enqueued whose flag word nobody has looked at yet
   int ring_cur = 0;            // ring parity the next step launch reads
   int hbuf_cur = 0;            // consumed-counter parity the next step launch reads
@@ -917,7 +954,9 @@ tg::KParams step_params(tg_handle* h) {
   return p;
 }
 
+int join_shards(tg_handle* h);
 int launch_observe_dict(tg_handle* h) {
+  { const int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }  // (reads what the shard streams' step launches wrote)
   tg::ObserveParams o{};
   o.board = (const uint8_t*)h->buf[TG_BUF_BOARD];
   o.rec = (const uint32_t*)h->buf[TG_BUF_REC];
@@ -929,6 +968,27 @@ int launch_observe_dict(tg_handle* h) {
   h->L.observe(o, h->stream);
   HIPCHK(h, hipGetLastError());
   return TG_OK;
+}
+
+// FUNCTIONAL handles, behind a state upload (the whole batch is new): word 4 of d_err := does a piece now lie on top of filled cells?
+int launch_fn_overlap(tg_handle* h) {
+  if (h->cfg.ruleset != TG_RULESET_FUNCTIONAL || !h->d_cols) return TG_OK;
+  HIPCHK(h, hipMemsetAsync((uint32_t*)h->d_err + 4, 0, sizeof(uint32_t), h->stream));
+  const tg::KParams kp = step_params(h);
+  FnOverlapParams q{};
+  q.board = (const uint8_t*)h->buf[TG_BUF_BOARD];
+  q.rec = (const uint32_t*)h->buf[TG_BUF_REC];
+  q.word = (uint32_t*)h->d_err + 4;
+  q.batch = h->B; q.W = h->W; q.H = h->H;
+  for (int i = 0; i < 7; ++i) q.shapes[i] = kp.shapes[i];
+  hipLaunchKernelGGL(fn_overlap_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, q);
+  HIPCHK(h, hipGetLastError());
+  h->fn_overlap_pending = true;
+  return TG_OK;
+}
+// ... while this holds, transitions take the exact path (one transition per launch + the observe kernel)
+inline bool fn_exact_path(const tg_handle* h) {
+  return (h->fn_overlap || h->fn_overlap_pending) && h->cfg.ruleset == TG_RULESET_FUNCTIONAL && h->cfg.obs_mode != TG_OBS_NONE;
 }
 
 // ---- shards: fork (step launches) / join (everything else) ----
@@ -991,6 +1051,12 @@ int check_dev_state(tg_handle* h) {
     return fail(h, TG_EINVAL, "a locked piece added its id onto filled cells and the sum left the nibble range of this handle's packed board "
                               "(only a state uploaded with the piece on top of filled cells does that): the boards are no longer what the "
                               "reference would hold; TG_PACKED=0 creates handles that keep bytes");
+  }
+  if (h->fn_overlap_pending) {  // (the stream has been waited for: fn_overlap_kernel's answer is there)
+    uint32_t w = 0;
+    HIPCHK(h, hipMemcpy(&w, (uint32_t*)h->d_err + 4, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    h->fn_overlap = w != 0;
+    h->fn_overlap_pending = false;
   }
   if (!h->dev_state_pending) return TG_OK;
   h->dev_state_pending = false;
@@ -1510,6 +1576,7 @@ int tg_reset(tg_handle* h, const uint64_t* seeds, const uint8_t* mask) {
   }
   h->L.reset(p, h->stream);
   HIPCHK(h, hipGetLastError());
+  if (!mask) h->fn_overlap = h->fn_overlap_pending = false;  // every env starts over: no uploaded piece is left on filled cells
   {
     int rc = launch_prepare_bits(h, p.mask, 0);
     if (rc != TG_OK) return rc;
@@ -1565,7 +1632,7 @@ static int step_impl(tg_handle* h, const int32_t* actions, int kind, bool waited
   }
   after_launch(h, p);
   HIPCHK(h, hipGetLastError());
-  if ((h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) && !h->dict_in_kernel) return launch_observe_dict(h);
+  if (((h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) && !h->dict_in_kernel) || fn_exact_path(h)) return launch_observe_dict(h);
   return TG_OK;
 }
 
@@ -1605,7 +1672,7 @@ static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, u
   // max 16) consecutive transitions of a rollout — one launch floor and one slab round trip per group instead of per
   // transition.  tg_step always launches one transition.
   const int fuse_max = h->fuse_max;
-  const bool post_kernel = (h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) && !h->dict_in_kernel;
+  const bool post_kernel = ((h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) && !h->dict_in_kernel) || fn_exact_path(h);
   const size_t obs_stride = (size_t)h->B * obs_bytes_per_env(&h->cfg);
   if (obs_traj_dev && h->cfg.obs_mode == TG_OBS_NONE) return fail(h, TG_EINVAL, "tg_rollout: the handle has no observation (TG_OBS_NONE)");
   // trajectories are written by the step kernel itself when it packs the observation (bits kernel, BOARD / FN);
@@ -1841,18 +1908,20 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
     HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_RNG], rng, B * sizeof(tg_rng_rec), hipMemcpyHostToDevice, h->stream));
     h->rng_valid.assign(B, 1);
   }
+  { int rc = launch_fn_overlap(h); if (rc != TG_OK) return rc; }
   {
     int rc = launch_prepare_bits(h, nullptr, 1);
     if (rc != TG_OK) return rc;
   }
-  // TG_BUF_OBS of the DICT / RGB surfaces is kept up to date incrementally by the transitions (holder / queue strips are
-  // stored only when they change): re-pack it from the uploaded state
-  if (h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) {
+  // TG_BUF_OBS shows the uploaded state (as after tg_set_state_dev): re-packed for every surface — the DICT / RGB surfaces are only
+  // kept up to date incrementally by the transitions (holder / queue strips are stored only when they change), and a BOARD / FN
+  // observation left as the last transition wrote it would show a board that is gone
+  if (h->cfg.obs_mode != TG_OBS_NONE) {
     int rc = launch_observe_dict(h);
     if (rc != TG_OK) return rc;
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  return TG_OK;
+  return check_dev_state(h);  // (reads fn_overlap_kernel's answer)
 }
 
 int tg_get_state_dev(tg_handle* h, uint8_t* board_dev, tg_env_rec* rec_dev, tg_rng_rec* rng_dev) {
@@ -1891,6 +1960,7 @@ int tg_set_state_dev(tg_handle* h, const uint8_t* board_dev, const tg_env_rec* r
     HIPCHK(h, hipGetLastError());
     h->dev_state_pending = true;
   }
+  { int rc = launch_fn_overlap(h); if (rc != TG_OK) return rc; }
   { int rc = launch_prepare_bits(h, nullptr, 1); if (rc != TG_OK) return rc; }
   if (h->cfg.obs_mode != TG_OBS_NONE) return launch_observe_dict(h);  // (the observation of the restored state)
   return TG_OK;
