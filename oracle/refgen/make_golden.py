@@ -15,6 +15,9 @@ Fixtures (all NumPy rule-set, i.e. envs/tetris.py — the graded oracle of BASEL
   grouped_features_*.npz per-placement feature tensors [4W][W+3] (grouped wrapper + FeatureVectorObservation)
   ref_tests_grouped.npz  the reference tests' own mock board / CSV board / 40-entry mask (data only)
   rgb_<cfg>.npz          RgbObservation frames (wrappers/observation.py:38-74) along random traces incl. hold swaps
+  poked_<cfg>.npz        HAND-MADE states in the style of the reference's own tests (tests/test_base_env/**: board / x / y /
+                         active_tetromino / holder / queue / has_swapped / game_over assigned directly) x each of the 8 actions, then 15
+                         random transitions; the grouped wrapper's mask / placement boards / features and the RGB frame of the same states
 """
 from __future__ import annotations
 
@@ -392,6 +395,159 @@ def gen_rgb(ref, name, width, height, queue_size, B, T, seed):
     print(f"{name}: {B*T} frames, episodes={int(done.sum())}, swaps={(actions == 6).sum()}")
 
 
+def gen_poked(ref, name, width, height, queue_size, n_states, seed, gravity=True, T=16, n_grouped=None):
+    """Hand-made states: the state class the reference's own tests use — `env.unwrapped.board[...] = 2`,
+    `.active_tetromino = ...`, `.x = ...` (tests/test_base_env/**) — and the one where round 5's two late bugs lived.  Per state:
+    reset(seed), then everything a caller can assign is assigned: the playfield (random fill with values 2..8, rows that are ALREADY full,
+    fills that reach the spawn rows, and — flagged `bedrock_row` — a playfield row of bedrock cells, which clear_filled_rows never takes,
+    envs/tetris.py:493),  the piece (any id / rotation / position the reference's slicing tolerates: x in [0, Wp - n], y in [0, Hp - n],
+    incl. on top of filled cells and inside the bedrock; narrowed to x in
+    [1, Wp - n - 1], y in [0, Hp - n - 1] because a move probes one cell further and the reference raises there), holder, queue, bag + bag index, has_swapped, game_over.  The generator keeps
+    the state reset(seed) left.  Then for EACH of the 8 actions a deep copy of the env takes that action followed by T - 1 random ones
+    (no harness reset: the recording of a copy ends with its first done) -> reward / done / lines / observation CRC / x / y / piece per
+    transition, full snapshots behind the first transition and at the end.  On the same states: the grouped wrapper's legal mask and
+    4W placement boards, FeatureVectorObservation of the state and of every placement, the RgbObservation frame."""
+    import copy
+
+    from tetris_gymnasium.components.tetromino import Tetromino
+
+    rng = np.random.default_rng(seed)
+    Hp, Wp, P = height + 4, width + 8, 4
+    NA = 4 * width
+    ng = n_states if n_grouped is None else n_grouped
+    keys = ("x", "y", "piece", "matrix", "queue", "holder_piece", "holder_matrix", "bag", "bag_index", "has_swapped", "game_over")
+    st_board = np.zeros((n_states, Hp, Wp), np.uint8)
+    st = {k: [None] * n_states for k in keys}
+    st_rot = np.zeros(n_states, np.uint8)
+    st_holder_rot = np.zeros(n_states, np.uint8)
+    st_crc = np.zeros(n_states, np.uint32)
+    bedrock_row = np.zeros(n_states, np.uint8)
+    seeds = np.zeros(n_states, np.uint64)
+    B = 8 * n_states
+    actions = np.zeros((T, B), np.int8)
+    reward = np.zeros((T, B), np.int16)
+    done = np.zeros((T, B), np.uint8)
+    lines = np.zeros((T, B), np.uint8)
+    valid = np.zeros((T, B), np.uint8)
+    crc = np.zeros((T, B), np.uint32)
+    xs = np.zeros((T, B), np.uint8); ys = np.zeros((T, B), np.uint8); pieces = np.zeros((T, B), np.uint8)
+    first_board = np.zeros((B, Hp, Wp), np.uint8)
+    first = {k: [None] * B for k in keys}
+    last_board = np.zeros((B, Hp, Wp), np.uint8)
+    last = {k: [None] * B for k in keys}
+    g_mask = np.zeros((ng, NA), np.uint8)
+    g_boards = np.zeros((ng, NA, Hp, Wp), np.uint8)
+    g_feats = np.zeros((ng, NA, width + 3), np.uint8)
+    cur_feats = np.zeros((n_states, width + 3), np.uint8)
+    Wrgb = Wp + 4 * max(1, queue_size)
+    rgb = np.zeros((n_states, Hp, Wrgb, 3), np.uint8)
+    t0 = time.time()
+
+    def rotated(env, pid, k):
+        t = copy.deepcopy(env.tetrominoes[pid])
+        for _ in range(k):
+            t = env.rotate(t, True)
+        return t
+
+    for i in range(n_states):
+        env = make_env(ref, width, height, gravity, queue_size)
+        seeds[i] = 1000 + i
+        env.reset(seed=int(seeds[i]))
+        # ---- playfield ----
+        mode = i % 6
+        pf = np.zeros((height, width), np.uint8)
+        if mode >= 1:
+            top = int(rng.integers(0, height - 2)) if mode == 4 else int(rng.integers(height // 3, height - 1))
+            dens = float(rng.uniform(0.35, 0.9))
+            fill = rng.random((height - top, width)) < dens
+            pf[top:] = np.where(fill, rng.integers(2, 9, (height - top, width)), 0).astype(np.uint8)
+        if mode in (2, 3, 5):  # rows that are already full (a board only a caller can provide)
+            for row in rng.choice(np.arange(height // 4, height), size=int(rng.integers(1, 4)), replace=False):
+                pf[row] = rng.integers(2, 9, width)
+        if mode == 5 and i % 12 == 5:  # a playfield row of bedrock cells
+            row = int(rng.integers(height // 2, height))
+            pf[row] = 1
+            bedrock_row[i] = 1
+        env.board[:height, P:P + width] = pf
+        # ---- piece ----
+        for attempt in range(64):
+            pid, k = int(rng.integers(0, 7)), int(rng.integers(0, 4))
+            t = rotated(env, pid, k)
+            n = t.matrix.shape[0]
+            # (every position a step may probe — x - 1, x + 1, y + 1 — must slice inside the padded board: beyond it the reference raises)
+            x, y = int(rng.integers(1, Wp - n)), int(rng.integers(0, Hp - n))
+            if i % 3 == 0 or not env.collision(t, x, y):  # (a third of the states: wherever it falls, incl. on filled cells / bedrock)
+                break
+        env.active_tetromino, env.x, env.y = t, x, y
+        st_rot[i] = k
+        # ---- holder / queue / bag / flags ----
+        if rng.random() < 0.6:
+            hk = int(rng.integers(0, 4))
+            env.holder.queue.clear()
+            env.holder.queue.append(rotated(env, int(rng.integers(0, 7)), hk))
+            st_holder_rot[i] = hk
+        env.has_swapped = bool(rng.random() < 0.4)
+        env.game_over = bool(rng.random() < 0.1)
+        env.queue.queue.clear()
+        for _ in range(queue_size):
+            env.queue.queue.append(int(rng.integers(0, 7)))
+        env.randomizer.bag = rng.permutation(7).astype(np.int8)
+        env.randomizer.index = int(rng.integers(0, 7))
+        # ---- the state ----
+        s0 = snapshot(env)
+        st_board[i] = s0["board"]
+        for k_ in keys:
+            st[k_][i] = s0[k_]
+        st_crc[i] = obs_crc(env._get_obs())
+        cur_feats[i] = ref.FeatureVectorObservation(env).observation(env._get_obs())
+        rgb[i] = ref.RgbObservation(env).observation(env._get_obs())
+        if i < ng:
+            e2 = copy.deepcopy(env)
+            gw = ref.GroupedActionsObservations(e2)
+            g_boards[i] = gw.observation(e2._get_obs())
+            g_mask[i] = gw.legal_actions_mask
+            e3 = copy.deepcopy(env)
+            gf = ref.GroupedActionsObservations(e3, observation_wrappers=[ref.FeatureVectorObservation(e3)])
+            g_feats[i] = gf.observation(e3._get_obs())
+        # ---- every action, then random ones ----
+        for a in range(8):
+            j = 8 * i + a
+            e = copy.deepcopy(env)
+            for t_ in range(T):
+                act = a if t_ == 0 else int(rng.integers(0, 8))
+                actions[t_, j] = act
+                obs, r, d, _, info = e.step(act)
+                assert r == int(r)
+                valid[t_, j] = 1
+                reward[t_, j], done[t_, j], lines[t_, j] = int(r), int(d), int(info["lines_cleared"])
+                crc[t_, j] = obs_crc(obs)
+                xs[t_, j], ys[t_, j], pieces[t_, j] = e.x, e.y, e.active_tetromino.id - 2
+                if t_ == 0:
+                    s1 = snapshot(e)
+                    first_board[j] = s1["board"]
+                    for k_ in keys:
+                        first[k_][j] = s1[k_]
+                if d:
+                    break
+            s2 = snapshot(e)
+            last_board[j] = s2["board"]
+            for k_ in keys:
+                last[k_][j] = s2[k_]
+    out = dict(width=width, height=height, gravity=int(gravity), queue_size=queue_size, n_states=n_states, T=T, seeds=seeds,
+               st_board=st_board, st_rot=st_rot, st_holder_rot=st_holder_rot, st_crc=st_crc, bedrock_row=bedrock_row,
+               actions=actions, reward=reward, done=done, lines=lines, valid=valid, crc=crc, x=xs, y=ys, piece=pieces,
+               first_board=first_board, last_board=last_board, g_mask=g_mask, g_boards=g_boards, g_feats=g_feats,
+               cur_feats=cur_feats, rgb=rgb)
+    for k_ in keys:
+        out["st_" + k_] = np.array(st[k_]).astype(np.uint8)
+        out["first_" + k_] = np.array(first[k_]).astype(np.uint8)
+        out["last_" + k_] = np.array(last[k_]).astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: {n_states} states x 8 actions x <= {T} transitions in {time.time()-t0:.1f}s  valid={int(valid.sum())} "
+          f"dones={int(done.sum())} first-step locks={(reward[0] != 0).sum()} lines={int(lines.sum())} (first step {int(lines[0].sum())}) "
+          f"bedrock-row states={int(bedrock_row.sum())} game_over states={int(np.array(st['game_over']).sum())}")
+
+
 def gen_ref_tests_grouped(ref):
     """Data held by the reference's own grouped tests: the mock board (tests/helpers/mock.py:5-47 applied to
     a fresh env), the CSV board after action 21 (tests/test_grouped_env/expected_result_i_placement.csv) and
@@ -507,6 +663,9 @@ def main():
                                                     terminate_on_illegal=False, p_any=0.25),
         "rgb_10x20": lambda: gen_rgb(ref, "rgb_10x20", 10, 20, 4, 8, 160, 51),
         "rgb_20x40": lambda: gen_rgb(ref, "rgb_20x40", 20, 40, 7, 2, 200, 52),
+        "poked_10x20": lambda: gen_poked(ref, "poked_10x20", 10, 20, 4, 192, 61),
+        "poked_10x20_g0": lambda: gen_poked(ref, "poked_10x20_g0", 10, 20, 4, 72, 62, gravity=False, n_grouped=0),
+        "poked_20x40": lambda: gen_poked(ref, "poked_20x40", 20, 40, 7, 60, 63, n_grouped=12),
     }
     for name, fn in jobs.items():
         if args.only and args.only != name:

@@ -104,3 +104,95 @@ def replay_trace(make_backend, fx, max_steps=None, check_state_every=1):
             for i in np.flatnonzero(term):
                 assert obs_crc(obs, i) == int(fx["reset_crc"][t][i]), f"post-reset obs mismatch t={t} env={i}"
     return be
+
+
+# ---- hand-made ("poked") states: oracle/refgen/make_golden.py gen_poked ----
+SNAP_KEYS = ("queue", "bag", "bag_index", "holder_piece", "has_swapped", "game_over")
+
+
+def poked_upload(fx, board, rec, skip=None):
+    """Write the fixture's hand-made states (each replicated 8 times, one copy per first action) into a backend's (board, rec)
+    arrays as get_state() returned them behind reset(seeds): everything the reference's tests assign directly — playfield, piece,
+    rotation, position, holder, queue, bag, bag index, has_swapped, game_over.  `skip` [n_states] bool: states left as reset made them."""
+    n, Q = int(fx["n_states"]), int(fx["queue_size"])
+    keep = np.ones(n, bool) if skip is None else ~np.asarray(skip, bool)
+    rep = lambda a: np.repeat(np.asarray(a), 8, axis=0)  # noqa: E731
+    m = rep(keep)
+    board[m] = rep(crop(fx["st_board"]))[m]
+    rec["piece"][m] = rep(fx["st_piece"])[m]
+    rec["rot"][m] = rep(fx["st_rot"])[m]
+    rec["x"][m] = rep(fx["st_x"])[m]
+    rec["y"][m] = rep(fx["st_y"])[m]
+    rec["val"][m] = rep(fx["st_piece"])[m] + 2
+    rec["flags"][m] = (rep(fx["st_game_over"]) | (rep(fx["st_has_swapped"]) << 1))[m]
+    hp = rep(fx["st_holder_piece"])
+    rec["holder_piece"][m] = hp[m]
+    rec["holder_rot"][m] = np.where(hp == 255, 0, rep(fx["st_holder_rot"]))[m]
+    rec["holder_val"][m] = np.where(hp == 255, 0, hp + 2)[m]
+    rec["bag_index"][m] = rep(fx["st_bag_index"])[m]
+    rec["bag"][m] = rep(fx["st_bag"])[m]
+    rec["queue"][m, :Q] = rep(fx["st_queue"])[m]
+    return m
+
+
+def _cmp_snapshot(fx, prefix, board, rec, sel, msg):
+    """(board, rec) of the envs `sel` against the reference's snapshot arrays `<prefix>_*` of the fixture."""
+    Q = int(fx["queue_size"])
+    np.testing.assert_array_equal(board[sel], crop(fx[prefix + "_board"])[sel], err_msg=f"board {msg}")
+    np.testing.assert_array_equal(rec["x"][sel], fx[prefix + "_x"][sel], err_msg=f"x {msg}")
+    np.testing.assert_array_equal(rec["y"][sel], fx[prefix + "_y"][sel], err_msg=f"y {msg}")
+    np.testing.assert_array_equal(rec["piece"][sel], fx[prefix + "_piece"][sel], err_msg=f"piece {msg}")
+    np.testing.assert_array_equal(rec["queue"][sel][:, :Q], fx[prefix + "_queue"][sel], err_msg=f"queue {msg}")
+    np.testing.assert_array_equal(rec["bag"][sel], fx[prefix + "_bag"][sel], err_msg=f"bag {msg}")
+    np.testing.assert_array_equal(rec["bag_index"][sel], fx[prefix + "_bag_index"][sel], err_msg=f"bag_index {msg}")
+    np.testing.assert_array_equal(rec["holder_piece"][sel], fx[prefix + "_holder_piece"][sel], err_msg=f"holder {msg}")
+    np.testing.assert_array_equal(((rec["flags"] & 2) >> 1)[sel], fx[prefix + "_has_swapped"][sel], err_msg=f"has_swapped {msg}")
+    np.testing.assert_array_equal((rec["flags"] & 1)[sel], fx[prefix + "_game_over"][sel], err_msg=f"game_over {msg}")
+    for i in np.flatnonzero(sel):
+        np.testing.assert_array_equal(matrix16(rec["piece"][i], rec["rot"][i], rec["val"][i]), fx[prefix + "_matrix"][i],
+                                      err_msg=f"matrix env={i} {msg}")
+        if rec["holder_piece"][i] != 255:
+            np.testing.assert_array_equal(matrix16(rec["holder_piece"][i], rec["holder_rot"][i], rec["holder_val"][i]),
+                                          fx[prefix + "_holder_matrix"][i], err_msg=f"holder matrix env={i} {msg}")
+
+
+def replay_poked(be, fx, skip=None, upload=None, step=None, check_obs=True):
+    """Drive a backend through a poked_* fixture: upload the hand-made states, take every state's 8 first actions and the 15
+    random transitions behind them, compare every output with the reference's as long as its recording of that copy lasts
+    (`valid`).  be: the backend interface of replay_trace, constructed for batch 8 * n_states and reset with poked_seeds(fx);
+    upload(board, rec): how the state gets in (default be.set_state); step(t, actions) -> (reward, terminated, lines)."""
+    T = int(fx["T"])
+    board, rec, _ = be.get_state()
+    m = poked_upload(fx, board, rec, skip)
+    (upload or (lambda b, r: be.set_state(board=b, rec=r)))(board, rec)
+    if check_obs:
+        obs = be.observe_dict()
+        for i in np.flatnonzero(m):
+            assert obs_crc(obs, i) == int(fx["st_crc"][i // 8]), f"observation of the uploaded state, env {i} (state {i // 8})"
+    valid = fx["valid"].astype(bool) & m[None, :]
+    last_t = valid.sum(axis=0) - 1  # the transition behind which the reference's `last_*` snapshot was taken
+    for t in range(T):
+        a = fx["actions"][t].astype(np.int32)
+        rew, term, lines = (step(t, a) if step else be.step(a))
+        v = valid[t]
+        np.testing.assert_array_equal(np.asarray(rew)[v].astype(np.int64), fx["reward"][t][v].astype(np.int64), err_msg=f"reward t={t}")
+        np.testing.assert_array_equal(np.asarray(term)[v], fx["done"][t][v], err_msg=f"terminated t={t}")
+        np.testing.assert_array_equal(np.asarray(lines)[v], fx["lines"][t][v], err_msg=f"lines t={t}")
+        if check_obs:
+            obs = be.observe_dict()
+            bad = [i for i in np.flatnonzero(v) if obs_crc(obs, i) != int(fx["crc"][t][i])]
+            assert not bad, f"observation crc mismatch t={t} envs={bad[:8]} (states {[i // 8 for i in bad[:8]]}, actions {[i % 8 for i in bad[:8]]})"
+        board, rec, _ = be.get_state()
+        np.testing.assert_array_equal(rec["x"][v], fx["x"][t][v], err_msg=f"x t={t}")
+        np.testing.assert_array_equal(rec["y"][v], fx["y"][t][v], err_msg=f"y t={t}")
+        np.testing.assert_array_equal(rec["piece"][v], fx["piece"][t][v], err_msg=f"piece t={t}")
+        if t == 0:
+            _cmp_snapshot(fx, "first", board, rec, v, "behind the first transition")
+        sel = v & (last_t == t)
+        if sel.any():
+            _cmp_snapshot(fx, "last", board, rec, sel, f"at the end of the recording (t={t})")
+    return m
+
+
+def poked_seeds(fx):
+    return np.repeat(fx["seeds"].astype(np.uint64), 8)

@@ -460,7 +460,8 @@ def test_rng_role_every_nth_launch(every, W, H, Q, B, grouped, monkeypatch):
 
 
 @pytest.mark.parametrize("fuse", [1, 16])
-@pytest.mark.parametrize("W,H,Q,B,grouped", [(10, 20, 4, 1000, False), (20, 40, 7, 300, True), (6, 12, 2, 100, False), (12, 24, 4, 77 * 4, False)])
+@pytest.mark.parametrize("W,H,Q,B,grouped", [(10, 20, 4, 1000, False), (20, 40, 7, 300, True), (6, 12, 2, 100, False), (12, 24, 4, 77 * 4, False),
+                                             (20, 40, 7, 32 * 9 + 20, True), (20, 40, 4, 32 * 5 + 16, False)])  # (kFeatSeq: ragged second / empty second group)
 def test_packed_board_handles(fuse, W, H, Q, B, grouped, monkeypatch):
     """TG_PACKED=1: the handle keeps its board as nibbles (tg_kernel_bits.h kFeatPacked — what large working sets pick by
     themselves) and the uint8 TG_BUF_BOARD is brought up to date on demand.  Single steps, rollouts, trajectories, masked
@@ -522,7 +523,7 @@ def test_packed_board_handles(fuse, W, H, Q, B, grouped, monkeypatch):
 
 @pytest.mark.parametrize("fuse", [1, 16])
 @pytest.mark.parametrize("autoreset", [N.AUTORESET_SAME_STEP, N.AUTORESET_NEXT_STEP])
-@pytest.mark.parametrize("W,H,B", [(10, 20, 1000), (12, 24, 77 * 4), (6, 12, 100)])
+@pytest.mark.parametrize("W,H,B", [(10, 20, 1000), (12, 24, 77 * 4), (6, 12, 100), (20, 40, 32 * 4 + 20)])
 def test_packed_board_functional_handles(fuse, autoreset, W, H, B, monkeypatch):
     """TG_PACKED=1 with the FUNCTIONAL rule-set (what its handles above ~50 Mi cells pick by themselves): single steps,
     rollouts with and without the trajectory, masked resets, host and device state round trips, uploaded tall boards and
@@ -604,6 +605,48 @@ def test_packed_board_functional_handles(fuse, autoreset, W, H, B, monkeypatch):
     with pytest.raises(Exception, match="nibble range"):
         e.step(np.full(B, 6, np.int8))
         e.sync()
+    e.close()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_packed_functional_exact_path_reads_the_current_board(overlap, monkeypatch):
+    """behind a tg_set_state_dev a FUNCTIONAL handle takes the exact path (one transition per launch + the observe
+    kernel) until something waits on the stream, and for good while an uploaded piece lies on filled cells.  On a nibble-packed handle the
+    step kernel maintains the nibbles only, so the observe kernel must see the uint8 board brought up to date FIRST — it used to re-pack
+    the boards of the last upload.  No sync between the upload and the transitions; hard drops so that every transition locks."""
+    monkeypatch.setenv("TG_PACKED", "1")
+    B, W, H = 700, 10, 20
+    e = Engine(B, W, H, ruleset=N.RULESET_FUNCTIONAL, queue_size=7, obs_mode=N.OBS_FN, autoreset=N.AUTORESET_SAME_STEP)
+    assert int(e.step_kernel_name().rstrip(">").split(",")[-1]) & 256
+    o = po.OracleBatch(B, W, H, po.RULESET_FUNCTIONAL, True, 7)
+    seeds = np.arange(77, 77 + B, dtype=np.uint64)
+    e.reset(seeds); o.reset(seeds)
+    rng = np.random.default_rng(5 + overlap)
+    for _ in range(6):
+        a = rng.integers(0, 7, B).astype(np.int8)
+        e.step(a); o.step(a.astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+    if overlap:  # a low stack of 2s under every second env's piece: its lock adds 2..8 onto them — sums that still fit a nibble
+        b, r, g = o.get_state()
+        b[::2, 1:3, :] = 2
+        r["y"][::2] = 0; r["rot"][::2] = 0; r["x"][::2] = (W + 8) // 2 - 2
+        r["flags"][::2] = 0
+        o.set_state(board=b, rec=r, rng=g); e.set_state(board=b, rec=r, rng=g)
+        e.set_state_device(*e.get_state_device())
+    else:
+        e.set_state_device(*e.get_state_device())  # (no wait behind it: fn_overlap_pending)
+    for k in range(5):
+        a = np.full(B, 6, np.int8) if k % 2 == 0 else rng.integers(0, 7, B).astype(np.int8)
+        if k == 3:  # a fused request in the same window: still the exact path underneath
+            acts = np.stack([a, np.full(B, 6, np.int8), a])
+            d = e.dev_alloc(acts.nbytes); e.dev_upload(d, acts); e.step_k_device(d, 3); e.dev_free(d)
+            for row in acts:
+                o.step(row.astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+        else:
+            got = e.step(a)
+            exp = o.step(a.astype(np.int32), autoreset=po.AUTORESET_SAME_STEP)
+            np.testing.assert_array_equal(got[0], exp[0]); np.testing.assert_array_equal(got[1], exp[1])
+        np.testing.assert_array_equal(e.observation(), o.observe(po.OBS_FN), err_msg=f"obs after transition {k}")
+    _cmp_state(e, o, "end")
     e.close()
 
 

@@ -73,6 +73,7 @@ constexpr int g_stagger = 0;
 
 int g_simds = 1024;  // SIMDs of the device (4 per CU)
 int g_split = 1;     // TG_SPLIT=0: never pick the instantiations with two stream waves per workgroup (kFeatSplit)
+int g_seq = 1;       // TG_SEQ=0: never pick the instantiations whose stream wave walks two env groups (kFeatSeq; A/B runs)
 
 // Process-wide settings, read once (the first tg_create; the devices of a node are alike): the SIMD count the instantiation
 // rules above compare grids against, TG_SPLIT, and TG_KERNEL (which the product library only accepts as "bits").
@@ -82,6 +83,7 @@ void process_init(int device) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) g_simds = 4 * prop.multiProcessorCount;
   if (const char* w = getenv("TG_SPLIT")) g_split = atoi(w) != 0;
+  if (const char* w = getenv("TG_SEQ")) g_seq = atoi(w) != 0;
   if (const char* k = getenv("TG_KERNEL")) {
 #ifdef TG_LEGACY_KERNELS
     g_kernel_lanes = strcmp(k, "wave") == 0    ? 0
@@ -111,6 +113,9 @@ int bits_feat_base(const tg::KParams& p, const int RS, const bool dict_ok, const
 int bits_feat_rt(const tg::KParams& p, const int RS, const bool dict_ok, const bool rgb_ok, const int epw, const bool split_ok, const int rgb_helpers_max) {
   constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj;
   const int feat = bits_feat_base(p, RS, dict_ok, rgb_ok, epw, split_ok);
+  // boards above 640 cells (16 envs per stream wave), packed, one transition per launch: workgroups of 32 envs whose stream wave walks
+  // two groups (tg_kernel_bits.h kFeatSeq; config 5: 22.6 -> see profiles/r06/)
+  if (g_seq && (feat & tg::kFeatPacked) && !(feat & M) && epw == 16) return feat | tg::kFeatSeq;
   // two stream waves per workgroup (kFeatSplit) while all workgroups of the launch — the RNG role's included — are resident
   // with three waves each at the occupancy the instantiation is compiled for
   const int base = feat & ~tg::kFeatWide;
@@ -194,11 +199,16 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     const tg::BitsParams bp{p.cols, p.ahead,
                             ring4 + (size_t)p.ring_cur * p.ring_stride, const_cast<uint4*>(ring4) + (size_t)(1 - p.ring_cur) * p.ring_stride,
                             p.hbuf + hrd, p.hbuf + hwr, p.inl, nrb, p.ring_fill};
-    const int n_step_wgs = (p.batch + BG::EPW - 1) / BG::EPW;
-    const dim3 grid(nrb + n_step_wgs);
     constexpr int M = tg::kFeatMulti, T = tg::kFeatTraj, D = tg::kFeatDict, S = tg::kFeatSample, F = tg::kFeatFinal, R = tg::kFeatRgb;
     const int feat = bits_feat<W, H, RS>(p);
-    const size_t lds = RS == TG_RULESET_FUNCTIONAL ? ((feat & F) ? BG::BYTES_FNX : BG::BYTES_FNX0)
+    constexpr int NSEQ = tg::bits_nseq<W, H>(tg::kFeatPacked | tg::kFeatSeq);  // (2 for the sizes that have kFeatSeq instantiations)
+    using BGS = tg::BitsGeo<W, H, NSEQ>;
+    const bool seq = NSEQ > 1 && (feat & tg::kFeatSeq);
+    const int epw_l = seq ? BGS::EPW : BG::EPW;
+    const int n_step_wgs = (p.batch + epw_l - 1) / epw_l;
+    const dim3 grid(nrb + n_step_wgs);
+    const size_t lds = seq ? (size_t)(RS == TG_RULESET_FUNCTIONAL ? BGS::BYTES_FNX0 : BGS::BYTES)
+                       : RS == TG_RULESET_FUNCTIONAL ? ((feat & F) ? BG::BYTES_FNX : BG::BYTES_FNX0)
                        : ((feat & D) ? ((feat & tg::kFeatSplit) ? BG::BYTES_DICT_SPLIT : BG::BYTES_DICT)
                                      : ((feat & R) ? ((feat & tg::kFeatMaskWave) ? ((feat & tg::kFeatMany) ? BG::BYTES_RGB_X6 : BG::BYTES_RGB_X) : BG::BYTES_RGB) : ((feat & F) ? BG::BYTES_FIN : BG::BYTES)));
 #define TG_LAUNCH_BITS(FT)                                                                                                  \
@@ -209,6 +219,13 @@ void launch_step(const tg::KParams& p, hipStream_t s) {
     if (feat == (M | T | F)) { TG_LAUNCH_BITS(M | T | F); return; }
     if constexpr (tg::bits_packed<W, H>(tg::kFeatPacked)) {
       constexpr int K = tg::kFeatPacked;
+      if constexpr (NSEQ > 1) {
+        constexpr int Q = tg::kFeatSeq;
+        if (feat == (K | Q)) { TG_LAUNCH_BITS(K | Q); return; }
+        if constexpr (RS == TG_RULESET_NUMPY) {
+          if (feat == (K | T | S | Q)) { TG_LAUNCH_BITS(K | T | S | Q); return; }
+        }
+      }
       if (feat == K) { TG_LAUNCH_BITS(K); return; }
       if (feat == (K | M)) { TG_LAUNCH_BITS(K | M); return; }
       if (feat == (K | M | T)) { TG_LAUNCH_BITS(K | M | T); return; }
@@ -344,7 +361,8 @@ struct RtcSize {
   std::map<int, hipFunction_t> step;  // by FEAT
   hipFunction_t reset = nullptr, observe = nullptr, prepare = nullptr, features = nullptr, placements = nullptr;
   int W = 0, H = 0, RS = 0;
-  int geo[12] = {};  // EPW, BYTES, BYTES_DICT, BYTES_RGB, BYTES_FIN, BYTES_FNX, DICT_OK, RGB_OK, cols_bytes, placements lds, NSW0, SPLIT_OK
+  int geo[14] = {};  // EPW, BYTES, BYTES_DICT, BYTES_RGB, BYTES_FIN, BYTES_FNX, DICT_OK, RGB_OK, cols_bytes, placements lds, NSW0, SPLIT_OK,
+                     // kFeatSeq: EPW (0: the size has no such instantiations), BYTES
 };
 std::mutex g_rtc_mu;
 std::map<std::string, RtcSize*> g_rtc;  // "dev:W:H:RS" → module (lives as long as the process)
@@ -372,11 +390,14 @@ std::vector<int> rtc_feats(int RS, int W = 0, int H = 0) {
                           D | tg::kFeatMaskWave, M | T | D | tg::kFeatMaskWave, R | tg::kFeatMaskWave, R | tg::kFeatMaskWave | tg::kFeatMany, M | T | S | R | tg::kFeatMaskWave};
     if (W && packed_geometry(W, H))
       for (int f : {K, K | M, K | M | T, K | T | S, K | M | T | S}) v.push_back(f);
+    if (W && packed_geometry(W, H) && tg::bits_eps0(W, H) == 16)
+      for (int f : {K | tg::kFeatSeq, K | T | S | tg::kFeatSeq}) v.push_back(f);
     return v;
   }
   std::vector<int> v = {0, M, M | T, F, M | T | F, Wd, M | Wd, P, P | M, P | M | T};
   if (W && packed_geometry(W, H))
     for (int f : {K, K | M, K | M | T}) v.push_back(f);
+  if (W && packed_geometry(W, H) && tg::bits_eps0(W, H) == 16) v.push_back(K | tg::kFeatSeq);
   return v;
 }
 
@@ -408,13 +429,15 @@ std::string rtc_build(int device, int W, int H, int RS, RtcSize** out) {
   snprintf(nb, sizeof nb, "tg::bits_prepare_kernel<%d, %d>", W, H); names.push_back(nb);
   snprintf(nb, sizeof nb, "tg::features_kernel<%d, %d>", W, H); names.push_back(nb);
   snprintf(nb, sizeof nb, "tg::placements_kernel<%d, %d>", W, H); names.push_back(nb);
-  char srcb[1024];
+  char srcb[2048];
   snprintf(srcb, sizeof srcb,
            "#include \"tg_kernel_bits.h\"\n#include \"tg_kernel_features.h\"\n#include \"tg_kernel_placements.h\"\n"
            "typedef tg::BitsGeo<%d, %d> TgBG;\n"
-           "extern \"C\" __constant__ int tg_rtc_geo[12] = {TgBG::EPW, TgBG::BYTES, TgBG::BYTES_DICT, TgBG::BYTES_RGB, TgBG::BYTES_FIN, "
+           "typedef tg::BitsGeo<%d, %d, tg::bits_nseq<%d, %d>(tg::kFeatPacked | tg::kFeatSeq)> TgBGS;\n"
+           "extern \"C\" __constant__ int tg_rtc_geo[14] = {TgBG::EPW, TgBG::BYTES, TgBG::BYTES_DICT, TgBG::BYTES_RGB, TgBG::BYTES_FIN, "
            "TgBG::BYTES_FNX, TgBG::DICT_OK ? 1 : 0, TgBG::RGB_OK ? 1 : 0, (int)tg::bits_cols_bytes<%d, %d>(), "
-           "(int)tg::placements_lds_bytes<%d, %d>(), TgBG::NSW0, TgBG::SPLIT_OK ? 1 : 0};\n", W, H, W, H, W, H);
+           "(int)tg::placements_lds_bytes<%d, %d>(), TgBG::NSW0, TgBG::SPLIT_OK ? 1 : 0, "
+           "TgBGS::EPW != TgBG::EPW ? TgBGS::EPW : 0, TgBGS::BYTES};\n", W, H, W, H, W, H, W, H, W, H);
   const std::string src = srcb;
   const std::vector<std::string> optv = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + dir, "-mllvm", "-amdgpu-kernarg-preload-count=16",
                                          "-mllvm", "-amdgpu-sched-strategy=max-ilp"};
@@ -549,10 +572,13 @@ Launchers rtc_launchers(const RtcSize* r) {
     const size_t hrd = RS == TG_RULESET_NUMPY ? (size_t)p.hbuf_cur * p.ring_stride : 0, hwr = RS == TG_RULESET_NUMPY ? (size_t)(1 - p.hbuf_cur) * p.ring_stride : 0;
     tg::BitsParams bp{p.cols, p.ahead, ring4 + (size_t)p.ring_cur * p.ring_stride, const_cast<uint4*>(ring4) + (size_t)(1 - p.ring_cur) * p.ring_stride,
                       p.hbuf + hrd, p.hbuf + hwr, p.inl, nrb, p.ring_fill};
-    const int n_step_wgs = (p.batch + EPW - 1) / EPW;
     const bool split_ok = r->geo[11] != 0;  // (BitsGeo::SPLIT_OK)
     const int feat = bits_feat_rt(p, RS, dict_ok, rgb_ok, EPW, split_ok, rgb_helpers_max);
-    const size_t lds = RS == TG_RULESET_FUNCTIONAL ? ((feat & F) ? r->geo[5] : r->geo[5] - 2 * r->geo[0] * 8)  // (BYTES_FNX / BYTES_FNX0)
+    const bool seq = (feat & tg::kFeatSeq) && r->geo[12] > 0;
+    const int epw_l = seq ? r->geo[12] : EPW;
+    const int n_step_wgs = (p.batch + epw_l - 1) / epw_l;
+    const size_t lds = seq ? (size_t)(r->geo[13] + (RS == TG_RULESET_FUNCTIONAL ? 128 * 12 : 0))  // (BitsGeo<.., 2>::BYTES / BYTES_FNX0)
+                       : RS == TG_RULESET_FUNCTIONAL ? ((feat & F) ? r->geo[5] : r->geo[5] - 2 * r->geo[0] * 8)  // (BYTES_FNX / BYTES_FNX0)
                        : ((feat & D) ? r->geo[2] + ((feat & tg::kFeatSplit) ? 16 * (W + 8) * (H + 4) : 0)  // (BYTES_DICT_SPLIT: + GD * PC)
                                      : ((feat & R) ? r->geo[3] + ((feat & tg::kFeatMaskWave) ? ((feat & tg::kFeatMany) ? 6 : 2) * 4 * ((((H + 4) * (W + 24)) + 15) / 16 * 16) : 0)  // (BYTES_RGB_X: + 2 GR IDB)
                                                    : ((feat & F) ? r->geo[4] : r->geo[1])));
@@ -955,8 +981,12 @@ tg::KParams step_params(tg_handle* h) {
 }
 
 int join_shards(tg_handle* h);
+int ensure_board(tg_handle* h);
 int launch_observe_dict(tg_handle* h) {
   { const int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }  // (reads what the shard streams' step launches wrote)
+  // (packed handles: the step kernel maintains the nibbles only — the observe kernel reads the uint8 board.  A no-op unless the handle is
+  // packed and stale; without it the exact path of a packed FUNCTIONAL handle re-packed the boards of the last upload: ADVICE r05)
+  { const int rcb = ensure_board(h); if (rcb != TG_OK) return rcb; }
   tg::ObserveParams o{};
   o.board = (const uint8_t*)h->buf[TG_BUF_BOARD];
   o.rec = (const uint32_t*)h->buf[TG_BUF_REC];

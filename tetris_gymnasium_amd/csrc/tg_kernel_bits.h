@@ -139,14 +139,15 @@ constexpr int bits_epw(const int W, const int H) { return bits_eps0(W, H); }
 constexpr int bits_nsw0(const int W, const int H) {  // stream waves a workgroup of this board size has at least
   return bits_epw(W, H) / bits_eps0(W, H);
 }
-// dynamic LDS of one workgroup of step_kernel_bits
-template <int W, int H>
+// dynamic LDS of one workgroup of step_kernel_bits.  NSEQ > 1 (kFeatSeq, round 6): the workgroup serves NSEQ x bits_epw envs — the logic
+// wave decides them all at once, one env per lane — while its stream wave walks them in NSEQ groups through ONE slab block in LDS.
+template <int W, int H, int NSEQ = 1>
 struct BitsGeo {
   using T = ColT<H>;
   static constexpr int S = W * H;
-  static constexpr int EPW = bits_epw(W, H);
+  static constexpr int EPW = bits_epw(W, H) * NSEQ;
   static constexpr int NSW0 = bits_nsw0(W, H);
-  static constexpr int SLABS = ((EPW * S + 15) / 16) * 16;
+  static constexpr int SLABS = ((EPW / NSEQ * S + 15) / 16) * 16;
   static constexpr int NCH = SLABS / 16;
   static constexpr int NIT = (NCH + 63) / 64;
   static constexpr int OFF_TAB = SLABS;             // cell table, column table, cell table (logic wave's copy), row-mask table, colour table: 5 x 64 B
@@ -163,7 +164,7 @@ struct BitsGeo {
   static constexpr int BYTES_DICT = OFF_OLDPW + EPW * 4;
   static constexpr int OFF_DICT2 = BYTES_DICT;             // (kFeatSplit: the second stream wave's board staging buffer)
   static constexpr int BYTES_DICT_SPLIT = BYTES_DICT + GD * PC;
-  static constexpr bool DICT_OK = NSW0 == 1 && PC % 16 == 0 && EPW % GD == 0 && H % 2 == 0 && W % 2 == 0;  // (row pairs as whole dwords)
+  static constexpr bool DICT_OK = NSEQ == 1 && NSW0 == 1 && PC % 16 == 0 && EPW % GD == 0 && H % 2 == 0 && W % 2 == 0;  // (row pairs as whole dwords)
   // TG_OBS_RGB packed in the kernel (queue_size 4): uint4 post2[EPW] {queue bytes | holder} published by the logic wave,
   // then one id-image staging buffer of GR envs per wave.  Image row = padded board row | 4 queue pieces x 4 columns.
   static constexpr int RS = W + 8 + 16;
@@ -174,7 +175,7 @@ struct BitsGeo {
   static constexpr int BYTES_RGB = BYTES + EPW * 16 + 2 * GR * IDB;
   static constexpr int BYTES_RGB_X = BYTES_RGB + 2 * GR * IDB;  // (kFeatMaskWave with kFeatRgb: two helper waves with a staging buffer each)
   static constexpr int BYTES_RGB_X6 = BYTES_RGB + 6 * GR * IDB; // (... | kFeatMany: six)
-  static constexpr bool RGB_OK = NSW0 == 1 && NPX % 4 == 0 && H % 2 == 0 && W % 2 == 0 && (EPW / 2) % GR == 0;
+  static constexpr bool RGB_OK = NSEQ == 1 && NSW0 == 1 && NPX % 4 == 0 && H % 2 == 0 && W % 2 == 0 && (EPW / 2) % GR == 0;
   // TG_FLAG_FINAL_OBS (observation BOARD / FN only, never together with the dict staging): uint2 [2][EPW] behind BYTES —
   // the terminal piece of every env that ends its episode in this transition
   static constexpr int OFF_FIN = BYTES;
@@ -188,12 +189,12 @@ struct BitsGeo {
   // workgroups of two waves, compiled for four waves per SIMD) is resident in one round: 14.4 -> 11.x us (profiles/r05/batch_sweep.log)
   static constexpr int OFF_FNX0 = BYTES;
   static constexpr int BYTES_FNX0 = BYTES + 128 * 8 + 128 * 4;
-  static_assert(BYTES_FNX == bits_lds_bytes_max(W, H, EPW), "bits_lds_bytes_max restates this layout");
+  static_assert(NSEQ > 1 || BYTES_FNX == bits_lds_bytes_max(W, H, EPW), "bits_lds_bytes_max restates this layout");
   static_assert(NSW0 == 1 || BYTES_FNX <= 65536, "two stream waves' worth of envs only while the workgroup's LDS stays within 64 KiB");
   static constexpr int WC = bits_cols_words<W, H>();  // column-mask words per env in HBM
   // two stream waves per workgroup (each owns half of the envs and their slabs: no exchange between them) when the halves
   // are whole 16-byte chunks
-  static constexpr bool SPLIT_OK = NSW0 == 1 && EPW == 64 && ((EPW / 2) * S) % 16 == 0;
+  static constexpr bool SPLIT_OK = NSEQ == 1 && NSW0 == 1 && EPW == 64 && ((EPW / 2) * S) % 16 == 0;
 };
 
 
@@ -464,6 +465,19 @@ template <int W, int H>
 constexpr bool bits_packed(const int feat) {
   return (feat & kFeatPacked) != 0 && (BitsGeo<W, H>::EPW * W * H) % 32 == 0 && (W * H) % 2 == 0 &&
          !(feat & (kFeatDict | kFeatRgb | kFeatFinal | kFeatSplit | kFeatWide));
+}
+// kFeatSeq (round 6; boards above 640 cells — 16 envs per stream wave —, packed, one transition per launch: config 5).  Those launches
+// were residency-bound: a workgroup of 16 envs holds two waves of 128 VGPRs, so EIGHT workgroups = 128 envs fit a CU, 65 536 envs need
+// two rounds, and the second round pays the whole latency chain (first loads -> logic -> publish -> slab work) again: +3.7 us at the
+// ninth workgroup per CU (profiles/r05/config5_batch_sweep.log) — while the logic wave ran with 16 of its 64 lanes.  Here a workgroup
+// serves 32 envs: the logic wave decides them in ONE pass (32 lanes live, half the logic instructions per env), the stream wave
+// requests BOTH 16-env slab groups up front (packed: 2 x 28 registers), then expands / applies / writes back / streams out one group
+// after the other through the same 12.8 KB of LDS — no second barrier, the second group's data has arrived long before its turn.  LDS
+// per workgroup 20 032 B -> eight per CU = 256 envs: the 2 048 workgroups of 65 536 envs are resident in one round.
+constexpr int kFeatSeq = 2048;
+template <int W, int H>
+constexpr int bits_nseq(const int feat) {
+  return ((feat & kFeatSeq) && bits_packed<W, H>(feat) && !(feat & kFeatMulti) && bits_eps0(W, H) == 16) ? 2 : 1;
 }
 // packed 16-byte chunk (32 cells) -> the two 16-byte chunks of uint8 cells, and back (values < 16)
 __device__ __forceinline__ void nib_expand(const u32x4 pk, u32x4& a, u32x4& b) {
@@ -809,7 +823,7 @@ void step_kernel_bits(
     const KParams p, const BitsParams bp) {
   constexpr bool MULTI = (FEAT & kFeatMulti) != 0, TRAJ = (FEAT & kFeatTraj) != 0, DICTK = (FEAT & kFeatDict) != 0,
                  SAMPLE = (FEAT & kFeatSample) != 0, FINAL = (FEAT & kFeatFinal) != 0, RGBK = (FEAT & kFeatRgb) != 0;
-  using BG = BitsGeo<W, H>;
+  using BG = BitsGeo<W, H, bits_nseq<W, H>(FEAT)>;
   using T = ColT<H>;
   [[maybe_unused]] constexpr int S = BG::S, EPW = BG::EPW, NCH = BG::NCH, NIT = BG::NIT, CST = BG::CST;
   constexpr T ONES = ~T(0);
@@ -1016,6 +1030,176 @@ void step_kernel_bits(
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         }
       }
+      TG_ROLE_END();
+    }
+  }
+  if constexpr (bits_nseq<W, H>(FEAT) > 1) {
+    if (__builtin_expect(wave >= 1, 0)) {
+      // =====================================================================================================
+      // STREAM WAVE of the kFeatSeq instantiations (packed board, one transition per launch, boards above 640 cells): the workgroup's
+      // envs in NSEQ groups of EPS, one after the other through ONE slab block in LDS.  Every group's packed slabs are requested up front
+      // (they sit in registers until the group's turn: no load latency between the groups, no second barrier — the logic wave has
+      // published all groups at once); per group: expand -> lock cells / row compaction / resets -> write-back -> piece -> observation.
+      // =====================================================================================================
+      constexpr int NSEQ = bits_nseq<W, H>(FEAT), EPS = BG::EPW / NSEQ, NCHP = NCH / 2, NITP = (NCHP + 63) / 64;
+      static_assert(!MULTI && bits_packed<W, H>(FEAT) && !DICTK && !RGBK && !FINAL && NCH == EPS * S / 16, "kFeatSeq: packed one-transition builds");
+      __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_sleep(32);  // (the logic waves' records first: see the general stream wave)
+      uint64_t tab_cells = 0;
+      if (lane < 7) tab_cells = c_cells.cells[lane];
+      u32x4 stage[NSEQ][NITP];
+#pragma unroll
+      for (int g = 0; g < NSEQ; ++g) {
+        const uint32_t gb = (uint32_t)(g * EPS);
+        const uint32_t nl = nlive > gb ? (nlive - gb < (uint32_t)EPS ? nlive - gb : (uint32_t)EPS) : 0u;
+        const uint32_t ncp = nl ? (nl * (uint32_t)S / 2u + 15u) / 16u : 1u;  // (an empty group of a ragged workgroup re-reads chunk 0 of group 0)
+        const u32x4* gsrc = reinterpret_cast<const u32x4*>(hot_board + (size_t)(base_env + (nl ? gb : 0u)) * (S / 2));
+#pragma unroll
+        for (int k = 0; k < NITP; ++k) {
+          const uint32_t c = (uint32_t)lane + 64u * k;
+          stage[g][k] = gsrc[c < ncp ? c : ncp - 1u];
+        }
+      }
+      if (lane < 7) cell_tab[lane] = tab_cells;
+      TG_LATE_ARGS();
+      auto differs = [](const u32x4 a, const u32x4 b) -> bool { return ((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) != 0u; };
+      const bool fn = p.obs_mode == TG_OBS_FN;
+#pragma unroll
+      for (int g = 0; g < NSEQ; ++g) {
+        const uint32_t gb = (uint32_t)(g * EPS);
+        const uint32_t nl = nlive > gb ? (nlive - gb < (uint32_t)EPS ? nlive - gb : (uint32_t)EPS) : 0u;
+        if (g > 0 && nl == 0u) break;  // (ragged last workgroup)
+        const uint32_t benv = base_env + gb;
+        const bool lv = (uint32_t)lane < nl;
+        const int sl = lv ? lane : (int)nl - 1;
+        const bool full = nl == (uint32_t)EPS;
+        const uint32_t nbytes = nl * (uint32_t)S, nchunks = (nbytes + 15u) / 16u, nchunks_p = (nbytes / 2u + 15u) / 16u;
+#pragma unroll
+        for (int k = 0; k < NITP; ++k) {
+          const uint32_t c = (uint32_t)lane + 64u * k;
+          u32x4 a, b;
+          nib_expand(stage[g][k], a, b);
+          if (c < nchunks_p) { lds4[2 * c] = a; lds4[2 * c + 1] = b; }
+        }
+        if (g == 0) {
+          TG_BITS_STAMP(1);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+          __builtin_amdgcn_s_barrier();  // the logic wave has published what happened to every env of the workgroup
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+          __builtin_amdgcn_s_setprio(3);
+          TG_BITS_STAMP(2);
+        } else {
+          wave_sync();
+        }
+        const uint4 po = post[(int)gb + sl];  // (layout: the general stream wave)
+        const bool place = lv && ((po.x >> 24) & 1u), do_clear = lv && ((po.x >> 25) & 1u), do_reset = lv && ((po.x >> 26) & 1u);
+        const bool dirty = place || do_reset;
+        LaneBoard<W, H, 1> bd;
+        bd.my = lds + sl * S;
+        bd.sub = 0;
+        if (__any(dirty)) {
+          const bool nib_over = bd.template stamp<RULESET == TG_RULESET_FUNCTIONAL>(
+              po.x & 0xFFFFu, (int)(po.y & 0xFFu), (int)((po.y >> 8) & 0xFFu), (po.x >> 16) & 0xFFu, RULESET == TG_RULESET_FUNCTIONAL, place);
+          if constexpr (RULESET == TG_RULESET_FUNCTIONAL) {
+            if (nib_over) *p.nib_over = 1u;
+          }
+          wave_sync();
+          uint64_t todo = __ballot(do_clear);
+          while (todo) {
+            const int l = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            (void)clear_rows<W, H, RULESET>(lds + l * S, lane);
+          }
+          todo = __ballot(do_reset);
+          while (todo) {
+            const int l = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            uint32_t* sw = reinterpret_cast<uint32_t*>(lds + l * S);
+            for (int i = lane; i < S / 4; i += 64) sw[i] = 0u;
+          }
+          wave_sync();
+          // board write-back, chunk-major (see the general stream wave): the last full group compares against the registers it was
+          // loaded into, the others store the packed chunks that hold cells of a changed env
+          const uint64_t dm = __ballot(dirty);
+          u32x4* pdst = reinterpret_cast<u32x4*>(hot_board + (size_t)benv * (S / 2));
+          const __amdgpu_buffer_rsrc_t pwin = st_window(pdst, nchunks_p * 16u);
+          const bool keep_b0 = full && g == NSEQ - 1;
+#pragma unroll
+          for (int k0 = 0; k0 < NITP; k0 += 4) {
+            u32x4 pa[4], pb[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int c = lane + 64 * (k0 + kk);
+              const int cc = c < NCHP ? c : NCHP - 1;
+              pa[kk] = lds4[2 * cc]; pb[kk] = lds4[2 * cc + 1];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              if (k0 + kk >= NITP) continue;
+              const uint32_t c = (uint32_t)lane + 64u * (uint32_t)(k0 + kk);
+              const u32x4 pw = nib_pack(pa[kk], pb[kk]);
+              const uint32_t e0 = (32u * c) / (uint32_t)S, e1r = (32u * c + 31u) / (uint32_t)S;
+              const uint32_t e1 = e1r < (uint32_t)EPS ? e1r : (uint32_t)EPS - 1u;
+              const bool hit = keep_b0 ? differs(pw, stage[g][k0 + kk])
+                                       : ((((dm >> (e0 < (uint32_t)EPS ? e0 : (uint32_t)EPS - 1u)) | (dm >> e1)) & 1ull) != 0);
+              st_state_if(pwin, 16u * c, pw, c < nchunks_p && hit);
+            }
+          }
+        }
+        if (g == NSEQ - 1) TG_BITS_STAMP(3);
+        if (need_slab) {
+          const bool show = lv && ((po.z >> 24) & 1u);
+          bd.stamp(po.z & 0xFFFFu, (int)(po.w & 0xFFu), (int)((po.w >> 8) & 0xFFu), fn ? 0xFFu : ((po.z >> 16) & 0xFFu), false, show);
+          wave_sync();
+          u32x4* odst = reinterpret_cast<u32x4*>(p.obs + (size_t)benv * S);
+          u32x4* odst2 = reinterpret_cast<u32x4*>((obs_traj ? obs_traj : p.obs) + (size_t)benv * S);  // (trajectory slot 0 of a one-transition rollout)
+          if (full) {
+            u32x4 o[NIT];
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+              const int c = lane + 64 * k;
+              o[k] = lds4[c < NCH ? c : NCH - 1];
+            }
+            if (fn) {
+#pragma unroll
+              for (int k = 0; k < NIT; ++k) o[k] = bits_bin4(o[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+              const int c = lane + 64 * k;
+              if (64 * k + 63 >= NCH) {  // the last, partial pass: the window drops the lanes behind the block
+                __builtin_amdgcn_raw_buffer_store_b128(o[k], st_window(odst, (uint32_t)NCH * 16u), 16u * (uint32_t)c, 0, 2);
+                if (obs_traj) __builtin_amdgcn_raw_buffer_store_b128(o[k], st_window(odst2, (uint32_t)NCH * 16u), 16u * (uint32_t)c, 0, 2);
+                continue;
+              }
+              st_stream(&odst[c], o[k]);
+              if (obs_traj) st_stream(&odst2[c], o[k]);
+            }
+          } else {
+            for (uint32_t c = lane; c < nchunks; c += 64) {
+              u32x4 vv = lds4[c];
+              if (fn) vv = u32x4{bits_bin1(vv.x), bits_bin1(vv.y), bits_bin1(vv.z), bits_bin1(vv.w)};
+              if (c * 16u + 16u <= nbytes) {
+                odst[c] = vv;
+                if (obs_traj) odst2[c] = vv;
+              } else {  // ragged tail of a partial group
+                const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
+                for (uint32_t i = 0; c * 16u + i < nbytes; ++i) {
+                  const uint8_t bv = (uint8_t)(w4[i >> 2] >> (8 * (i & 3)));
+                  reinterpret_cast<uint8_t*>(odst)[c * 16u + i] = bv;
+                  if (obs_traj) reinterpret_cast<uint8_t*>(odst2)[c * 16u + i] = bv;
+                }
+              }
+            }
+          }
+          if (g + 1 < NSEQ) wave_sync();  // (the next group's expansion overwrites the slab block)
+        }
+      }
+      TG_BITS_STAMP(4);
+      TG_TIMING(if (p.dbg && lane == 0) {
+        for (int i = 0; i < 5; ++i) p.dbg[(size_t)step_block * 16 + 8 + i] = tstamp[i];
+        p.dbg[(size_t)step_block * 16 + 14] = __builtin_amdgcn_s_getreg(63492);
+      })
       TG_ROLE_END();
     }
   }
