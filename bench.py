@@ -57,6 +57,63 @@ def free_port() -> int:
     return port
 
 
+def parse_cpulist(text: str):
+    """'0-3,8,10-11' (sysfs cpulist) -> [0, 1, 2, 3, 8, 10, 11]"""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def cpus_near_pci_device(bdf: str, sysfs: str = "/sys"):
+    """(numa_node, cpus) of the PCI device `bdf` ('0000:c1:00.0'): /sys/bus/pci/devices/<bdf>/numa_node and that node's cpulist;
+    (-1, []) when the platform does not say (one node, a VM, no such file)."""
+    try:
+        node = int(open(os.path.join(sysfs, "bus", "pci", "devices", bdf.lower(), "numa_node")).read().strip())
+        if node < 0:
+            return -1, []
+        return node, parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")).read())
+    except (OSError, ValueError):
+        return -1, []
+
+
+def bind_near_device(lib, device: int, sysfs: str = "/sys") -> str:
+    """Bind this rank's process (its launch thread, and the CPU baseline's threads on rank 0) to the cores of the NUMA node its GPU hangs
+    off — on a two-socket host a launch thread on the far socket pays the cross-socket hop on every doorbell write and completion
+    read.  Returns what was done, for the bench line (`per_rank_binding`).  TG_BENCH_BIND=0 switches it off."""
+    import ctypes
+
+    if os.environ.get("TG_BENCH_BIND", "1") == "0":
+        return "off (TG_BENCH_BIND=0)"
+    buf = ctypes.create_string_buffer(64)
+    if not hasattr(lib, "tg_device_pci_bus_id") or lib.tg_device_pci_bus_id(int(device), buf, 64) != 0:
+        return "unbound (no PCI bus id)"
+    bdf = buf.value.decode()
+    node, cpus = cpus_near_pci_device(bdf, sysfs)
+    if not cpus or not hasattr(os, "sched_setaffinity"):
+        return f"unbound ({bdf}: numa_node {node})"
+    allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))  # (a cgroup / taskset of the job stays in force)
+    if not allowed:
+        return f"unbound ({bdf}: node {node} has no allowed cpu)"
+    os.sched_setaffinity(0, allowed)
+    return f"{bdf} node {node} cpus {allowed[0]}-{allowed[-1]} ({len(allowed)})"
+
+
+def device_for_rank(local: int, world: int, ndev: int, share: bool):
+    """(device ordinal, error text or None): one process per GPU.  More ranks than visible devices is an error — a mis-provisioned
+    8-GPU run would otherwise produce a plausible-looking line from ranks that silently share devices — unless --share-devices
+    says it is meant (exercising the N > 1 path on a smaller box; the line then carries a note)."""
+    if ndev <= 0:
+        return -1, "no HIP device visible (this engine has no CPU fallback)"
+    if world > ndev and not share:
+        return -1, (f"--gpus {world} but only {ndev} HIP device(s) visible: one process per GPU needs {world}; pass --share-devices to let "
+                    f"ranks share devices round-robin (tests the N > 1 path, not a scaling measurement)")
+    return local % ndev, None
+
+
 def launch_ranks(n: int, argv, script: str | None = None, timeout_s: float = 3600.0) -> int:
     """Spawn `n` fresh rank processes of `script` (default: this file) with the torchrun environment contract and wait.
     Returns the first non-zero exit code (the other ranks are then terminated by PID), else 0.  Makes no HIP call."""
@@ -110,7 +167,9 @@ class Dist:
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29511")
+            if "MASTER_PORT" not in os.environ:  # (no fixed default: two jobs on one host would meet on it)
+                raise SystemExit("bench.py: WORLD_SIZE > 1 without MASTER_PORT — launch with `python bench.py --gpus N` (picks a free "
+                                 "port) or torchrun / torch.distributed.run")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
             self.pg = dist
 
@@ -137,6 +196,14 @@ class Dist:
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         self.pg.all_gather(parts, mine)
         return [float(p[0]) for p in parts]
+
+    def gather_obj(self, value):
+        """A small picklable value of every rank, in rank order (metadata: device ordinals, core bindings)."""
+        if self.pg is None:
+            return [value]
+        parts = [None] * self.world
+        self.pg.all_gather_object(parts, value)
+        return parts
 
     def gather_u64(self, value: int):
         """A 64-bit integer of every rank, in rank order (the shard checksums: metadata, not data path)."""
@@ -576,8 +643,31 @@ def shards_block(local, *, per_shard=8192, steps=256, warmup=32):
         out[f"k{k}"] = {"shards": k, "envs": B, "us_per_step": dt / steps * 1e6, "host_us_per_step": t_enq / steps * 1e6,
                         "value": B * steps / dt, "unit": "env steps/s",
                         "us_per_step_regions": [round(r[0] / steps * 1e6, 2) for r in regions]}
-        for e, d in zip(v.engines, ptrs):
-            e.dev_free(d)
+        # the same shards driven through tg_rollout in chunks of 16 transitions (TetrisVectorEnv.rollout_device): one enqueue per shard
+        # and chunk instead of one per shard and transition — the form for one process in front of several devices
+        K = steps // 16 * 16
+        a8 = np.ascontiguousarray(acts[warmup:warmup + K].astype(np.int8))
+        p8, po, pr = [], [], []
+        for e in v.engines:
+            d = e.dev_alloc(a8.nbytes); e.dev_upload(d, a8); p8.append(d)
+            po.append(e.dev_alloc(K * per_shard * 200)); pr.append(e.dev_alloc(K * per_shard * 8))
+        v.rollout_device(p8, 32, po, pr, chunk=16)
+        for e in v.engines:
+            e.sync()
+        regions = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            v.rollout_device(p8, K, po, pr, chunk=16)
+            t_enq = time.perf_counter() - t0
+            for e in v.engines:
+                e.sync()
+            regions.append((time.perf_counter() - t0, t_enq))
+        dt, t_enq = sorted(regions)[1]
+        out[f"k{k}"]["fused16"] = {"us_per_step": dt / K * 1e6, "host_us_per_step": t_enq / K * 1e6, "value": B * K / dt,
+                                   "unit": "env steps/s", "note": "tg_rollout, 16 transitions per launch, trajectory slots on the device"}
+        for e, d, d8, do, dr in zip(v.engines, ptrs, p8, po, pr):
+            for x in (d, d8, do, dr):
+                e.dev_free(x)
         v.close()
     return out
 
@@ -593,6 +683,8 @@ def parse(argv=None):
     ap.add_argument("--obs", choices=["board", "dict", "fn", "none", "rgb"], default="board")
     ap.add_argument("--ruleset", choices=["numpy", "functional"], default="numpy")
     ap.add_argument("--reps", type=int, default=7, help="repetitions of the timed region for the roofline median (>= 5)")
+    ap.add_argument("--share-devices", action="store_true", help="--gpus N with fewer than N visible devices: let ranks share devices "
+                                                                "round-robin (exercises the N > 1 path; not a scaling measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=6.0, help="seconds of CPU work per thread count of the headline's cpu_baseline")
     ap.add_argument("--fuse", type=int, default=1,
@@ -641,7 +733,7 @@ def compact_line(out, blocks):
     r = out["roofline"]
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                 "vs_baseline", "dtype", "data", "config", "per_rank_ms_per_step", "per_rank_device",
-                                "n_devices_visible") if k in out}
+                                "n_devices_visible", "per_rank_binding") if k in out}
     line["per_rank_ms_per_step"] = [round(x, 6) for x in line["per_rank_ms_per_step"]]
     line["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_us", "clock",
                                               "kernel_us_hip_events", "kernel_us_rocprof", "frac_hip_events", "frac_measured_bytes",
@@ -664,8 +756,9 @@ def compact_line(out, blocks):
                 mini[name] = [float(f"{b['board']['host']['value']:.4g}"), float(f"{b['board']['device_actions']['value']:.4g}")]
             elif name == "single_env":  # Tetris().step loop, steps/s
                 mini[name] = [float(f"{b['plain_loop']['value']:.4g}")]
-            elif name == "vector_env_shards":  # host microseconds per step driving 1 / 8 shards from one Python process
-                mini[name] = [round(b["k1"]["host_us_per_step"], 2), round(b["k8"]["host_us_per_step"], 2)]
+            elif name == "vector_env_shards":  # host microseconds per step driving 1 / 8 shards from one Python process; ... 8 shards through tg_rollout
+                mini[name] = [round(b["k1"]["host_us_per_step"], 2), round(b["k8"]["host_us_per_step"], 2),
+                              round(b["k8"].get("fused16", {}).get("host_us_per_step", 0.0), 2)]
         line["blocks"] = mini
         line["blocks_key"] = "[env steps/s, roofline.frac, kernel us per launch]; full blocks: blocks_file and the '[bench-block]' lines above"
     return line
@@ -680,11 +773,14 @@ def rank_main(args) -> int:
     D = Dist()
     from tetris_gymnasium_amd import _native as N
 
-    ndev = N.load().tg_device_count()  # (first HIP call of this process: the launcher has long since forked)
-    if ndev <= 0:
-        print("bench.py: no HIP device visible (this engine has no CPU fallback)", file=sys.stderr)
-        return 3
-    local = D.local % ndev  # more ranks than devices only when exercising the N > 1 path on a smaller box
+    lib = N.load()
+    ndev = lib.tg_device_count()  # (first HIP call of this process: the launcher has long since forked)
+    local, err = device_for_rank(D.local, D.world, ndev, args.share_devices)
+    if err:
+        print("bench.py: " + err, file=sys.stderr)
+        D.close()
+        return 3 if ndev <= 0 else 4
+    binding = D.gather_obj(bind_near_device(lib, local))
     reps = max(5, args.reps)
     want_cpu = not args.no_cpu_baseline
     blocks = {}
@@ -728,7 +824,7 @@ def rank_main(args) -> int:
                "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "u8", "data": "synthetic", "config": head["config"],
                "per_rank_ms_per_step": head["per_rank_ms_per_step"], "per_rank_device": head["per_rank_device"],
-               "n_devices_visible": ndev, "roofline": head["roofline"]}
+               "n_devices_visible": ndev, "per_rank_binding": binding, "roofline": head["roofline"]}
         if D.world > ndev:
             out["note"] = (f"{D.world} ranks on {ndev} visible device(s): ranks share devices round-robin — this exercises the "
                            f"N > 1 path, it is not a scaling measurement")

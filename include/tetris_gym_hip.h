@@ -27,11 +27,13 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 5 /* 2: tg_config launch knobs, tg_dev_copy, tg_get_state_dev / tg_set_state_dev
+#define TG_ABI_VERSION 6 /* 2: tg_config launch knobs, tg_dev_copy, tg_get_state_dev / tg_set_state_dev
                           * 3: TG_BUF_HOST_PACK, tg_host_pack_layout, tg_fetch_many, tg_step_fetch_many, tg_shape_mask
                           * 4: tg_config.action_ids / rewards (ActionsMapping / RewardsMapping as per-handle data),
                           *    TG_OUT_COMMITTED / TG_OUT_ILLEGAL in tg_step_out.flags
-                          * 5: tg_observe_as, tg_features_as (a wrapper's observation of ANY handle's current state) */
+                          * 5: tg_observe_as, tg_features_as (a wrapper's observation of ANY handle's current state)
+                          * 6: tg_device_pci_bus_id; an ActionsMapping whose hard_drop aliases an earlier field is accepted;
+                          *    tg_set_state(_dev) refuses playfield rows of bedrock cells (NUMPY rule-set) */
 
 /* ---- rule-sets (the reference contains two different Tetris rule-sets) ---- */
 #define TG_RULESET_NUMPY 0      /* envs/tetris.py (the graded oracle) */
@@ -85,6 +87,8 @@ extern "C" {
  *   TG_FN_LAZY=0..7    FUNCTIONAL look-ahead test hook: bits 0-1 when a lock sorts the reset bag ahead (0 tall stack only,
  *                      1 never, 2 always), bit 2 the key chain never catches up behind a reset
  *   TG_SPLIT=0         never pick the instantiations with two stream waves per workgroup (tests: both builds must agree)
+ *   TG_SEQ=0           never pick the instantiations whose stream wave walks two env groups (boards above 640 cells, packed, one
+ *                      transition per launch; A/B runs and tests: both builds must agree)
  *   TG_PACKED=0|1      forbid / force the nibble-packed board format (default: handles of >= 20 Mi cells)
  *   TG_KERNEL=bits     anything else needs the test-only legacy library (make -C csrc legacy) and is refused by the product
  *   TG_CSRC_DIR, TG_CACHE_DIR   where the kernel headers are / where compiled code objects of non-built-in board sizes are
@@ -125,15 +129,19 @@ typedef struct tg_config {
    *   (mappings/actions.py:12-19).  Tetris.step compares the incoming action with the fields in the order of its elif chain
    *   (envs/tetris.py:222-256: left, right, down, cw, ccw, swap, hard_drop, no_op; the first match wins, an id that matches
    *   no field only takes gravity) and skips gravity iff action == hard_drop (:259).  The action space stays Discrete(8)
-   *   (:192), so only ids 0..7 are reachable; field values outside that range are legal and unreachable.  Refused
-   *   (TG_EUNSUPPORTED): a mapping in which hard_drop shares its value with a field earlier in the chain (that id would run
-   *   the other operation and then skip gravity — no entry of the kernel's action table says that).
+   *   (:192), so only ids 0..7 are reachable; field values outside that range are legal and unreachable.  A mapping in
+   *   which hard_drop shares its value with a field earlier in the chain is taken as the reference takes it: that id runs
+   *   the other operation and then skips gravity (its own table entry since round 6).
    * rewards (TG_FLAG_CUSTOM_REWARDS, else ignored = the stock 1, 1, 0, -0.1): alife, clear_line, game_over,
    *   invalid_action (mappings/rewards.py:12-15).  A commit returns score(lines) + alife, or game_over when the piece
    *   already collides / the spawn collides (envs/tetris.py:461-474); clear_line is a field the reference never reads
    *   (score is rows^2 * width, :621-630) and is carried for completeness; invalid_action is the reward of a masked-out
    *   action of the grouped action set (wrappers/grouped.py:238).  The step kernel works in float32; the exact Python value
-   *   (int + float in double precision) is what TG_BUF_HOST_PACK holds — recomputed from tg_step_out.flags / lines. */
+   *   (int + float in double precision) is what TG_BUF_HOST_PACK holds — recomputed from tg_step_out.flags / lines.
+   *   Precision of what is NOT recomputed: tg_step_out.reward (what tg_fetch / Engine.step / Engine.rollout return) and the
+   *   running episode return tg_episode_rec.ret — hence the "episode returns" array of TG_BUF_HOST_PACK and
+   *   infos["episode"]["r"] of the vector adapter — are float32 sums of float32 rewards: exact for the stock mapping and every
+   *   dyadic one, float32-accurate for a mapping such as alife = 0.1 (the per-step rewards beside them are exact doubles). */
   int32_t action_ids[8];
   double rewards[4];
 } tg_config;
@@ -228,6 +236,10 @@ int tg_abi_version(void);
 
 /* Number of visible HIP devices (does not initialise a context beyond hipGetDeviceCount). */
 int tg_device_count(void);
+
+/* PCI bus id ("0000:c1:00.0") of HIP device `device` into buf (NUL-terminated): lets a launcher find the device's NUMA node
+ * (/sys/bus/pci/devices/<id>/numa_node) and bind its rank's host thread next to it (bench.py --gpus N).  TG_EINVAL / TG_EHIP. */
+int tg_device_pci_bus_id(int device, char* buf, int len);
 
 /* Create an engine instance: allocates all device state (SoA) for cfg->batch envs on cfg->device.
  * Envs are NOT reset by create; call tg_reset. */

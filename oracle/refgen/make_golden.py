@@ -15,6 +15,7 @@ Fixtures (all NumPy rule-set, i.e. envs/tetris.py — the graded oracle of BASEL
   grouped_features_*.npz per-placement feature tensors [4W][W+3] (grouped wrapper + FeatureVectorObservation)
   ref_tests_grouped.npz  the reference tests' own mock board / CSV board / 40-entry mask (data only)
   rgb_<cfg>.npz          RgbObservation frames (wrappers/observation.py:38-74) along random traces incl. hold swaps
+  grouped_rgb_10x20.npz  the grouped wrapper with observation_wrappers=[RgbObservation]: one RGB image per placement
   poked_<cfg>.npz        HAND-MADE states in the style of the reference's own tests (tests/test_base_env/**: board / x / y /
                          active_tetromino / holder / queue / has_swapped / game_over assigned directly) x each of the 8 actions, then 15
                          random transitions; the grouped wrapper's mask / placement boards / features and the RGB frame of the same states
@@ -548,6 +549,44 @@ def gen_poked(ref, name, width, height, queue_size, n_states, seed, gravity=True
           f"bedrock-row states={int(bedrock_row.sum())} game_over states={int(np.array(st['game_over']).sum())}")
 
 
+def gen_grouped_rgb(ref, name, width, height, queue_size, T, seed):
+    """GroupedActionsObservations(env, observation_wrappers=[RgbObservation(env)]) (wrappers/grouped.py:181-204 feeding
+    wrappers/observation.py:38-74): one RGB image per placement — the placement board (ones for an illegal placement, zeros for a
+    game-over one) beside the env's holder / queue strips — plus info["board"], the image of the env's own observation."""
+    rng = np.random.default_rng(seed)
+    base = make_env(ref, width, height, True, queue_size)
+    env = ref.GroupedActionsObservations(base, observation_wrappers=[ref.RgbObservation(base)])
+    obs, info = env.reset(seed=seed)
+    NA = 4 * width
+    shape = obs.shape
+    assert shape[0] == NA and shape[-1] == 3, shape
+    first_obs, first_board, first_mask = obs.astype(np.uint8), info["board"].astype(np.uint8), env.legal_actions_mask.astype(np.uint8)
+    actions = np.zeros(T, np.int16)
+    frames = np.zeros((T,) + shape, np.uint8)
+    boards = np.zeros((T,) + shape[1:], np.uint8)
+    masks = np.zeros((T, NA), np.uint8)
+    done = np.zeros(T, np.uint8)
+    reward = np.zeros(T, np.float64)
+    for t in range(T):
+        legal = np.flatnonzero(env.legal_actions_mask == 1)
+        a = int(rng.choice(legal)) if len(legal) else 0
+        if t % 5 == 4:  # a hold in between, so that the holder strip fills (the base env's own swap action)
+            base.step(base.actions.swap)
+            env.observation(base._get_obs())
+            legal = np.flatnonzero(env.legal_actions_mask == 1)
+            a = int(rng.choice(legal)) if len(legal) else 0
+        actions[t] = a
+        obs, r, d, _, info = env.step(a)
+        frames[t], boards[t], masks[t], done[t], reward[t] = obs, info["board"], env.legal_actions_mask, int(d), float(r)
+        if d:
+            obs, info = env.reset()
+            frames[t], boards[t], masks[t] = obs, info["board"], env.legal_actions_mask  # (what the next action is drawn from)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), width=width, height=height, queue_size=queue_size, T=T, seed=seed,
+                        actions=actions, frames=frames, boards=boards, masks=masks, done=done, reward=reward,
+                        first_obs=first_obs, first_board=first_board, first_mask=first_mask)
+    print(f"{name}: {T} grouped steps with RGB placements {frames.shape}, episodes={int(done.sum())}")
+
+
 def gen_ref_tests_grouped(ref):
     """Data held by the reference's own grouped tests: the mock board (tests/helpers/mock.py:5-47 applied to
     a fresh env), the CSV board after action 21 (tests/test_grouped_env/expected_result_i_placement.csv) and
@@ -619,6 +658,10 @@ def gen_features(ref):
 # rotate_counterclockwise, hard_drop, swap, no_op
 MAP_PERM = (3, 7, 0, 5, 1, 2, 4, 6)
 MAP_DUP = (0, 1, 2, 3, 3, 5, 6, 12)  # ccw duplicates cw (unreachable), ids 4 and 7 belong to no field
+# hard_drop sharing its value with a field the elif chain tests EARLIER (envs/tetris.py:222-259): that id runs the other operation and
+# then skips gravity (`action != self.actions.hard_drop` is false); no id hard-drops, pieces lock by gravity alone
+MAP_ALIAS_LEFT = (5, 1, 2, 3, 4, 5, 6, 7)  # move_left == hard_drop == 5; id 0 belongs to no field
+MAP_ALIAS_SWAP = (0, 1, 2, 6, 4, 6, 6, 7)  # rotate_clockwise == hard_drop == swap == 6: the rotation wins, no gravity; ids 3, 5: no field
 
 
 def main():
@@ -656,6 +699,10 @@ def main():
                                              action_ids=MAP_PERM, rewards=(0.5, 10, -5.25, -0.25)),
         "mapped_10x20_g0": lambda: run_trace(ref, "mapped_10x20_g0", 10, 20, False, 4, 24, 256, 12361,
                                              action_ids=MAP_DUP, rewards=(2, 1, -7, -0.1)),
+        "mapped_alias_left_10x20": lambda: run_trace(ref, "mapped_alias_left_10x20", 10, 20, True, 4, 32, 320, 12362,
+                                                     action_ids=MAP_ALIAS_LEFT, rewards=(1, 1, 0, -0.1)),
+        "mapped_alias_swap_10x20": lambda: run_trace(ref, "mapped_alias_swap_10x20", 10, 20, True, 4, 32, 320, 12363,
+                                                     action_ids=MAP_ALIAS_SWAP, rewards=(0.25, 1, -2, -0.1)),
         "mapped_clears_10x20": lambda: gen_clears(ref, "mapped_clears_10x20", 10, 20, 4, 48, 256, 779, 7,
                                                   action_ids=MAP_PERM, rewards=(0, 10, -5, -1)),
         "mapped_grouped_10x20": lambda: gen_grouped(ref, "mapped_grouped_10x20", 10, 20, 4, 16, 96, 34, 0,
@@ -663,6 +710,7 @@ def main():
                                                     terminate_on_illegal=False, p_any=0.25),
         "rgb_10x20": lambda: gen_rgb(ref, "rgb_10x20", 10, 20, 4, 8, 160, 51),
         "rgb_20x40": lambda: gen_rgb(ref, "rgb_20x40", 20, 40, 7, 2, 200, 52),
+        "grouped_rgb_10x20": lambda: gen_grouped_rgb(ref, "grouped_rgb_10x20", 10, 20, 4, 40, 71),
         "poked_10x20": lambda: gen_poked(ref, "poked_10x20", 10, 20, 4, 192, 61),
         "poked_10x20_g0": lambda: gen_poked(ref, "poked_10x20_g0", 10, 20, 4, 72, 62, gravity=False, n_grouped=0),
         "poked_20x40": lambda: gen_poked(ref, "poked_20x40", 20, 40, 7, 60, 63, n_grouped=12),

@@ -5,7 +5,7 @@ over everything a caller can do in any order: base steps, grouped steps through 
 snapshots and restores, attribute writes, in-place edits of handed-out arrays, plain attribute reads, wrapper observations.  After
 every operation the env's observation — and at random the wrappers' observations, the action mask and the host-side attributes — must
 equal the oracle's.  (The wrappers keep an auxiliary engine / write state back on demand: this is the test of that bookkeeping.)
-usage: python tests/fuzz_drop_in.py [n_walks] [seed]     (not collected by pytest)"""
+usage: python tests/fuzz_drop_in.py [n_walks] [seed]     (long runs; tests/test_gpu_fuzz.py runs a bounded slice of run_walk under pytest -m gpu)"""
 import os
 import sys
 import time
@@ -18,13 +18,12 @@ from oracle import pyoracle as po  # noqa: E402
 from tetris_gymnasium_amd.envs import Tetris  # noqa: E402
 from tetris_gymnasium_amd.wrappers import FeatureVectorObservation, GroupedActionsObservations, RgbObservation  # noqa: E402
 
-NW = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 OPS = int(os.environ.get("FUZZ_OPS", 250))
 SIZES = [(10, 20), (6, 12), (8, 16), (10, 24), (12, 24)]
 
-t0 = time.time()
-for wi in range(NW):
+
+def run_walk(SEED, wi, OPS=OPS):
+    """Walk `wi` of seed `SEED`: raises AssertionError naming the configuration and the last operations, returns the line the CLI prints."""
     r = np.random.default_rng([SEED, wi])
     W, H = SIZES[int(r.integers(len(SIZES)))]
     Q = int(r.integers(1, 8))
@@ -119,6 +118,14 @@ for wi in range(NW):
             log.append("read attributes")
             _ = (base.board, base.queue.get_queue(), base.holder.get_tetrominoes(), base.active_tetromino, base.has_swapped, base.game_over)
         check(log[-1] if log else "nothing")
-    print(f"ok   {tag}: {OPS} operations", flush=True)
     grp.close()
-print(f"{NW} walks, seed {SEED}: {time.time() - t0:.0f} s")
+    return f"ok   {tag}: {OPS} operations"
+
+
+if __name__ == "__main__":
+    NW = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = time.time()
+    for wi in range(NW):
+        print(run_walk(SEED, wi), flush=True)
+    print(f"{NW} walks, seed {SEED}: {time.time() - t0:.0f} s")

@@ -5,7 +5,7 @@ gravity, autoreset mode, observation surface, action set, launch knobs (transiti
 mappings, batch size; per configuration a few hundred transitions in rollouts of random length with, in between, masked and
 seeded resets and a get_state / set_state round trip.  Every transition's outputs and observation and, after every rollout, the
 whole state (boards, records, generators) must equal the oracle's.
-usage: python tests/fuzz_parity.py [n_configs] [seed]     (not collected by pytest)"""
+usage: python tests/fuzz_parity.py [n_configs] [seed]     (long runs; tests/test_gpu_fuzz.py runs a bounded slice of run_config under pytest -m gpu)"""
 import os
 import sys
 import time
@@ -17,15 +17,15 @@ sys.path.insert(0, ROOT)
 from oracle import pyoracle as po  # noqa: E402
 from tetris_gymnasium_amd import Engine, _native as N  # noqa: E402
 
-NCFG = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 MAX_RTC = int(os.environ.get("FUZZ_RTC_SIZES", 3))  # board sizes compiled at run time (tens of seconds each on a fresh box)
 BUILT_IN = [(10, 20), (20, 40), (6, 12), (8, 16), (10, 24), (12, 24)]
 PO_OBS = {N.OBS_BOARD: po.OBS_BOARD, N.OBS_FN: po.OBS_FN, N.OBS_DICT: po.OBS_DICT, N.OBS_RGB: po.OBS_RGB}
 PO_AR = {N.AUTORESET_NONE: po.AUTORESET_NONE, N.AUTORESET_SAME_STEP: po.AUTORESET_SAME_STEP, N.AUTORESET_NEXT_STEP: po.AUTORESET_NEXT_STEP}
 
-top = np.random.default_rng(SEED)
-rtc_sizes = [(int(top.integers(4, 17)), int(top.integers(6, 31))) for _ in range(MAX_RTC)]
+
+def draw_rtc_sizes(seed, n=MAX_RTC):
+    top = np.random.default_rng(seed)
+    return [(int(top.integers(4, 17)), int(top.integers(6, 31))) for _ in range(n)]
 
 
 def same_state(e, o, numpy_rules, where):
@@ -50,8 +50,9 @@ def same_obs(got, ref, where):
         assert np.array_equal(got, ref), f"observation differs {where}"
 
 
-t_start = time.time()
-for ci in range(NCFG):
+def run_config(SEED, ci, rtc_sizes=(), steps=None):
+    """Configuration `ci` of seed `SEED` (the draw depends on nothing else but the run-time-compiled sizes offered): raises AssertionError
+    naming the configuration, returns the line the CLI prints."""
     r = np.random.default_rng([SEED, ci])
     W, H = BUILT_IN[int(r.integers(len(BUILT_IN)))] if (r.random() < 0.75 or not rtc_sizes) else rtc_sizes[int(r.integers(len(rtc_sizes)))]
     numpy_rules = bool(r.random() < 0.65)
@@ -76,19 +77,24 @@ for ci in range(NCFG):
         rws = (float(r.integers(-4, 5)) / 2, 1.0, float(r.integers(-9, 1)), -0.25)
     tag = (f"{W}x{H} {'numpy' if numpy_rules else 'functional'} Q={Q} g={int(gravity)} autoreset={autoreset} obs={obs} grouped={int(grouped)}"
            f"{'/toi' if grouped and toi else ''} B={B}{' streams=2' if streams > 1 else ''}{' packed' if packed else ''} fuse={fuse} ring={ring_fill} rng_every={rng_every}{' mapped' if ids else ''}")
+    packed_before = os.environ.get("TG_PACKED")
     os.environ["TG_PACKED"] = "1" if packed else "0"
     try:
         e = Engine(B, W, H, ruleset=rs, gravity=gravity, queue_size=Q, obs_mode=obs, autoreset=autoreset, grouped=grouped,
                    terminate_on_illegal=toi, fuse=fuse, ring_fill=ring_fill, rng_every=rng_every, actions_mapping=ids, rewards_mapping=rws, streams=streams)
     except Exception as ex:  # (a configuration tg_create refuses is not a parity failure: say so and go on)
-        print(f"skip {tag}: {str(ex)[:120]}")
-        continue
+        return f"skip {tag}: {str(ex)[:120]}"
+    finally:  # (read by tg_create only: the caller's environment is left as it was)
+        if packed_before is None:
+            os.environ.pop("TG_PACKED", None)
+        else:
+            os.environ["TG_PACKED"] = packed_before
     o = po.OracleBatch(B, W, H, rs, gravity, Q, action_ids=ids, rewards=rws, nthreads=8 if B > 1000 else 1)
     seeds = r.integers(1, 1 << 40, B).astype(np.uint64)
     e.reset(seeds); o.reset(seeds)
     same_state(e, o, numpy_rules, f"after reset [{tag}]")
     na = 4 * W if grouped else (8 if numpy_rules else 7)
-    done, total = 0, int(os.environ.get("FUZZ_STEPS", 260)) // (4 if B > 1000 else 1)
+    done, total = 0, int(steps or os.environ.get("FUZZ_STEPS", 260)) // (4 if B > 1000 else 1)
     while done < total:
         K = int(r.choice([1, 1, 3, 16, 40]))
         acts = r.integers(0, na, (K, B))
@@ -151,6 +157,41 @@ for ci in range(NCFG):
             st = e.get_state()
             e.set_state(*st)
             same_state(e, o, numpy_rules, f"after a get_state / set_state round trip at {done} [{tag}]")
-    print(f"ok   {tag}: {done} transitions  [{e.step_kernel_name(fuse, grouped)}]", flush=True)
+        elif u < 0.53 and numpy_rules:
+            # hand-made records (round 6; the reference's tests assign these attributes directly, tests/test_base_env/**): any piece /
+            # rotation / position the reference's slicing tolerates — on filled cells, inside the bedrock —, holder, queue, bag, flags
+            bb, rc, gg = o.get_state()
+            sel = r.random(B) < 0.6
+            nmat = np.array([4, 2, 3, 3, 3, 3, 3])
+            pc = r.integers(0, 7, B)
+            n = nmat[pc]
+            rc["piece"][sel] = pc[sel]
+            rc["rot"][sel] = r.integers(0, 4, B)[sel]
+            rc["x"][sel] = (1 + r.integers(0, 1 << 30, B) % (W + 8 - n - 1))[sel]
+            rc["y"][sel] = (r.integers(0, 1 << 30, B) % (H + 4 - n))[sel]
+            rc["val"][sel] = pc[sel] + 2
+            hp = np.where(r.random(B) < 0.5, r.integers(0, 7, B), 255)
+            rc["holder_piece"][sel] = hp[sel]
+            rc["holder_rot"][sel] = np.where(hp == 255, 0, r.integers(0, 4, B))[sel]
+            rc["holder_val"][sel] = np.where(hp == 255, 0, hp + 2)[sel]
+            rc["flags"][sel] = ((r.random(B) < 0.08) | ((r.random(B) < 0.4) << 1)).astype(np.uint8)[sel]
+            rc["queue"][sel, :Q] = r.integers(0, 7, (B, Q))[sel]
+            rc["bag"][sel] = np.stack([r.permutation(7) for _ in range(B)])[sel]
+            rc["bag_index"][sel] = r.integers(0, 7, B)[sel]
+            e.set_state(rec=rc); o.set_state(rec=rc)
+            same_state(e, o, numpy_rules, f"after a record upload at {done} [{tag}]")
+            if obs != N.OBS_NONE:
+                same_obs(e.observation(), o.observe(PO_OBS[obs]), f"after a record upload at {done} [{tag}]")
+    line = f"ok   {tag}: {done} transitions  [{e.step_kernel_name(fuse, grouped)}]"
     e.close()
-print(f"{NCFG} configurations, seed {SEED}: {time.time() - t_start:.0f} s")
+    return line
+
+
+if __name__ == "__main__":
+    NCFG = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t_start = time.time()
+    sizes = draw_rtc_sizes(SEED)
+    for ci in range(NCFG):
+        print(run_config(SEED, ci, sizes), flush=True)
+    print(f"{NCFG} configurations, seed {SEED}: {time.time() - t_start:.0f} s")

@@ -4,7 +4,7 @@ random batch size, shard count (several handles on one device), autoreset mode, 
 grouped action set, mappings, copy / no-copy, and per step a random choice between the host path (NumPy results, one call into the
 C ABI) and the device-resident path (views downloaded for the comparison).  Observations, rewards (as Python computes them),
 terminations, `infos["lines_cleared"]`, the episode statistics and the grouped action mask must equal the oracle's at every step.
-usage: python tests/fuzz_vector_env.py [n_configs] [seed]     (not collected by pytest)"""
+usage: python tests/fuzz_vector_env.py [n_configs] [seed]     (long runs; tests/test_gpu_fuzz.py runs a bounded slice of run_config under pytest -m gpu)"""
 import os
 import sys
 import time
@@ -16,8 +16,6 @@ sys.path.insert(0, ROOT)
 from oracle import pyoracle as po  # noqa: E402
 from tetris_gymnasium_amd.vector import TetrisVectorEnv  # noqa: E402
 
-NCFG = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 STEPS = int(os.environ.get("FUZZ_STEPS", 160))
 SIZES = [(10, 20), (6, 12), (8, 16), (10, 24), (12, 24), (20, 40)]
 PO_OBS = {"dict": po.OBS_DICT, "board": po.OBS_BOARD, "rgb": po.OBS_RGB, "functional": po.OBS_FN}
@@ -31,8 +29,8 @@ def same_obs(got, ref, where):
         assert np.array_equal(np.asarray(got), ref), f"observation differs {where}"
 
 
-t0 = time.time()
-for ci in range(NCFG):
+def run_config(SEED, ci, STEPS=STEPS):
+    """Configuration `ci` of seed `SEED`: raises AssertionError naming the configuration, returns the line the CLI prints."""
     r = np.random.default_rng([SEED, ci])
     W, H = SIZES[int(r.integers(len(SIZES)))]
     functional = r.random() < 0.25
@@ -107,6 +105,14 @@ for ci in range(NCFG):
             ret[count] += rw[count]; ln[count] += 1
         prev = term.copy()
         n_eps += int(term.sum()); ret[term] = 0; ln[term] = 0
-    print(f"ok   {tag}: {STEPS} steps, {n_eps} episodes ended", flush=True)
     env.close()
-print(f"{NCFG} configurations, seed {SEED}: {time.time() - t0:.0f} s")
+    return f"ok   {tag}: {STEPS} steps, {n_eps} episodes ended"
+
+
+if __name__ == "__main__":
+    NCFG = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = time.time()
+    for ci in range(NCFG):
+        print(run_config(SEED, ci), flush=True)
+    print(f"{NCFG} configurations, seed {SEED}: {time.time() - t0:.0f} s")

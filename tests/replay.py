@@ -156,11 +156,13 @@ def _cmp_snapshot(fx, prefix, board, rec, sel, msg):
                                           fx[prefix + "_holder_matrix"][i], err_msg=f"holder matrix env={i} {msg}")
 
 
-def replay_poked(be, fx, skip=None, upload=None, step=None, check_obs=True):
+def replay_poked(be, fx, skip=None, upload=None, step=None, check_obs=True, rollout=None):
     """Drive a backend through a poked_* fixture: upload the hand-made states, take every state's 8 first actions and the 15
     random transitions behind them, compare every output with the reference's as long as its recording of that copy lasts
     (`valid`).  be: the backend interface of replay_trace, constructed for batch 8 * n_states and reset with poked_seeds(fx);
-    upload(board, rec): how the state gets in (default be.set_state); step(t, actions) -> (reward, terminated, lines)."""
+    upload(board, rec): how the state gets in (default be.set_state); step(t, actions) -> (reward, terminated, lines);
+    rollout(actions[T, B]) -> (reward, terminated, lines)[T, B]: all T transitions in fused launches instead — the outputs of every
+    transition are compared, the state where the reference's recording runs to the end."""
     T = int(fx["T"])
     board, rec, _ = be.get_state()
     m = poked_upload(fx, board, rec, skip)
@@ -171,6 +173,18 @@ def replay_poked(be, fx, skip=None, upload=None, step=None, check_obs=True):
             assert obs_crc(obs, i) == int(fx["st_crc"][i // 8]), f"observation of the uploaded state, env {i} (state {i // 8})"
     valid = fx["valid"].astype(bool) & m[None, :]
     last_t = valid.sum(axis=0) - 1  # the transition behind which the reference's `last_*` snapshot was taken
+    if rollout is not None:
+        rew, term, lines = rollout(fx["actions"].astype(np.int8))
+        for t in range(T):
+            v = valid[t]
+            np.testing.assert_array_equal(np.asarray(rew[t])[v].astype(np.int64), fx["reward"][t][v].astype(np.int64), err_msg=f"reward t={t}")
+            np.testing.assert_array_equal(np.asarray(term[t])[v], fx["done"][t][v], err_msg=f"terminated t={t}")
+            np.testing.assert_array_equal(np.asarray(lines[t])[v], fx["lines"][t][v], err_msg=f"lines t={t}")
+        board, rec, _ = be.get_state()
+        sel = valid[T - 1] & (last_t == T - 1)
+        assert sel.sum() > sel.size // 8
+        _cmp_snapshot(fx, "last", board, rec, sel, "behind the fused launch")
+        return m
     for t in range(T):
         a = fx["actions"][t].astype(np.int32)
         rew, term, lines = (step(t, a) if step else be.step(a))

@@ -902,7 +902,7 @@ class MappedEngineBackend(EngineBackend):
         return self.e.host_pack()["rewards"]
 
 
-@pytest.mark.parametrize("name", ["mapped_10x20_g1", "mapped_10x20_g0", "mapped_clears_10x20"])
+@pytest.mark.parametrize("name", ["mapped_10x20_g1", "mapped_10x20_g0", "mapped_clears_10x20", "mapped_alias_left_10x20", "mapped_alias_swap_10x20"])
 def test_engine_replays_reference_trace_with_custom_mappings(golden_dir, name):
     """Outputs of the reference's Tetris(actions_mapping=..., rewards_mapping=...): a permutation of the action ids with float
     rewards, a mapping with a duplicate value and ids that no field holds, line clears with integer rewards.  Rewards are

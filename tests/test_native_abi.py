@@ -114,10 +114,12 @@ def test_custom_action_mappings_are_validated_before_any_device_call():
             lib.tg_destroy(h)
         return rc, msg
 
+    # hard_drop sharing its value with a field Tetris.step tests earlier: accepted since round 6 (that id runs the other operation and
+    # skips gravity, envs/tetris.py:222-259; replayed against the reference in tests/test_gpu_parity.py, fixture mapped_alias_10x20)
     rc, msg = create((5, 1, 2, 3, 4, 5, 6, 7))  # move_left == hard_drop
-    assert rc == N.EUNSUPPORTED and "hard_drop" in msg
+    assert rc in (0, N.EHIP) and "hard_drop" not in msg
     rc, msg = create((0, 1, 2, 3, 4, 5, 5, 7))  # swap == hard_drop: swap is tested first
-    assert rc == N.EUNSUPPORTED and "hard_drop" in msg
+    assert rc in (0, N.EHIP) and "hard_drop" not in msg
     rc, msg = create((0, 1, 2, 3, 3, 5, 6, 12))  # a duplicate among the others and an unreachable value: fine
     assert rc in (0, N.EHIP) and "hard_drop" not in msg
     rc, msg = create((3, 7, 0, 5, 1, 2, 4, 6), (0.5, 10, float("nan"), -0.25))

@@ -40,7 +40,7 @@ def test_oracle_replays_reference_trace(golden_dir, name):
     replay.replay_trace(OracleBackend, fx)
 
 
-MAPPED = ["mapped_10x20_g1", "mapped_10x20_g0", "mapped_clears_10x20"]
+MAPPED = ["mapped_10x20_g1", "mapped_10x20_g0", "mapped_clears_10x20", "mapped_alias_left_10x20", "mapped_alias_swap_10x20"]
 
 
 @pytest.mark.parametrize("name", MAPPED)

@@ -13,7 +13,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TG_LIB") or os.path.join(_PKG, "libtetris_gym_hip.so")  # TG_LIB: the test-only legacy build
 
-ABI_VERSION = 5  # include/tetris_gym_hip.h TG_ABI_VERSION
+ABI_VERSION = 6  # include/tetris_gym_hip.h TG_ABI_VERSION
 RULESET_NUMPY, RULESET_FUNCTIONAL = 0, 1
 OBS_NONE, OBS_BOARD, OBS_DICT, OBS_FN, OBS_RGB = 0, 1, 2, 3, 4
 AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = 0, 1, 2
@@ -65,6 +65,7 @@ _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 SYMBOLS = {
     "tg_abi_version": (_i, []),
     "tg_device_count": (_i, []),
+    "tg_device_pci_bus_id": (_i, [_i, C.c_char_p, _i]),
     "tg_create": (_i, [C.POINTER(TgConfig), C.POINTER(_vp)]),
     "tg_destroy": (None, [_vp]),
     "tg_last_error": (C.c_char_p, [_vp]),

@@ -679,7 +679,12 @@ __global__ __launch_bounds__(256) void sanitize_state_kernel(const SanitizeParam
   };
   fix(d0, 0, 6, 0);                                   // piece
   fix(d0, 8, 3, 0);                                   // rot
-  fix(d0, 16, (uint32_t)p.W + 4u, 7);                 // x
+  // x <= Wp - n, n = the native matrix of the piece (I 4, O 2, the others 3; FUNCTIONAL: 4 x 4 boxes throughout): as far as the
+  // reference's own slicing reaches (envs/tetris.py:408-427 raises beyond) — every such position lies wholly in the right bedrock
+  {
+    const uint32_t pc = d0 & 0xFFu;
+    fix(d0, 16, (uint32_t)p.W + 4u + (p.ruleset == TG_RULESET_NUMPY ? (pc == 1u ? 2u : (pc == 0u ? 0u : 1u)) : 0u), 7);  // x
+  }
   fix(d0, 24, (uint32_t)p.H + 3u, 0);                 // y
   if (((d1 >> 16) & 0xFFu) != TG_NONE) { fix(d1, 16, 6, TG_NONE); fix(d1, 24, 3, 0); }  // holder piece / rot
   fix(d2, 8, 7, 7);                                   // bag index
@@ -777,6 +782,8 @@ struct tg_handle {
                                // kernel keeps THIS current, TG_BUF_BOARD is brought up to date on demand (ensure_board)
   bool board_stale = false;    // TG_BUF_BOARD is behind d_pboard
   uint32_t* h_nib_over = nullptr;  // packed FUNCTIONAL handles: page-locked flag word the step kernel raises (KParams::nib_over)
+  uint32_t* h_fn_over = nullptr;   // FUNCTIONAL handles with an observation: page-locked copy of fn_overlap_kernel's word + the event behind
+  hipEvent_t fn_ev = nullptr;      // that copy — the answer is picked up without waiting for the stream (resolve_fn_overlap)
   int* d_err = nullptr;        // flag word of sanitize_state_kernel (tg_set_state_dev); word 4: fn_overlap_kernel
   bool fn_overlap = false;         // FUNCTIONAL: the uploaded state holds a piece on top of filled cells (fn_overlap_kernel's word, read back)
   bool fn_overlap_pending = false; // ... a tg_set_state_dev has been enqueued whose word nobody has read yet (treated as "may hold one")
@@ -916,20 +923,22 @@ int alloc_buf(tg_handle* h, int which, size_t n) {
 // The per-action table of the step kernel for a handle's ActionsMapping (tg_config.action_ids: field values in declaration
 // order move_left, move_right, move_down, rotate_clockwise, rotate_counterclockwise, hard_drop, swap, no_op).  Entry a =
 // what Tetris.step does with action id a: the FIRST field of its elif chain (envs/tetris.py:222-256: left, right, down, cw,
-// ccw, swap, hard_drop, no_op) whose value equals a; none → only gravity, like no_op.  Returns false for the one shape the
-// table cannot say: hard_drop sharing its value with an earlier field of the chain (the other operation, then no gravity).
-bool act_lut_from_ids(const int32_t ids[8], uint64_t* lut) {
+// ccw, swap, hard_drop, no_op) whose value equals a; none → only gravity, like no_op.  A hard_drop that shares its value with an
+// EARLIER field of the chain (round 6): that field's branch runs and the gravity block is skipped, because its guard compares the
+// action with `self.actions.hard_drop` again (:259) — the entry of that operation with the hard-drop bit set beside its check / swap
+// bit, which the logic wave reads as "this operation, then no gravity" (tg_kernel_bits.h).
+void act_lut_from_ids(const int32_t ids[8], uint64_t* lut) {
   static const int chain[8] = {0, 1, 2, 3, 4, 6, 5, 7};  // declaration index of the chain's k-th comparison
   uint64_t v = 0;
   for (int a = 0; a < 8; ++a) {
     int op = 7;  // no_op
     for (int k = 0; k < 8; ++k)
       if (ids[chain[k]] == a) { op = chain[k]; break; }
-    if (ids[5] == a && op != 5) return false;
-    v |= ((tg::kActLutNumpy >> (8 * op)) & 0xFFull) << (8 * a);
+    uint64_t e = (tg::kActLutNumpy >> (8 * op)) & 0xFFull;
+    if (ids[5] == a && op != 5) e |= 0x40ull;  // (op is one of left / right / down / cw / ccw / swap: every one of them has bit 5 or 7)
+    v |= e << (8 * a);
   }
   *lut = v;
-  return true;
 }
 
 tg::KParams step_params(tg_handle* h) {
@@ -1013,12 +1022,31 @@ int launch_fn_overlap(tg_handle* h) {
   for (int i = 0; i < 7; ++i) q.shapes[i] = kp.shapes[i];
   hipLaunchKernelGGL(fn_overlap_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, q);
   HIPCHK(h, hipGetLastError());
+  if (h->h_fn_over) {  // the answer travels to a page-locked word; the event says when it is there
+    HIPCHK(h, hipMemcpyAsync(h->h_fn_over, (uint32_t*)h->d_err + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipEventRecord(h->fn_ev, h->stream));
+  }
   h->fn_overlap_pending = true;
   return TG_OK;
 }
-// ... while this holds, transitions take the exact path (one transition per launch + the observe kernel)
-inline bool fn_exact_path(const tg_handle* h) {
-  return (h->fn_overlap || h->fn_overlap_pending) && h->cfg.ruleset == TG_RULESET_FUNCTIONAL && h->cfg.obs_mode != TG_OBS_NONE;
+// A pending answer is taken as soon as its copy has completed — no wait: a device-resident loop that restores states
+// (tg_set_state_dev) and never synchronises used to stay on the exact path for good.
+inline void resolve_fn_overlap(tg_handle* h) {
+  if (!h->fn_overlap_pending || !h->fn_ev) return;
+  if (hipEventQuery(h->fn_ev) == hipSuccess) {
+    h->fn_overlap = *(volatile uint32_t*)h->h_fn_over != 0;
+    h->fn_overlap_pending = false;
+  } else {
+    (void)hipGetLastError();  // (hipErrorNotReady is not an error of the call that asked)
+  }
+}
+// ... while this holds, transitions take the exact path (one transition per launch + the observe kernel).  The flag is re-evaluated
+// behind every transition of that path (step_impl / rollout_impl), so it falls by itself once no piece lies on filled cells any more
+// (the pieces moved or locked) — it used to stay until the next full reset or upload.
+inline bool fn_exact_path(tg_handle* h) {
+  if (h->cfg.ruleset != TG_RULESET_FUNCTIONAL || h->cfg.obs_mode == TG_OBS_NONE) return false;
+  resolve_fn_overlap(h);
+  return h->fn_overlap || h->fn_overlap_pending;
 }
 
 // ---- shards: fork (step launches) / join (everything else) ----
@@ -1084,7 +1112,8 @@ int check_dev_state(tg_handle* h) {
   }
   if (h->fn_overlap_pending) {  // (the stream has been waited for: fn_overlap_kernel's answer is there)
     uint32_t w = 0;
-    HIPCHK(h, hipMemcpy(&w, (uint32_t*)h->d_err + 4, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (h->h_fn_over) w = *(volatile uint32_t*)h->h_fn_over;
+    else HIPCHK(h, hipMemcpy(&w, (uint32_t*)h->d_err + 4, sizeof(uint32_t), hipMemcpyDeviceToHost));
     h->fn_overlap = w != 0;
     h->fn_overlap_pending = false;
   }
@@ -1094,6 +1123,10 @@ int check_dev_state(tg_handle* h) {
   HIPCHK(h, hipMemcpy(&flags, h->d_err, sizeof(int), hipMemcpyDeviceToHost));
   if (!flags) return TG_OK;
   HIPCHK(h, hipMemsetAsync(h->d_err, 0, sizeof(int), h->stream));
+  if (flags & 4)
+    return fail(h, TG_EUNSUPPORTED, "tg_set_state_dev: an uploaded board holds a playfield row of bedrock cells (value 1 in every column); the "
+                                    "reference never clears such a row (envs/tetris.py:493) and this engine's row test cannot tell it from a filled "
+                                    "one — the next lock there clears it%s", (flags & 3) ? " (and other fields were out of range and clamped)" : "");
   return fail(h, TG_EINVAL, "tg_set_state_dev: the uploaded device state held values tg_set_state refuses (%s%s); they were clamped so that "
                             "nothing indexes out of range — the engine's state is not what was uploaded",
               (flags & 1) ? "record field out of range" : "", (flags & 2) ? ((flags & 1) ? ", board byte out of range" : "board byte out of range") : "");
@@ -1135,6 +1168,7 @@ int launch_prepare_bits(tg_handle* h, const uint8_t* d_mask, int force) {
   q.ruleset = h->cfg.ruleset;
   q.force = force;
   q.queue_size = h->Q;
+  q.err = h->d_err;
   h->L.prepare(q, h->stream);
   HIPCHK(h, hipGetLastError());
   return TG_OK;
@@ -1318,6 +1352,12 @@ int tg_device_count(void) {
   return n;
 }
 
+int tg_device_pci_bus_id(int device, char* buf, int len) {
+  if (!buf || len < 13) return TG_EINVAL;
+  buf[0] = 0;
+  return hipDeviceGetPCIBusId(buf, len, device) == hipSuccess ? TG_OK : TG_EHIP;
+}
+
 const char* tg_last_error(const tg_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 int tg_obs_bytes_per_env(const tg_config* cfg) { return cfg ? (int)obs_bytes_per_env(cfg) : TG_EINVAL; }
@@ -1366,9 +1406,7 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
   if ((cfg->flags & (TG_FLAG_CUSTOM_ACTIONS | TG_FLAG_CUSTOM_REWARDS)) && cfg->ruleset != TG_RULESET_NUMPY)
     return fail(nullptr, TG_EINVAL, "tg_create: ActionsMapping / RewardsMapping belong to the NUMPY rule-set (envs/tetris.py:83-84)");
   uint64_t act_lut = tg::kActLutNumpy;
-  if ((cfg->flags & TG_FLAG_CUSTOM_ACTIONS) && !act_lut_from_ids(cfg->action_ids, &act_lut))
-    return fail(nullptr, TG_EUNSUPPORTED, "tg_create: ActionsMapping.hard_drop (%d) shares its value with a field that Tetris.step "
-                "tests earlier (envs/tetris.py:222-256): that id would run the other operation and skip gravity", cfg->action_ids[5]);
+  if (cfg->flags & TG_FLAG_CUSTOM_ACTIONS) act_lut_from_ids(cfg->action_ids, &act_lut);
   if (cfg->flags & TG_FLAG_CUSTOM_REWARDS)
     for (int i = 0; i < 4; ++i)
       if (!(cfg->rewards[i] == cfg->rewards[i]) || cfg->rewards[i] > 3.0e38 || cfg->rewards[i] < -3.0e38)
@@ -1488,6 +1526,11 @@ int tg_create(const tg_config* cfg, tg_handle** out) {
         *h->h_nib_over = 0;
       }
     }
+    if (cfg->ruleset == TG_RULESET_FUNCTIONAL && cfg->obs_mode != TG_OBS_NONE) {
+      CRCHK(hipHostMalloc((void**)&h->h_fn_over, 64, hipHostMallocDefault));
+      *h->h_fn_over = 0;
+      CRCHK(hipEventCreateWithFlags(&h->fn_ev, hipEventDisableTiming));
+    }
   }
 #ifdef TG_PHASE_TIMING
   CRCHK(hipMalloc(&h->dbg, ((B + 15) / 16) * 16 * 8));
@@ -1550,6 +1593,8 @@ void tg_destroy(tg_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->arena) (void)hipFree(h->arena);
   if (h->h_nib_over) (void)hipHostFree(h->h_nib_over);
+  if (h->h_fn_over) (void)hipHostFree(h->h_fn_over);
+  if (h->fn_ev) (void)hipEventDestroy(h->fn_ev);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1662,7 +1707,12 @@ static int step_impl(tg_handle* h, const int32_t* actions, int kind, bool waited
   }
   after_launch(h, p);
   HIPCHK(h, hipGetLastError());
-  if (((h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) && !h->dict_in_kernel) || fn_exact_path(h)) return launch_observe_dict(h);
+  const bool exact = fn_exact_path(h);
+  if (((h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) && !h->dict_in_kernel) || exact) {
+    const int rco = launch_observe_dict(h);
+    if (rco != TG_OK) return rco;
+    if (exact && h->fn_overlap) return launch_fn_overlap(h);  // (does a piece still lie on filled cells? — see fn_exact_path)
+  }
   return TG_OK;
 }
 
@@ -1702,7 +1752,8 @@ static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, u
   // max 16) consecutive transitions of a rollout — one launch floor and one slab round trip per group instead of per
   // transition.  tg_step always launches one transition.
   const int fuse_max = h->fuse_max;
-  const bool post_kernel = ((h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) && !h->dict_in_kernel) || fn_exact_path(h);
+  const bool exact = fn_exact_path(h);
+  const bool post_kernel = ((h->cfg.obs_mode == TG_OBS_DICT || h->cfg.obs_mode == TG_OBS_RGB) && !h->dict_in_kernel) || exact;
   const size_t obs_stride = (size_t)h->B * obs_bytes_per_env(&h->cfg);
   if (obs_traj_dev && h->cfg.obs_mode == TG_OBS_NONE) return fail(h, TG_EINVAL, "tg_rollout: the handle has no observation (TG_OBS_NONE)");
   // trajectories are written by the step kernel itself when it packs the observation (bits kernel, BOARD / FN);
@@ -1762,6 +1813,7 @@ static int rollout_impl(tg_handle* h, const int8_t* actions_dev, bool sampled, u
   int rc = enqueue();
   if (rc != TG_OK) return rc;
   HIPCHK(h, hipGetLastError());
+  if (exact && h->fn_overlap) return launch_fn_overlap(h);  // (re-evaluated behind the K transitions: see fn_exact_path)
   return TG_OK;
 }
 
@@ -1898,7 +1950,9 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
     for (size_t i = 0; i < B; ++i) {
       const tg_env_rec& r = rec[i];
       if (r.piece > 6 || r.rot > 3 || (r.holder_piece != TG_NONE && (r.holder_piece > 6 || r.holder_rot > 3)) ||
-          r.bag_index > 7 || r.x > h->W + 4 || r.y > h->H + 3)
+          r.bag_index > 7 || r.y > h->H + 3 ||
+          // (x <= Wp - n: the reach of the reference's own slicing, see sanitize_state_kernel)
+          r.x > h->W + 4 + (h->cfg.ruleset == TG_RULESET_NUMPY ? (r.piece == 1 ? 2 : (r.piece == 0 ? 0 : 1)) : 0))
         return fail(h, TG_EINVAL, "tg_set_state: record %zu out of range (piece %d rot %d holder %d bag_index %d x %d y %d)", i,
                     r.piece, r.rot, r.holder_piece, r.bag_index, r.x, r.y);
       for (int k = 0; k < 7; ++k)
@@ -1924,10 +1978,15 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
     for (size_t i = 0; i < B; ++i) {
       bool any_full = false;
       const uint8_t* b = board + i * h->cells;
-      for (int r = 0; r < h->H && !any_full; ++r) {
-        bool full = true;
-        for (int c = 0; c < h->W; ++c) full &= b[r * h->W + c] != 0;
-        any_full = full;
+      for (int r = 0; r < h->H; ++r) {
+        bool full = true, ones = true;
+        for (int c = 0; c < h->W; ++c) { full &= b[r * h->W + c] != 0; ones &= b[r * h->W + c] == 1; }
+        any_full |= full;
+        // (the reference never clears a row of bedrock cells, envs/tetris.py:493 `& ~(board == 1).all(axis=1)`; the column masks of the
+        // step kernel hold one bit per cell and would clear it with the next lock: refused rather than stepped differently)
+        if (ones && h->cfg.ruleset == TG_RULESET_NUMPY)
+          return fail(h, TG_EUNSUPPORTED, "tg_set_state: row %d of board %zu consists of bedrock cells (value 1) only; the reference never clears such "
+                                          "a row (envs/tetris.py:493) and this engine's row test cannot tell it from a filled one", r, i);
       }
       tmp[i].flags = (uint8_t)((tmp[i].flags & ~TG_F_FULLROW) | (any_full ? TG_F_FULLROW : 0));
     }

@@ -1893,7 +1893,9 @@ void step_kernel_bits(
   int ty = s.y + (int)((e >> 2) & 1u);
   int tr = (s.rot + (int)((e >> 3) & 3u)) & 3;
   const bool check = (e & 0x20u) != 0;
-  const bool hard = stepped & ((e & 0x40u) != 0);
+  // (NUMPY: bit 6 beside a check / swap bit is not a hard drop but "this operation, then no gravity" — the entry tg_create builds for
+  // an ActionsMapping whose hard_drop shares its value with a field Tetris.step tests earlier, envs/tetris.py:222-259)
+  const bool hard = stepped & (RULESET == TG_RULESET_NUMPY ? (e & 0xE0u) == 0x40u : (e & 0x40u) != 0);
   // swap (envs/tetris.py:242-252, components/tetromino_holder.py:31-49)
   const bool swap_eff = RULESET == TG_RULESET_NUMPY && (stepped & ((e & 0x80u) != 0) & !(s.flags & TG_F_HAS_SWAPPED));
   // NUMPY: the visible queue is consumed lazily.  A transition takes at most two pieces from the env's stream (a hold
@@ -2018,7 +2020,8 @@ void step_kernel_bits(
   const bool coll_below = accept ? cT1 : cC1;
   if (RULESET == TG_RULESET_FUNCTIONAL) drop_reward = (accept & ((e & 4u) != 0)) ? 1 : drop_reward;  // soft drop (tetris_fn.py:183-190)
   {
-    const bool gq = moving & (grav != 0) & !hard;  // envs/tetris.py:259-264; functional/core.py:150-182 + tetris_fn.py:242-247
+    // envs/tetris.py:259-264 (`action != self.actions.hard_drop`: bit 6 of the entry); functional/core.py:150-182 + tetris_fn.py:242-247
+    const bool gq = moving & (grav != 0) & (RULESET == TG_RULESET_NUMPY ? (e & 0x40u) == 0 : !hard);
     const bool fall = gq & !coll_below;
     s.y += fall ? 1 : 0;
     if (RULESET == TG_RULESET_NUMPY) {
@@ -2629,6 +2632,7 @@ struct PrepareParams {
   int cur;              // ring parity the next launch reads
   int hcur;             // consumed-counter parity the next launch reads
   int queue_size;       // FUNCTIONAL: the bag length (EnvConfig.queue_size)
+  int* err;             // or null: flag word of the handle (bit 2: a playfield row of bedrock cells, NUMPY rule-set — see the kernel)
 };
 
 template <int W, int H>
@@ -2638,12 +2642,22 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
   if (env >= p.batch) return;
   const uint8_t* b = p.board + (size_t)env * W * H;
   T* gc = reinterpret_cast<T*>(p.cols) + (size_t)env * bits_cols_words<W, H>();
+  T ones = (T)~T(0);  // rows whose every cell is 1
   for (int c = 0; c < W; ++c) {
-    T v = 0;
-    for (int rr = 0; rr < H; ++rr) v |= (T)(b[rr * W + c] != 0 ? 1 : 0) << rr;
+    T v = 0, o = 0;
+    for (int rr = 0; rr < H; ++rr) {
+      const uint8_t cell = b[rr * W + c];
+      v |= (T)(cell != 0 ? 1 : 0) << rr;
+      o |= (T)(cell == 1 ? 1 : 0) << rr;
+    }
     gc[c] = v;
+    ones &= o;
   }
   if (bits_cols_words<W, H>() > W) gc[W] = 0;
+  // NUMPY rule-set: the reference's clear_filled_rows never takes a row that consists of bedrock cells (value 1) only
+  // (envs/tetris.py:493 `& ~(board == 1).all(axis=1)`), the column masks cannot tell it from a filled one.  Play never makes such a
+  // row; tg_set_state refuses it on the host, an upload through tg_set_state_dev is flagged here and reported at the next wait.
+  if (p.ruleset == TG_RULESET_NUMPY && p.err && ones != 0) atomicOr(p.err, 4);
   const size_t B = (size_t)p.batch;
   const bool moved = p.force || (p.mask ? p.mask[env] != 0 : true);
   uint4* ring4 = reinterpret_cast<uint4*>(p.ring);

@@ -179,7 +179,13 @@ class Tetris(EnvBase):
         if self._handed is None:
             return False
         old, self._handed = self._handed, None
-        return (not self._stale) and old != self._fingerprint()
+        changed = (not self._stale) and old != self._fingerprint()
+        if not changed and not self._stale:
+            # (nothing changed and the host copy is still current: the caller may still hold the reference it was given —
+            # `b = env.board; env.render(); b[...] = v; env.step()` edits the live array in the reference — so the
+            # fingerprint stays armed; it is dropped only when the host copy is replaced: _pull, _push, a step)
+            self._handed = old
+        return changed
 
     def _flush(self):
         """host-side edits (attribute writes, in-place changes of handed-out objects) → device"""

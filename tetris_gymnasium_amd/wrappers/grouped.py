@@ -7,22 +7,26 @@ from .. import _native as N
 from .._gym_compat import spaces
 from ..envs.tetris import TetrisState
 from ._device import WrapperBase, aux_engine, mirror
-from .observation import FeatureVectorObservation
+from .observation import FeatureVectorObservation, RgbObservation
 
 
 class GroupedActionsObservations(WrapperBase):
     """action = column * 4 + rotations → teleport + hard drop; observation = one entry per action (the board each
-    placement would produce, or its feature vector when `observation_wrappers=[FeatureVectorObservation(env)]`);
-    `info["action_mask"]` marks placements that collide with the frame.  Enumeration, mask, features and the grouped
-    transition all run on the device."""
+    placement would produce, its feature vector when `observation_wrappers=[FeatureVectorObservation(env)]`, its RGB image when
+    `observation_wrappers=[RgbObservation(env)]`); `info["action_mask"]` marks placements that collide with the frame.
+    Enumeration, mask, features and the grouped transition all run on the device.  The RGB form (reference wrappers/grouped.py:
+    181-204 feeding wrappers/observation.py:38-74 with every placement board and the env's holder / queue) is composed on the host:
+    the placement boards of tg_grouped_enumerate through the colour table, beside the strip columns of the env's own RGB frame
+    (tg_observe_as) — 4W small images per call of a single-env class are not worth a kernel.  Any other wrapper list is refused."""
 
     def __init__(self, env, observation_wrappers=None, terminate_on_illegal_action: bool = True):
         super().__init__(env)
         u = env.unwrapped
         if observation_wrappers and not (len(observation_wrappers) == 1 and
-                                         isinstance(observation_wrappers[0], FeatureVectorObservation)):
-            raise NotImplementedError("observation_wrappers: only [FeatureVectorObservation(env)] has a device kernel")
+                                         isinstance(observation_wrappers[0], (FeatureVectorObservation, RgbObservation))):
+            raise NotImplementedError("observation_wrappers: [FeatureVectorObservation(env)] and [RgbObservation(env)] are supported")
         self.observation_wrappers = observation_wrappers
+        self._rgb = bool(observation_wrappers) and isinstance(observation_wrappers[0], RgbObservation)
         self.terminate_on_illegal_action = terminate_on_illegal_action
         self.action_space = spaces.Discrete(u.width * 4)
         single = observation_wrappers[-1].observation_space.shape if observation_wrappers else \
@@ -30,7 +34,7 @@ class GroupedActionsObservations(WrapperBase):
         self.observation_space = spaces.Box(low=0, high=u.height * u.width, shape=(u.width * 4,) + tuple(single),
                                             dtype=np.float32)
         self.legal_actions_mask = np.ones(self.action_space.n)
-        self._aux = aux_engine(env, obs_mode=N.OBS_NONE, grouped=True, features=bool(observation_wrappers),
+        self._aux = aux_engine(env, obs_mode=N.OBS_NONE, grouped=True, features=bool(observation_wrappers) and not self._rgb,
                                terminate_on_illegal=terminate_on_illegal_action)
         self._seen = None  # the state version of the wrapped env that the auxiliary engine holds (wrappers/_device.py mirror)
         self._wb = self._writeback  # (ONE bound-method object: the env keeps it while our write-back is pending, Tetris._defer)
@@ -43,6 +47,16 @@ class GroupedActionsObservations(WrapperBase):
 
     # -- observation of the env's CURRENT state (the aux engine must already mirror it) ---------------
     def _observe(self):
+        if self._rgb:
+            u = self.env.unwrapped
+            mask, boards = self._aux.placement_boards()
+            self.legal_actions_mask = mask[0].astype(np.float64)
+            frame = self._aux.observe_as(N.OBS_RGB)[0]  # the env's own image: its strip columns are every placement's
+            colors = np.array([p.color_rgb for p in u.pixels], np.uint8)
+            out = np.empty((boards.shape[1],) + frame.shape, np.uint8)
+            out[:, :, :u.width_padded] = colors[boards[0]]
+            out[:, :, u.width_padded:] = frame[None, :, u.width_padded:]
+            return out, frame
         if self.observation_wrappers:
             placement, current = self._aux.features()
             self.legal_actions_mask = self._aux.legal_mask()[0].astype(np.float64)
