@@ -293,6 +293,7 @@ static const mappings_t STOCK_MAPPINGS = {0, 1, 2, 3, 4, 5, 6, 7, 1.0, 1.0, 0.0,
 typedef struct {
   const mappings_t* map;
   double last_reward; /* the reward of the last step as Python computes it (int + float in double precision) */
+  int last_flags;     /* TG_OUT_* of the last step (tg_step_out.flags: commit_active_tetromino ran / the grouped action was masked out) */
   int W, H, P, Wp, Hp, gravity, qsize;
   uint8_t board[MAXCELLS]; /* padded (H+P) x (W+2P), bedrock = 1 */
   tetromino active;
@@ -426,6 +427,7 @@ static void np_project(const env_t* e, const tetromino* t, int x, int y, uint8_t
 
 /* envs/tetris.py:450-479 commit_active_tetromino */
 static void commit_active_tetromino(env_t* e, double* reward, int* lines_cleared) {
+  e->last_flags |= TG_OUT_COMMITTED;
   *lines_cleared = 0;
   if (collision(e, &e->active, e->x, e->y)) {
     *reward = e->map->game_over; /* :462 */
@@ -462,6 +464,7 @@ static double np_step(env_t* e, int action, int* lines) {
   double reward = 0;
   const mappings_t* A = e->map; /* self.actions: the elif chain compares with the mapping's fields, in this order */
   *lines = 0;
+  e->last_flags &= TG_OUT_ILLEGAL; /* (grouped_step sets that bit in front of the no_op it forwards) */
   tetromino* t = &e->active;
   if (action == A->move_left) {
     if (!collision(e, t, e->x - 1, e->y)) e->x -= 1;
@@ -779,8 +782,10 @@ static float grouped_step(env_t* e, int action, int terminate_on_illegal, int* l
   uint8_t legal[4 * 32];
   grouped_enumerate(e, legal, NULL); /* the mask the wrapper cached from its last observation() */
   *illegal = 0;
+  e->last_flags = 0;
   if (legal[action] == 0) {
     *illegal = 1;
+    e->last_flags = TG_OUT_ILLEGAL;
     if (terminate_on_illegal) {
       *terminated = 1;
       *lines = 0;
@@ -880,6 +885,10 @@ void tgo_last_rewards(const tgo_batch* b, double* out) {
   for (int i = 0; i < b->batch; ++i) out[i] = b->e[i].last_reward;
 }
 
+void tgo_last_flags(const tgo_batch* b, uint8_t* out) {
+  for (int i = 0; i < b->batch; ++i) out[i] = (uint8_t)b->e[i].last_flags;
+}
+
 void tgo_destroy(tgo_batch* b) {
   if (!b) return;
   free(b->e);
@@ -917,10 +926,11 @@ void tgo_step(tgo_batch* b, const int32_t* actions, float* reward, uint8_t* term
       reset_one(b, i, 0, 0);
       reward[i] = 0.0f; terminated[i] = 0; lines[i] = 0;
       e->last_reward = 0.0;
+      e->last_flags = 0;
       continue;
     }
-    if (b->ruleset == TG_RULESET_NUMPY) rw = (float)np_step(e, actions[i], &ln);
-    else { rw = fn_step(e, actions[i], &ln); e->last_reward = (double)rw; }
+    if (b->ruleset == TG_RULESET_NUMPY) { e->last_flags = 0; rw = (float)np_step(e, actions[i], &ln); }
+    else { rw = fn_step(e, actions[i], &ln); e->last_reward = (double)rw; e->last_flags = 0; }
     reward[i] = rw;
     terminated[i] = (uint8_t)e->game_over;
     lines[i] = (uint8_t)ln;
@@ -945,6 +955,7 @@ void tgo_grouped_step(tgo_batch* b, const int32_t* actions, float* reward, uint8
       reset_one(b, i, 0, 0);
       reward[i] = 0.0f; terminated[i] = 0; lines[i] = 0;
       e->last_reward = 0.0;
+      e->last_flags = 0;
       if (illegal) illegal[i] = 0;
       continue;
     }

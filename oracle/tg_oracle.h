@@ -33,6 +33,8 @@ void tgo_destroy(tgo_batch* b);
 void tgo_set_mappings(tgo_batch* b, const int32_t action_ids[8], const double rewards[4]);
 /* the rewards of the last tgo_step / tgo_grouped_step as Python computes them (double precision) */
 void tgo_last_rewards(const tgo_batch* b, double* out);
+/* tg_step_out.flags of the last tgo_step / tgo_grouped_step (TG_OUT_COMMITTED, TG_OUT_ILLEGAL) */
+void tgo_last_flags(const tgo_batch* b, uint8_t* out);
 
 /* same semantics as tg_reset / tg_step (include/tetris_gym_hip.h) */
 void tgo_reset(tgo_batch* b, const uint64_t* seeds, const uint8_t* mask);

@@ -212,6 +212,11 @@ def load() -> C.CDLL:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64 missing
         raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    if hasattr(lib, "tgo_create") and os.environ.get("TG_LIB_IS_CPU_CHECKER") != "1":
+        # (TG_LIB pointing at the test infrastructure's CPU implementation of this ABI: a bisect tool for developers, never a
+        # fallback — it is taken only when asked for twice)
+        raise NativeLibraryError(f"{LIB_PATH} is the CPU checker's implementation of the C ABI, not the HIP engine: set "
+                                 f"TG_LIB_IS_CPU_CHECKER=1 as well to drive the host side against it (tests only)")
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)
         fn.restype = res

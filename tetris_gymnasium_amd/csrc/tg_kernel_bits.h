@@ -1123,6 +1123,8 @@ void step_kernel_bits(
           const uint64_t dm = __ballot(dirty);
           u32x4* pdst = reinterpret_cast<u32x4*>(hot_board + (size_t)benv * (S / 2));
           const __amdgpu_buffer_rsrc_t pwin = st_window(pdst, nchunks_p * 16u);
+          // (measured and not adopted, profiles/r06/ab_seq_variants.log: the compare for EVERY group — group 0's registers kept alive to
+          // its write-back, 11 MB fewer bytes stored per launch — 18.3 -> 19.2 us; the slab loads without the initial sleep: 19.2)
           const bool keep_b0 = full && g == NSEQ - 1;
 #pragma unroll
           for (int k0 = 0; k0 < NITP; k0 += 4) {
