@@ -479,6 +479,10 @@ def gen_poked(ref, name, width, height, queue_size, n_states, seed, gravity=True
             x, y = int(rng.integers(1, Wp - n)), int(rng.integers(0, Hp - n))
             if i % 3 == 0 or not env.collision(t, x, y):  # (a third of the states: wherever it falls, incl. on filled cells / bedrock)
                 break
+        if i % 16 == 9:  # the deepest row the slicing tolerates: an O piece wholly inside the bottom bedrock (then e.g. a hold swap)
+            pid, k = 1, int(rng.integers(0, 4))
+            t = rotated(env, pid, k)
+            x, y = int(rng.integers(1, Wp - 2)), Hp - 2 - 1
         env.active_tetromino, env.x, env.y = t, x, y
         st_rot[i] = k
         # ---- holder / queue / bag / flags ----
@@ -487,7 +491,7 @@ def gen_poked(ref, name, width, height, queue_size, n_states, seed, gravity=True
             env.holder.queue.clear()
             env.holder.queue.append(rotated(env, int(rng.integers(0, 7)), hk))
             st_holder_rot[i] = hk
-        env.has_swapped = bool(rng.random() < 0.4)
+        env.has_swapped = bool(rng.random() < 0.4) and i % 16 != 9
         env.game_over = bool(rng.random() < 0.1)
         env.queue.queue.clear()
         for _ in range(queue_size):

@@ -1925,7 +1925,9 @@ void step_kernel_bits(
   // the six columns around the piece: padded columns wb .. wb+5 (the current piece spans wb+1 .. wb+4, a tentative
   // one wb+dxT .. wb+dxT+3 with dxT in 0..2).  An out-of-range position (only by tg_set_state) collides everywhere.
   const int wb = (swap_eff ? tx : s.x) - 1;
-  const bool oob = ((unsigned)wb > (unsigned)(W + 2)) | ((unsigned)s.y > (unsigned)H);
+  // (the row test belongs to the position the window serves: a hold swap moves the piece to row 0 — round 6's record-upload fuzz: an
+  // O piece uploaded at y = H + 1, the deepest row the reference's slicing tolerates, then `swap`, was locked where it stood)
+  const bool oob = ((unsigned)wb > (unsigned)(W + 2)) | (!swap_eff & ((unsigned)s.y > (unsigned)H));
   // (out of range: all six window words are the bedrock column; so are those of a dead lane, which shares its slot with the
   // last live env — the lock's unconditional write-back below must not restore what that env has just changed)
   const int wbo = (oob | !live) ? -16 : wb;
