@@ -92,8 +92,9 @@ def test_product_never_imports_the_oracle():
 
 
 def test_custom_action_mappings_are_validated_before_any_device_call():
-    """tg_create checks an ActionsMapping on the host: hard_drop sharing its value with a field Tetris.step tests earlier
-    (envs/tetris.py:222-256) is refused; any other assignment gets as far as the device lookup (no GPU here)."""
+    """tg_create turns an ActionsMapping into the kernel's action table on the host: every assignment — since round 6 also hard_drop
+    sharing its value with a field Tetris.step tests earlier (envs/tetris.py:222-259: that operation, then no gravity) — gets as far as
+    the device lookup (no GPU here); rewards must be finite."""
     import ctypes as C
 
     lib = N.load()
