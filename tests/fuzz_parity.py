@@ -182,6 +182,28 @@ def run_config(SEED, ci, rtc_sizes=(), steps=None):
             same_state(e, o, numpy_rules, f"after a record upload at {done} [{tag}]")
             if obs != N.OBS_NONE:
                 same_obs(e.observation(), o.observe(PO_OBS[obs]), f"after a record upload at {done} [{tag}]")
+        elif u < 0.53 and not packed:
+            # ... and of the functional rule-set (engine == oracle only: the oracle's functional side is pinned by the reference's restated
+            # known answers, not by vectors): any piece / rotation in its 4 x 4 box at x in [1, W + 3], y in [0, H - 1] — every position a
+            # move may probe stays inside the padded board, where lax.dynamic_slice does not clamp (functional/core.py:86-100) —, bag, bag
+            # index, game_over.  (Packed handles refuse the sums a piece on filled cells makes: tests/test_gpu_parity.py covers that.)
+            bb, rc, gg = o.get_state()
+            sel = r.random(B) < 0.6
+            pc = r.integers(0, 7, B)
+            rc["piece"][sel] = pc[sel]
+            rc["rot"][sel] = r.integers(0, 4, B)[sel]
+            rc["x"][sel] = r.integers(1, W + 4, B)[sel]
+            rc["y"][sel] = r.integers(0, H, B)[sel]
+            rc["val"][sel] = pc[sel] + 2
+            rc["flags"][sel] = (r.random(B) < 0.08).astype(np.uint8)[sel]
+            bag = np.zeros((B, 7), np.uint8)
+            bag[:, :Q] = np.stack([r.permutation(Q) for _ in range(B)])
+            rc["bag"][sel] = bag[sel]
+            rc["bag_index"][sel] = r.integers(0, Q + 1, B)[sel]
+            e.set_state(rec=rc); o.set_state(rec=rc)
+            same_state(e, o, numpy_rules, f"after a record upload at {done} [{tag}]")
+            if obs != N.OBS_NONE:
+                same_obs(e.observation(), o.observe(PO_OBS[obs]), f"after a record upload at {done} [{tag}]")
     line = f"ok   {tag}: {done} transitions  [{e.step_kernel_name(fuse, grouped)}]"
     e.close()
     return line
