@@ -461,7 +461,8 @@ def test_rng_role_every_nth_launch(every, W, H, Q, B, grouped, monkeypatch):
 
 @pytest.mark.parametrize("fuse", [1, 16])
 @pytest.mark.parametrize("W,H,Q,B,grouped", [(10, 20, 4, 1000, False), (20, 40, 7, 300, True), (6, 12, 2, 100, False), (12, 24, 4, 77 * 4, False),
-                                             (20, 40, 7, 32 * 9 + 20, True), (20, 40, 4, 32 * 5 + 16, False)])  # (kFeatSeq: ragged second / empty second group)
+                                             (20, 40, 7, 32 * 9 + 20, True), (20, 40, 4, 32 * 5 + 16, False),  # (kFeatSeq: ragged second / empty second group)
+                                             (22, 30, 4, 32 * 2 + 24, False)])  # (... of a board size compiled at run time: 660 cells, 64-bit column masks)
 def test_packed_board_handles(fuse, W, H, Q, B, grouped, monkeypatch):
     """TG_PACKED=1: the handle keeps its board as nibbles (tg_kernel_bits.h kFeatPacked — what large working sets pick by
     themselves) and the uint8 TG_BUF_BOARD is brought up to date on demand.  Single steps, rollouts, trajectories, masked
@@ -472,6 +473,8 @@ def test_packed_board_handles(fuse, W, H, Q, B, grouped, monkeypatch):
     na = 4 * W if grouped else 8
     e = Engine(B, W, H, queue_size=Q, obs_mode=N.OBS_BOARD, autoreset=N.AUTORESET_SAME_STEP, grouped=grouped)
     assert int(e.step_kernel_name().rstrip(">").split(",")[-1]) & 256
+    # (boards above 640 cells: a one-transition launch is the 32-env workgroup whose stream wave walks two slab groups — kFeatSeq)
+    assert bool(int(e.step_kernel_name(1).rstrip(">").split(",")[-1]) & 2048) == (W * H > 640)
     o = po.OracleBatch(B, W, H, N.RULESET_NUMPY, True, Q)
     seeds = np.arange(5, 5 + B, dtype=np.uint64)
     e.reset(seeds); o.reset(seeds)
@@ -523,7 +526,7 @@ def test_packed_board_handles(fuse, W, H, Q, B, grouped, monkeypatch):
 
 @pytest.mark.parametrize("fuse", [1, 16])
 @pytest.mark.parametrize("autoreset", [N.AUTORESET_SAME_STEP, N.AUTORESET_NEXT_STEP])
-@pytest.mark.parametrize("W,H,B", [(10, 20, 1000), (12, 24, 77 * 4), (6, 12, 100), (20, 40, 32 * 4 + 20)])
+@pytest.mark.parametrize("W,H,B", [(10, 20, 1000), (12, 24, 77 * 4), (6, 12, 100), (20, 40, 32 * 4 + 20), (22, 30, 32 + 12)])
 def test_packed_board_functional_handles(fuse, autoreset, W, H, B, monkeypatch):
     """TG_PACKED=1 with the FUNCTIONAL rule-set (what its handles above ~50 Mi cells pick by themselves): single steps,
     rollouts with and without the trajectory, masked resets, host and device state round trips, uploaded tall boards and
@@ -534,6 +537,7 @@ def test_packed_board_functional_handles(fuse, autoreset, W, H, B, monkeypatch):
     monkeypatch.setenv("TG_FUSE", str(fuse))
     e = Engine(B, W, H, ruleset=N.RULESET_FUNCTIONAL, queue_size=7, obs_mode=N.OBS_FN, autoreset=autoreset)
     assert int(e.step_kernel_name().rstrip(">").split(",")[-1]) & 256
+    assert bool(int(e.step_kernel_name(1).rstrip(">").split(",")[-1]) & 2048) == (W * H > 640)  # (kFeatSeq)
     o = po.OracleBatch(B, W, H, po.RULESET_FUNCTIONAL, True, 7)
     seeds = np.arange(31, 31 + B, dtype=np.uint64)
     e.reset(seeds); o.reset(seeds)
