@@ -103,4 +103,14 @@ def test_bedrock_rows_inside_the_playfield_are_refused(golden_dir):
     b[3] = replay.crop(fx["st_board"])[i]
     with pytest.raises(Exception, match="bedrock"):
         e.set_state(board=b)
+    # ... and through tg_set_state_dev: the host cannot look, the kernel that rebuilds the column masks flags it and the next call
+    # that waits for the stream reports it once (TG_EUNSUPPORTED)
+    db, dr, dg = e.get_state_device()
+    e.dev_upload(db.ptr, np.ascontiguousarray(b))
+    e.set_state_device(board=db)
+    with pytest.raises(Exception, match="bedrock"):
+        e.sync()
+    e.set_state(board=np.zeros_like(b))  # a clean board again: the handle goes on
+    e.sync()
+    e.step(np.zeros(8, np.int32))
     e.close()
