@@ -93,7 +93,9 @@ extern "C" {
  *   TG_KERNEL=bits     anything else needs the test-only legacy library (make -C csrc legacy) and is refused by the product
  *   TG_CSRC_DIR, TG_CACHE_DIR   where the kernel headers are / where compiled code objects of non-built-in board sizes are
  *                      cached (default: <library dir>/csrc, ~/.cache/tetris_gym_hip)
- * (Python side: TG_LIB = path of the library to load, TG_HIP_RUNTIME = system | torch | auto, TG_VERBOSE.) */
+ * (Python side: TG_LIB = path of the library to load — the test-only legacy build, or, together with TG_LIB_IS_CPU_CHECKER=1, the CPU
+ * checker's implementation of this ABI (oracle/tg_oracle_abi.c: a bisect tool, refused without the second variable) —,
+ * TG_HIP_RUNTIME = system | torch | auto, TG_VERBOSE.) */
 
 typedef struct tg_config {
   int32_t struct_size; /* = sizeof(tg_config); ABI guard */

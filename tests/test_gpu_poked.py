@@ -100,9 +100,11 @@ def test_bedrock_rows_inside_the_playfield_are_refused(golden_dir):
     e = Engine(8, 10, 20, obs_mode=N.OBS_BOARD)
     e.reset(np.arange(1, 9, dtype=np.uint64))
     b, r, g = e.get_state()
+    b0 = b.copy()
     b[3] = replay.crop(fx["st_board"])[i]
     with pytest.raises(Exception, match="bedrock"):
         e.set_state(board=b)
+    np.testing.assert_array_equal(e.get_state()[0], b0)  # (refused in front of the upload: the engine is as it was)
     # ... and through tg_set_state_dev: the host cannot look, the kernel that rebuilds the column masks flags it and the next call
     # that waits for the stream reports it once (TG_EUNSUPPORTED)
     db, dr, dg = e.get_state_device()

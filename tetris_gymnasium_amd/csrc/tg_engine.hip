@@ -1968,6 +1968,21 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
       for (size_t i = 0; i < B * h->cells; ++i)
         if (board[i] >= 0x80)
           return fail(h, TG_EINVAL, "tg_set_state: board byte %zu is %d; cells of the functional rule-set are 0 or a tetromino value 2..8", i, board[i]);
+    // (every refusal in front of the first upload: a refused call leaves the engine as it was)
+    std::vector<uint8_t> any_full(B, 0);
+    for (size_t i = 0; i < B; ++i) {
+      const uint8_t* b = board + i * h->cells;
+      for (int r = 0; r < h->H; ++r) {
+        bool full = true, ones = true;
+        for (int c = 0; c < h->W; ++c) { full &= b[r * h->W + c] != 0; ones &= b[r * h->W + c] == 1; }
+        any_full[i] |= full ? 1 : 0;
+        // (the reference never clears a row of bedrock cells, envs/tetris.py:493 `& ~(board == 1).all(axis=1)`; the column masks of the
+        // step kernel hold one bit per cell and would clear it with the next lock: refused rather than stepped differently)
+        if (ones && h->cfg.ruleset == TG_RULESET_NUMPY)
+          return fail(h, TG_EUNSUPPORTED, "tg_set_state: row %d of board %zu consists of bedrock cells (value 1) only; the reference never clears such "
+                                          "a row (envs/tetris.py:493) and this engine's row test cannot tell it from a filled one", r, i);
+      }
+    }
     HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_BOARD], board, B * h->cells, hipMemcpyHostToDevice, h->stream));
     tmp.resize(B);
     if (rec) std::memcpy(tmp.data(), rec, B * sizeof(tg_env_rec));
@@ -1975,21 +1990,8 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
       HIPCHK(h, hipMemcpyAsync(tmp.data(), h->buf[TG_BUF_REC], B * sizeof(tg_env_rec), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
     }
-    for (size_t i = 0; i < B; ++i) {
-      bool any_full = false;
-      const uint8_t* b = board + i * h->cells;
-      for (int r = 0; r < h->H; ++r) {
-        bool full = true, ones = true;
-        for (int c = 0; c < h->W; ++c) { full &= b[r * h->W + c] != 0; ones &= b[r * h->W + c] == 1; }
-        any_full |= full;
-        // (the reference never clears a row of bedrock cells, envs/tetris.py:493 `& ~(board == 1).all(axis=1)`; the column masks of the
-        // step kernel hold one bit per cell and would clear it with the next lock: refused rather than stepped differently)
-        if (ones && h->cfg.ruleset == TG_RULESET_NUMPY)
-          return fail(h, TG_EUNSUPPORTED, "tg_set_state: row %d of board %zu consists of bedrock cells (value 1) only; the reference never clears such "
-                                          "a row (envs/tetris.py:493) and this engine's row test cannot tell it from a filled one", r, i);
-      }
-      tmp[i].flags = (uint8_t)((tmp[i].flags & ~TG_F_FULLROW) | (any_full ? TG_F_FULLROW : 0));
-    }
+    for (size_t i = 0; i < B; ++i)
+      tmp[i].flags = (uint8_t)((tmp[i].flags & ~TG_F_FULLROW) | (any_full[i] ? TG_F_FULLROW : 0));
     rec = tmp.data();
   }
   if (rec) HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_REC], rec, B * sizeof(tg_env_rec), hipMemcpyHostToDevice, h->stream));
