@@ -407,7 +407,8 @@ def gen_poked(ref, name, width, height, queue_size, n_states, seed, gravity=True
     the state reset(seed) left.  Then for EACH of the 8 actions a deep copy of the env takes that action followed by T - 1 random ones
     (no harness reset: the recording of a copy ends with its first done) -> reward / done / lines / observation CRC / x / y / piece per
     transition, full snapshots behind the first transition and at the end.  On the same states: the grouped wrapper's legal mask and
-    4W placement boards, FeatureVectorObservation of the state and of every placement, the RgbObservation frame."""
+    4W placement boards, EVERY one of its 4W actions stepped (reward, done, lines, board, piece and position after),
+    FeatureVectorObservation of the state and of every placement, the RgbObservation frame."""
     import copy
 
     from tetris_gymnasium.components.tetromino import Tetromino
@@ -438,6 +439,10 @@ def gen_poked(ref, name, width, height, queue_size, n_states, seed, gravity=True
     last = {k: [None] * B for k in keys}
     g_mask = np.zeros((ng, NA), np.uint8)
     g_boards = np.zeros((ng, NA, Hp, Wp), np.uint8)
+    # ... and EVERY grouped action stepped from the state (wrappers/grouped.py:209-269; terminate_on_illegal_action=True)
+    gs_reward = np.zeros((ng, NA), np.float64); gs_done = np.zeros((ng, NA), np.uint8); gs_lines = np.zeros((ng, NA), np.uint8)
+    gs_board = np.zeros((ng, NA, Hp, Wp), np.uint8)
+    gs_x = np.zeros((ng, NA), np.uint8); gs_y = np.zeros((ng, NA), np.uint8); gs_piece = np.zeros((ng, NA), np.uint8)
     g_feats = np.zeros((ng, NA, width + 3), np.uint8)
     cur_feats = np.zeros((n_states, width + 3), np.uint8)
     Wrgb = Wp + 4 * max(1, queue_size)
@@ -514,6 +519,14 @@ def gen_poked(ref, name, width, height, queue_size, n_states, seed, gravity=True
             e3 = copy.deepcopy(env)
             gf = ref.GroupedActionsObservations(e3, observation_wrappers=[ref.FeatureVectorObservation(e3)])
             g_feats[i] = gf.observation(e3._get_obs())
+            for a in range(NA):
+                e4 = copy.deepcopy(env)
+                g4 = ref.GroupedActionsObservations(e4)
+                g4.observation(e4._get_obs())  # (the wrapper steps against the mask of its last observation)
+                _, r4, d4, _, info4 = g4.step(a)
+                gs_reward[i, a], gs_done[i, a], gs_lines[i, a] = float(r4), int(d4), int(info4["lines_cleared"])
+                gs_board[i, a] = e4.board
+                gs_x[i, a], gs_y[i, a], gs_piece[i, a] = e4.x, e4.y, e4.active_tetromino.id - 2
         # ---- every action, then random ones ----
         for a in range(8):
             j = 8 * i + a
@@ -542,7 +555,8 @@ def gen_poked(ref, name, width, height, queue_size, n_states, seed, gravity=True
                st_board=st_board, st_rot=st_rot, st_holder_rot=st_holder_rot, st_crc=st_crc, bedrock_row=bedrock_row,
                actions=actions, reward=reward, done=done, lines=lines, valid=valid, crc=crc, x=xs, y=ys, piece=pieces,
                first_board=first_board, last_board=last_board, g_mask=g_mask, g_boards=g_boards, g_feats=g_feats,
-               cur_feats=cur_feats, rgb=rgb)
+               cur_feats=cur_feats, rgb=rgb, gs_reward=gs_reward, gs_done=gs_done, gs_lines=gs_lines, gs_board=gs_board,
+               gs_x=gs_x, gs_y=gs_y, gs_piece=gs_piece)
     for k_ in keys:
         out["st_" + k_] = np.array(st[k_]).astype(np.uint8)
         out["first_" + k_] = np.array(first[k_]).astype(np.uint8)

@@ -110,13 +110,13 @@ def replay_trace(make_backend, fx, max_steps=None, check_state_every=1):
 SNAP_KEYS = ("queue", "bag", "bag_index", "holder_piece", "has_swapped", "game_over")
 
 
-def poked_upload(fx, board, rec, skip=None):
-    """Write the fixture's hand-made states (each replicated 8 times, one copy per first action) into a backend's (board, rec)
-    arrays as get_state() returned them behind reset(seeds): everything the reference's tests assign directly — playfield, piece,
-    rotation, position, holder, queue, bag, bag index, has_swapped, game_over.  `skip` [n_states] bool: states left as reset made them."""
-    n, Q = int(fx["n_states"]), int(fx["queue_size"])
-    keep = np.ones(n, bool) if skip is None else ~np.asarray(skip, bool)
-    rep = lambda a: np.repeat(np.asarray(a), 8, axis=0)  # noqa: E731
+def poked_upload(fx, board, rec, skip=None, reps=8, n=None):
+    """Write the fixture's hand-made states (the first `n`, each replicated `reps` times: one copy per first action) into a backend's
+    (board, rec) arrays as get_state() returned them behind reset(seeds): everything the reference's tests assign directly — playfield,
+    piece, rotation, position, holder, queue, bag, bag index, has_swapped, game_over.  `skip` [n_states] bool: states left as reset made them."""
+    n, Q = int(fx["n_states"]) if n is None else int(n), int(fx["queue_size"])
+    keep = (np.ones(n, bool) if skip is None else ~np.asarray(skip, bool)[:n])
+    rep = lambda a: np.repeat(np.asarray(a)[:n], reps, axis=0)  # noqa: E731
     m = rep(keep)
     board[m] = rep(crop(fx["st_board"]))[m]
     rec["piece"][m] = rep(fx["st_piece"])[m]
@@ -208,5 +208,28 @@ def replay_poked(be, fx, skip=None, upload=None, step=None, check_obs=True, roll
     return m
 
 
-def poked_seeds(fx):
-    return np.repeat(fx["seeds"].astype(np.uint64), 8)
+def poked_seeds(fx, reps=8, n=None):
+    return np.repeat(fx["seeds"].astype(np.uint64)[:n], reps)
+
+
+def replay_poked_grouped(be_grouped_step, get_state, set_state, fx, skip=None):
+    """Every one of the grouped wrapper's 4W actions from every hand-made state (wrappers/grouped.py:209-269, terminate_on_illegal_action
+    = True): the backend holds n_grouped x 4W envs — state i replicated 4W times — and takes action a in copy a.  be_grouped_step(actions)
+    -> (reward, terminated, lines)."""
+    ng, NA = fx["gs_reward"].shape
+    board, rec, _ = get_state()
+    m = poked_upload(fx, board, rec, skip, reps=NA, n=ng)
+    set_state(board, rec)
+    a = np.tile(np.arange(NA, dtype=np.int32), ng)
+    rew, term, lines = be_grouped_step(a)
+    flat = lambda k: fx[k].reshape(ng * NA, *fx[k].shape[2:])  # noqa: E731
+    np.testing.assert_array_equal(np.asarray(rew)[m], flat("gs_reward").astype(np.float32)[m], err_msg="grouped reward")
+    np.testing.assert_array_equal(np.asarray(term)[m], flat("gs_done")[m], err_msg="grouped terminated")
+    np.testing.assert_array_equal(np.asarray(lines)[m], flat("gs_lines")[m], err_msg="grouped lines")
+    board, rec, _ = get_state()
+    legal = m & (np.repeat(fx["g_mask"], 1, axis=0).reshape(-1) == 1)  # (an illegal action returns before touching the env)
+    np.testing.assert_array_equal(board[legal], crop(flat("gs_board"))[legal], err_msg="board behind a grouped action")
+    np.testing.assert_array_equal(rec["x"][legal], flat("gs_x")[legal]); np.testing.assert_array_equal(rec["y"][legal], flat("gs_y")[legal])
+    np.testing.assert_array_equal(rec["piece"][legal], flat("gs_piece")[legal])
+    assert legal.sum() > ng and (~legal & m).sum() > 0 and int(flat("gs_lines")[m].sum()) > 0
+    return m

@@ -91,6 +91,21 @@ def test_engine_wrapper_surfaces_on_poked_states(golden_dir, name):
     e.close()
 
 
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("name", ["poked_10x20", "poked_20x40"])
+def test_engine_grouped_steps_from_poked_states(golden_dir, name, packed, monkeypatch):
+    """Every one of the grouped wrapper's 4W actions from every hand-made state through the step kernel's grouped action set
+    (wrappers/grouped.py:209-269): reward (-0.1 on a masked-out action), termination, lines, board / piece / position after."""
+    monkeypatch.setenv("TG_PACKED", "1" if packed else "0")
+    fx = replay.load(golden_dir, name)
+    ng, NA = fx["gs_reward"].shape
+    e = Engine(ng * NA, int(fx["width"]), int(fx["height"]), ruleset=N.RULESET_NUMPY, queue_size=int(fx["queue_size"]), obs_mode=N.OBS_BOARD,
+               grouped=True, terminate_on_illegal=True)
+    e.reset(replay.poked_seeds(fx, NA, ng))
+    replay.replay_poked_grouped(e.step, e.get_state, lambda b, r: e.set_state(board=b, rec=r), fx, skip=fx["bedrock_row"].astype(bool))
+    e.close()
+
+
 def test_bedrock_rows_inside_the_playfield_are_refused(golden_dir):
     """A playfield row of bedrock cells (value 1 in every column) is never taken by the reference's clear_filled_rows
     (envs/tetris.py:493: `~(board == 1).all(axis=1)`); the engine's row test is `every cell non-zero`, so such a board is refused
