@@ -236,7 +236,9 @@ int tg_grouped_sample(tg_handle* h, uint32_t seed, uint32_t counter) {
   return h ? failv(h, TG_EUNSUPPORTED, "tg_grouped_sample (oracle ABI): the engine's sampling hash is not restated here") : TG_EINVAL;
 }
 int tg_grouped_rollout(tg_handle* h, uint32_t seed, uint32_t counter0, int K, int8_t* a, uint8_t* o, tg_step_out* r) {
-  (void)seed; (void)counter0; (void)K; (void)a; (void)o; (void)r;
+  (void)seed; (void)counter0; (void)a; (void)o; (void)r;
+  if (h && K > 0 && h->cfg.action_set != TG_ACTIONS_GROUPED)
+    return failv(h, TG_EINVAL, "tg_grouped_rollout: handle was not created with TG_ACTIONS_GROUPED");
   return h ? failv(h, TG_EUNSUPPORTED, "tg_grouped_rollout (oracle ABI): the engine's sampling hash is not restated here") : TG_EINVAL;
 }
 
@@ -269,9 +271,10 @@ int tg_observe(tg_handle* h) { if (!h) return TG_EINVAL; repack_obs(h); return T
 int tg_observe_as(tg_handle* h, int obs_mode, void* obs_dev, size_t bytes) {
   if (!h || !obs_dev) return h ? failv(h, TG_EINVAL, "tg_observe_as: null buffer") : TG_EINVAL;
   const size_t need = (size_t)h->B * obs_bytes_for(&h->cfg, obs_mode);
-  if (need == 0 || bytes < need) return failv(h, TG_EINVAL, "tg_observe_as: surface %d needs %zu bytes", obs_mode, need);
+  if (need == 0) return failv(h, TG_EINVAL, "tg_observe_as: unknown obs_mode %d", obs_mode);
   if ((obs_mode == TG_OBS_DICT || obs_mode == TG_OBS_RGB) && h->cfg.ruleset != TG_RULESET_NUMPY)
-    return failv(h, TG_EINVAL, "tg_observe_as: the dict / RGB surfaces belong to the NUMPY rule-set");
+    return failv(h, TG_EINVAL, "tg_observe_as: TG_OBS_DICT / TG_OBS_RGB are observations of the NUMPY rule-set");
+  if (bytes < need) return failv(h, TG_EINVAL, "tg_observe_as: %zu bytes given, this surface takes %zu", bytes, need);
   tgo_observe(h->b, obs_mode, obs_dev, NTHREADS);
   return TG_OK;
 }
