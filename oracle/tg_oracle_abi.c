@@ -14,6 +14,9 @@
  * features / features_as / grouped_enumerate / fetch / fetch_many / step_fetch_many / device_ptr / host_pack / episode statistics /
  * the memory helpers.  Not implemented (TG_EUNSUPPORTED): tg_grouped_sample, tg_grouped_rollout (the engine's own sampling hash),
  * TG_FLAG_FINAL_OBS, tg_stream_copy_gbps, tg_device_pci_bus_id.
+ * Round 6, this container (no GPU): `TG_LIB=... TG_LIB_IS_CPU_CHECKER=1 pytest tests -m gpu` -> 315 of the 426 GPU-marked tests pass on
+ * this library in 6 minutes; the other 111 assert engine-only things (step-kernel names and FEAT bits, nibble-packed boards, the final
+ * observation, the device-side sampling hash, run-time compilation refusals, host-time budgets).
  */
 #include <stdarg.h>
 #include <stdio.h>
