@@ -33,7 +33,7 @@ extern "C" {
                           *    TG_OUT_COMMITTED / TG_OUT_ILLEGAL in tg_step_out.flags
                           * 5: tg_observe_as, tg_features_as (a wrapper's observation of ANY handle's current state)
                           * 6: tg_device_pci_bus_id; an ActionsMapping whose hard_drop aliases an earlier field is accepted;
-                          *    tg_set_state(_dev) refuses playfield rows of bedrock cells (NUMPY rule-set) */
+                          *    NUMPY records: `score` / `reserved` are device-private (tg_get_state returns 0) */
 
 /* ---- rule-sets (the reference contains two different Tetris rule-sets) ---- */
 #define TG_RULESET_NUMPY 0      /* envs/tetris.py (the graded oracle) */
@@ -164,8 +164,9 @@ typedef struct tg_env_rec { /* 32 bytes */
   uint8_t bag_index;    /* NUMPY: BagRandomizer.index 0..6; FUNCTIONAL: queue_index 0..7 */
   uint8_t bag[7];       /* NUMPY: BagRandomizer.bag; FUNCTIONAL: State.queue */
   uint8_t queue[7];     /* NUMPY: visible TetrominoQueue (first queue_size entries); FUNCTIONAL: unused */
-  float score;          /* FUNCTIONAL: State.score (float32). NUMPY: unused (0) */
-  uint32_t reserved;
+  float score;          /* FUNCTIONAL: State.score (float32). NUMPY: 0 through tg_get_state; on the device these two words are private */
+  uint32_t reserved;    /* (NUMPY: the mask of playfield rows that consist of bedrock cells — value 1 — only, which the reference's
+                           clear_filled_rows never takes, envs/tetris.py:493; rebuilt from the board behind every upload / reset) */
 } tg_env_rec;
 
 #define TG_NONE 0xFF

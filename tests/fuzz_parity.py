@@ -151,6 +151,9 @@ def run_config(SEED, ci, rtc_sizes=(), steps=None):
             for i in np.flatnonzero(r.random(B) < 0.5):
                 for row in r.choice(np.arange(H // 3, H), size=int(r.integers(1, 4)), replace=False):
                     bb[i, row] = r.integers(2, 9, W)
+            if H > 5:  # (round 6) a row of bedrock cells below the spawn rows: never cleared under the NUMPY rules (envs/tetris.py:493)
+                for i in np.flatnonzero(r.random(B) < 0.25):
+                    bb[i, int(r.integers(max(4, H // 3), H))] = 1
             e.set_state(board=bb); o.set_state(board=bb)
             same_state(e, o, numpy_rules, f"after a board upload at {done} [{tag}]")
         elif u < 0.43:  # the state through the host and back: nothing may change, the look-ahead is rebuilt

@@ -333,11 +333,14 @@ __device__ __forceinline__ int clear_rows(uint8_t* slab, int lane) {
   uint8_t rowb[W];
   const int r = lane < H ? lane : H - 1;
   bool full = lane < H;
+  bool ones = RULESET == TG_RULESET_NUMPY;  // NUMPY: a row of bedrock cells only is never taken (envs/tetris.py:493)
 #pragma unroll
   for (int c = 0; c < W; ++c) {
     rowb[c] = slab[r * W + c];
     full &= rowb[c] != 0;
+    ones &= rowb[c] == 1;
   }
+  full &= !ones;
   const uint64_t F = __ballot(full);
   const int n = __popcll(F);
   if (n > 0) {

@@ -1124,9 +1124,9 @@ int check_dev_state(tg_handle* h) {
   if (!flags) return TG_OK;
   HIPCHK(h, hipMemsetAsync(h->d_err, 0, sizeof(int), h->stream));
   if (flags & 4)
-    return fail(h, TG_EUNSUPPORTED, "tg_set_state_dev: an uploaded board holds a playfield row of bedrock cells (value 1 in every column); the "
-                                    "reference never clears such a row (envs/tetris.py:493) and this engine's row test cannot tell it from a filled "
-                                    "one — the next lock there clears it%s", (flags & 3) ? " (and other fields were out of range and clamped)" : "");
+    return fail(h, TG_EUNSUPPORTED, "tg_set_state_dev: an uploaded board holds a row of bedrock cells (value 1 in every column) inside the four "
+                                    "spawn rows: not supported (bedrock rows from row 4 down are); the engine holds the board as uploaded%s",
+                (flags & 3) ? " (and other fields were out of range and clamped)" : "");
   return fail(h, TG_EINVAL, "tg_set_state_dev: the uploaded device state held values tg_set_state refuses (%s%s); they were clamped so that "
                             "nothing indexes out of range — the engine's state is not what was uploaded",
               (flags & 1) ? "record field out of range" : "", (flags & 2) ? ((flags & 1) ? ", board byte out of range" : "board byte out of range") : "");
@@ -1920,9 +1920,10 @@ int tg_get_state(tg_handle* h, uint8_t* board, tg_env_rec* rec, tg_rng_rec* rng)
   HIPCHK(h, hipStreamSynchronize(h->stream));
   { const int rcc = check_dev_state(h); if (rcc != TG_OK) return rcc; }
   if (rec)
-    for (size_t i = 0; i < B; ++i) {  // device-private: full-row hint, look-ahead permutation
+    for (size_t i = 0; i < B; ++i) {  // device-private: full-row hint, look-ahead permutation / (NUMPY) the mask of bedrock rows
       rec[i].flags &= (uint8_t)~TG_F_FULLROW;
       rec[i].reserved = 0;
+      if (h->cfg.ruleset == TG_RULESET_NUMPY) rec[i].score = 0.0f;
     }
   return TG_OK;
 }
@@ -1976,11 +1977,18 @@ int tg_set_state(tg_handle* h, const uint8_t* board, const tg_env_rec* rec, cons
         bool full = true, ones = true;
         for (int c = 0; c < h->W; ++c) { full &= b[r * h->W + c] != 0; ones &= b[r * h->W + c] == 1; }
         any_full[i] |= full ? 1 : 0;
-        // (the reference never clears a row of bedrock cells, envs/tetris.py:493 `& ~(board == 1).all(axis=1)`; the column masks of the
-        // step kernel hold one bit per cell and would clear it with the next lock: refused rather than stepped differently)
-        if (ones && h->cfg.ruleset == TG_RULESET_NUMPY)
+        // (the reference never clears a row of bedrock cells, envs/tetris.py:493 `& ~(board == 1).all(axis=1)`.  The default kernel keeps
+        // such rows as a mask in the record — bits_prepare_kernel / step_kernel_bits `brow` —; the earlier step kernels of the test-only
+        // library test rows on bytes and would clear it with the next lock: refused there rather than stepped differently)
+        if (ones && h->cfg.ruleset == TG_RULESET_NUMPY && !h->d_cols)
           return fail(h, TG_EUNSUPPORTED, "tg_set_state: row %d of board %zu consists of bedrock cells (value 1) only; the reference never clears such "
-                                          "a row (envs/tetris.py:493) and this engine's row test cannot tell it from a filled one", r, i);
+                                          "a row (envs/tetris.py:493): the earlier step kernels (TG_KERNEL) do not model that", r, i);
+        // (... and one inside the four spawn rows is refused by the default kernel too: the grouped wrapper's legal mask — a drop from
+        // y = 0 that ends on a value-1 cell, wrappers/grouped.py:147-166 — would depend on the reference's drop loop tunnelling through the
+        // row from a colliding start, which the closed-form mask of every kernel here does not model)
+        if (ones && r < 4 && h->cfg.ruleset == TG_RULESET_NUMPY)
+          return fail(h, TG_EUNSUPPORTED, "tg_set_state: row %d of board %zu, one of the four spawn rows, consists of bedrock cells (value 1) only: "
+                                          "not supported (bedrock rows from row 4 down are)", r, i);
       }
     }
     HIPCHK(h, hipMemcpyAsync(h->buf[TG_BUF_BOARD], board, B * h->cells, hipMemcpyHostToDevice, h->stream));

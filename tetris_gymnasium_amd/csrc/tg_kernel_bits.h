@@ -1700,6 +1700,12 @@ void step_kernel_bits(
   // ---- B: rule logic (per lane, branch-free except wave-uniform any() branches) ----
   LaneS s;
   lane_unpack(s, ra, rb);
+  // NUMPY: the playfield rows that consist of bedrock cells (value 1) only — clear_filled_rows never takes such a row
+  // (envs/tetris.py:493: `& ~(board == 1).all(axis=1)`), the column masks cannot tell it from a filled one.  Only an uploaded board
+  // holds one; bits_prepare_kernel finds them and keeps the row mask in the two words of the record this rule-set does not use
+  // (score | reserved: device-private, stripped by tg_get_state).  It rides in registers the record load fills anyway.
+  T brow = 0;
+  if (RULESET == TG_RULESET_NUMPY) brow = (T)((uint64_t)__float_as_uint(s.score) | ((uint64_t)s.reserved << 32));
   if (DICTK) {  // the box TG_BUF_OBS's mask array shows: the env's piece as the launch starts (tg_reset / tg_set_state re-pack it)
     reinterpret_cast<uint32_t*>(lds + BG::OFF_OLDPW)[slot] = (uint32_t)(s.x & 0xFF) | ((uint32_t)(s.y & 0xFF) << 8) | ((uint32_t)(s.piece & 0xFF) << 16);
   }
@@ -2090,6 +2096,7 @@ void step_kernel_bits(
     T full = PLAY;
 #pragma unroll
     for (int c = 0; c < W; ++c) full &= v[c];
+    if (RULESET == TG_RULESET_NUMPY) full &= (T)~brow;
     full = place ? full : T(0);
     lines = popc_t(full);
     do_clear = lines > 0;
@@ -2110,6 +2117,17 @@ void step_kernel_bits(
         }
         x |= top;
         if (do_clear) { v[c] = (T)(x | FLOOR); colsL[1 + c] = v[c]; }
+      }
+      if (RULESET == TG_RULESET_NUMPY && __any(brow != 0)) {  // the bedrock rows move down with the rows above a cleared one
+        T x = (T)(brow & PLAY);
+        T f = full;
+        while (f) {
+          const int rr = ctz_t(f);
+          f &= (T)(f - 1);
+          const T lowm = (T)((T(1) << rr) - 1);
+          x = (T)((x & (T)~((lowm << 1) | 1)) | ((x & lowm) << 1));
+        }
+        brow = do_clear ? x : brow;
       }
     }
     s.flags &= place ? ~TG_F_FULLROW : ~0;
@@ -2280,6 +2298,7 @@ void step_kernel_bits(
         s.hp = TG_NONE; s.hr = 0; s.hv = 0;
         s.flags = 0;
         s.score = 0.0f;
+        brow = 0;  // (a fresh board)
       }
     }
   };
@@ -2552,6 +2571,7 @@ void step_kernel_bits(
   if (RULESET == TG_RULESET_NUMPY) __builtin_amdgcn_s_setprio(0);
   // ---- D: per-env stores: first record half, episode statistics, column masks ----
   const bool cols_dirty = cols_dirty_any;
+  if (RULESET == TG_RULESET_NUMPY) { s.score = __uint_as_float((uint32_t)brow); s.reserved = (uint32_t)((uint64_t)brow >> 32); }
   uint4 oa, ob;
   lane_pack(s, oa, ob);
   uint4* rec_out = reinterpret_cast<uint4*>(hot_rec) + (size_t)env * 2;
@@ -2636,7 +2656,7 @@ struct PrepareParams {
   int cur;              // ring parity the next launch reads
   int hcur;             // consumed-counter parity the next launch reads
   int queue_size;       // FUNCTIONAL: the bag length (EnvConfig.queue_size)
-  int* err;             // or null: flag word of the handle (bit 2: a playfield row of bedrock cells, NUMPY rule-set — see the kernel)
+  int* err;             // or null: flag word of the handle (bit 2: a row of bedrock cells inside the four spawn rows — see the kernel)
 };
 
 template <int W, int H>
@@ -2658,10 +2678,12 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
     ones &= o;
   }
   if (bits_cols_words<W, H>() > W) gc[W] = 0;
-  // NUMPY rule-set: the reference's clear_filled_rows never takes a row that consists of bedrock cells (value 1) only
-  // (envs/tetris.py:493 `& ~(board == 1).all(axis=1)`), the column masks cannot tell it from a filled one.  Play never makes such a
-  // row; tg_set_state refuses it on the host, an upload through tg_set_state_dev is flagged here and reported at the next wait.
-  if (p.ruleset == TG_RULESET_NUMPY && p.err && ones != 0) atomicOr(p.err, 4);
+  // (NUMPY rule-set: `ones` = the rows the reference's clear_filled_rows never takes, envs/tetris.py:493 — kept in the record below.
+  // One inside the four spawn rows is refused — tg_set_state on the host, here for an upload through tg_set_state_dev, reported at the
+  // next wait —: the grouped wrapper's legality would then depend on the reference's drop loop tunnelling through it from a colliding
+  // start, wrappers/grouped.py:147-166, which the closed-form legal mask does not model.)
+  ones &= (T)(((T)1 << (H - 1) << 1) - 1);
+  if (p.ruleset == TG_RULESET_NUMPY && p.err && (ones & T(0xF)) != 0) atomicOr(p.err, 4);
   const size_t B = (size_t)p.batch;
   const bool moved = p.force || (p.mask ? p.mask[env] != 0 : true);
   uint4* ring4 = reinterpret_cast<uint4*>(p.ring);
@@ -2713,7 +2735,8 @@ __global__ __launch_bounds__(256) void bits_prepare_kernel(const PrepareParams p
     rec[4] = (d4 & 0xFFFFFF00u) | (uint32_t)((bag >> 48) & 0xFF);
     rng_store(r, p.rng + env, 0);
   }
-  rec[7] = 0;
+  rec[6] = (uint32_t)ones;  // the bedrock rows of the board (step_kernel_bits: `brow`); NUMPY uses neither score nor reserved
+  rec[7] = (uint32_t)((uint64_t)ones >> 32);
   // T = kRing - 1, H = 0: entries 0 .. kRing - 2 ahead; "the state after entry -1" = the generator as it stands in
   // tg_rng_rec (loc = kLocRec), which this kernel leaves where the reference's generator is
   uint64_t w[2] = {(uint64_t)(kRing - 1) << 56, 0};

@@ -98,11 +98,14 @@ __global__ __launch_bounds__(kBlock) void features_kernel(const FeatureParams p)
 
   // board → bit masks: lane r owns row r; one ballot per column
   uint32_t rowbits = 0;
+  bool row_ones = true;  // this lane's row consists of bedrock cells (value 1) only: clear_filled_rows never takes it (envs/tetris.py:493)
   {
     const int r = lane < H ? lane : H - 1;
 #pragma unroll
     for (int c = 0; c < W; ++c) {
-      const bool f = lane < H && slab[r * W + c] != 0;
+      const uint8_t cell = slab[r * W + c];
+      const bool f = lane < H && cell != 0;
+      row_ones &= cell == 1;
       rowbits |= (f ? 1u : 0u) << c;
       const uint64_t colm = __ballot(f);
       if (lane == c) cm[c] = (M)colm;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void features_kernel(const FeatureParams p)
   }
   constexpr uint32_t FULL = W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u);
   // rows that are ALREADY full (only a caller-provided board holds one): clear_filled_rows takes them with every placement
-  const M PRE = (M)__ballot(lane < H && (rowbits & FULL) == FULL);
+  const M PRE = (M)__ballot(lane < H && (rowbits & FULL) == FULL && !row_ones);
   wave_sync();
   const M FLOOR = (M)(M(1) << H);
 

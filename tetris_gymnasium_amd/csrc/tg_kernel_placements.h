@@ -61,12 +61,15 @@ __global__ __launch_bounds__(kBlock) void placements_kernel(const PlacementParam
 
   // board → bit masks (lane r owns row r; one ballot per column), and the padded base board (envs/tetris.py:632-641)
   bool pre_full = false;  // a row that is ALREADY full (only a caller-provided board holds one): clear_filled_rows takes it with every placement
+  bool row_ones = true;   // this lane's row consists of bedrock cells (value 1) only: never taken (envs/tetris.py:493)
   {
     uint32_t rowbits = 0;
     const int r = lane < H ? lane : H - 1;
 #pragma unroll
     for (int c = 0; c < W; ++c) {
-      const bool f = lane < H && slab[r * W + c] != 0;
+      const uint8_t cell = slab[r * W + c];
+      const bool f = lane < H && cell != 0;
+      row_ones &= cell == 1;
       rowbits |= (f ? 1u : 0u) << c;
       const uint64_t colm = __ballot(f);
       if (lane == c) cm[c] = (M)colm;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void placements_kernel(const PlacementParam
     if (lane < H) rm[lane] = rowbits;
     {
       constexpr uint32_t FULLC = W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u);
-      pre_full = __ballot(lane < H && (rowbits & FULLC) == FULLC) != 0;
+      pre_full = __ballot(lane < H && (rowbits & FULLC) == FULLC && !row_ones) != 0;
     }
     for (int i = lane; i < PB; i += 64) {
       const int R = i / WP, C = i - R * WP;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void placements_kernel(const PlacementParam
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if ((int)(q[j] / WP) == r) bits |= 1u << (q[j] % WP - 4);
-      const uint64_t fm = __ballot(lane < H && (bits & FULL) == FULL);
+      const uint64_t fm = __ballot(lane < H && (bits & FULL) == FULL && !row_ones);
       F = (M)fm;
       n = (int)__popcll(fm);
     }
