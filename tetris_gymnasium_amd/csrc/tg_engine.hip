@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <functional>
@@ -2184,11 +2185,17 @@ int tg_sync(tg_handle* h) {
   HIPCHK(h, hipSetDevice(h->cfg.device));
   { int rcj = join_shards(h); if (rcj != TG_OK) return rcj; }
   // short waits are polled (a blocking hipStreamSynchronize costs tens of microseconds of wake-up latency, which is
-  // several step launches); after ~200 us of polling fall back to the blocking wait
-  for (int i = 0; i < 4000; ++i) {
-    const hipError_t q = hipStreamQuery(h->stream);
-    if (q == hipSuccess) return check_dev_state(h);
-    if (q != hipErrorNotReady) return fail(h, TG_EHIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+  // several step launches); after 2 ms of polling fall back to the blocking wait.  (Rounds 2-5 polled a fixed 4 000 queries
+  // = ~140 us: a 20-launch region — the driver's bench command — ends right at that boundary, and the hand-over to the blocking
+  // wait put a tail of +0.5 ... +1.3 us per launch on one region in ten: profiles/r06/region20_sync_poll.log)
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    for (int i = 0; i < 256; ++i) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) return check_dev_state(h);
+      if (q != hipErrorNotReady) return fail(h, TG_EHIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+    }
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return check_dev_state(h);
