@@ -462,7 +462,8 @@ def test_rng_role_every_nth_launch(every, W, H, Q, B, grouped, monkeypatch):
 @pytest.mark.parametrize("fuse", [1, 16])
 @pytest.mark.parametrize("W,H,Q,B,grouped", [(10, 20, 4, 1000, False), (20, 40, 7, 300, True), (6, 12, 2, 100, False), (12, 24, 4, 77 * 4, False),
                                              (20, 40, 7, 32 * 9 + 20, True), (20, 40, 4, 32 * 5 + 16, False),  # (kFeatSeq: ragged second / empty second group)
-                                             (22, 30, 4, 32 * 2 + 24, False)])  # (... of a board size compiled at run time: 660 cells, 64-bit column masks)
+                                             (22, 30, 4, 32 * 2 + 24, False),   # (... of a board size compiled at run time: 660 cells, 64-bit column masks)
+                                             (32, 24, 4, 32 + 28, False)])       # (... the widest board: 768 cells, 32-bit masks, every row-mask bit in use)
 def test_packed_board_handles(fuse, W, H, Q, B, grouped, monkeypatch):
     """TG_PACKED=1: the handle keeps its board as nibbles (tg_kernel_bits.h kFeatPacked — what large working sets pick by
     themselves) and the uint8 TG_BUF_BOARD is brought up to date on demand.  Single steps, rollouts, trajectories, masked
