@@ -103,3 +103,47 @@ def test_update_state_matches_the_oracle_step(gravity):
             assert bool(st.game_over) == bool(term[0])
             if term[0]:
                 break
+
+
+@pytest.mark.parametrize("padding", [3, 5, 8])
+def test_a_state_of_another_padding_is_the_padding_4_state_shifted(padding):
+    """EnvConfig.padding (reference functional/core.py:23,59,79,198) on the host restatement, which clamps its 4x4 windows the
+    way lax.dynamic_slice does: along random play (incl. hard drops against both walls and rotations there) a game with
+    padding p >= 3 is the padding-4 game with x moved by p - 4 inside a frame of 1-cells p wide — the equivalence the engine's
+    functional surface rests on (envs/tetris_fn.py docstring).  With padding 2 it is not (shown on the probe that breaks it)."""
+    def play(p, seed, steps, gravity):
+        cfg = EnvConfig(10, 20, p, 7, gravity)
+        key = prng.PRNGKey(seed)
+        from tetris_gymnasium_amd.functional import core as fc
+        from tetris_gymnasium_amd.functional.queue import bag_queue_get_next_element, create_bag_queue
+        queue, qi = create_bag_queue(cfg, key)
+        piece, queue, qi, _ = bag_queue_get_next_element(cfg, queue, qi, key)
+        x, y = fc.get_initial_x_y(cfg, TETROMINOES, piece)
+        st = State(rng_key=prng.split(key)[0], board=fc.create_board(cfg), active_tetromino=np.int32(piece), rotation=np.int32(0),
+                   x=np.int32(x), y=np.int32(y), queue=np.asarray(queue, np.int32), queue_index=np.int32(qi),
+                   game_over=np.bool_(False), score=np.float32(0))
+        rng = np.random.default_rng(seed)
+        out = []
+        for t in range(steps):
+            r = rng.random()  # runs against a wall with rotations there, then a drop: stacks grow at both edges
+            a = (seed + t // 24) % 2 if r < 0.5 else (6 if r < 0.53 else int(rng.integers(0, 7)))
+            if not st.game_over:
+                st, lines = tetris_fn.update_state(a, cfg, st, tetrominoes=TETROMINOES)
+            frame = np.array(st.board, copy=True); frame[:20, p:p + 10] = 1
+            out.append((int(st.x) - (p - 4), int(st.y), int(st.rotation), int(st.active_tetromino), float(st.score), bool(st.game_over),
+                        st.board[:20, p:p + 10].tobytes(), bool((frame == 1).all()), list(st.queue), int(st.queue_index)))
+        return out
+
+    xs = set()
+    for seed in range(1, 25):
+        ref, got = play(4, seed, 400, seed % 3 != 0), play(padding, seed, 400, seed % 3 != 0)
+        for t, (a, b) in enumerate(zip(ref, got)):
+            assert a == b and a[7], f"padding {padding} seed {seed} t={t}: {a[:6]} != {b[:6]}"
+        xs.update(a[0] for a in ref)
+    assert min(xs) <= 2 and max(xs) >= 12, xs  # (an upright I against the left wall; an O / upright piece against the right one)
+    if padding == 3:  # one below, the reference itself leaves the frame in ordinary play: an upright I (column 2 of its matrix) at the left
+        from tetris_gymnasium_amd.functional import core as fc  # wall sits at x = 0 and probes x = -1, which dynamic_slice clamps to 0
+        up = TETROMINOES.matrices[0, 3]
+        b2, b4 = fc.create_board(EnvConfig(10, 20, 2, 7, True)), fc.create_board(EnvConfig(10, 20, 4, 7, True))
+        assert not fc.collision(b2, up, 0, 5) and not fc.collision(b2, up, -1, 5)   # "free": the piece would walk into the wall
+        assert not fc.collision(b4, up, 2, 5) and fc.collision(b4, up, 1, 5)

@@ -87,7 +87,7 @@ def test_rejects_custom_plug_points_before_touching_the_gpu():
     with pytest.raises(NotImplementedError):
         F.reset(TETROMINOES, F.PRNGKey(0), cfg, create_queue_fn=lambda c, k: None)
     with pytest.raises(NotImplementedError):
-        F.reset(TETROMINOES, F.PRNGKey(0), EnvConfig(10, 20, 3, 7))
+        F.reset(TETROMINOES, F.PRNGKey(0), EnvConfig(10, 20, 2, 7))  # (padding >= 3 is served: test_gpu_surfaces.py)
     with pytest.raises(NotImplementedError):
         F.reset(object(), F.PRNGKey(0), cfg)
 

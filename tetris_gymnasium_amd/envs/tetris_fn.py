@@ -6,6 +6,13 @@ carries a private token naming the engine generation that produced it; passing i
 usual rollout loop) skips the host→device upload.  Stock TETROMINOES and the stock 7-bag queue only —
 anything else is rejected explicitly.
 
+`EnvConfig.padding` (reference functional/core.py:23,59,79,198): any value >= 3.  The engine keeps boards as playfields (the
+bedrock frame is implicit) and piece positions in the coordinates of a 4-wide frame; a State of another padding is that
+state with x moved by `padding - 4` and a wider or narrower frame of 1-cells around the board — exact as long as every
+4x4 window the rules read lies inside the framed array, which holds for every position play can reach once padding >= 3
+(a hand-made position whose window would be clamped by lax.dynamic_slice under one of the two paddings is refused).  Below
+3 the reference's own windows are clamped in ordinary play (an upright I against the left wall): refused.
+
 PARITY UNPINNED (piece sequences): they follow jax 0.5.3's threefry split / permutation as restated from its source
 (partitionable scheme) and the `jnp.take(-H)` row-0 corner of clear_filled_rows as read from jax semantics; neither is
 pinned against a live jax (none installable in the build container).  `python -m oracle.refgen.make_golden_fn` pins
@@ -127,13 +134,14 @@ LazyArray.__hash__ = None
 
 _engines: dict = {}
 _ids = itertools.count(1)
+_ENGINE_PADDING = 4  # the frame the engine's piece coordinates are in (include/tetris_gym_hip.h: tg_config.padding)
 
 
 class _Slot:
     def __init__(self, config: EnvConfig, batch: int):
         self.engine = Engine(batch, config.width, config.height, ruleset=N.RULESET_FUNCTIONAL,
                              gravity=config.gravity_enabled, queue_size=int(config.queue_size), obs_mode=N.OBS_FN,
-                             padding=config.padding)
+                             padding=_ENGINE_PADDING)
         self.id = next(_ids)
         self.generation = 0
 
@@ -149,8 +157,9 @@ def _check(tetrominoes, config, *fns):
         if f not in (create_bag_queue, bag_queue_get_next_element):
             raise NotImplementedError("the HIP engine implements the stock 7-bag queue only "
                                       "(create_bag_queue / bag_queue_get_next_element)")
-    if config.padding != 4 or not 1 <= int(config.queue_size) <= 7:
-        raise NotImplementedError("the HIP engine needs padding=4 and a bag length queue_size in 1..7 (stock tetromino set)")
+    if int(config.padding) < 3 or not 1 <= int(config.queue_size) <= 7:
+        raise NotImplementedError("the HIP engine needs padding >= 3 (below that lax.dynamic_slice clamps the reference's 4x4 "
+                                  "windows in ordinary play) and a bag length queue_size in 1..7 (stock tetromino set)")
 
 
 def _slot(config: EnvConfig, batch: int) -> _Slot:
@@ -170,17 +179,24 @@ def _download(slot: _Slot, config) -> dict:
     board, rec, rng = slot.engine.get_state()
     return dict(
         rng_key=rng["key"].copy(), board=_pad(board, config), active_tetromino=rec["piece"].astype(np.int32),
-        rotation=rec["rot"].astype(np.int32), x=rec["x"].astype(np.int32), y=rec["y"].astype(np.int32),
+        rotation=rec["rot"].astype(np.int32), x=rec["x"].astype(np.int32) + (int(config.padding) - _ENGINE_PADDING),
+        y=rec["y"].astype(np.int32),
         queue=rec["bag"][:, : config.queue_size].astype(np.int32), queue_index=rec["bag_index"].astype(np.int32),
         game_over=(rec["flags"] & N.F_GAME_OVER).astype(bool), score=rec["score"].astype(np.float32))
 
 
 def _upload(slot: _Slot, config, leaves: dict):
     e = slot.engine
-    B, p = e.B, config.padding
+    B, p = e.B, int(config.padding)
     rec = np.zeros(B, N.ENV_REC)
     rec["piece"] = leaves["active_tetromino"]; rec["rot"] = np.asarray(leaves["rotation"]) & 3
-    rec["x"] = leaves["x"]; rec["y"] = leaves["y"]; rec["val"] = np.asarray(leaves["active_tetromino"]) + 2
+    x, y = np.asarray(leaves["x"], np.int64) - (p - _ENGINE_PADDING), np.asarray(leaves["y"], np.int64)
+    if p != _ENGINE_PADDING:  # (x is now in the engine's frame)  a window that one of the two frames would clamp: not the same state
+        lo, hi, ymax = max(0, _ENGINE_PADDING - p), config.width + min(_ENGINE_PADDING, p), config.height + min(0, p - _ENGINE_PADDING)
+        if ((x < lo) | (x > hi) | (y < 0) | (y > ymax)).any():
+            raise NotImplementedError(f"padding={p}: a piece whose 4x4 window leaves the framed board (x outside {lo + p - 4}..{hi + p - 4} "
+                                      f"or y outside 0..{ymax}) is clamped differently by the reference and by the engine's 4-wide frame")
+    rec["x"] = x; rec["y"] = y; rec["val"] = np.asarray(leaves["active_tetromino"]) + 2
     rec["flags"] = np.where(np.asarray(leaves["game_over"], bool), N.F_GAME_OVER, 0)
     rec["holder_piece"] = N.NONE
     rec["bag"][:, : config.queue_size] = np.asarray(leaves["queue"]).reshape(B, -1)
@@ -237,7 +253,8 @@ def step(tetrominoes, state: State, action, config, queue_fn=bag_queue_get_next_
 def _leaves_from_buffers(config, B, board, rec, rng) -> dict:
     return dict(
         rng_key=rng["key"].copy(), board=_pad(board, config), active_tetromino=rec["piece"].astype(np.int32),
-        rotation=rec["rot"].astype(np.int32), x=rec["x"].astype(np.int32), y=rec["y"].astype(np.int32),
+        rotation=rec["rot"].astype(np.int32), x=rec["x"].astype(np.int32) + (int(config.padding) - _ENGINE_PADDING),
+        y=rec["y"].astype(np.int32),
         queue=rec["bag"][:, : config.queue_size].astype(np.int32), queue_index=rec["bag_index"].astype(np.int32),
         game_over=(rec["flags"] & N.F_GAME_OVER).astype(bool), score=rec["score"].astype(np.float32))
 
