@@ -90,15 +90,15 @@ def test_engine_wrapper_surfaces_on_poked_states(golden_dir, name):
 
 
 @pytest.mark.parametrize("packed", [False, True])
-@pytest.mark.parametrize("name", ["poked_10x20", "poked_20x40"])
+@pytest.mark.parametrize("name", ["poked_10x20", "poked_20x40"])  # (the gravity-off job carries no grouped part)
 def test_engine_grouped_steps_from_poked_states(golden_dir, name, packed, monkeypatch):
     """Every one of the grouped wrapper's 4W actions from every hand-made state through the step kernel's grouped action set
     (wrappers/grouped.py:209-269): reward (-0.1 on a masked-out action), termination, lines, board / piece / position after."""
     monkeypatch.setenv("TG_PACKED", "1" if packed else "0")
     fx = replay.load(golden_dir, name)
     ng, NA = fx["gs_reward"].shape
-    e = Engine(ng * NA, int(fx["width"]), int(fx["height"]), ruleset=N.RULESET_NUMPY, queue_size=int(fx["queue_size"]), obs_mode=N.OBS_BOARD,
-               grouped=True, terminate_on_illegal=True)
+    e = Engine(ng * NA, int(fx["width"]), int(fx["height"]), ruleset=N.RULESET_NUMPY, gravity=bool(fx["gravity"]), queue_size=int(fx["queue_size"]),
+               obs_mode=N.OBS_BOARD, grouped=True, terminate_on_illegal=True)
     e.reset(replay.poked_seeds(fx, NA, ng))
     replay.replay_poked_grouped(e.step, e.get_state, lambda b, r: e.set_state(board=b, rec=r), fx)
     e.close()

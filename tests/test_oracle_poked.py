@@ -41,12 +41,12 @@ def test_oracle_wrappers_on_poked_states(golden_dir, name):
     np.testing.assert_array_equal(o.observe(po.OBS_RGB)[::8], fx["rgb"])
 
 
-@pytest.mark.parametrize("name", ["poked_10x20", "poked_20x40"])
+@pytest.mark.parametrize("name", ["poked_10x20", "poked_20x40"])  # (the gravity-off job carries no grouped part)
 def test_oracle_grouped_steps_from_poked_states(golden_dir, name):
     """Every grouped action (column x rotation: teleport + hard drop, illegal -> terminate with -0.1) from every hand-made state."""
     fx = replay.load(golden_dir, name)
     ng, NA = fx["gs_reward"].shape
-    o = po.OracleBatch(ng * NA, int(fx["width"]), int(fx["height"]), po.RULESET_NUMPY, True, int(fx["queue_size"]))
+    o = po.OracleBatch(ng * NA, int(fx["width"]), int(fx["height"]), po.RULESET_NUMPY, bool(fx["gravity"]), int(fx["queue_size"]))
     o.reset(replay.poked_seeds(fx, NA, ng))
     replay.replay_poked_grouped(lambda a: o.grouped_step(a, terminate_on_illegal=True)[:3], o.get_state,
                                 lambda b, r: o.set_state(board=b, rec=r), fx)
